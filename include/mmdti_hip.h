@@ -1,0 +1,221 @@
+/* mmdti_hip.h -- C ABI of libmmdti_hip.so: the MI355X (gfx950) kernels behind the
+ * MM-DTI dual-encoder contrastive fine-tune step.
+ *
+ * The reference (ndlongvn/MM-DTI) has no native layer: its hot path is Python
+ * calling torch / Uni-Core / HuggingFace ops.  Each entry point below replaces
+ * the ATen / Uni-Core-CUDA kernels that one reference call site reaches; the
+ * call site is cited per function as file:line relative to the reference root.
+ * The host-side mirror of the reference's module interface (same class names,
+ * ctor/forward signatures, parameter names) lives in mm-dti_amd/mmdti_hip/models
+ * and binds these symbols through ctypes.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is DEVICE memory unless noted.
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on
+ *     it (no host sync, no allocation, graph-capture safe).
+ *   - bf16 tensors are raw uint16 bit patterns (`void*` in the signature).
+ *   - return value: MMDTI_OK or an error code; mmdti_last_error() gives the text
+ *     (thread-local).  Argument validation happens on the host BEFORE any launch.
+ *   - "atomic accumulate" outputs must be zeroed by the caller (gradient arena).
+ *   - dropout: p in [0,1); mask = Philox4x32-10(seed, site, element index); the
+ *     backward entry regenerates the same mask from (seed, site).
+ */
+#ifndef MMDTI_HIP_H
+#define MMDTI_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mmdti_stream_t;
+
+#define MMDTI_OK 0
+#define MMDTI_ERR_INVALID 1
+#define MMDTI_ERR_LAUNCH 2
+
+#define MMDTI_ACT_NONE 0
+#define MMDTI_ACT_GELU 1      /* erf GELU; optional aux_out = pre-activation (bf16) */
+#define MMDTI_ACT_GELU_BWD 2  /* multiply by gelu'(aux_in) */
+
+#define MMDTI_DT_F32 0
+#define MMDTI_DT_BF16 1
+#define MMDTI_DT_F32_ATOMIC 2 /* atomicAdd into fp32 C (split-K / gradient accumulation) */
+
+#define MMDTI_CT_REGRESS 0
+#define MMDTI_CT_SINGLE 1
+#define MMDTI_CT_MULTI 2
+
+const char* mmdti_last_error(void);
+int mmdti_abi_version(void);
+
+/* ---- GEMM: C = epi(alpha * A.B^T) ----------------------------------------------------------
+ * Replaces nn.Linear / torch.bmm fwd+bwd: unicore in_proj/out_proj/fc1/fc2 (models/transformers.py:137-139),
+ * gbf_proj (models/mm_model.py:554), RobertaModel linears (mm_model.py:562), InfoNCE projections
+ * (models/infonce.py:28-29), BertCrossEncoder linears (models/mm_module.py:486-488,527,545,581).
+ * A: transA=0 -> [M,K] row-major (lda), transA=1 -> stored [K,M].  B: transB=0 -> [N,K] ("weight" layout),
+ * transB=1 -> stored [K,N].  lda/ldb multiples of 8, 16-byte aligned bases.  If K%8 != 0 the k-contiguous
+ * operand must hold zeros in its padded tail.  Batch index z = outer*batch_inner + inner.  */
+int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void* B, void* C, int M, int N, int K, int lda,
+                    int ldb, int ldc, int transA, int transB, int batch_outer, int batch_inner, long long sAo,
+                    long long sAi, long long sBo, long long sBi, long long sCo, long long sCi, int splitk,
+                    float alpha, float beta, const float* bias, const float* residual, int ldr, int act,
+                    const void* aux_in, void* aux_out, int ld_aux, int c_dtype, float drop_p,
+                    unsigned long long seed, unsigned int site);
+
+/* ---- LayerNorm (unicore LayerNorm eps 1e-5: transformers.py:69,71,114,161; BertLayerNorm eps 1e-12:
+ * mm_module.py:320-333; HF nn.LayerNorm) -------------------------------------------------------
+ * y = LN(x)*gamma+beta, then optional dropout, then rows with row_zero[r]!=0 forced to 0
+ * (transformers.py:115-118).  Writes y_f32 and/or y_bf16 (either may be null). */
+int mmdti_layernorm_fwd(mmdti_stream_t stream, const float* x, const float* gamma, const float* beta, float eps,
+                        int rows, int D, float* y_f32, void* y_bf16, float* mean, float* rstd,
+                        const unsigned char* row_zero, float drop_p, unsigned long long seed, unsigned int site);
+/* dx = dres + LN'(dy) ; dgamma/dbeta atomic accumulate.  dy is fp32 (dy_dtype=MMDTI_DT_F32) or bf16. */
+int mmdti_layernorm_bwd(mmdti_stream_t stream, const void* dy, int dy_dtype, const float* x, const float* gamma,
+                        const float* mean, const float* rstd, int rows, int D, const float* dres, float* dx,
+                        float* dgamma, float* dbeta, const unsigned char* row_zero, float drop_p,
+                        unsigned long long seed, unsigned int site);
+
+/* ---- small utilities ------------------------------------------------------------------------ */
+/* out[c] += sum_r x[r,c]  (bias gradients of every Linear) */
+int mmdti_colsum_bf16(mmdti_stream_t stream, const void* x_bf16, int rows, int cols, int ld, float* out);
+/* y = bf16(dropout(x)) elementwise; dropout site indexes elements 0..n-1 */
+int mmdti_cast_f32_bf16(mmdti_stream_t stream, const float* x, void* y_bf16, long long n, float drop_p,
+                        unsigned long long seed, unsigned int site);
+int mmdti_cast_bf16_f32(mmdti_stream_t stream, const void* x_bf16, float* y, long long n);
+/* y = dropout(x) in fp32 (F.dropout on fp32 activations: infonce.py:24, mm_model.py:390-391,79,82) */
+int mmdti_dropout_f32(mmdti_stream_t stream, const float* x, float* y, long long n, float drop_p,
+                      unsigned long long seed, unsigned int site);
+/* y += a*x (fp32) */
+int mmdti_axpy_f32(mmdti_stream_t stream, const float* x, float* y, long long n, float a);
+
+/* ---- Embedding (nn.Embedding: mm_model.py:552; HF roberta embeddings) ---------------------- */
+int mmdti_embedding_fwd(mmdti_stream_t stream, const long long* ids, const float* table, long long n, int D,
+                        int vocab, float* out, int accumulate);
+/* dtable[ids[i]] += dout[i] (atomic), rows with ids==padding_idx skipped (padding_idx<0: none) */
+int mmdti_embedding_bwd(mmdti_stream_t stream, const long long* ids, const float* dout, long long n, int D,
+                        int vocab, long long padding_idx, float* dtable);
+/* RoBERTa position ids: cumsum(ids!=pad)*(ids!=pad)+pad, int64, bit-exact (modeling_roberta.py:142-155) */
+int mmdti_roberta_position_ids(mmdti_stream_t stream, const long long* ids, int B, int L, long long pad_idx,
+                               long long* out);
+
+/* ---- Gaussian pair-distance basis (GaussianLayer.forward, mm_model.py:254-269; gaussian :211-224) */
+int mmdti_gbf_features_fwd(mmdti_stream_t stream, const float* dist, const long long* edge_type, const float* mul,
+                           const float* bias, const float* means, const float* stds, long long P, int K, int E,
+                           void* feat_bf16);
+int mmdti_gbf_features_bwd(mmdti_stream_t stream, const float* dist, const long long* edge_type, const float* mul,
+                           const float* bias, const float* means, const float* stds, long long P, int K, int E,
+                           const void* dfeat_bf16, float* dmul, float* dbias, float* dmeans, float* dstds);
+/* [B,N,N,H] fp32 -> [B,H,N,ld] fp32 (mm_model.py:555-556 permute(0,3,1,2).contiguous()) and its gradient
+ * [B,H,N,ld] fp32 -> [B,N,N,H] bf16 */
+int mmdti_pair_permute_fwd(mmdti_stream_t stream, const float* x, float* out, int B, int N, int H, int ld);
+int mmdti_pair_permute_bwd(mmdti_stream_t stream, const float* g, void* out_bf16, int B, int N, int H, int ld);
+
+/* ---- Pair-bias attention, head_dim 8 (unicore SelfMultiheadAttention + softmax_dropout with
+ * return_attn=True, reached from transformers.py:137-139; key-padding merge :122-135) ------------
+ * S = scale*q.k^T + bias_in (+ -inf at padded keys); s_out = S (next layer's bias AND the saved activation);
+ * O = dropout(softmax(S)).v.   qkv: [B,N,3*H*8] bf16 (q|k|v);  bias_in/s_out: [B,H,N,ld] fp32. */
+int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, const float* bias_in, float* s_out,
+                        void* o_bf16, const unsigned char* key_pad, int B, int N, int H, int ld, float scale,
+                        float drop_p, unsigned long long seed, unsigned int site);
+/* g (in/out, [B,H,N,ld] fp32): on entry dL/dS_l from the layers above (ignored if g_in_zero), on exit
+ * dL/dS_l total = dL/d(bias_in).  dqkv: [B,N,3*H*8] bf16. */
+int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, const float* s, const void* do_bf16, float* g,
+                        void* dqkv_bf16, int B, int N, int H, int ld, float scale, int g_in_zero, float drop_p,
+                        unsigned long long seed, unsigned int site);
+
+/* ---- Row softmax over materialised scores (HF eager_attention_forward :158-183; BertCoAttention
+ * mm_module.py:497-514) ------------------------------------------------------------------------
+ * s: [B*heads*Lq, ld] fp32 (already scaled); key_add: [B,Lk] fp32 additive mask or null.
+ * p_bf16 = softmax (saved), pd_bf16 = dropout(p) (may equal p_bf16 when drop_p==0); pad columns [Lk,ld) = 0. */
+int mmdti_softmax_fwd(mmdti_stream_t stream, const float* s, const float* key_add, void* p_bf16, void* pd_bf16,
+                      int B, int heads, int Lq, int Lk, int ld, float drop_p, unsigned long long seed,
+                      unsigned int site);
+/* ds = scale * p*(dp' - sum(dp'*p)),  dp' = dropout-backward(dp) */
+int mmdti_softmax_bwd(mmdti_stream_t stream, const void* p_bf16, const float* dp, void* ds_bf16, int B, int heads,
+                      int Lq, int Lk, int ld, float scale, float drop_p, unsigned long long seed,
+                      unsigned int site);
+
+/* ---- GELU on bf16 (kept for un-fused call sites) ------------------------------------------- */
+int mmdti_gelu_fwd_bf16(mmdti_stream_t stream, const void* u_bf16, void* y_bf16, long long n);
+
+/* ---- InfoNCE head (models/infonce.py) ------------------------------------------------------- */
+/* unmasked mean over dim 1 (infonce.py:32-33): x [B,S,ld] bf16 -> out [B,D] fp32 */
+int mmdti_seq_mean_fwd(mmdti_stream_t stream, const void* x_bf16, int B, int S, int D, int ld, float* out);
+/* dx[b,s,:] = dout[b,:]/S  (bf16, [B,S,ld]; pad columns zeroed) */
+int mmdti_seq_mean_bwd(mmdti_stream_t stream, const float* dout, int B, int S, int D, int ld, void* dx_bf16);
+/* F.normalize(x, dim=-1) (infonce.py:104-105; contrastive.py:22-23) */
+int mmdti_l2norm_fwd(mmdti_stream_t stream, const float* x, int B, int D, int ldx, float* xhat, float* inv_norm);
+int mmdti_l2norm_bwd(mmdti_stream_t stream, const float* dxhat, const float* xhat, const float* inv_norm, int B,
+                     int D, int ldx, float* dx);
+/* One direction of the symmetric CE (infonce.py:93-98) for anchors rows [row0,row0+Bl) of qh_all against all
+ * Bg keys kh_all (global negatives under DDP).  loss_sum += sum_i CE_i (atomic), dq rows written,
+ * dk accumulated atomically.  Gradients are of (1/(2*Bg)) * sum_i CE_i. */
+int mmdti_infonce_dir(mmdti_stream_t stream, const float* qh_all, const float* kh_all, int Bg, int D, int row0,
+                      int Bl, float temperature, float* loss_sum, float* dq_all, float* dk_all);
+
+/* ---- ConR / SupCon (models/contrastive.py:3-59, 62-112, 114-169) --------------------------- */
+/* fhat: L2-normalised features [B,D].  labels_f: [B] fp32 (regress: mean target; single: class id as float);
+ * labels_i: [B,C] int64 (multi).  pred: [B] fp32 (regress).  weights: [B] fp32 or null.
+ * Outputs: loss (scalar, overwritten), G [B,B] = dL/dprod. */
+int mmdti_ct_loss_fwd(mmdti_stream_t stream, int mode, const float* fhat, int B, int D, const float* labels_f,
+                      const long long* labels_i, int C, const float* pred, const float* weights, float w, float t,
+                      float e, float coef, float* loss, float* G);
+/* dfhat[i] = (1/t) * sum_j (G[i,j]+G[j,i]) fhat[j] */
+int mmdti_ct_loss_bwd(mmdti_stream_t stream, const float* fhat, const float* G, int B, int D, float t, float* dfhat);
+
+/* ---- FDS (models/fds.py; utils/util.py:159-169) --------------------------------------------- */
+/* bins[i] = int((label_i - min_value)//bin_width) in fp32 floor-division arithmetic (fds.py:125,164), int32;
+ * flags[0] = any(bin==bucket_start), flags[1] = any(bin==bucket_num-1) (flags must be zeroed by the caller). */
+int mmdti_fds_bins(mmdti_stream_t stream, const float* labels, int n, float min_value, float bin_width,
+                   int bucket_start, int bucket_num, int* bins, int* flags);
+/* FDS.smooth (fds.py:157-190): y = calibrate_mean_var(x, m1[b], v1[b], m2[b], v2[b]) per row bucket; scale_out[r,c]
+ * = d y/d x (for backward).  Stats arrays are [bucket_num-bucket_start, D]. */
+int mmdti_fds_smooth(mmdti_stream_t stream, const float* x, const int* bins, const int* flags, int n, int D,
+                     int bucket_start, int bucket_num, const float* m1, const float* v1, const float* m2,
+                     const float* v2, float* y, float* scale_out);
+/* FDS.update_running_stats (fds.py:116-155) for all buckets: per-bucket mean / unbiased var of features, EMA into
+ * running_mean/var with `factor`, num_samples_tracked += count. */
+int mmdti_fds_update_stats(mmdti_stream_t stream, const float* feats, const int* bins, const int* flags, int n,
+                           int D, int bucket_start, int bucket_num, float factor, float* running_mean,
+                           float* running_var, float* num_samples_tracked);
+/* FDS._update_last_epoch_stats smoothing (fds.py:86-99): reflect-pad + conv1d across buckets */
+int mmdti_fds_smooth_stats(mmdti_stream_t stream, const float* stat, int nb, int D, const float* window, int ks,
+                           float* out);
+
+/* ---- masked pooling (mm_model.py:572-576) --------------------------------------------------- */
+/* pooled[b] = (sum_{valid n} a[b,n] + sum_{valid l} t[b,l]) / (n_valid_a + n_valid_t);  a:[B,Na,D], t:[B,Nt,D] fp32,
+ * masks uint8 (1 = valid). */
+int mmdti_masked_pool_fwd(mmdti_stream_t stream, const float* a, const float* t, const unsigned char* mask_a,
+                          const unsigned char* mask_t, int B, int Na, int Nt, int D, float* pooled);
+int mmdti_masked_pool_bwd(mmdti_stream_t stream, const float* dpooled, const unsigned char* mask_a,
+                          const unsigned char* mask_t, int B, int Na, int Nt, int D, float* da, float* dt);
+
+/* ---- small fp32 linear for the classification head (mm_model.py:44-84) ---------------------- */
+/* y = act(x.W^T + b); act: 0 none, 3 tanh */
+int mmdti_linear_f32_fwd(mmdti_stream_t stream, const float* x, const float* W, const float* b, int rows, int in_f,
+                         int out_f, int act, float* y);
+/* given dy (wrt post-activation y) and y: dx (overwrite), dW/db atomic accumulate */
+int mmdti_linear_f32_bwd(mmdti_stream_t stream, const float* x, const float* W, const float* y, const float* dy,
+                         int rows, int in_f, int out_f, int act, float* dx, float* dW, float* db);
+/* task losses (models/nnmodel.py:24-34): mean-reduced MSE / cross-entropy, loss + dlogits in one pass */
+int mmdti_mse_loss(mmdti_stream_t stream, const float* pred, const float* target, int n, float* loss, float* dpred);
+int mmdti_ce_loss(mmdti_stream_t stream, const float* logits, const long long* target, int B, int C, float* loss,
+                  float* dlogits);
+
+/* ---- optimizer step on the flat arenas (tasks/trainer.py:160,270-282) ---------------------- */
+/* sum of squares of g into out[0] (atomic; zero first) */
+int mmdti_sumsq_f32(mmdti_stream_t stream, const float* g, long long n, float* out);
+/* Adam (torch.optim.Adam semantics, eps outside sqrt of bias-corrected v): p,m,v updated in place; also refreshes the
+ * bf16 shadow copy of p.  grad is multiplied by *grad_scale_dev (device scalar, e.g. clip coefficient) if non-null. */
+int mmdti_adam_step(mmdti_stream_t stream, float* p, const float* g, float* m, float* v, void* p_bf16, long long n,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                    const float* grad_scale_dev);
+
+/* ---- hardware probes used by the test-suite ------------------------------------------------- */
+/* out[64*4] <- what ds_read_b64_tr_b16 returns to each lane for an LDS image holding element index == value */
+int mmdti_probe_tr_read(mmdti_stream_t stream, int row_stride_elems, unsigned short* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMDTI_HIP_H */

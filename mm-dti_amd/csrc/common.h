@@ -1,0 +1,122 @@
+// Shared device/host helpers for the MM-DTI gfx950 kernels.
+// gfx950 only: 64-lane waves, bf16 MFMA, 160 KiB LDS.  No CUDA/portability shims.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "../../include/mmdti_hip.h"
+
+namespace mmdti {
+
+typedef uint16_t bf16_t;  // raw bf16 bits in memory
+
+// ---- error plumbing (host) -------------------------------------------------
+void set_error(const char* fmt, ...);
+#define MMDTI_REQUIRE(cond, ...)                 \
+  do {                                           \
+    if (!(cond)) {                               \
+      ::mmdti::set_error(__VA_ARGS__);           \
+      return MMDTI_ERR_INVALID;                  \
+    }                                            \
+  } while (0)
+#define MMDTI_LAUNCH_CHECK()                                              \
+  do {                                                                    \
+    hipError_t e__ = hipGetLastError();                                   \
+    if (e__ != hipSuccess) {                                              \
+      ::mmdti::set_error("%s:%d launch failed: %s", __FILE__, __LINE__,   \
+                         hipGetErrorString(e__));                         \
+      return MMDTI_ERR_LAUNCH;                                            \
+    }                                                                     \
+  } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- bf16 <-> f32 ----------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even; NaN stays NaN, +-inf stays inf.
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+// ---- wave-level reductions (64 lanes) --------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// Sum 8 per-lane values over the 64 lanes; lane l (l<8) ends up holding the total of
+// value index bitrev-free index (l & 7) -- see implementation: returns total of v[lane&7].
+__device__ __forceinline__ float wave_sum8_scatter(const float (&v)[8], int lane) {
+  // halve the value count while exchanging across lane bits 0,1,2, then all-reduce bits 3..5
+  float a[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float keep = (lane & 1) ? v[2 * i + 1] : v[2 * i];
+    float send = (lane & 1) ? v[2 * i] : v[2 * i + 1];
+    a[i] = keep + __shfl_xor(send, 1, 64);
+  }  // lane bit0 selects value parity: a[i] = partial of v[2i + (lane&1)]
+  float b[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float keep = (lane & 2) ? a[2 * i + 1] : a[2 * i];
+    float send = (lane & 2) ? a[2 * i] : a[2 * i + 1];
+    b[i] = keep + __shfl_xor(send, 2, 64);
+  }  // b[i] = partial of v[4i + 2*((lane>>1)&1) + (lane&1)]
+  float keep = (lane & 4) ? b[1] : b[0];
+  float send = (lane & 4) ? b[0] : b[1];
+  float c = keep + __shfl_xor(send, 4, 64);  // partial of v[4*((lane>>2)&1) + 2*((lane>>1)&1) + (lane&1)] = v[lane&7]
+  c += __shfl_xor(c, 8, 64);
+  c += __shfl_xor(c, 16, 64);
+  c += __shfl_xor(c, 32, 64);
+  return c;
+}
+
+// ---- counter-based RNG for dropout (Philox4x32-10) --------------------------
+// One call yields 4 x 32 random bits for counter (ctr_lo, ctr_hi, site, 0) under key (seed_lo, seed_hi).
+struct Rand4 {
+  uint32_t x, y, z, w;
+};
+__device__ __forceinline__ Rand4 philox4(uint64_t seed, uint32_t site, uint64_t ctr) {
+  uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = site, c3 = 0x2545F491u;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return Rand4{c0, c1, c2, c3};
+}
+// keep-mask for element index `idx` of dropout site `site`: one Philox call covers 4 consecutive
+// elements (idx>>2), lane picks word idx&3.  keep iff u32 >= thresh, thresh = p * 2^32.
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t site, uint64_t idx, uint32_t thresh) {
+  Rand4 r = philox4(seed, site, idx >> 2);
+  uint32_t w = (idx & 3) == 0 ? r.x : (idx & 3) == 1 ? r.y : (idx & 3) == 2 ? r.z : r.w;
+  return w >= thresh;
+}
+static inline uint32_t dropout_thresh(float p) {
+  if (p <= 0.f) return 0u;
+  double t = (double)p * 4294967296.0;
+  if (t >= 4294967295.0) return 0xFFFFFFFFu;
+  return (uint32_t)t;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float kInvSqrt2Pi = 0.39894228040143267794f;
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * kInvSqrt2Pi * __expf(-0.5f * x * x);
+}
+
+}  // namespace mmdti

@@ -1,0 +1,493 @@
+// Bandwidth-bound helpers of the fine-tune step: casts, dropout, column sums, embeddings, RoBERTa position ids,
+// row softmax over materialised attention scores, masked pooling, GELU, sum of squares, Adam.
+// All are simple streams; 16-byte accesses per lane wherever the layout allows (cdna guide G13).
+#include "common.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+namespace mmdti {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static inline int grid_for(long long n, int per_block) {
+  long long b = (n + per_block - 1) / per_block;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ---------------------------------------------------------------- casts / dropout / axpy
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y,
+                                                            long long n4, long long n, uint32_t thresh, float dscale,
+                                                            uint64_t seed, uint32_t site) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    float o[4] = {v.x, v.y, v.z, v.w};
+    if (thresh) {
+      Rand4 r = philox4(seed, site, (uint64_t)i);
+      uint32_t rw[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = rw[e] >= thresh ? o[e] * dscale : 0.f;
+    }
+    uint2 pk;
+    pk.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+    pk.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+    reinterpret_cast<uint2*>(y)[i] = pk;
+  }
+  // tail (n % 4)
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    long long i = (n & ~3LL) + threadIdx.x;
+    float o = x[i];
+    if (thresh) o = dropout_keep(seed, site, (uint64_t)i, thresh) ? o * dscale : 0.f;
+    y[i] = f2bf(o);
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = bf2f(x[i]);
+}
+
+__global__ __launch_bounds__(256) void dropout_f32_kernel(const float* __restrict__ x, float* __restrict__ y, long long n,
+                                                          uint32_t thresh, float dscale, uint64_t seed, uint32_t site) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float o = x[i];
+    if (thresh) o = dropout_keep(seed, site, (uint64_t)i, thresh) ? o * dscale : 0.f;
+    y[i] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, float a) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] += a * x[i];
+}
+
+__global__ __launch_bounds__(256) void gelu_bf16_kernel(const bf16_t* __restrict__ u, bf16_t* __restrict__ y, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    y[i] = f2bf(gelu_erf(bf2f(u[i])));
+}
+
+// ---------------------------------------------------------------- column sum (bias gradients)
+// block = 256 threads: 32 column-chunks(8 cols each, 16 B) x 8 row lanes; grid.x over column groups of 256, grid.y rows
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, int rows, int cols, int ld,
+                                                          float* __restrict__ out) {
+  __shared__ float red[8][256 + 8];
+  const int cc = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * 256 + cc * 8;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c0 < cols) {
+    for (int r = blockIdx.y * 8 + rl; r < rows; r += gridDim.y * 8) {
+      const bf16_t* p = x + (long long)r * ld + c0;
+      if (c0 + 8 <= cols) {
+        uint4 u = *reinterpret_cast<const uint4*>(p);
+        uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[2 * i] += __uint_as_float(w[i] << 16);
+          acc[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u);
+        }
+      } else {
+        for (int i = 0; i < cols - c0; ++i) acc[i] += bf2f(p[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[rl][cc * 8 + i] = acc[i];
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < cols) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += red[r][threadIdx.x];
+    atomicAdd(out + c, s);
+  }
+}
+
+// ---------------------------------------------------------------- embeddings
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(const long long* __restrict__ ids, const float* __restrict__ table,
+                                                            long long n, int D4, int vocab, float* __restrict__ out, int accumulate) {
+  const long long total = n * D4;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const long long i = t / D4;
+    const int c = (int)(t - i * D4);
+    long long id = ids[i];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    float4 v = reinterpret_cast<const float4*>(table)[id * D4 + c];
+    if (accumulate) {
+      float4 o = reinterpret_cast<float4*>(out)[t];
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    reinterpret_cast<float4*>(out)[t] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const long long* __restrict__ ids, const float* __restrict__ dout,
+                                                            long long n, int D, int vocab, long long padding_idx,
+                                                            float* __restrict__ dtable) {
+  const long long total = n * D;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const long long i = t / D;
+    const int c = (int)(t - i * D);
+    long long id = ids[i];
+    if (id == padding_idx || id < 0 || id >= vocab) continue;
+    atomicAdd(dtable + id * D + c, dout[t]);
+  }
+}
+
+// one wave per sequence: inclusive scan of (ids != pad) across the row in chunks of 64
+__global__ __launch_bounds__(64) void roberta_posids_kernel(const long long* __restrict__ ids, int L, long long pad,
+                                                            long long* __restrict__ out) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int carry = 0;
+  for (int l0 = 0; l0 < L; l0 += 64) {
+    const int l = l0 + lane;
+    const int m = (l < L && ids[(long long)b * L + l] != pad) ? 1 : 0;
+    int s = m;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int t = __shfl_up(s, o, 64);
+      if (lane >= o) s += t;
+    }
+    if (l < L) out[(long long)b * L + l] = (long long)((carry + s) * m) + pad;
+    carry += __shfl(s, 63, 64);
+  }
+}
+
+// ---------------------------------------------------------------- row softmax over materialised scores
+// one wave per row; Lk <= 1024
+template <int NCH>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ s, const float* __restrict__ key_add,
+                                                          bf16_t* __restrict__ p_out, bf16_t* __restrict__ pd_out,
+                                                          long long rows, int heads, int Lq, int Lk, int ld, uint32_t thresh,
+                                                          float dscale, uint64_t seed, uint32_t site) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int b = (int)(row / ((long long)heads * Lq));
+  const float* sr = s + row * ld;
+  float v[NCH];
+  float m = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int j = c * 64 + lane;
+    v[c] = -INFINITY;
+    if (j < Lk) v[c] = sr[j] + (key_add ? key_add[(long long)b * Lk + j] : 0.f);
+    m = fmaxf(m, v[c]);
+  }
+  m = wave_max(m);
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    v[c] = (c * 64 + lane < Lk) ? __expf(v[c] - m) : 0.f;
+    sum += v[c];
+  }
+  const float inv = 1.0f / wave_sum(sum);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int j = c * 64 + lane;
+    if (j >= ld) continue;
+    const float p = v[c] * inv;  // 0 in the pad columns [Lk, ld)
+    p_out[row * ld + j] = f2bf(p);
+    if (pd_out != p_out) {
+      float pd = p;
+      if (thresh) pd = dropout_keep(seed, site, (uint64_t)row * Lk + j, thresh) ? p * dscale : 0.f;
+      pd_out[row * ld + j] = f2bf(j < Lk ? pd : 0.f);
+    }
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restrict__ p_in, const float* __restrict__ dp,
+                                                          bf16_t* __restrict__ ds, long long rows, int Lk, int ld, float scale,
+                                                          uint32_t thresh, float dscale, uint64_t seed, uint32_t site) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float p[NCH], d[NCH];
+  float dl = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int j = c * 64 + lane;
+    p[c] = d[c] = 0.f;
+    if (j < Lk) {
+      p[c] = bf2f(p_in[row * ld + j]);
+      d[c] = dp[row * ld + j];
+      if (thresh) d[c] = dropout_keep(seed, site, (uint64_t)row * Lk + j, thresh) ? d[c] * dscale : 0.f;
+    }
+    dl += p[c] * d[c];
+  }
+  dl = wave_sum(dl);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int j = c * 64 + lane;
+    if (j < ld) ds[row * ld + j] = f2bf(j < Lk ? scale * p[c] * (d[c] - dl) : 0.f);
+  }
+}
+
+// ---------------------------------------------------------------- masked pooling (mm_model.py:572-576)
+__global__ __launch_bounds__(256) void masked_pool_fwd_kernel(const float* __restrict__ a, const float* __restrict__ t,
+                                                              const unsigned char* __restrict__ ma, const unsigned char* __restrict__ mt,
+                                                              int Na, int Nt, int D, float* __restrict__ pooled) {
+  const int b = blockIdx.x;
+  __shared__ int cnt;
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int i = 0; i < Na; ++i) c += ma[b * Na + i] ? 1 : 0;
+    for (int i = 0; i < Nt; ++i) c += mt[b * Nt + i] ? 1 : 0;
+    cnt = c;
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float s = 0.f;
+    for (int i = 0; i < Na; ++i)
+      if (ma[b * Na + i]) s += a[((long long)b * Na + i) * D + d];
+    for (int i = 0; i < Nt; ++i)
+      if (mt[b * Nt + i]) s += t[((long long)b * Nt + i) * D + d];
+    pooled[(long long)b * D + d] = s / (float)cnt;
+  }
+}
+
+__global__ __launch_bounds__(256) void masked_pool_bwd_kernel(const float* __restrict__ dp, const unsigned char* __restrict__ ma,
+                                                              const unsigned char* __restrict__ mt, int Na, int Nt, int D,
+                                                              float* __restrict__ da, float* __restrict__ dt) {
+  const int b = blockIdx.x;
+  __shared__ int cnt;
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int i = 0; i < Na; ++i) c += ma[b * Na + i] ? 1 : 0;
+    for (int i = 0; i < Nt; ++i) c += mt[b * Nt + i] ? 1 : 0;
+    cnt = c;
+  }
+  __syncthreads();
+  const float inv = 1.0f / (float)cnt;
+  for (int t = threadIdx.x; t < (Na + Nt) * D; t += 256) {
+    const int i = t / D, d = t - i * D;
+    const float g = dp[(long long)b * D + d] * inv;
+    if (i < Na) da[((long long)b * Na + i) * D + d] = ma[b * Na + i] ? g : 0.f;
+    else dt[((long long)b * Nt + (i - Na)) * D + d] = mt[b * Nt + (i - Na)] ? g : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------- sum of squares / Adam
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, float* __restrict__ out) {
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += g[i] * g[i];
+  s = wave_sum(s);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, bf16_t* __restrict__ pb, long long n, float lr, float b1,
+                                                   float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                   const float* __restrict__ gscale) {
+  const float gs = gscale ? *gscale : 1.0f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float gi = g[i] * gs;
+    float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= (lr / bc1) * mi / denom;
+    p[i] = pi;
+    if (pb) pb[i] = f2bf(pi);
+  }
+}
+
+// ---------------------------------------------------------------- hardware probe: ds_read_b64_tr_b16 semantics
+__global__ __launch_bounds__(64) void probe_tr_kernel(int stride, unsigned short* out) {
+  __shared__ __attribute__((aligned(16))) unsigned short img[64 * 64];
+  for (int i = threadIdx.x; i < 64 * 64; i += 64) img[i] = (unsigned short)i;
+  __syncthreads();
+  const int lane = threadIdx.x;
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  // group g reads the 4x16 block starting at row 4*g, column 0: lane 4q+p supplies &img[(4g+q)*stride + 4p]
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  const unsigned short* src = &img[(4 * g + q) * stride + 4 * pp];
+  s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)src);
+  for (int i = 0; i < 4; ++i) out[lane * 4 + i] = (unsigned short)r[i];
+}
+
+}  // namespace mmdti
+using namespace mmdti;
+
+extern "C" const char* mmdti_last_error(void) { return g_err; }
+extern "C" int mmdti_abi_version(void) { return 1; }
+
+#define DROP_SETUP(name)                                                                  \
+  MMDTI_REQUIRE(drop_p >= 0.f && drop_p < 1.f, name ": dropout p out of range");          \
+  const uint32_t th = dropout_thresh(drop_p);                                             \
+  const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f
+
+extern "C" int mmdti_cast_f32_bf16(mmdti_stream_t stream, const float* x, void* y_bf16, long long n, float drop_p,
+                                   unsigned long long seed, unsigned int site) {
+  MMDTI_REQUIRE(x && y_bf16 && n > 0, "cast_f32_bf16: bad arguments");
+  MMDTI_REQUIRE(aligned16(x) && (reinterpret_cast<uintptr_t>(y_bf16) & 7) == 0, "cast_f32_bf16: alignment");
+  DROP_SETUP("cast_f32_bf16");
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     (bf16_t*)y_bf16, n / 4, n, th, sc, (uint64_t)seed, (uint32_t)site);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_cast_bf16_f32(mmdti_stream_t stream, const void* x_bf16, float* y, long long n) {
+  MMDTI_REQUIRE(x_bf16 && y && n > 0, "cast_bf16_f32: bad arguments");
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x_bf16, y, n);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_dropout_f32(mmdti_stream_t stream, const float* x, float* y, long long n, float drop_p,
+                                 unsigned long long seed, unsigned int site) {
+  MMDTI_REQUIRE(x && y && n > 0, "dropout_f32: bad arguments");
+  DROP_SETUP("dropout_f32");
+  hipLaunchKernelGGL(dropout_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, th, sc,
+                     (uint64_t)seed, (uint32_t)site);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_axpy_f32(mmdti_stream_t stream, const float* x, float* y, long long n, float a) {
+  MMDTI_REQUIRE(x && y && n > 0, "axpy_f32: bad arguments");
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, a);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_gelu_fwd_bf16(mmdti_stream_t stream, const void* u_bf16, void* y_bf16, long long n) {
+  MMDTI_REQUIRE(u_bf16 && y_bf16 && n > 0, "gelu_fwd_bf16: bad arguments");
+  hipLaunchKernelGGL(gelu_bf16_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)u_bf16, (bf16_t*)y_bf16, n);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_colsum_bf16(mmdti_stream_t stream, const void* x_bf16, int rows, int cols, int ld, float* out) {
+  MMDTI_REQUIRE(x_bf16 && out && rows > 0 && cols > 0 && ld >= cols, "colsum_bf16: bad arguments");
+  MMDTI_REQUIRE(ld % 8 == 0 && aligned16(x_bf16), "colsum_bf16: ld%%8 and 16-byte alignment required");
+  int gy = cdiv(rows, 8 * 16);
+  if (gy > 512) gy = 512;
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(cols, 256), gy), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x_bf16, rows, cols, ld, out);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_embedding_fwd(mmdti_stream_t stream, const long long* ids, const float* table, long long n,
+                                   int D, int vocab, float* out, int accumulate) {
+  MMDTI_REQUIRE(ids && table && out && n > 0 && D > 0 && D % 4 == 0 && vocab > 0, "embedding_fwd: bad arguments");
+  MMDTI_REQUIRE(aligned16(table) && aligned16(out), "embedding_fwd: alignment");
+  hipLaunchKernelGGL(embedding_fwd_kernel, dim3(grid_for(n * (D / 4), 256)), dim3(256), 0, (hipStream_t)stream, ids,
+                     table, n, D / 4, vocab, out, accumulate);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_embedding_bwd(mmdti_stream_t stream, const long long* ids, const float* dout, long long n,
+                                   int D, int vocab, long long padding_idx, float* dtable) {
+  MMDTI_REQUIRE(ids && dout && dtable && n > 0 && D > 0 && vocab > 0, "embedding_bwd: bad arguments");
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(grid_for(n * D, 256)), dim3(256), 0, (hipStream_t)stream, ids, dout,
+                     n, D, vocab, padding_idx, dtable);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_roberta_position_ids(mmdti_stream_t stream, const long long* ids, int B, int L,
+                                          long long pad_idx, long long* out) {
+  MMDTI_REQUIRE(ids && out && B > 0 && L > 0, "roberta_position_ids: bad arguments");
+  hipLaunchKernelGGL(roberta_posids_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, ids, L, pad_idx, out);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_softmax_fwd(mmdti_stream_t stream, const float* s, const float* key_add, void* p_bf16,
+                                 void* pd_bf16, int B, int heads, int Lq, int Lk, int ld, float drop_p,
+                                 unsigned long long seed, unsigned int site) {
+  MMDTI_REQUIRE(s && p_bf16 && pd_bf16 && B > 0 && heads > 0 && Lq > 0 && Lk > 0, "softmax_fwd: bad arguments");
+  MMDTI_REQUIRE(ld >= Lk && Lk <= 1024 && ld <= 1024, "softmax_fwd: need Lk <= ld <= 1024");
+  DROP_SETUP("softmax_fwd");
+  MMDTI_REQUIRE(drop_p == 0.f || pd_bf16 != p_bf16, "softmax_fwd: dropout needs a separate pd buffer");
+  const long long rows = (long long)B * heads * Lq;
+  dim3 grid(cdiv(rows, 4)), block(256);
+#define SM_F(NCH)                                                                                                  \
+  hipLaunchKernelGGL((softmax_fwd_kernel<NCH>), grid, block, 0, (hipStream_t)stream, s, key_add, (bf16_t*)p_bf16, \
+                     (bf16_t*)pd_bf16, rows, heads, Lq, Lk, ld, th, sc, (uint64_t)seed, (uint32_t)site)
+  const int nch = (ld + 63) / 64;
+  if (nch <= 1) SM_F(1); else if (nch <= 2) SM_F(2); else if (nch <= 3) SM_F(3); else if (nch <= 4) SM_F(4);
+  else if (nch <= 8) SM_F(8); else SM_F(16);
+#undef SM_F
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_softmax_bwd(mmdti_stream_t stream, const void* p_bf16, const float* dp, void* ds_bf16, int B,
+                                 int heads, int Lq, int Lk, int ld, float scale, float drop_p,
+                                 unsigned long long seed, unsigned int site) {
+  MMDTI_REQUIRE(p_bf16 && dp && ds_bf16 && B > 0 && heads > 0 && Lq > 0 && Lk > 0, "softmax_bwd: bad arguments");
+  MMDTI_REQUIRE(ld >= Lk && ld <= 1024, "softmax_bwd: need Lk <= ld <= 1024");
+  DROP_SETUP("softmax_bwd");
+  const long long rows = (long long)B * heads * Lq;
+  dim3 grid(cdiv(rows, 4)), block(256);
+#define SM_B(NCH)                                                                                              \
+  hipLaunchKernelGGL((softmax_bwd_kernel<NCH>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)p_bf16, dp, \
+                     (bf16_t*)ds_bf16, rows, Lk, ld, scale, th, sc, (uint64_t)seed, (uint32_t)site)
+  const int nch = (ld + 63) / 64;
+  if (nch <= 1) SM_B(1); else if (nch <= 2) SM_B(2); else if (nch <= 3) SM_B(3); else if (nch <= 4) SM_B(4);
+  else if (nch <= 8) SM_B(8); else SM_B(16);
+#undef SM_B
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_masked_pool_fwd(mmdti_stream_t stream, const float* a, const float* t,
+                                     const unsigned char* mask_a, const unsigned char* mask_t, int B, int Na, int Nt,
+                                     int D, float* pooled) {
+  MMDTI_REQUIRE(a && t && mask_a && mask_t && pooled && B > 0 && Na > 0 && Nt > 0 && D > 0, "masked_pool_fwd: bad arguments");
+  hipLaunchKernelGGL(masked_pool_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a, t, mask_a, mask_t, Na, Nt, D, pooled);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_masked_pool_bwd(mmdti_stream_t stream, const float* dpooled, const unsigned char* mask_a,
+                                     const unsigned char* mask_t, int B, int Na, int Nt, int D, float* da, float* dt) {
+  MMDTI_REQUIRE(dpooled && mask_a && mask_t && da && dt && B > 0 && Na > 0 && Nt > 0 && D > 0, "masked_pool_bwd: bad arguments");
+  hipLaunchKernelGGL(masked_pool_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dpooled, mask_a, mask_t, Na, Nt, D, da, dt);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_sumsq_f32(mmdti_stream_t stream, const float* g, long long n, float* out) {
+  MMDTI_REQUIRE(g && out && n > 0, "sumsq_f32: bad arguments");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_adam_step(mmdti_stream_t stream, float* p, const float* g, float* m, float* v, void* p_bf16,
+                               long long n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                               int step, const float* grad_scale_dev) {
+  MMDTI_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                     (bf16_t*)p_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale_dev);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_probe_tr_read(mmdti_stream_t stream, int row_stride_elems, unsigned short* out) {
+  MMDTI_REQUIRE(out && row_stride_elems >= 16 && row_stride_elems <= 64 && row_stride_elems % 4 == 0, "probe_tr_read: bad stride");
+  hipLaunchKernelGGL(probe_tr_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, row_stride_elems, out);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}

@@ -1,0 +1,503 @@
+// Batch-coupled heads of the fine-tune step: InfoNCE (models/infonce.py), ConR / SupCon (models/contrastive.py),
+// FDS (models/fds.py, utils/util.py:159-169), the classification head (models/mm_model.py:44-84) and the task
+// losses (models/nnmodel.py:24-34).  All are B x B or B x D problems (B = molecules per rank, <= a few thousand):
+// latency-bound, so each is a small number of single-pass kernels with the gradient produced in the same pass as
+// the loss (no materialised autograd graph, no host sync, no Python loops over B as in the reference).
+#include "common.h"
+
+namespace mmdti {
+
+__device__ __forceinline__ float block_sum(float v, float* red) {  // 256 threads
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// ---------------------------------------------------------------- unmasked sequence mean (infonce.py:32-33)
+__global__ __launch_bounds__(256) void seq_mean_fwd_kernel(const bf16_t* __restrict__ x, int S, int D, int ld, float* __restrict__ out) {
+  const int b = blockIdx.x;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float s = 0.f;
+    for (int i = 0; i < S; ++i) s += bf2f(x[((long long)b * S + i) * ld + d]);
+    out[(long long)b * D + d] = s / (float)S;
+  }
+}
+__global__ __launch_bounds__(256) void seq_mean_bwd_kernel(const float* __restrict__ dout, int S, int D, int ld, bf16_t* __restrict__ dx) {
+  const long long row = blockIdx.x;  // b*S + s
+  const int b = (int)(row / S);
+  for (int d = threadIdx.x; d < ld; d += 256)
+    dx[row * ld + d] = f2bf(d < D ? dout[(long long)b * D + d] / (float)S : 0.f);
+}
+
+// ---------------------------------------------------------------- F.normalize (eps 1e-12)
+__global__ __launch_bounds__(64) void l2norm_fwd_kernel(const float* __restrict__ x, int D, int ldx, float* __restrict__ xh, float* __restrict__ invn) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float s = 0.f;
+  for (int d = lane; d < D; d += 64) { float v = x[(long long)b * ldx + d]; s += v * v; }
+  const float inv = 1.0f / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+  for (int d = lane; d < D; d += 64) xh[(long long)b * D + d] = x[(long long)b * ldx + d] * inv;
+  if (lane == 0) invn[b] = inv;
+}
+// dx = inv * (dxh - xh * <dxh, xh>)
+__global__ __launch_bounds__(64) void l2norm_bwd_kernel(const float* __restrict__ dxh, const float* __restrict__ xh, const float* __restrict__ invn,
+                                                        int D, int ldx, float* __restrict__ dx) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float s = 0.f;
+  for (int d = lane; d < D; d += 64) s += dxh[(long long)b * D + d] * xh[(long long)b * D + d];
+  s = wave_sum(s);
+  const float inv = invn[b];
+  for (int d = lane; d < D; d += 64) dx[(long long)b * ldx + d] = inv * (dxh[(long long)b * D + d] - xh[(long long)b * D + d] * s);
+}
+
+// ---------------------------------------------------------------- InfoNCE, one direction (infonce.py:93-98)
+// block per anchor row i (global index row0+i): logits_j = <q_i, k_j>/T over all Bg keys; CE with label i.
+__global__ __launch_bounds__(256) void infonce_dir_kernel(const float* __restrict__ q, const float* __restrict__ k, int Bg, int D, int row0,
+                                                          float invT, float* __restrict__ loss_sum, float* __restrict__ dq,
+                                                          float* __restrict__ dk) {
+  extern __shared__ float sm[];  // qrow[D] | logits[Bg] | red[4] | dqrow[D]
+  float* qrow = sm;
+  float* lg = sm + D;
+  float* red = lg + Bg;
+  float* dqrow = red + 4;
+  const int i = row0 + blockIdx.x;
+  for (int d = threadIdx.x; d < D; d += 256) { qrow[d] = q[(long long)i * D + d]; dqrow[d] = 0.f; }
+  __syncthreads();
+  float m = -INFINITY;
+  for (int j = threadIdx.x; j < Bg; j += 256) {
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) s += qrow[d] * k[(long long)j * D + d];
+    s *= invT;
+    lg[j] = s;
+    m = fmaxf(m, s);
+  }
+  m = block_max(m, red);
+  float se = 0.f;
+  for (int j = threadIdx.x; j < Bg; j += 256) se += __expf(lg[j] - m);
+  se = block_sum(se, red);
+  const float lse = m + __logf(se);
+  if (threadIdx.x == 0) atomicAdd(loss_sum, lse - lg[i]);
+  const float gscale = 0.5f / (float)Bg;  // d[(CE_a + CE_b)/2 mean over Bg]/d CE_i
+  for (int j = threadIdx.x; j < Bg; j += 256) {
+    const float gl = (__expf(lg[j] - lse) - (j == i ? 1.f : 0.f)) * gscale * invT;
+    for (int d = 0; d < D; ++d) {
+      atomicAdd(&dqrow[d], gl * k[(long long)j * D + d]);
+      atomicAdd(dk + (long long)j * D + d, gl * qrow[d]);
+    }
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += 256) atomicAdd(dq + (long long)i * D + d, dqrow[d]);
+}
+
+// ---------------------------------------------------------------- ConR / SupCon
+// block per anchor i.  prod_ij = <f_i,f_j>/t.  See contrastive.py for the masks.
+__global__ __launch_bounds__(256) void ct_fwd_kernel(int mode, const float* __restrict__ fh, int B, int D, const float* __restrict__ lab_f,
+                                                     const long long* __restrict__ lab_i, int C, const float* __restrict__ pred,
+                                                     const float* __restrict__ wts, float w, float invt, float e, float thr,
+                                                     float* __restrict__ loss, float* __restrict__ G) {
+  extern __shared__ float sm[];  // frow[D] | prod[B] | red[4]
+  float* frow = sm;
+  float* prod = sm + D;
+  float* red = prod + B;
+  const int i = blockIdx.x;
+  for (int d = threadIdx.x; d < D; d += 256) frow[d] = fh[(long long)i * D + d];
+  __syncthreads();
+  float e_pos = 0.f, e_neg = 0.f, npos = 0.f, nneg = 0.f, nle = 0.f, spos = 0.f;
+  for (int j = threadIdx.x; j < B; j += 256) {
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) s += frow[d] * fh[(long long)j * D + d];
+    s *= invt;
+    prod[j] = s;
+    bool pos, neg;
+    float pw;
+    if (mode == MMDTI_CT_REGRESS) {
+      const float ld = fabsf(lab_f[i] - lab_f[j]);
+      const bool le = ld <= w;
+      pos = le && (j != i);
+      neg = (!le) && (fabsf(pred[i] - pred[j]) <= w);
+      pw = ld * (wts ? wts[i] : 1.f) * e;
+      nle += le ? 1.f : 0.f;
+    } else if (mode == MMDTI_CT_SINGLE) {
+      const bool eq = lab_f[i] == lab_f[j];
+      pos = eq && (j != i);
+      neg = !eq;
+      pw = wts ? wts[j] : 1.f;
+    } else {
+      int cnt = 0;
+      for (int c = 0; c < C; ++c) cnt += (lab_i[(long long)i * C + c] == lab_i[(long long)j * C + c]) ? 1 : 0;
+      const bool ge = ((float)cnt / (float)C) >= thr;
+      pos = ge && (j != i);
+      neg = !ge;
+      pw = wts ? wts[j] : 1.f;
+    }
+    // exp(prod*mask): masked-out entries contribute exp(0)=1 to the positive sum (contrastive.py:35,52)
+    e_pos += pos ? __expf(s) : 1.f;
+    if (neg) e_neg += pw * __expf(s);
+    npos += pos ? 1.f : 0.f;
+    nneg += neg ? 1.f : 0.f;
+    spos += pos ? s : 0.f;
+    // stash the mask class in G for the second pass: 1 = pos, 2 = neg (scaled later)
+    G[(long long)i * B + j] = pos ? 1.f : (neg ? 2.f : 0.f);
+  }
+  e_pos = block_sum(e_pos, red);
+  e_neg = block_sum(e_neg, red);
+  npos = block_sum(npos, red);
+  nneg = block_sum(nneg, red);
+  nle = block_sum(nle, red);
+  spos = block_sum(spos, red);
+  float denom = (mode == MMDTI_CT_REGRESS) ? nle : (npos == 0.f ? 1.f : npos);
+  const float Dn = e_pos + e_neg;
+  const float flag = nneg > 0.f ? 1.f : 0.f;
+  const float li = flag * (npos * __logf(Dn) - spos) / denom;
+  if (threadIdx.x == 0) atomicAdd(loss, li / (float)B);
+  const float cg = flag / denom / (float)B;
+  for (int j = threadIdx.x; j < B; j += 256) {
+    const float cls = G[(long long)i * B + j];
+    float g = 0.f;
+    if (cls == 1.f) {
+      g = cg * (npos / Dn * __expf(prod[j]) - 1.f);
+    } else if (cls == 2.f) {
+      float pw;
+      if (mode == MMDTI_CT_REGRESS) pw = fabsf(lab_f[i] - lab_f[j]) * (wts ? wts[i] : 1.f) * e;
+      else pw = wts ? wts[j] : 1.f;
+      g = cg * (npos / Dn * pw * __expf(prod[j]));
+    }
+    G[(long long)i * B + j] = g;
+  }
+}
+
+__global__ __launch_bounds__(256) void ct_bwd_kernel(const float* __restrict__ fh, const float* __restrict__ G, int B, int D, float invt,
+                                                     float* __restrict__ dfh) {
+  extern __shared__ float gs[];  // [B] combined coefficient
+  const int i = blockIdx.x;
+  for (int j = threadIdx.x; j < B; j += 256) gs[j] = (G[(long long)i * B + j] + G[(long long)j * B + i]) * invt;
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float s = 0.f;
+    for (int j = 0; j < B; ++j) s += gs[j] * fh[(long long)j * D + d];
+    dfh[(long long)i * D + d] = s;
+  }
+}
+
+// ---------------------------------------------------------------- FDS
+// python-style floor division in fp32 (c10::div_floor_floating), as `(value - min)//bin_width` evaluates (fds.py:125)
+__device__ __forceinline__ float div_floor_f32(float a, float b) {
+  if (b == 0.f) return a / b;
+  float mod = fmodf(a, b);
+  float div = (a - mod) / b;
+  if ((mod != 0.f) && ((b < 0.f) != (mod < 0.f))) div -= 1.f;
+  float fd;
+  if (div != 0.f) {
+    fd = floorf(div);
+    if (div - fd > 0.5f) fd += 1.f;
+  } else {
+    fd = copysignf(0.f, a / b);
+  }
+  return fd;
+}
+
+__global__ __launch_bounds__(256) void fds_bins_kernel(const float* __restrict__ labels, int n, float minv, float bw, int bs, int bn,
+                                                       int* __restrict__ bins, int* __restrict__ flags) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int b = (int)div_floor_f32(labels[i] - minv, bw);
+  bins[i] = b;
+  if (b == bs) atomicOr(&flags[0], 1);
+  if (b == bn - 1) atomicOr(&flags[1], 1);
+}
+
+// effective bucket of a sample (fds.py:134-139,167-177): first bucket takes bins <= start, last takes bins >= num-1, but
+// only when some sample of the batch sits exactly in that bucket (the reference iterates torch.unique(label_bin)).
+__device__ __forceinline__ int fds_eff_bucket(int b, int bs, int bn, const int* flags) {
+  if (b <= bs) return (b == bs || flags[0]) ? bs : -1;                          // `label == bucket_start` branch: rows <=
+  if (bs != bn - 1 && b >= bn - 1) return (b == bn - 1 || flags[1]) ? bn - 1 : -1;  // last bucket: rows >=
+  if (b > bn - 1) return -1;
+  return b;
+}
+
+// one wave per sample row
+__global__ __launch_bounds__(256) void fds_smooth_kernel(const float* __restrict__ x, const int* __restrict__ bins, const int* __restrict__ flags,
+                                                         int n, int D, int bs, int bn, const float* __restrict__ m1, const float* __restrict__ v1,
+                                                         const float* __restrict__ m2, const float* __restrict__ v2, float* __restrict__ y,
+                                                         float* __restrict__ scale_out) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int eb = fds_eff_bucket(bins[r], bs, bn, flags);
+  bool active = eb >= 0;
+  long long so = 0;
+  if (active) {
+    so = (long long)(eb - bs) * D;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += v1[so + d];
+    active = !(wave_sum(s) < 1e-10f);  // calibrate_mean_var early-out (utils/util.py:160-161)
+  }
+  for (int d = lane; d < D; d += 64) {
+    float xv = x[(long long)r * D + d], sc = 1.f, o = xv;
+    if (active) {
+      const float a = v1[so + d];
+      if (a != 0.f) {  // zero-variance columns stay untouched (util.py:162-166)
+        sc = sqrtf(fminf(fmaxf(v2[so + d] / a, 0.1f), 10.f));
+        o = (xv - m1[so + d]) * sc + m2[so + d];
+      }
+    }
+    y[(long long)r * D + d] = o;
+    if (scale_out) scale_out[(long long)r * D + d] = sc;
+  }
+}
+
+// block per bucket, thread per feature column (strided); two passes like torch.mean / torch.var
+__global__ __launch_bounds__(256) void fds_update_kernel(const float* __restrict__ f, const int* __restrict__ bins, const int* __restrict__ flags,
+                                                         int n, int D, int bs, int bn, float factor, float* __restrict__ rmean,
+                                                         float* __restrict__ rvar, float* __restrict__ tracked) {
+  const int bucket = bs + blockIdx.x;
+  __shared__ int s_cnt, s_exact;
+  if (threadIdx.x == 0) { s_cnt = 0; s_exact = 0; }
+  __syncthreads();
+  int c = 0, ex = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    c += (fds_eff_bucket(bins[i], bs, bn, flags) == bucket) ? 1 : 0;
+    ex += (bins[i] == bucket) ? 1 : 0;
+  }
+  atomicAdd(&s_cnt, c);
+  atomicAdd(&s_exact, ex);
+  __syncthreads();
+  const int cnt = s_cnt;
+  if (s_exact == 0 || cnt == 0) return;  // bucket not in torch.unique(label_bin): untouched
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i)
+      if (fds_eff_bucket(bins[i], bs, bn, flags) == bucket) s += f[(long long)i * D + d];
+    const float mean = s / (float)cnt;
+    float q = 0.f;
+    for (int i = 0; i < n; ++i)
+      if (fds_eff_bucket(bins[i], bs, bn, flags) == bucket) { float t = f[(long long)i * D + d] - mean; q += t * t; }
+    const float var = cnt > 1 ? q / (float)(cnt - 1) : q / (float)cnt;
+    const long long o = (long long)blockIdx.x * D + d;
+    rmean[o] = (1.f - factor) * mean + factor * rmean[o];
+    rvar[o] = (1.f - factor) * var + factor * rvar[o];
+  }
+  if (threadIdx.x == 0) tracked[blockIdx.x] += (float)cnt;
+}
+
+// reflect-pad + conv1d across the bucket axis (fds.py:86-99)
+__global__ __launch_bounds__(256) void fds_smooth_stats_kernel(const float* __restrict__ stat, int nb, int D, const float* __restrict__ win,
+                                                               int ks, float* __restrict__ out) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= nb * D) return;
+  const int b = t / D, d = t - b * D, half = (ks - 1) / 2;
+  float s = 0.f;
+  for (int k = 0; k < ks; ++k) {
+    int j = b + k - half;
+    if (j < 0) j = -j;
+    if (j >= nb) j = 2 * (nb - 1) - j;
+    s += win[k] * stat[(long long)j * D + d];
+  }
+  out[t] = s;
+}
+
+// ---------------------------------------------------------------- small fp32 linear (classification head)
+__global__ __launch_bounds__(256) void linear_f32_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
+                                                             int rows, int in_f, int out_f, int act, float* __restrict__ y) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)rows * out_f) return;
+  const int r = (int)(t / out_f), o = (int)(t - (long long)r * out_f);
+  float s = b ? b[o] : 0.f;
+  for (int k = 0; k < in_f; ++k) s += x[(long long)r * in_f + k] * W[(long long)o * in_f + k];
+  y[t] = act == 3 ? tanhf(s) : s;
+}
+// dz = dy * act'(y); dx = dz W ; dW += dz^T x ; db += colsum dz.  grid.x over rows*in_f (dx), then dW part.
+__global__ __launch_bounds__(256) void linear_f32_bwd_dx_kernel(const float* __restrict__ W, const float* __restrict__ y, const float* __restrict__ dy,
+                                                                int rows, int in_f, int out_f, int act, float* __restrict__ dx) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)rows * in_f) return;
+  const int r = (int)(t / in_f), k = (int)(t - (long long)r * in_f);
+  float s = 0.f;
+  for (int o = 0; o < out_f; ++o) {
+    float dz = dy[(long long)r * out_f + o];
+    if (act == 3) { float yy = y[(long long)r * out_f + o]; dz *= (1.f - yy * yy); }
+    s += dz * W[(long long)o * in_f + k];
+  }
+  dx[t] = s;
+}
+__global__ __launch_bounds__(256) void linear_f32_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                                                                int rows, int in_f, int out_f, int act, float* __restrict__ dW, float* __restrict__ db) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)out_f * (in_f + 1)) return;
+  const int o = (int)(t / (in_f + 1)), k = (int)(t - (long long)o * (in_f + 1));
+  float s = 0.f;
+  for (int r = 0; r < rows; ++r) {
+    float dz = dy[(long long)r * out_f + o];
+    if (act == 3) { float yy = y[(long long)r * out_f + o]; dz *= (1.f - yy * yy); }
+    s += dz * (k < in_f ? x[(long long)r * in_f + k] : 1.f);
+  }
+  if (k < in_f) atomicAdd(dW + (long long)o * in_f + k, s);
+  else if (db) atomicAdd(db + o, s);
+}
+
+// ---------------------------------------------------------------- task losses
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ p, const float* __restrict__ t, int n, float* __restrict__ loss, float* __restrict__ dp) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float d = p[i] - t[i];
+    s += d * d;
+    dp[i] = 2.f * d / (float)n;
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) *loss = s / (float)n;
+}
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ lg, const long long* __restrict__ tg, int B, int C, float* __restrict__ loss,
+                                                 float* __restrict__ dl) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) {
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, lg[(long long)i * C + c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(lg[(long long)i * C + c] - m);
+    const float lse = m + logf(se);
+    const int y = (int)tg[i];
+    s += lse - lg[(long long)i * C + y];
+    for (int c = 0; c < C; ++c) dl[(long long)i * C + c] = (expf(lg[(long long)i * C + c] - lse) - (c == y ? 1.f : 0.f)) / (float)B;
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) *loss = s / (float)B;
+}
+
+}  // namespace mmdti
+using namespace mmdti;
+
+extern "C" int mmdti_seq_mean_fwd(mmdti_stream_t stream, const void* x_bf16, int B, int S, int D, int ld, float* out) {
+  MMDTI_REQUIRE(x_bf16 && out && B > 0 && S > 0 && D > 0 && ld >= D, "seq_mean_fwd: bad arguments");
+  hipLaunchKernelGGL(seq_mean_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x_bf16, S, D, ld, out);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+extern "C" int mmdti_seq_mean_bwd(mmdti_stream_t stream, const float* dout, int B, int S, int D, int ld, void* dx_bf16) {
+  MMDTI_REQUIRE(dout && dx_bf16 && B > 0 && S > 0 && D > 0 && ld >= D, "seq_mean_bwd: bad arguments");
+  hipLaunchKernelGGL(seq_mean_bwd_kernel, dim3(B * S), dim3(256), 0, (hipStream_t)stream, dout, S, D, ld, (bf16_t*)dx_bf16);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+extern "C" int mmdti_l2norm_fwd(mmdti_stream_t stream, const float* x, int B, int D, int ldx, float* xhat, float* inv_norm) {
+  MMDTI_REQUIRE(x && xhat && inv_norm && B > 0 && D > 0 && ldx >= D, "l2norm_fwd: bad arguments");
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, x, D, ldx, xhat, inv_norm);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+extern "C" int mmdti_l2norm_bwd(mmdti_stream_t stream, const float* dxhat, const float* xhat, const float* inv_norm, int B, int D, int ldx, float* dx) {
+  MMDTI_REQUIRE(dxhat && xhat && inv_norm && dx && B > 0 && D > 0 && ldx >= D, "l2norm_bwd: bad arguments");
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, dxhat, xhat, inv_norm, D, ldx, dx);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+extern "C" int mmdti_infonce_dir(mmdti_stream_t stream, const float* qh_all, const float* kh_all, int Bg, int D, int row0, int Bl,
+                                 float temperature, float* loss_sum, float* dq_all, float* dk_all) {
+  MMDTI_REQUIRE(qh_all && kh_all && loss_sum && dq_all && dk_all, "infonce_dir: null pointer");
+  MMDTI_REQUIRE(Bg > 0 && D > 0 && row0 >= 0 && Bl > 0 && row0 + Bl <= Bg, "infonce_dir: bad sizes (Bg=%d row0=%d Bl=%d)", Bg, row0, Bl);
+  MMDTI_REQUIRE(temperature > 0.f, "infonce_dir: temperature must be positive");
+  const size_t smem = (2 * (size_t)D + Bg + 4) * sizeof(float);
+  MMDTI_REQUIRE(smem <= 64 * 1024, "infonce_dir: global batch %d too large for the LDS logits row", Bg);
+  hipLaunchKernelGGL(infonce_dir_kernel, dim3(Bl), dim3(256), smem, (hipStream_t)stream, qh_all, kh_all, Bg, D, row0,
+                     1.0f / temperature, loss_sum, dq_all, dk_all);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_ct_loss_fwd(mmdti_stream_t stream, int mode, const float* fhat, int B, int D, const float* labels_f,
+                                 const long long* labels_i, int C, const float* pred, const float* weights, float w, float t,
+                                 float e, float coef, float* loss, float* G) {
+  MMDTI_REQUIRE(mode >= 0 && mode <= 2, "ct_loss_fwd: bad mode %d", mode);
+  MMDTI_REQUIRE(fhat && loss && G && B > 0 && D > 0 && t > 0.f, "ct_loss_fwd: bad arguments");
+  MMDTI_REQUIRE(mode == MMDTI_CT_MULTI ? (labels_i && C > 0) : (labels_f != nullptr), "ct_loss_fwd: labels missing");
+  MMDTI_REQUIRE(mode != MMDTI_CT_REGRESS || pred, "ct_loss_fwd: regress needs predictions");
+  const size_t smem = ((size_t)D + B + 4) * sizeof(float);
+  MMDTI_REQUIRE(smem <= 64 * 1024, "ct_loss_fwd: B+D too large for LDS");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) { set_error("ct_loss_fwd: memset failed"); return MMDTI_ERR_LAUNCH; }
+  const float thr = mode == MMDTI_CT_MULTI ? (float)((double)coef / (double)C) : 0.f;
+  hipLaunchKernelGGL(ct_fwd_kernel, dim3(B), dim3(256), smem, s, mode, fhat, B, D, labels_f, labels_i, C, pred, weights, w,
+                     1.0f / t, e, thr, loss, G);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+extern "C" int mmdti_ct_loss_bwd(mmdti_stream_t stream, const float* fhat, const float* G, int B, int D, float t, float* dfhat) {
+  MMDTI_REQUIRE(fhat && G && dfhat && B > 0 && D > 0 && t > 0.f, "ct_loss_bwd: bad arguments");
+  MMDTI_REQUIRE((size_t)B * sizeof(float) <= 64 * 1024, "ct_loss_bwd: B too large");
+  hipLaunchKernelGGL(ct_bwd_kernel, dim3(B), dim3(256), (size_t)B * sizeof(float), (hipStream_t)stream, fhat, G, B, D, 1.0f / t, dfhat);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_fds_bins(mmdti_stream_t stream, const float* labels, int n, float min_value, float bin_width, int bucket_start,
+                              int bucket_num, int* bins, int* flags) {
+  MMDTI_REQUIRE(labels && bins && flags && n > 0 && bucket_num > bucket_start && bucket_start >= 0, "fds_bins: bad arguments");
+  hipLaunchKernelGGL(fds_bins_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, labels, n, min_value, bin_width,
+                     bucket_start, bucket_num, bins, flags);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+extern "C" int mmdti_fds_smooth(mmdti_stream_t stream, const float* x, const int* bins, const int* flags, int n, int D, int bucket_start,
+                                int bucket_num, const float* m1, const float* v1, const float* m2, const float* v2, float* y,
+                                float* scale_out) {
+  MMDTI_REQUIRE(x && bins && flags && m1 && v1 && m2 && v2 && y && n > 0 && D > 0, "fds_smooth: bad arguments");
+  hipLaunchKernelGGL(fds_smooth_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, x, bins, flags, n, D, bucket_start,
+                     bucket_num, m1, v1, m2, v2, y, scale_out);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+extern "C" int mmdti_fds_update_stats(mmdti_stream_t stream, const float* feats, const int* bins, const int* flags, int n, int D,
+                                      int bucket_start, int bucket_num, float factor, float* running_mean, float* running_var,
+                                      float* num_samples_tracked) {
+  MMDTI_REQUIRE(feats && bins && flags && running_mean && running_var && num_samples_tracked && n > 0 && D > 0, "fds_update_stats: bad arguments");
+  MMDTI_REQUIRE(bucket_num > bucket_start, "fds_update_stats: empty bucket range");
+  hipLaunchKernelGGL(fds_update_kernel, dim3(bucket_num - bucket_start), dim3(256), 0, (hipStream_t)stream, feats, bins, flags, n, D,
+                     bucket_start, bucket_num, factor, running_mean, running_var, num_samples_tracked);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+extern "C" int mmdti_fds_smooth_stats(mmdti_stream_t stream, const float* stat, int nb, int D, const float* window, int ks, float* out) {
+  MMDTI_REQUIRE(stat && window && out && nb > 0 && D > 0 && ks > 0 && (ks - 1) / 2 < nb, "fds_smooth_stats: bad arguments");
+  hipLaunchKernelGGL(fds_smooth_stats_kernel, dim3(cdiv((long long)nb * D, 256)), dim3(256), 0, (hipStream_t)stream, stat, nb, D, window, ks, out);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_linear_f32_fwd(mmdti_stream_t stream, const float* x, const float* W, const float* b, int rows, int in_f, int out_f,
+                                    int act, float* y) {
+  MMDTI_REQUIRE(x && W && y && rows > 0 && in_f > 0 && out_f > 0 && (act == 0 || act == 3), "linear_f32_fwd: bad arguments");
+  hipLaunchKernelGGL(linear_f32_fwd_kernel, dim3(cdiv((long long)rows * out_f, 256)), dim3(256), 0, (hipStream_t)stream, x, W, b, rows,
+                     in_f, out_f, act, y);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+extern "C" int mmdti_linear_f32_bwd(mmdti_stream_t stream, const float* x, const float* W, const float* y, const float* dy, int rows,
+                                    int in_f, int out_f, int act, float* dx, float* dW, float* db) {
+  MMDTI_REQUIRE(x && W && dy && rows > 0 && in_f > 0 && out_f > 0 && (act == 0 || (act == 3 && y)), "linear_f32_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (dx) hipLaunchKernelGGL(linear_f32_bwd_dx_kernel, dim3(cdiv((long long)rows * in_f, 256)), dim3(256), 0, s, W, y, dy, rows, in_f, out_f, act, dx);
+  if (dW) hipLaunchKernelGGL(linear_f32_bwd_dw_kernel, dim3(cdiv((long long)out_f * (in_f + 1), 256)), dim3(256), 0, s, x, y, dy, rows, in_f, out_f, act, dW, db);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+extern "C" int mmdti_mse_loss(mmdti_stream_t stream, const float* pred, const float* target, int n, float* loss, float* dpred) {
+  MMDTI_REQUIRE(pred && target && loss && dpred && n > 0, "mse_loss: bad arguments");
+  hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, target, n, loss, dpred);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+extern "C" int mmdti_ce_loss(mmdti_stream_t stream, const float* logits, const long long* target, int B, int C, float* loss, float* dlogits) {
+  MMDTI_REQUIRE(logits && target && loss && dlogits && B > 0 && C > 0, "ce_loss: bad arguments");
+  hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, target, B, C, loss, dlogits);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}

@@ -1,0 +1,306 @@
+// Pair-bias multi-head attention for the Uni-Mol tower (64 heads x head_dim 8), forward and backward.
+//
+// Replaces unicore SelfMultiheadAttention + softmax_dropout (fused CUDA op upstream) as reached from
+// models/transformers.py:137-139 with return_attn=True, including the key-padding merge of :122-135:
+//     S_l = scale * q.k^T + S_{l-1}          (S_0 = Gaussian pair bias, -inf at padded keys)
+//     O   = dropout(softmax(S_l)) . v
+// S_l is an OUTPUT (it is the next layer's bias and the activation saved for backward), so the score tile is
+// never kept on chip only: the kernel is a stream over the [B,H,N,N] pair tensor and is HBM-bound
+// (head_dim 8 => 32 flop per 8 B of pair traffic).  One workgroup per (molecule, head); lanes own KEYS
+// (K/V rows live in registers for the whole tile), waves walk query rows, so every pair-tensor access is a
+// fully coalesced row segment and dK/dV need no cross-lane traffic.
+//
+// Backward recomputes P from the saved S and carries the running pair gradient G in place:
+//     G_l = G_{l+1} + softmax'(S_l)    dq = scale * G_l k,  dk = scale * G_l^T q,  dv = Pd^T dO
+#include "common.h"
+
+namespace mmdti {
+
+constexpr int HD = 8;
+
+__device__ __forceinline__ void load8_bf16(const bf16_t* p, float (&o)[8]) {
+  uint4 u = *reinterpret_cast<const uint4*>(p);
+  uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o[2 * i] = __uint_as_float(w[i] << 16);
+    o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void store8_bf16(bf16_t* p, const float (&v)[8]) {
+  uint4 u;
+  u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+  u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+  u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = u;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void pair_attn_fwd_kernel(const bf16_t* __restrict__ qkv,
+                                                            const float* __restrict__ bias_in,
+                                                            float* __restrict__ s_out, bf16_t* __restrict__ o,
+                                                            const unsigned char* __restrict__ key_pad, int N, int H,
+                                                            int ld, float scale, uint32_t thresh, float dscale,
+                                                            uint64_t seed, uint32_t site) {
+  __shared__ __attribute__((aligned(16))) float sq[NCH * 64][HD];
+  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  const int D = H * HD, D3 = 3 * D;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bf16_t* base = qkv + (long long)b * N * D3 + h * HD;
+  for (int t = tid; t < N; t += 256) {
+    float q[8];
+    load8_bf16(base + (long long)t * D3, q);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) sq[t][d] = q[d];
+  }
+  float k[NCH][8], v[NCH][8];
+  bool masked[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int j = c * 64 + lane;
+    masked[c] = true;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) k[c][d] = v[c][d] = 0.f;
+    if (j < N) {
+      load8_bf16(base + (long long)j * D3 + D, k[c]);
+      load8_bf16(base + (long long)j * D3 + 2 * D, v[c]);
+      masked[c] = key_pad ? key_pad[b * N + j] != 0 : false;
+    }
+  }
+  __syncthreads();
+  const float NEG_INF = -INFINITY;
+  for (int i = wave; i < N; i += 4) {
+    const float4 q0 = *reinterpret_cast<const float4*>(&sq[i][0]);
+    const float4 q1 = *reinterpret_cast<const float4*>(&sq[i][4]);
+    const long long rowoff = ((long long)bh * N + i) * ld;
+    float sv[NCH];
+    float m = NEG_INF;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int j = c * 64 + lane;
+      float s = NEG_INF;
+      if (j < N) {
+        float dot = q0.x * k[c][0] + q0.y * k[c][1] + q0.z * k[c][2] + q0.w * k[c][3] + q1.x * k[c][4] +
+                    q1.y * k[c][5] + q1.z * k[c][6] + q1.w * k[c][7];
+        s = masked[c] ? NEG_INF : scale * dot + bias_in[rowoff + j];
+        s_out[rowoff + j] = s;
+      }
+      sv[c] = s;
+      m = fmaxf(m, s);
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      sv[c] = __expf(sv[c] - m);
+      sum += sv[c];
+    }
+    const float inv = 1.0f / wave_sum(sum);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      float p = sv[c] * inv;
+      if (thresh) {
+        const int j = c * 64 + lane;
+        bool keep = dropout_keep(seed, site, ((uint64_t)bh * N + i) * N + j, thresh);
+        p = keep ? p * dscale : 0.f;
+      }
+#pragma unroll
+      for (int d = 0; d < 8; ++d) acc[d] += p * v[c][d];
+    }
+    const float tot = wave_sum8_scatter(acc, lane);
+    if (lane < 8) o[((long long)b * N + i) * D + h * HD + lane] = f2bf(tot);
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void pair_attn_bwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ s,
+                                                            const bf16_t* __restrict__ dO, float* __restrict__ g,
+                                                            bf16_t* __restrict__ dqkv, int N, int H, int ld,
+                                                            float scale, int g_in_zero, uint32_t thresh, float dscale,
+                                                            uint64_t seed, uint32_t site) {
+  __shared__ __attribute__((aligned(16))) float sq[NCH * 64][HD];
+  __shared__ __attribute__((aligned(16))) float sdo[NCH * 64][HD];
+  __shared__ __attribute__((aligned(16))) float red[NCH * 64][2 * HD];
+  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  const int D = H * HD, D3 = 3 * D;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bf16_t* base = qkv + (long long)b * N * D3 + h * HD;
+  for (int t = tid; t < NCH * 64; t += 256) {
+    float q[8] = {0, 0, 0, 0, 0, 0, 0, 0}, d_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (t < N) {
+      load8_bf16(base + (long long)t * D3, q);
+      load8_bf16(dO + ((long long)b * N + t) * D + h * HD, d_);
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      sq[t][d] = q[d];
+      sdo[t][d] = d_[d];
+      red[t][d] = 0.f;
+      red[t][8 + d] = 0.f;
+    }
+  }
+  float k[NCH][8], v[NCH][8], dk[NCH][8], dv[NCH][8];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int j = c * 64 + lane;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) k[c][d] = v[c][d] = dk[c][d] = dv[c][d] = 0.f;
+    if (j < N) {
+      load8_bf16(base + (long long)j * D3 + D, k[c]);
+      load8_bf16(base + (long long)j * D3 + 2 * D, v[c]);
+    }
+  }
+  __syncthreads();
+  const float NEG_INF = -INFINITY;
+  for (int i = wave; i < N; i += 4) {
+    float q[8], dd[8];
+    {
+      const float4 a0 = *reinterpret_cast<const float4*>(&sq[i][0]), a1 = *reinterpret_cast<const float4*>(&sq[i][4]);
+      const float4 b0 = *reinterpret_cast<const float4*>(&sdo[i][0]), b1 = *reinterpret_cast<const float4*>(&sdo[i][4]);
+      q[0] = a0.x; q[1] = a0.y; q[2] = a0.z; q[3] = a0.w; q[4] = a1.x; q[5] = a1.y; q[6] = a1.z; q[7] = a1.w;
+      dd[0] = b0.x; dd[1] = b0.y; dd[2] = b0.z; dd[3] = b0.w; dd[4] = b1.x; dd[5] = b1.y; dd[6] = b1.z; dd[7] = b1.w;
+    }
+    const long long rowoff = ((long long)bh * N + i) * ld;
+    float p[NCH], dpp[NCH], pd[NCH];
+    float m = NEG_INF;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int j = c * 64 + lane;
+      p[c] = (j < N) ? s[rowoff + j] : NEG_INF;
+      m = fmaxf(m, p[c]);
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      p[c] = __expf(p[c] - m);
+      sum += p[c];
+    }
+    const float inv = 1.0f / wave_sum(sum);
+    float dl = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      p[c] *= inv;
+      float dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) dp += dd[d] * v[c][d];
+      float keepscale = 1.f;
+      if (thresh) {
+        const int j = c * 64 + lane;
+        keepscale = dropout_keep(seed, site, ((uint64_t)bh * N + i) * N + j, thresh) ? dscale : 0.f;
+      }
+      dpp[c] = dp * keepscale;
+      pd[c] = p[c] * keepscale;
+      dl += dpp[c] * p[c];
+    }
+    dl = wave_sum(dl);
+    float dq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int j = c * 64 + lane;
+      float gg = 0.f;
+      if (j < N) {
+        gg = p[c] * (dpp[c] - dl);
+        if (!g_in_zero) gg += g[rowoff + j];
+        g[rowoff + j] = gg;
+      }
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        dq[d] += gg * k[c][d];
+        dk[c][d] += gg * q[d];
+        dv[c][d] += pd[c] * dd[d];
+      }
+    }
+    const float tot = wave_sum8_scatter(dq, lane) * scale;
+    if (lane < 8) dqkv[((long long)b * N + i) * D3 + h * HD + lane] = f2bf(tot);
+  }
+  // combine the 4 waves' dK / dV partials through LDS atomics
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int j = c * 64 + lane;
+    if (j < N) {
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        atomicAdd(&red[j][d], dk[c][d] * scale);
+        atomicAdd(&red[j][8 + d], dv[c][d]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < N; t += 256) {
+    float a[8], c2[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      a[d] = red[t][d];
+      c2[d] = red[t][8 + d];
+    }
+    bf16_t* dst = dqkv + ((long long)b * N + t) * D3 + h * HD;
+    store8_bf16(dst + D, a);
+    store8_bf16(dst + 2 * D, c2);
+  }
+}
+
+}  // namespace mmdti
+using namespace mmdti;
+
+static int check_common(const char* fn, int B, int N, int H, int ld) {
+  MMDTI_REQUIRE(B > 0 && N > 0 && H > 0, "%s: B,N,H must be positive", fn);
+  MMDTI_REQUIRE(N <= 320, "%s: N=%d exceeds the supported 320 atoms (+BOS/EOS)", fn, N);
+  MMDTI_REQUIRE(ld >= N, "%s: ld (%d) < N (%d)", fn, ld, N);
+  MMDTI_REQUIRE((long long)B * H <= 2147483647LL, "%s: grid too large", fn);
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, const float* bias_in, float* s_out,
+                                   void* o_bf16, const unsigned char* key_pad, int B, int N, int H, int ld,
+                                   float scale, float drop_p, unsigned long long seed, unsigned int site) {
+  if (int e = check_common("pair_attn_fwd", B, N, H, ld)) return e;
+  MMDTI_REQUIRE(qkv_bf16 && bias_in && s_out && o_bf16, "pair_attn_fwd: null pointer");
+  MMDTI_REQUIRE(aligned16(qkv_bf16), "pair_attn_fwd: qkv must be 16-byte aligned");
+  MMDTI_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "pair_attn_fwd: dropout p out of range");
+  const uint32_t th = dropout_thresh(drop_p);
+  const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  dim3 grid(B * H), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define PA_F(NCH)                                                                                                   \
+  hipLaunchKernelGGL((pair_attn_fwd_kernel<NCH>), grid, block, 0, s, (const bf16_t*)qkv_bf16, bias_in, s_out,      \
+                     (bf16_t*)o_bf16, key_pad, N, H, ld, scale, th, sc, (uint64_t)seed, (uint32_t)site)
+  switch ((N + 63) / 64) {
+    case 1: PA_F(1); break;
+    case 2: PA_F(2); break;
+    case 3: PA_F(3); break;
+    case 4: PA_F(4); break;
+    default: PA_F(5); break;
+  }
+#undef PA_F
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, const float* s, const void* do_bf16,
+                                   float* g, void* dqkv_bf16, int B, int N, int H, int ld, float scale,
+                                   int g_in_zero, float drop_p, unsigned long long seed, unsigned int site) {
+  if (int e = check_common("pair_attn_bwd", B, N, H, ld)) return e;
+  MMDTI_REQUIRE(qkv_bf16 && s && do_bf16 && g && dqkv_bf16, "pair_attn_bwd: null pointer");
+  MMDTI_REQUIRE(aligned16(qkv_bf16) && aligned16(do_bf16) && aligned16(dqkv_bf16), "pair_attn_bwd: alignment");
+  const uint32_t th = dropout_thresh(drop_p);
+  const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  dim3 grid(B * H), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define PA_B(NCH)                                                                                                   \
+  hipLaunchKernelGGL((pair_attn_bwd_kernel<NCH>), grid, block, 0, st, (const bf16_t*)qkv_bf16, s,                  \
+                     (const bf16_t*)do_bf16, g, (bf16_t*)dqkv_bf16, N, H, ld, scale, g_in_zero, th, sc,            \
+                     (uint64_t)seed, (uint32_t)site)
+  switch ((N + 63) / 64) {
+    case 1: PA_B(1); break;
+    case 2: PA_B(2); break;
+    case 3: PA_B(3); break;
+    case 4: PA_B(4); break;
+    default: PA_B(5); break;
+  }
+#undef PA_B
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}

@@ -1,0 +1,404 @@
+"""Tensor-level wrappers over the C ABI (include/mmdti_hip.h).
+
+PyTorch is used here only as plumbing: device memory (torch.empty), the current HIP stream, and dtype/shape
+bookkeeping.  Every function launches hand-written gfx950 kernels through ctypes; nothing falls back to ATen math.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._abi import lib, MMDTIError
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_TANH = 0, 1, 2, 3
+DT_F32, DT_BF16, DT_F32_ATOMIC = 0, 1, 2
+CT_REGRESS, CT_SINGLE, CT_MULTI = 0, 1, 2
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk(t, dtype, name, contiguous=True):
+    if not t.is_cuda:
+        raise MMDTIError(f"{name}: expected a device tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise MMDTIError(f"{name}: expected {dtype}, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        raise MMDTIError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+def _u8(mask):
+    """bool mask -> uint8 view (no copy)."""
+    if mask is None:
+        return None
+    if mask.dtype == torch.bool:
+        return mask.contiguous().view(torch.uint8)
+    return mask.contiguous().to(torch.uint8)
+
+
+# --------------------------------------------------------------------------------------------- GEMM
+def gemm(A, B, *, M, N, K, lda, ldb, out=None, ldc=None, transA=False, transB=False, batch=(1, 1),
+         sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, alpha=1.0, beta=0.0, bias=None, residual=None, act=ACT_NONE,
+         aux_in=None, aux_out=None, out_dtype=BF16, atomic=False, drop_p=0.0, seed=0, site=0, out_shape=None):
+    """C = epi(alpha * A.B^T); see mmdti_gemm_bf16.  A/B are bf16 tensors (any shape; lda/ldb given explicitly)."""
+    _chk(A, BF16, "gemm.A", contiguous=False)
+    _chk(B, BF16, "gemm.B", contiguous=False)
+    ldc = N if ldc is None else ldc
+    if out is None:
+        shape = out_shape if out_shape is not None else ((M, N) if batch == (1, 1) else (batch[0], batch[1], M, N))
+        out = torch.empty(shape, device=A.device, dtype=out_dtype)
+    c_dtype = DT_F32_ATOMIC if atomic else (DT_BF16 if out.dtype == BF16 else DT_F32)
+    if atomic and out.dtype != F32:
+        raise MMDTIError("gemm: atomic accumulation needs an fp32 output")
+    lib().mmdti_gemm_bf16(_stream(), A.data_ptr(), B.data_ptr(), out.data_ptr(), M, N, K, lda, ldb, ldc,
+                          int(transA), int(transB), batch[0], batch[1], sA[0], sA[1], sB[0], sB[1], sC[0], sC[1],
+                          splitk, float(alpha), float(beta), _p(bias), _p(residual), ldc if residual is None else residual.stride(-2),
+                          act, _p(aux_in), _p(aux_out), N if (aux_in is None and aux_out is None) else (aux_in if aux_in is not None else aux_out).stride(-2),
+                          c_dtype, float(drop_p), int(seed), int(site))
+    return out
+
+
+def linear_fwd(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=BF16, aux_out=None, drop_p=0.0, seed=0, site=0):
+    """y[M,N] = epi(x[M,K] . w[N,K]^T + bias)."""
+    M, K = x.shape[0], x.shape[-1]
+    N = w.shape[0]
+    return gemm(x, w, M=M, N=N, K=K, lda=x.stride(0), ldb=w.stride(0), bias=bias, act=act, residual=residual,
+                out_dtype=out_dtype, aux_out=aux_out, drop_p=drop_p, seed=seed, site=site)
+
+
+def linear_bwd_input(dy, w, *, act=ACT_NONE, aux_in=None, out_dtype=BF16, K_valid=None):
+    """dx[M,K] = dy[M,N] . w[N,K]  (optionally * gelu'(aux_in))."""
+    M, N = dy.shape
+    K = w.shape[1]
+    return gemm(dy, w, M=M, N=K, K=(N if K_valid is None else K_valid), lda=dy.stride(0), ldb=w.stride(0), transB=True, act=act, aux_in=aux_in,
+                out_dtype=out_dtype)
+
+
+def _splitk_for(M, N, K):
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    ktiles = (K + 63) // 64
+    sk = max(1, min(ktiles, (512 + tiles - 1) // tiles))
+    return sk
+
+
+def linear_bwd_weight(dy, x, dw, *, rows=None):
+    """dw[N,K] += dy[M,N]^T . x[M,K]   (fp32 atomic accumulate into the gradient arena)."""
+    M = dy.shape[0] if rows is None else rows
+    N, K = dw.shape
+    gemm(dy, x, M=N, N=K, K=M, lda=dy.stride(0), ldb=x.stride(0), transA=True, transB=True, out=dw, ldc=dw.stride(0),
+         atomic=True, splitk=_splitk_for(N, K, M))
+    return dw
+
+
+def colsum(x, out, cols=None):
+    _chk(x, BF16, "colsum.x", contiguous=False)
+    _chk(out, F32, "colsum.out")
+    lib().mmdti_colsum_bf16(_stream(), x.data_ptr(), x.shape[0], x.shape[1] if cols is None else cols, x.stride(0), out.data_ptr())
+    return out
+
+
+# --------------------------------------------------------------------------------------------- LayerNorm
+def layernorm_fwd(x, gamma, beta, eps, *, want_f32=False, want_bf16=True, row_zero=None, drop_p=0.0, seed=0, site=0):
+    _chk(x, F32, "layernorm.x")
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y32 = torch.empty_like(x) if want_f32 else None
+    y16 = torch.empty(x.shape, device=x.device, dtype=BF16) if want_bf16 else None
+    mean = torch.empty(rows, device=x.device, dtype=F32)
+    rstd = torch.empty(rows, device=x.device, dtype=F32)
+    rz = _u8(row_zero)
+    lib().mmdti_layernorm_fwd(_stream(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), rows, D, _p(y32), _p(y16),
+                              mean.data_ptr(), rstd.data_ptr(), _p(rz), float(drop_p), int(seed), int(site))
+    return y32, y16, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, *, dres=None, row_zero=None, drop_p=0.0, seed=0, site=0):
+    D = x.shape[-1]
+    rows = x.numel() // D
+    dx = torch.empty_like(x)
+    rz = _u8(row_zero)
+    lib().mmdti_layernorm_bwd(_stream(), dy.data_ptr(), DT_BF16 if dy.dtype == BF16 else DT_F32, x.data_ptr(), gamma.data_ptr(),
+                              mean.data_ptr(), rstd.data_ptr(), rows, D, _p(dres), dx.data_ptr(), _p(dgamma), _p(dbeta), _p(rz),
+                              float(drop_p), int(seed), int(site))
+    return dx
+
+
+# --------------------------------------------------------------------------------------------- small utilities
+def cast_bf16(x, drop_p=0.0, seed=0, site=0):
+    _chk(x, F32, "cast_bf16.x")
+    y = torch.empty(x.shape, device=x.device, dtype=BF16)
+    lib().mmdti_cast_f32_bf16(_stream(), x.data_ptr(), y.data_ptr(), x.numel(), float(drop_p), int(seed), int(site))
+    return y
+
+
+def cast_f32(x):
+    _chk(x, BF16, "cast_f32.x")
+    y = torch.empty(x.shape, device=x.device, dtype=F32)
+    lib().mmdti_cast_bf16_f32(_stream(), x.data_ptr(), y.data_ptr(), x.numel())
+    return y
+
+
+def dropout_f32(x, p, seed, site):
+    _chk(x, F32, "dropout_f32.x")
+    if p == 0.0:
+        return x
+    y = torch.empty_like(x)
+    lib().mmdti_dropout_f32(_stream(), x.data_ptr(), y.data_ptr(), x.numel(), float(p), int(seed), int(site))
+    return y
+
+
+def axpy_(y, x, a=1.0):
+    lib().mmdti_axpy_f32(_stream(), x.data_ptr(), y.data_ptr(), x.numel(), float(a))
+    return y
+
+
+def embedding_fwd(ids, table, out=None, accumulate=False):
+    _chk(ids, torch.int64, "embedding.ids")
+    _chk(table, F32, "embedding.table")
+    V, D = table.shape
+    if out is None:
+        out = torch.empty(*ids.shape, D, device=table.device, dtype=F32)
+    lib().mmdti_embedding_fwd(_stream(), ids.data_ptr(), table.data_ptr(), ids.numel(), D, V, out.data_ptr(), int(accumulate))
+    return out
+
+
+def embedding_bwd(ids, dout, dtable, padding_idx=-1):
+    V, D = dtable.shape
+    lib().mmdti_embedding_bwd(_stream(), ids.data_ptr(), dout.data_ptr(), ids.numel(), D, V, int(padding_idx), dtable.data_ptr())
+    return dtable
+
+
+def roberta_position_ids(ids, pad_idx):
+    _chk(ids, torch.int64, "position_ids.ids")
+    out = torch.empty_like(ids)
+    lib().mmdti_roberta_position_ids(_stream(), ids.data_ptr(), ids.shape[0], ids.shape[1], int(pad_idx), out.data_ptr())
+    return out
+
+
+# --------------------------------------------------------------------------------------------- Gaussian basis / pair layout
+def gbf_features_fwd(dist, edge_type, mul, bias, means, stds):
+    _chk(dist, F32, "gbf.dist"); _chk(edge_type, torch.int64, "gbf.edge_type")
+    P, K, E = dist.numel(), means.numel(), mul.numel()
+    feat = torch.empty(P, K, device=dist.device, dtype=BF16)
+    lib().mmdti_gbf_features_fwd(_stream(), dist.data_ptr(), edge_type.data_ptr(), mul.data_ptr(), bias.data_ptr(), means.data_ptr(),
+                                 stds.data_ptr(), P, K, E, feat.data_ptr())
+    return feat
+
+
+def gbf_features_bwd(dist, edge_type, mul, bias, means, stds, dfeat, dmul, dbias, dmeans, dstds):
+    P, K, E = dist.numel(), means.numel(), mul.numel()
+    lib().mmdti_gbf_features_bwd(_stream(), dist.data_ptr(), edge_type.data_ptr(), mul.data_ptr(), bias.data_ptr(), means.data_ptr(),
+                                 stds.data_ptr(), P, K, E, dfeat.data_ptr(), dmul.data_ptr(), dbias.data_ptr(), dmeans.data_ptr(),
+                                 dstds.data_ptr())
+
+
+def pair_ld(N):
+    """row stride of the internal [B,H,N,ld] pair tensors (16-byte aligned rows)."""
+    return (N + 3) // 4 * 4
+
+
+def pair_permute_fwd(x, B, N, H, ld):
+    _chk(x, F32, "pair_permute_fwd.x")
+    out = torch.empty(B, H, N, ld, device=x.device, dtype=F32)
+    lib().mmdti_pair_permute_fwd(_stream(), x.data_ptr(), out.data_ptr(), B, N, H, ld)
+    return out
+
+
+def pair_permute_bwd(g, B, N, H, ld):
+    _chk(g, F32, "pair_permute_bwd.g")
+    out = torch.empty(B * N * N, H, device=g.device, dtype=BF16)
+    lib().mmdti_pair_permute_bwd(_stream(), g.data_ptr(), out.data_ptr(), B, N, H, ld)
+    return out
+
+
+# --------------------------------------------------------------------------------------------- pair-bias attention
+def pair_attn_fwd(qkv, bias_in, key_pad, B, N, H, ld, scale, drop_p=0.0, seed=0, site=0):
+    _chk(qkv, BF16, "pair_attn.qkv"); _chk(bias_in, F32, "pair_attn.bias")
+    s_out = torch.empty(B, H, N, ld, device=qkv.device, dtype=F32)
+    o = torch.empty(B * N, H * 8, device=qkv.device, dtype=BF16)
+    kp = _u8(key_pad)
+    lib().mmdti_pair_attn_fwd(_stream(), qkv.data_ptr(), bias_in.data_ptr(), s_out.data_ptr(), o.data_ptr(), _p(kp), B, N, H, ld,
+                              float(scale), float(drop_p), int(seed), int(site))
+    return s_out, o
+
+
+def pair_attn_bwd(qkv, s, do, g, B, N, H, ld, scale, g_in_zero, drop_p=0.0, seed=0, site=0):
+    dqkv = torch.empty_like(qkv)
+    lib().mmdti_pair_attn_bwd(_stream(), qkv.data_ptr(), s.data_ptr(), do.data_ptr(), g.data_ptr(), dqkv.data_ptr(), B, N, H, ld,
+                              float(scale), int(g_in_zero), float(drop_p), int(seed), int(site))
+    return dqkv
+
+
+# --------------------------------------------------------------------------------------------- softmax over materialised scores
+def softmax_fwd(s, key_add, B, heads, Lq, Lk, ld, drop_p=0.0, seed=0, site=0):
+    _chk(s, F32, "softmax.s")
+    p = torch.empty(B, heads, Lq, ld, device=s.device, dtype=BF16)
+    pd = torch.empty_like(p) if drop_p > 0 else p
+    lib().mmdti_softmax_fwd(_stream(), s.data_ptr(), _p(key_add), p.data_ptr(), pd.data_ptr(), B, heads, Lq, Lk, ld, float(drop_p),
+                            int(seed), int(site))
+    return p, pd
+
+
+def softmax_bwd(p, dp, B, heads, Lq, Lk, ld, scale, drop_p=0.0, seed=0, site=0):
+    ds = torch.empty(B, heads, Lq, ld, device=p.device, dtype=BF16)
+    lib().mmdti_softmax_bwd(_stream(), p.data_ptr(), dp.data_ptr(), ds.data_ptr(), B, heads, Lq, Lk, ld, float(scale), float(drop_p),
+                            int(seed), int(site))
+    return ds
+
+
+# --------------------------------------------------------------------------------------------- InfoNCE pieces
+def seq_mean_fwd(x, B, S, D, ld):
+    out = torch.empty(B, D, device=x.device, dtype=F32)
+    lib().mmdti_seq_mean_fwd(_stream(), x.data_ptr(), B, S, D, ld, out.data_ptr())
+    return out
+
+
+def seq_mean_bwd(dout, B, S, D, ld):
+    dx = torch.empty(B * S, ld, device=dout.device, dtype=BF16)
+    lib().mmdti_seq_mean_bwd(_stream(), dout.data_ptr(), B, S, D, ld, dx.data_ptr())
+    return dx
+
+
+def l2norm_fwd(x):
+    _chk(x, F32, "l2norm.x", contiguous=False)
+    B, D = x.shape
+    xh = torch.empty(B, D, device=x.device, dtype=F32)
+    inv = torch.empty(B, device=x.device, dtype=F32)
+    lib().mmdti_l2norm_fwd(_stream(), x.data_ptr(), B, D, x.stride(0), xh.data_ptr(), inv.data_ptr())
+    return xh, inv
+
+
+def l2norm_bwd(dxh, xh, inv):
+    B, D = xh.shape
+    dx = torch.empty(B, D, device=xh.device, dtype=F32)
+    lib().mmdti_l2norm_bwd(_stream(), dxh.data_ptr(), xh.data_ptr(), inv.data_ptr(), B, D, D, dx.data_ptr())
+    return dx
+
+
+def infonce_dir(qh_all, kh_all, row0, Bl, temperature, loss_sum, dq_all, dk_all):
+    Bg, D = qh_all.shape
+    lib().mmdti_infonce_dir(_stream(), qh_all.data_ptr(), kh_all.data_ptr(), Bg, D, row0, Bl, float(temperature), loss_sum.data_ptr(),
+                            dq_all.data_ptr(), dk_all.data_ptr())
+
+
+# --------------------------------------------------------------------------------------------- ConR / SupCon
+def ct_loss_fwd(mode, fhat, labels_f=None, labels_i=None, pred=None, weights=None, w=0.2, t=0.07, e=0.01, coef=1.0):
+    B, D = fhat.shape
+    loss = torch.empty(1, device=fhat.device, dtype=F32)
+    G = torch.empty(B, B, device=fhat.device, dtype=F32)
+    C = 0 if labels_i is None else labels_i.shape[1]
+    lib().mmdti_ct_loss_fwd(_stream(), mode, fhat.data_ptr(), B, D, _p(labels_f), _p(labels_i), C, _p(pred), _p(weights), float(w),
+                            float(t), float(e), float(coef), loss.data_ptr(), G.data_ptr())
+    return loss, G
+
+
+def ct_loss_bwd(fhat, G, t=0.07):
+    B, D = fhat.shape
+    d = torch.empty_like(fhat)
+    lib().mmdti_ct_loss_bwd(_stream(), fhat.data_ptr(), G.data_ptr(), B, D, float(t), d.data_ptr())
+    return d
+
+
+# --------------------------------------------------------------------------------------------- FDS
+def fds_bins(labels, min_value, bin_width, bucket_start, bucket_num):
+    _chk(labels, F32, "fds_bins.labels")
+    n = labels.numel()
+    bins = torch.empty(n, device=labels.device, dtype=torch.int32)
+    flags = torch.zeros(2, device=labels.device, dtype=torch.int32)
+    lib().mmdti_fds_bins(_stream(), labels.data_ptr(), n, float(min_value), float(bin_width), bucket_start, bucket_num, bins.data_ptr(),
+                         flags.data_ptr())
+    return bins, flags
+
+
+def fds_smooth(x, bins, flags, bucket_start, bucket_num, m1, v1, m2, v2, want_scale=True):
+    n, D = x.shape
+    y = torch.empty_like(x)
+    sc = torch.empty_like(x) if want_scale else None
+    lib().mmdti_fds_smooth(_stream(), x.data_ptr(), bins.data_ptr(), flags.data_ptr(), n, D, bucket_start, bucket_num, m1.data_ptr(),
+                           v1.data_ptr(), m2.data_ptr(), v2.data_ptr(), y.data_ptr(), _p(sc))
+    return y, sc
+
+
+def fds_update_stats(feats, bins, flags, bucket_start, bucket_num, factor, running_mean, running_var, tracked):
+    n, D = feats.shape
+    lib().mmdti_fds_update_stats(_stream(), feats.data_ptr(), bins.data_ptr(), flags.data_ptr(), n, D, bucket_start, bucket_num,
+                                 float(factor), running_mean.data_ptr(), running_var.data_ptr(), tracked.data_ptr())
+
+
+def fds_smooth_stats(stat, window):
+    nb, D = stat.shape
+    out = torch.empty_like(stat)
+    lib().mmdti_fds_smooth_stats(_stream(), stat.data_ptr(), nb, D, window.data_ptr(), window.numel(), out.data_ptr())
+    return out
+
+
+# --------------------------------------------------------------------------------------------- pooling / head / losses
+def masked_pool_fwd(a, t, mask_a, mask_t):
+    B, Na, D = a.shape
+    Nt = t.shape[1]
+    out = torch.empty(B, D, device=a.device, dtype=F32)
+    lib().mmdti_masked_pool_fwd(_stream(), a.data_ptr(), t.data_ptr(), mask_a.data_ptr(), mask_t.data_ptr(), B, Na, Nt, D, out.data_ptr())
+    return out
+
+
+def masked_pool_bwd(dp, mask_a, mask_t, Na, Nt):
+    B, D = dp.shape
+    da = torch.empty(B, Na, D, device=dp.device, dtype=F32)
+    dt = torch.empty(B, Nt, D, device=dp.device, dtype=F32)
+    lib().mmdti_masked_pool_bwd(_stream(), dp.data_ptr(), mask_a.data_ptr(), mask_t.data_ptr(), B, Na, Nt, D, da.data_ptr(), dt.data_ptr())
+    return da, dt
+
+
+def linear_f32_fwd(x, W, b, act=ACT_NONE):
+    rows, in_f = x.shape
+    out_f = W.shape[0]
+    y = torch.empty(rows, out_f, device=x.device, dtype=F32)
+    lib().mmdti_linear_f32_fwd(_stream(), x.data_ptr(), W.data_ptr(), _p(b), rows, in_f, out_f, act, y.data_ptr())
+    return y
+
+
+def linear_f32_bwd(x, W, y, dy, dW, db, act=ACT_NONE, want_dx=True):
+    rows, in_f = x.shape
+    out_f = W.shape[0]
+    dx = torch.empty_like(x) if want_dx else None
+    lib().mmdti_linear_f32_bwd(_stream(), x.data_ptr(), W.data_ptr(), _p(y), dy.data_ptr(), rows, in_f, out_f, act, _p(dx), _p(dW), _p(db))
+    return dx
+
+
+def mse_loss(pred, target):
+    loss = torch.empty(1, device=pred.device, dtype=F32)
+    d = torch.empty_like(pred)
+    lib().mmdti_mse_loss(_stream(), pred.data_ptr(), target.data_ptr(), pred.numel(), loss.data_ptr(), d.data_ptr())
+    return loss, d
+
+
+def ce_loss(logits, target):
+    B, C = logits.shape
+    loss = torch.empty(1, device=logits.device, dtype=F32)
+    d = torch.empty_like(logits)
+    lib().mmdti_ce_loss(_stream(), logits.data_ptr(), target.data_ptr(), B, C, loss.data_ptr(), d.data_ptr())
+    return loss, d
+
+
+def sumsq(g, out):
+    lib().mmdti_sumsq_f32(_stream(), g.data_ptr(), g.numel(), out.data_ptr())
+    return out
+
+
+def adam_step(p, g, m, v, p_bf16, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None):
+    lib().mmdti_adam_step(_stream(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(p_bf16), p.numel(), float(lr), float(beta1),
+                          float(beta2), float(eps), float(weight_decay), int(step), _p(grad_scale))
+
+
+def probe_tr_read(stride):
+    out = torch.empty(256, device="cuda", dtype=torch.int16)
+    lib().mmdti_probe_tr_read(_stream(), int(stride), out.data_ptr())
+    return out

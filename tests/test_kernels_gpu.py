@@ -1,0 +1,527 @@
+"""GPU parity tests, kernel level: every C-ABI entry point vs the CPU oracle / golden vectors.
+
+Tolerances: integer outputs bit-exact; fp32-math kernels 1e-5..1e-4 relative; kernels that store bf16 are compared
+against the oracle evaluated on the SAME bf16-rounded operands (accumulation-order tolerance), so a layout or
+indexing bug cannot hide behind bf16 noise.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mmdti_oracle as O
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from mmdti_hip import ops as _ops
+    return _ops
+
+
+def dev(t):
+    return t.cuda()
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def rt(t):
+    """bf16 round trip on the CPU."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def close(a, b, rtol, atol):
+    torch.testing.assert_close(a.detach().float().cpu(), b.detach().float().cpu(), rtol=rtol, atol=atol)
+
+
+G = lambda s: torch.Generator().manual_seed(s)
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (130, 50, 72), (300, 200, 512), (33, 1536, 512), (1000, 64, 128)])
+def test_gemm_nt(ops, M, N, K):
+    x, w, b = rt(torch.randn(M, K, generator=G(1))), rt(torch.randn(N, K, generator=G(2)) * 0.1), torch.randn(N, generator=G(3))
+    y = ops.linear_fwd(dev(bf(x)), dev(bf(w)), dev(b), out_dtype=torch.float32)
+    close(y, x @ w.T + b, 1e-4, 1e-4)
+    yb = ops.linear_fwd(dev(bf(x)), dev(bf(w)), dev(b), out_dtype=torch.bfloat16)
+    close(yb, rt(x @ w.T + b), 1e-2, 1e-2)
+
+
+def test_gemm_epilogues(ops):
+    M, N, K = 200, 192, 128
+    x, w, b = rt(torch.randn(M, K, generator=G(1))), rt(torch.randn(N, K, generator=G(2)) * 0.1), torch.randn(N, generator=G(3))
+    res = torch.randn(M, N, generator=G(4))
+    u_ref = x @ w.T + b
+    aux = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    y = ops.linear_fwd(dev(bf(x)), dev(bf(w)), dev(b), act=ops.ACT_GELU, aux_out=aux, out_dtype=torch.float32)
+    close(y, O.gelu(u_ref), 1e-4, 1e-4)
+    close(aux, rt(u_ref), 1e-2, 1e-2)
+    y = ops.linear_fwd(dev(bf(x)), dev(bf(w)), dev(b), residual=dev(res), out_dtype=torch.float32)
+    close(y, u_ref + res, 1e-4, 1e-4)
+    # gelu backward epilogue: dx = (dy . W) * gelu'(u)
+    dy = rt(torch.randn(M, N, generator=G(5)))
+    u = rt(torch.randn(M, K, generator=G(6)))
+    dx = ops.linear_bwd_input(dev(bf(dy)), dev(bf(w)), act=ops.ACT_GELU_BWD, aux_in=dev(bf(u)), out_dtype=torch.float32)
+    uu = u.clone().requires_grad_()
+    (gr,) = torch.autograd.grad(O.gelu(uu).sum(), uu)
+    close(dx, (dy @ w) * gr, 1e-4, 1e-4)
+
+
+def test_gemm_transposed_and_splitk(ops):
+    M, N, K = 777, 192, 160   # dW[N,K] = dy[M,N]^T x[M,K]
+    dy, x = rt(torch.randn(M, N, generator=G(1))), rt(torch.randn(M, K, generator=G(2)))
+    dw = torch.zeros(N, K, device="cuda")
+    ops.linear_bwd_weight(dev(bf(dy)), dev(bf(x)), dw)
+    close(dw, dy.T @ x, 1e-4, 2e-3)
+    ops.linear_bwd_weight(dev(bf(dy)), dev(bf(x)), dw)          # accumulates
+    close(dw, 2 * (dy.T @ x), 1e-4, 4e-3)
+    w = rt(torch.randn(N, K, generator=G(3)))
+    dx = ops.linear_bwd_input(dev(bf(dy)), dev(bf(w)), out_dtype=torch.float32)
+    close(dx, dy @ w, 1e-4, 2e-3)
+
+
+def test_gemm_batched_heads(ops):
+    # S[b,h] = q[b,:,h,:] . k[b,:,h,:]^T from a packed [B,L,3D] buffer, K-tail (Lk=13 not a multiple of 8) on P.V
+    B, L, H, hd = 3, 13, 4, 32
+    D = H * hd
+    qkv = rt(torch.randn(B, L, 3 * D, generator=G(1)))
+    dq = dev(bf(qkv))
+    ld = 16
+    S = torch.zeros(B, H, L, ld, device="cuda")
+    ops.gemm(dq, dq[:, :, D:], M=L, N=L, K=hd, lda=3 * D, ldb=3 * D, out=S, ldc=ld, batch=(B, H), sA=(L * 3 * D, hd),
+             sB=(L * 3 * D, hd), sC=(H * L * ld, L * ld), alpha=0.5)
+    q = qkv[..., :D].view(B, L, H, hd).transpose(1, 2)
+    k = qkv[..., D:2 * D].view(B, L, H, hd).transpose(1, 2)
+    v = qkv[..., 2 * D:].view(B, L, H, hd).transpose(1, 2)
+    close(S[..., :L], 0.5 * q @ k.transpose(-1, -2), 1e-4, 1e-3)
+    P = torch.zeros(B, H, L, ld)
+    P[..., :L] = torch.softmax(torch.randn(B, H, L, L, generator=G(2)), -1)
+    P = rt(P)
+    ctx = torch.empty(B, L, D, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(dev(bf(P)), dq[:, :, 2 * D:], M=L, N=hd, K=L, lda=ld, ldb=3 * D, transB=True, out=ctx, ldc=D, batch=(B, H),
+             sA=(H * L * ld, L * ld), sB=(L * 3 * D, hd), sC=(L * D, hd))
+    ref = (P[..., :L] @ v).transpose(1, 2).reshape(B, L, D)
+    close(ctx, ref, 1e-2, 1e-2)
+
+
+def test_gemm_dropout_epilogue(ops):
+    M, N, K = 256, 256, 64
+    x, w = torch.ones(M, K), torch.ones(N, K) / K
+    y1 = ops.linear_fwd(dev(bf(x)), dev(bf(w)), None, out_dtype=torch.float32, drop_p=0.25, seed=7, site=3)
+    y2 = ops.linear_fwd(dev(bf(x)), dev(bf(w)), None, out_dtype=torch.float32, drop_p=0.25, seed=7, site=3)
+    assert torch.equal(y1, y2)                                   # counter-based: reproducible
+    keep = (y1 != 0).float().mean().item()
+    assert abs(keep - 0.75) < 0.01
+    close(y1[y1 != 0], torch.full_like(y1[y1 != 0], 1 / 0.75), 1e-5, 1e-5)
+    y3 = ops.linear_fwd(dev(bf(x)), dev(bf(w)), None, out_dtype=torch.float32, drop_p=0.25, seed=8, site=3)
+    assert not torch.equal(y1, y3)
+
+
+def test_gemm_rejects_bad_arguments(ops):
+    from mmdti_hip._abi import MMDTIError
+    x = torch.zeros(16, 12, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(MMDTIError):
+        ops.gemm(x, x, M=16, N=16, K=12, lda=12, ldb=12)          # lda not a multiple of 8
+
+
+# ------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("rows,D,eps", [(37, 512, 1e-5), (260, 64, 1e-12), (5, 2048, 1e-5)])
+def test_layernorm(ops, rows, D, eps):
+    x = torch.randn(rows, D, generator=G(1)) * 2 + 0.5
+    g, b = 1 + 0.1 * torch.randn(D, generator=G(2)), 0.1 * torch.randn(D, generator=G(3))
+    rz = torch.zeros(rows, dtype=torch.bool); rz[::5] = True
+    y32, y16, mean, rstd = ops.layernorm_fwd(dev(x), dev(g), dev(b), eps, want_f32=True, want_bf16=True, row_zero=dev(rz))
+    ref = O.layer_norm(x, g, b, eps) * (~rz).unsqueeze(-1)
+    close(y32, ref, 1e-5, 1e-5)
+    close(y16, rt(ref), 1e-2, 1e-2)
+    # backward (fp32 dy and bf16 dy), with residual-gradient add
+    xr = x.clone().requires_grad_(); gr = g.clone().requires_grad_(); br = b.clone().requires_grad_()
+    dy = torch.randn(rows, D, generator=G(4)); dres = torch.randn(rows, D, generator=G(5))
+    out = O.layer_norm(xr, gr, br, eps) * (~rz).unsqueeze(-1)
+    (out * dy).sum().backward()
+    dg, db = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    dx = ops.layernorm_bwd(dev(dy), dev(x), dev(g), mean, rstd, dg, db, dres=dev(dres), row_zero=dev(rz))
+    close(dx, xr.grad + dres, 1e-4, 1e-4)
+    close(dg, gr.grad, 1e-4, 1e-3)
+    close(db, br.grad, 1e-4, 1e-3)
+    dg.zero_(); db.zero_()
+    dx = ops.layernorm_bwd(dev(bf(dy)), dev(x), dev(g), mean, rstd, dg, db, row_zero=dev(rz))
+    xr.grad = None
+    (O.layer_norm(xr, g, b, eps) * (~rz).unsqueeze(-1) * rt(dy)).sum().backward()
+    close(dx, xr.grad, 1e-4, 1e-4)
+
+
+def test_layernorm_dropout_consistency(ops):
+    rows, D = 64, 512
+    x = torch.randn(rows, D, generator=G(1)); g = torch.ones(D); b = torch.zeros(D)
+    y32, _, mean, rstd = ops.layernorm_fwd(dev(x), dev(g), dev(b), 1e-5, want_f32=True, want_bf16=False, drop_p=0.1, seed=5, site=1)
+    ref = O.layer_norm(x, g, b, 1e-5)
+    mask = (y32 != 0).cpu()
+    assert abs(mask.float().mean().item() - 0.9) < 0.01
+    close(y32.cpu()[mask], (ref / 0.9)[mask], 1e-5, 1e-5)
+    # backward regenerates the same mask: dx of a masked-out element's dy contribution is zero
+    dy = torch.ones(rows, D)
+    dg, db = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    ops.layernorm_bwd(dev(dy), dev(x), dev(g), mean, rstd, dg, db, drop_p=0.1, seed=5, site=1)
+    close(db, (mask.float() / 0.9).sum(0), 1e-5, 1e-4)
+
+
+# ------------------------------------------------------------------------------------------- pair attention
+def _pair_ref(qkv, bias, key_pad, H, scale, dO=None, g_in=None):
+    """oracle core of unimol_layer's attention on given (bf16-rounded) qkv.  Returns S,O and grads."""
+    B, N, D3 = qkv.shape
+    D = D3 // 3
+    hd = D // H
+    qkv = qkv.clone().requires_grad_()
+    bias = bias.clone().requires_grad_()
+    q, k, v = qkv.chunk(3, -1)
+    heads = lambda t: t.view(B, N, H, hd).transpose(1, 2)
+    b = bias
+    if key_pad is not None:
+        b = b.masked_fill(key_pad.view(B, 1, 1, N), float("-inf"))
+    S = (heads(q) * scale) @ heads(k).transpose(-1, -2) + b
+    P = torch.softmax(S, -1)
+    Oo = (P @ heads(v)).transpose(1, 2).reshape(B, N, D)
+    if dO is None:
+        return S, Oo
+    loss = (Oo * dO).sum()
+    if g_in is not None:
+        fin = torch.isfinite(S)
+        loss = loss + (torch.where(fin, S, torch.zeros_like(S)) * g_in).sum()
+    loss.backward()
+    return S, Oo, qkv.grad, bias.grad
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 7, 8), (3, 70, 4), (2, 130, 64), (1, 200, 2)])
+def test_pair_attn(ops, B, N, H):
+    D = H * 8
+    ld = ops.pair_ld(N)
+    scale = 8 ** -0.5
+    qkv = rt(torch.randn(B, N, 3 * D, generator=G(1)))
+    bias = torch.randn(B, H, N, N, generator=G(2))
+    key_pad = torch.zeros(B, N, dtype=torch.bool)
+    key_pad[0, N - max(1, N // 3):] = True
+    bias_ld = torch.zeros(B, H, N, ld); bias_ld[..., :N] = bias
+    s_out, o = ops.pair_attn_fwd(dev(bf(qkv)).view(B * N, 3 * D), dev(bias_ld), dev(key_pad), B, N, H, ld, scale)
+    dO = rt(torch.randn(B, N, D, generator=G(3)))
+    g_in = torch.randn(B, H, N, N, generator=G(4)).masked_fill(key_pad.view(B, 1, 1, N), 0.0)   # G is 0 at -inf entries
+    S, Oref, dqkv_ref, dbias_ref = _pair_ref(qkv, bias, key_pad, H, scale, dO, g_in)
+    s_cpu = s_out.cpu()[..., :N]
+    assert torch.equal(torch.isinf(s_cpu), torch.isinf(S.detach()))        # masked columns are exactly -inf
+    fin = torch.isfinite(S.detach())
+    close(s_cpu[fin], S.detach()[fin], 1e-5, 1e-5)
+    close(o.view(B, N, D), rt(Oref), 1e-2, 1e-2)
+    g = torch.zeros(B, H, N, ld); g[..., :N] = g_in
+    g = dev(g)
+    dqkv = ops.pair_attn_bwd(dev(bf(qkv)).view(B * N, 3 * D), s_out, dev(bf(dO)).view(B * N, D), g, B, N, H, ld, scale, False)
+    close(g.cpu()[..., :N][fin], (dbias_ref + 0)[fin], 1e-4, 1e-4)
+    close(dqkv.view(B, N, 3 * D), rt(dqkv_ref), 2e-2, 2e-2)
+    # g_in_zero path == g_in of zeros
+    g2 = dev(torch.full((B, H, N, ld), 7.0))
+    dq2 = ops.pair_attn_bwd(dev(bf(qkv)).view(B * N, 3 * D), s_out, dev(bf(dO)).view(B * N, D), g2, B, N, H, ld, scale, True)
+    _, _, dqkv0, dbias0 = _pair_ref(qkv, bias, key_pad, H, scale, dO, None)
+    close(g2.cpu()[..., :N][fin], dbias0[fin], 1e-4, 1e-4)
+    close(dq2.view(B, N, 3 * D), rt(dqkv0), 2e-2, 2e-2)
+
+
+def test_pair_attn_dropout(ops):
+    B, N, H = 2, 64, 8
+    D, ld, scale = H * 8, 64, 8 ** -0.5
+    qkv = rt(torch.randn(B, N, 3 * D, generator=G(1)))
+    qkv[..., 2 * D:] = 1.0                                   # v = 1  ->  O = sum_j dropout(P)_j
+    bias = torch.zeros(B, H, N, ld)
+    _, o = ops.pair_attn_fwd(dev(bf(qkv)).view(B * N, 3 * D), dev(bias), None, B, N, H, ld, scale, drop_p=0.5, seed=3, site=9)
+    o = o.float().cpu()
+    assert abs(o.mean().item() - 1.0) < 0.05 and o.std().item() > 0.05      # unbiased, actually random
+    _, o2 = ops.pair_attn_fwd(dev(bf(qkv)).view(B * N, 3 * D), dev(bias), None, B, N, H, ld, scale, drop_p=0.5, seed=3, site=9)
+    assert torch.equal(o2.float().cpu(), o)
+
+
+# ------------------------------------------------------------------------------------------- Gaussian basis, permutes
+def _gbf_params(E, K, seed=0):
+    g = G(seed)
+    return {"gbf.means.weight": torch.rand(1, K, generator=g) * 3, "gbf.stds.weight": torch.rand(1, K, generator=g) * 3 - 0.3,
+            "gbf.mul.weight": 1 + 0.1 * torch.randn(E, 1, generator=g), "gbf.bias.weight": 0.1 * torch.randn(E, 1, generator=g)}
+
+
+@pytest.mark.parametrize("B,N,K,V", [(2, 9, 16, 7), (2, 33, 128, 31)])
+def test_gbf_features(ops, B, N, K, V):
+    E = V * V
+    P = {k: v.requires_grad_() for k, v in _gbf_params(E, K).items()}
+    dist = torch.rand(B, N, N, generator=G(1)) * 6
+    et = torch.randint(0, E, (B, N, N), generator=G(2))
+    ref = O.gaussian_layer(dist, et, P)
+    args = [dev(P[k].detach().reshape(-1)) for k in ("gbf.mul.weight", "gbf.bias.weight", "gbf.means.weight", "gbf.stds.weight")]
+    feat = ops.gbf_features_fwd(dev(dist), dev(et), *args)
+    close(feat.view(B, N, N, K), rt(ref), 1e-2, 1e-3)
+    df = rt(torch.randn(B, N, N, K, generator=G(3)))
+    (ref * df).sum().backward()
+    grads = [torch.zeros_like(a) for a in args]
+    ops.gbf_features_bwd(dev(dist), dev(et), *args, dev(bf(df)).view(-1, K), *grads)
+    for gr, k in zip(grads, ("gbf.mul.weight", "gbf.bias.weight", "gbf.means.weight", "gbf.stds.weight")):
+        close(gr, P[k].grad.reshape(-1), 2e-3, 2e-3)
+
+
+def test_pair_permute(ops):
+    B, N, H = 2, 13, 8
+    ld = ops.pair_ld(N)
+    x = torch.randn(B, N, N, H, generator=G(1))
+    out = ops.pair_permute_fwd(dev(x), B, N, H, ld)
+    assert torch.equal(out.cpu()[..., :N], x.permute(0, 3, 1, 2).contiguous())       # pure data movement: bit-exact
+    g = torch.randn(B, H, N, ld, generator=G(2))
+    back = ops.pair_permute_bwd(dev(g), B, N, H, ld)
+    assert torch.equal(back.float().cpu().view(B, N, N, H), rt(g[..., :N].permute(0, 2, 3, 1)))
+
+
+# ------------------------------------------------------------------------------------------- softmax
+@pytest.mark.parametrize("B,h,Lq,Lk", [(2, 3, 5, 13), (2, 2, 70, 130), (1, 2, 9, 256)])
+def test_softmax(ops, B, h, Lq, Lk):
+    ld = (Lk + 7) // 8 * 8
+    s = torch.randn(B, h, Lq, ld, generator=G(1)) * 3
+    mask = torch.ones(B, Lk); mask[0, Lk // 2:] = 0
+    add = (1 - mask) * -10000.0
+    p, pd = ops.softmax_fwd(dev(s), dev(add), B, h, Lq, Lk, ld)
+    ref = torch.softmax(s[..., :Lk] + add.view(B, 1, 1, Lk), -1)
+    close(p.cpu()[..., :Lk], rt(ref), 1e-2, 1e-3)
+    assert (p.cpu()[..., Lk:] == 0).all()
+    dp = torch.randn(B, h, Lq, ld, generator=G(2))
+    pr = p.float().cpu()[..., :Lk]
+    ds_ref = 0.25 * pr * (dp[..., :Lk] - (dp[..., :Lk] * pr).sum(-1, keepdim=True))
+    ds = ops.softmax_bwd(p, dev(dp), B, h, Lq, Lk, ld, 0.25)
+    close(ds.cpu()[..., :Lk], rt(ds_ref), 1e-2, 1e-3)
+    assert (ds.cpu()[..., Lk:] == 0).all()
+    # roberta-style mask (dtype minimum) gives exact zeros too
+    p2, _ = ops.softmax_fwd(dev(s), dev((1 - mask) * torch.finfo(torch.float32).min), B, h, Lq, Lk, ld)
+    assert (p2.cpu()[0, :, :, Lk // 2:Lk] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------- embeddings / position ids
+def test_embedding_and_position_ids(ops, golden):
+    g = golden("g6_roberta_eager")
+    ids = torch.from_numpy(g["input_ids"])
+    pos = ops.roberta_position_ids(dev(ids), 1)
+    assert torch.equal(pos.cpu(), torch.from_numpy(g["position_ids"]))          # int64, bit-exact
+    big = torch.randint(0, 5, (7, 300), generator=G(1))
+    assert torch.equal(ops.roberta_position_ids(dev(big), 1).cpu(), O.roberta_position_ids(big, 1))
+    table = torch.randn(40, 32, generator=G(2))
+    out = ops.embedding_fwd(dev(ids), dev(table))
+    assert torch.equal(out.cpu(), table[ids])
+    ops.embedding_fwd(dev(pos), dev(table), out=out, accumulate=True)
+    close(out, table[ids] + table[pos.cpu()], 1e-6, 1e-6)
+    dout = torch.randn(*ids.shape, 32, generator=G(3))
+    dt = torch.zeros(40, 32, device="cuda")
+    ops.embedding_bwd(dev(ids), dev(dout), dt, padding_idx=1)
+    tr = table.clone().requires_grad_()
+    (torch.nn.functional.embedding(ids, tr, padding_idx=1) * dout).sum().backward()
+    close(dt, tr.grad, 1e-5, 1e-5)
+
+
+# ------------------------------------------------------------------------------------------- InfoNCE (golden G1)
+@pytest.mark.parametrize("B", [2, 16])
+def test_infonce_golden(ops, golden, B):
+    g = golden(f"g1_info_nce_B{B}")
+    q, k = dev(torch.from_numpy(g["q"])), dev(torch.from_numpy(g["k"]))
+    qh, qi = ops.l2norm_fwd(q)
+    kh, ki = ops.l2norm_fwd(k)
+    loss = torch.zeros(1, device="cuda")
+    dqh, dkh = torch.zeros_like(qh), torch.zeros_like(kh)
+    ops.infonce_dir(qh, kh, 0, B, 0.1, loss, dqh, dkh)
+    ops.infonce_dir(kh, qh, 0, B, 0.1, loss, dkh, dqh)
+    close(loss / (2 * B), torch.from_numpy(g["loss"]).reshape(1), 1e-5, 1e-6)
+    close(ops.l2norm_bwd(dqh, qh, qi), torch.from_numpy(g["dq"]), 1e-4, 1e-6)
+    close(ops.l2norm_bwd(dkh, kh, ki), torch.from_numpy(g["dk"]), 1e-4, 1e-6)
+
+
+def test_infonce_sharded_rows_equal_full(ops):
+    """global negatives: two 'ranks' each owning half of the anchors reproduce the single-process loss + grads."""
+    B, D = 24, 50
+    q, k = torch.randn(B, D, generator=G(1)), torch.randn(B, D, generator=G(2))
+    qh, _ = ops.l2norm_fwd(dev(q)); kh, _ = ops.l2norm_fwd(dev(k))
+    full = [torch.zeros(1, device="cuda"), torch.zeros_like(qh), torch.zeros_like(kh)]
+    ops.infonce_dir(qh, kh, 0, B, 0.1, *full); ops.infonce_dir(kh, qh, 0, B, 0.1, full[0], full[2], full[1])
+    part = [torch.zeros(1, device="cuda"), torch.zeros_like(qh), torch.zeros_like(kh)]
+    for r0 in (0, 12):
+        ops.infonce_dir(qh, kh, r0, 12, 0.1, *part); ops.infonce_dir(kh, qh, r0, 12, 0.1, part[0], part[2], part[1])
+    for a, b in zip(full, part):
+        close(a, b, 1e-5, 1e-6)
+    qr, kr = q.clone().requires_grad_(), k.clone().requires_grad_()
+    ref = O.info_nce(qr, kr)
+    close(full[0] / (2 * B), ref.reshape(1), 1e-5, 1e-6)
+
+
+def test_seq_mean(ops):
+    B, S, D, ld = 3, 11, 50, 64
+    x = torch.zeros(B, S, ld); x[..., :D] = torch.randn(B, S, D, generator=G(1))
+    x = rt(x)
+    m = ops.seq_mean_fwd(dev(bf(x)), B, S, D, ld)
+    close(m, x[..., :D].mean(1), 1e-5, 1e-6)
+    d = torch.randn(B, D, generator=G(2))
+    dx = ops.seq_mean_bwd(dev(d), B, S, D, ld).float().cpu().view(B, S, ld)
+    close(dx[..., :D], rt((d / S).unsqueeze(1).expand(B, S, D)), 1e-2, 1e-6)
+    assert (dx[..., D:] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------- ConR / SupCon (golden G3)
+def test_ct_losses_golden(ops, golden):
+    g = golden("g3_contrastive")
+    names = sorted({k.split("__")[0] for k in g})
+    assert len(names) >= 20
+    for name in names:
+        c = {k.split("__")[1]: v for k, v in g.items() if k.startswith(name + "__")}
+        f = torch.from_numpy(c["f"])
+        use_w = bool(c.get("use_w", False))
+        wts = dev(torch.from_numpy(c["wts"]).float()) if use_w else None
+        fh, inv = ops.l2norm_fwd(dev(f))
+        if name.startswith("regress"):
+            loss, Gm = ops.ct_loss_fwd(ops.CT_REGRESS, fh, labels_f=dev(torch.from_numpy(c["y"]).float().mean(1).contiguous()),
+                                       pred=dev(torch.from_numpy(c["yhat"]).float().mean(1).contiguous()), weights=wts,
+                                       w=float(c["w"]), e=0.01)
+        elif name.startswith("single"):
+            loss, Gm = ops.ct_loss_fwd(ops.CT_SINGLE, fh, labels_f=dev(torch.from_numpy(c["y"]).float().reshape(-1).contiguous()), weights=wts, e=0.2)
+        else:
+            loss, Gm = ops.ct_loss_fwd(ops.CT_MULTI, fh, labels_i=dev(torch.from_numpy(c["y"]).long().contiguous()), weights=wts, e=0.2)
+        df = ops.l2norm_bwd(ops.ct_loss_bwd(fh, Gm), fh, inv)
+        close(loss, torch.from_numpy(c["loss"]).reshape(1), 2e-4, 1e-6)
+        close(df, torch.from_numpy(c["df"]), 2e-3, 2e-6)
+
+
+# ------------------------------------------------------------------------------------------- FDS (golden G4)
+@pytest.mark.parametrize("tag", ["gauss51", "gauss52_bs2", "triang", "laplace"])
+def test_fds_golden(ops, golden, tag):
+    g = golden(f"g4_fds_{tag}")
+    bn, bs = int(g["cfg_bucket_num"]), int(g["cfg_bucket_start"])
+    mn, bw = float(g["min_value"]), float(g["bin_width"])
+    lab = torch.from_numpy(g["labels"])[:, 0].contiguous()
+    bins, flags = ops.fds_bins(dev(lab), mn, bw, bs, bn)
+    assert torch.equal(bins.cpu().long(), torch.from_numpy(g["label_bin"]).long())        # integer part: bit-exact
+    nb, D = bn - bs, 16
+    rm, rv, tr = torch.zeros(nb, D, device="cuda"), torch.ones(nb, D, device="cuda"), torch.zeros(nb, device="cuda")
+    feats0 = torch.from_numpy(g["feats0"])
+    ops.fds_update_stats(dev(feats0), bins, flags, bs, bn, 0.0, rm, rv, tr)              # epoch == start_update -> factor 0
+    close(rm, torch.from_numpy(g["s0_running_mean"]), 1e-4, 1e-5)
+    close(rv, torch.from_numpy(g["s0_running_var"]), 1e-4, 1e-5)
+    close(tr, torch.from_numpy(g["s0_num_samples_tracked"]), 0, 0)
+    win = dev(torch.from_numpy(g["window"]))
+    sm, sv = ops.fds_smooth_stats(rm, win), ops.fds_smooth_stats(rv, win)
+    close(sm, torch.from_numpy(g["s1_smoothed_mean_last_epoch"]), 1e-4, 1e-5)
+    close(sv, torch.from_numpy(g["s1_smoothed_var_last_epoch"]), 1e-4, 1e-5)
+    xb = torch.from_numpy(g["xb"])
+    b40, f40 = ops.fds_bins(dev(lab[:40].contiguous()), mn, bw, bs, bn)
+    y, sc = ops.fds_smooth(dev(xb), b40, f40, bs, bn, rm, rv, sm, sv)
+    close(y, torch.from_numpy(g["smooth1"]), 1e-4, 1e-4)
+    # second epoch: momentum 0.9
+    ops.fds_update_stats(dev(feats0 * 0.7 + 0.1), bins, flags, bs, bn, 0.9, rm, rv, tr)
+    close(rm, torch.from_numpy(g["s2_running_mean"]), 1e-4, 1e-5)
+    close(rv, torch.from_numpy(g["s2_running_var"]), 1e-4, 1e-5)
+    sm, sv = ops.fds_smooth_stats(rm, win), ops.fds_smooth_stats(rv, win)
+    y, sc = ops.fds_smooth(dev(xb), b40, f40, bs, bn, rm, rv, sm, sv)
+    close(y, torch.from_numpy(g["smooth2"]), 1e-4, 1e-4)
+    # d y / d x is the per-element scale
+    xr = xb.clone().requires_grad_()
+    fo = O.FDSOracle(D, mn, bw, bucket_num=bn, bucket_start=bs, kernel=str(g["cfg_kernel"]), ks=5, sigma=float(g["cfg_sigma"]))
+    fo.running_mean_last_epoch, fo.running_var_last_epoch = rm.cpu(), rv.cpu()
+    fo.smoothed_mean_last_epoch, fo.smoothed_var_last_epoch = sm.cpu(), sv.cpu()
+    fo.smooth(xr, torch.from_numpy(g["labels"])[:40], 5).sum().backward()
+    close(sc, xr.grad, 1e-4, 1e-5)
+
+
+def test_calibrate_branches_golden(ops, golden):
+    g = golden("g4_calibrate")
+    x = dev(torch.from_numpy(g["x"]))
+    bins = torch.zeros(6, device="cuda", dtype=torch.int32); flags = torch.ones(2, device="cuda", dtype=torch.int32)
+    st = lambda k: dev(torch.from_numpy(g[k]).reshape(1, 8))
+    for v1k, outk in (("v1", "out_full"), ("v1z", "out_part")):
+        y, _ = ops.fds_smooth(x, bins, flags, 0, 1, st("m1"), st(v1k), st("m2"), st("v2"))
+        close(y, torch.from_numpy(g[outk]), 1e-5, 1e-6)
+    y, _ = ops.fds_smooth(x, bins, flags, 0, 1, st("m1"), dev(torch.zeros(1, 8)), st("m2"), st("v2"))
+    close(y, torch.from_numpy(g["out_tiny"]), 0, 0)
+
+
+# ------------------------------------------------------------------------------------------- pooling / head / losses / adam
+def test_masked_pool(ops):
+    B, Na, Nt, D = 3, 7, 11, 64
+    a, t = torch.randn(B, Na, D, generator=G(1)), torch.randn(B, Nt, D, generator=G(2))
+    ma = torch.ones(B, Na, dtype=torch.bool); ma[0, 4:] = False
+    mt = torch.ones(B, Nt, dtype=torch.bool); mt[1, 6:] = False
+    ar, tr_ = a.clone().requires_grad_(), t.clone().requires_grad_()
+    ref = (torch.cat((ar * ma.unsqueeze(-1), tr_ * mt.unsqueeze(-1)), 1)).sum(1) / (ma.sum(1) + mt.sum(1)).view(-1, 1)
+    out = ops.masked_pool_fwd(dev(a), dev(t), dev(ma).view(torch.uint8), dev(mt).view(torch.uint8))
+    close(out, ref, 1e-5, 1e-6)
+    dp = torch.randn(B, D, generator=G(3))
+    (ref * dp).sum().backward()
+    da, dt = ops.masked_pool_bwd(dev(dp), dev(ma).view(torch.uint8), dev(mt).view(torch.uint8), Na, Nt)
+    close(da, ar.grad, 1e-5, 1e-6); close(dt, tr_.grad, 1e-5, 1e-6)
+
+
+def test_head_and_losses(ops):
+    B, D = 37, 64
+    x = torch.randn(B, D, generator=G(1))
+    P = {"classification_head.dense.weight": torch.randn(D, D, generator=G(2)) * 0.1, "classification_head.dense.bias": torch.randn(D, generator=G(3)) * 0.1,
+         "classification_head.out_proj.weight": torch.randn(2, D, generator=G(4)) * 0.1, "classification_head.out_proj.bias": torch.randn(2, generator=G(5)) * 0.1}
+    P = {k: v.requires_grad_() for k, v in P.items()}
+    xr = x.clone().requires_grad_()
+    logits = O.classification_head(xr, P)
+    tgt = torch.randint(0, 2, (B, 1), generator=G(6))
+    loss = O.task_loss(logits, tgt, "classification")
+    loss.backward()
+    w1, b1, w2, b2 = (dev(P[k].detach()) for k in P)
+    h = ops.linear_f32_fwd(dev(x), w1, b1, act=ops.ACT_TANH)
+    lg = ops.linear_f32_fwd(h, w2, b2)
+    close(lg, logits, 1e-5, 1e-6)
+    l, dl = ops.ce_loss(lg, dev(tgt.flatten()))
+    close(l, loss.reshape(1), 1e-5, 1e-6)
+    dw2, db2, dw1, db1 = (torch.zeros_like(t) for t in (w2, b2, w1, b1))
+    dh = ops.linear_f32_bwd(h, w2, lg, dl, dw2, db2)
+    dx = ops.linear_f32_bwd(dev(x), w1, h, dh, dw1, db1, act=ops.ACT_TANH)
+    close(dx, xr.grad, 1e-4, 1e-7)
+    for got, k in ((dw1, "dense.weight"), (db1, "dense.bias"), (dw2, "out_proj.weight"), (db2, "out_proj.bias")):
+        close(got, P["classification_head." + k].grad, 1e-4, 1e-7)
+    pred, tg = torch.randn(B, 1, generator=G(7)), torch.randn(B, 1, generator=G(8))
+    l, d = ops.mse_loss(dev(pred), dev(tg))
+    close(l, torch.nn.functional.mse_loss(pred, tg).reshape(1), 1e-5, 1e-6)
+    close(d, 2 * (pred - tg) / B, 1e-5, 1e-7)
+
+
+def test_adam_matches_torch(ops):
+    n = 1000
+    p0, g = torch.randn(n, generator=G(1)), torch.randn(n, generator=G(2))
+    pr = p0.clone().requires_grad_()
+    opt = torch.optim.Adam([pr], lr=1e-3, eps=1e-6)
+    p, m, v = dev(p0.clone()), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    pb = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+    for step in (1, 2, 3):
+        pr.grad = g * step
+        opt.step()
+        ops.adam_step(p, dev(g * step), m, v, pb, 1e-3, 0.9, 0.999, 1e-6, 0.0, step)
+    close(p, pr.detach(), 1e-5, 1e-6)
+    close(pb, rt(p.cpu()), 0, 0)
+    ss = torch.zeros(1, device="cuda")
+    ops.sumsq(dev(g), ss)
+    close(ss, (g * g).sum().reshape(1), 1e-5, 1e-5)
+
+
+def test_colsum_and_casts(ops):
+    x = rt(torch.randn(333, 200, generator=G(1)))
+    out = torch.zeros(200, device="cuda")
+    ops.colsum(dev(bf(x)), out)
+    close(out, x.sum(0), 1e-4, 1e-3)
+    y = torch.randn(1027, generator=G(2))
+    close(ops.cast_bf16(dev(y)), rt(y), 0, 0)
+    close(ops.cast_f32(dev(bf(y))), rt(y), 0, 0)
+    d = ops.dropout_f32(dev(torch.ones(100000)), 0.3, 11, 2).cpu()
+    assert abs((d != 0).float().mean().item() - 0.7) < 0.01
+
+
+def test_probe_tr_read_semantics(ops):
+    """ds_read_b64_tr_b16: lane i of a 16-lane group receives column i of a 4x16 block (rows q=0..3 in elements 0..3)."""
+    stride = 64
+    out = ops.probe_tr_read(stride).cpu().view(64, 4).long()
+    for lane in range(64):
+        g, i = lane // 16, lane % 16
+        exp = [(4 * g + q) * stride + i for q in range(4)]
+        assert out[lane].tolist() == exp, (lane, out[lane].tolist(), exp)
