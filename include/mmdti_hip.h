@@ -69,8 +69,10 @@ int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void* B, void* C
 int mmdti_layernorm_fwd(mmdti_stream_t stream, const float* x, const float* gamma, const float* beta, float eps,
                         int rows, int D, float* y_f32, void* y_bf16, float* mean, float* rstd,
                         const unsigned char* row_zero, float drop_p, unsigned long long seed, unsigned int site);
-/* dx = dres + LN'(dy) ; dgamma/dbeta atomic accumulate.  dy is fp32 (dy_dtype=MMDTI_DT_F32) or bf16. */
-int mmdti_layernorm_bwd(mmdti_stream_t stream, const void* dy, int dy_dtype, const float* x, const float* gamma,
+/* dx = dres + LN'(dy + dy_add) ; dgamma/dbeta atomic accumulate.  dy is fp32 (dy_dtype=MMDTI_DT_F32) or bf16;
+ * dy_add (fp32, nullable) is a second upstream gradient of the LN OUTPUT (post-LN residual: a = LN(y) feeds both the FFN
+ * and the next residual add); dres (fp32, nullable) is a gradient of the LN INPUT that bypasses the LN (pre-LN residual). */
+int mmdti_layernorm_bwd(mmdti_stream_t stream, const void* dy, int dy_dtype, const float* dy_add, const float* x, const float* gamma,
                         const float* mean, const float* rstd, int rows, int D, const float* dres, float* dx,
                         float* dgamma, float* dbeta, const unsigned char* row_zero, float drop_p,
                         unsigned long long seed, unsigned int site);

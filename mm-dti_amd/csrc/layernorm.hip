@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 constexpr int LN_BWD_ROWS_PER_WAVE = 8;
 
 template <int NV, bool DY_BF16>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ dy_add,
+                                                     const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, int rows, int D,
                                                      const float* __restrict__ dres, float* __restrict__ dx,
@@ -108,6 +109,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
       } else {
         float4 t = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dy_) + (long long)row * D)[c];
         d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+      }
+      if (dy_add) {
+        float4 t = reinterpret_cast<const float4*>(dy_add + (long long)row * D)[c];
+        d[0] += t.x; d[1] += t.y; d[2] += t.z; d[3] += t.w;
       }
       if (thresh) {
         Rand4 r = philox4(seed, site, ((uint64_t)row * D + (uint64_t)c * 4) >> 2);
@@ -189,7 +194,7 @@ extern "C" int mmdti_layernorm_fwd(mmdti_stream_t stream, const float* x, const 
   return MMDTI_OK;
 }
 
-extern "C" int mmdti_layernorm_bwd(mmdti_stream_t stream, const void* dy, int dy_dtype, const float* x,
+extern "C" int mmdti_layernorm_bwd(mmdti_stream_t stream, const void* dy, int dy_dtype, const float* dy_add, const float* x,
                                    const float* gamma, const float* mean, const float* rstd, int rows, int D,
                                    const float* dres, float* dx, float* dgamma, float* dbeta,
                                    const unsigned char* row_zero, float drop_p, unsigned long long seed,
@@ -204,7 +209,7 @@ extern "C" int mmdti_layernorm_bwd(mmdti_stream_t stream, const void* dy, int dy
   const size_t smem = 8 * (size_t)D * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
 #define LN_B(NV, BF)                                                                                               \
-  hipLaunchKernelGGL((ln_bwd_kernel<NV, BF>), grid, block, smem, s, dy, x, gamma, mean, rstd, rows, D, dres, dx,  \
+  hipLaunchKernelGGL((ln_bwd_kernel<NV, BF>), grid, block, smem, s, dy, dy_add, x, gamma, mean, rstd, rows, D, dres, dx,  \
                      dgamma, dbeta, row_zero, th, sc, (uint64_t)seed, (uint32_t)site)
   const bool bf = dy_dtype == MMDTI_DT_BF16;
   switch (ln_nv(D)) {

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void fds_smooth_kernel(const float* __restrict
   }
 }
 
-// block per bucket, thread per feature column (strided); two passes like torch.mean / torch.var
+// block per bucket, thread per feature column (strided)
 __global__ __launch_bounds__(256) void fds_update_kernel(const float* __restrict__ f, const int* __restrict__ bins, const int* __restrict__ flags,
                                                          int n, int D, int bs, int bn, float factor, float* __restrict__ rmean,
                                                          float* __restrict__ rvar, float* __restrict__ tracked) {
@@ -272,15 +272,20 @@ __global__ __launch_bounds__(256) void fds_update_kernel(const float* __restrict
   __syncthreads();
   const int cnt = s_cnt;
   if (s_exact == 0 || cnt == 0) return;  // bucket not in torch.unique(label_bin): untouched
+  // Welford, like ATen's var kernel: a constant column yields EXACTLY zero variance, which calibrate_mean_var's
+  // `v1 == 0` test (utils/util.py:162) depends on.
   for (int d = threadIdx.x; d < D; d += 256) {
-    float s = 0.f;
-    for (int i = 0; i < n; ++i)
-      if (fds_eff_bucket(bins[i], bs, bn, flags) == bucket) s += f[(long long)i * D + d];
-    const float mean = s / (float)cnt;
-    float q = 0.f;
-    for (int i = 0; i < n; ++i)
-      if (fds_eff_bucket(bins[i], bs, bn, flags) == bucket) { float t = f[(long long)i * D + d] - mean; q += t * t; }
-    const float var = cnt > 1 ? q / (float)(cnt - 1) : q / (float)cnt;
+    float mean = 0.f, m2 = 0.f;
+    int k = 0;
+    for (int i = 0; i < n; ++i) {
+      if (fds_eff_bucket(bins[i], bs, bn, flags) != bucket) continue;
+      const float xv = f[(long long)i * D + d];
+      ++k;
+      const float delta = xv - mean;
+      mean += delta / (float)k;
+      m2 += delta * (xv - mean);
+    }
+    const float var = cnt > 1 ? m2 / (float)(cnt - 1) : m2 / (float)cnt;
     const long long o = (long long)blockIdx.x * D + d;
     rmean[o] = (1.f - factor) * mean + factor * rmean[o];
     rvar[o] = (1.f - factor) * var + factor * rvar[o];

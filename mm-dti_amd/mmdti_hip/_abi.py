@@ -8,6 +8,11 @@ import ctypes
 import os
 import re
 
+# torch must load ITS bundled HIP runtime (torch/lib/libamdhip64.so) before libmmdti_hip.so is dlopen'ed: both have the
+# same SONAME, and the first one loaded serves the whole process.  Loading the system copy first leaves torch and the
+# kernels on different runtimes ("no ROCm-capable device is detected").
+import torch  # noqa: F401  (plumbing: device memory + streams)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(os.path.dirname(_HERE))
 HEADER = os.path.join(REPO_ROOT, "include", "mmdti_hip.h")

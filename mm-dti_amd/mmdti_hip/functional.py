@@ -1,0 +1,586 @@
+"""Module-level forward+backward of the fine-tune step, hand-scheduled over the C-ABI kernels.
+
+Each ``torch.autograd.Function`` below is ONE node in the autograd graph for a whole reference module (15-layer
+pair-bias encoder, RoBERTa tower, cross-modal block, InfoNCE head, ...).  Forward launches the kernels and keeps the
+activations the backward needs; backward launches the gradient kernels in reverse order.  Weight gradients are
+accumulated by the kernels straight into ``param.grad`` (views of the gradient arena), so autograd only carries the
+activation gradients between modules.  torch is plumbing here (memory, streams, graph edges) -- no ATen math.
+
+Precision contract (matches ``oracle.mmdti_oracle`` with ``bf16=True``): GEMM operands bf16, accumulation fp32, residual
+stream / LayerNorm statistics / softmax / pair-bias chain S fp32, q|k|v and attention probabilities stored bf16.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import List, Optional
+
+import torch
+
+from . import ops
+from .ops import BF16, F32
+from .runtime import wbf16, gbuf, dropout_state, notify_grads_ready
+
+
+# ------------------------------------------------------------------------------------------------- helpers
+def _lin_bwd_params(dy_bf16, x_bf16, weight, bias, rows=None):
+    """dW += dy^T x ; db += colsum(dy)   (atomic accumulation into param.grad)."""
+    gw = gbuf(weight)
+    if gw is not None:
+        ops.linear_bwd_weight(dy_bf16, x_bf16, gw, rows=rows)
+    if bias is not None:
+        gb = gbuf(bias)
+        if gb is not None:
+            ops.colsum(dy_bf16, gb, cols=bias.numel())
+
+
+class _Sites:
+    """Dropout site numbering inside one forward call."""
+
+    def __init__(self):
+        self.n = 0
+
+    def next(self):
+        self.n += 1
+        return self.n
+
+
+# ------------------------------------------------------------------------------------------------- Uni-Mol pair encoder
+class PairEncoderFn(torch.autograd.Function):
+    """TransformerEncoderWithPair.forward (models/transformers.py:96-183) minus the discarded aux outputs:
+    emb-LN -> dropout -> zero padded rows -> L x [pre-LN pair-bias attention + FFN, S chained] -> final LN.
+
+    inputs : emb [B,N,D] fp32, bias [B,H,N,ld] fp32 (ld >= N; standard layout is ld == N), padding_mask [B,N] bool|None
+    outputs: x [B,N,D] fp32, S_last [B,H,N,ld] fp32 (pre-softmax logits of the last layer, -inf at padded keys),
+             x_pre [B,N,D] fp32 (stream before the final LN; only the discarded x_norm aux output reads it)
+    """
+
+    @staticmethod
+    def forward(ctx, emb, bias, padding_mask, mod, training):
+        B, N, D = emb.shape
+        H = mod.attention_heads
+        ld = bias.shape[-1]
+        M = B * N
+        p_emb = mod.emb_dropout if training else 0.0
+        p_res = mod.dropout if training else 0.0
+        p_att = mod.attention_dropout if training else 0.0
+        seed = dropout_state.next_seed()
+        sites = _Sites()
+        st = SimpleNamespace(B=B, N=N, D=D, H=H, ld=ld, M=M, seed=seed, p_emb=p_emb, p_res=p_res, p_att=p_att, layers=[])
+        emb = emb.contiguous()
+        st.emb = emb
+        st.pad = padding_mask
+        st.site_emb = sites.next()
+        eln = mod.emb_layer_norm
+        x, _, st.emb_mean, st.emb_rstd = ops.layernorm_fwd(emb.view(M, D), eln.weight, eln.bias, eln.eps, want_f32=True, want_bf16=False,
+                                                           row_zero=None if padding_mask is None else padding_mask.reshape(-1),
+                                                           drop_p=p_emb, seed=seed, site=st.site_emb)
+        scale = (D // H) ** -0.5
+        s_prev = bias.contiguous()
+        for li, layer in enumerate(mod.layers):
+            L = SimpleNamespace(x=x)
+            ln1, ln2 = layer.self_attn_layer_norm, layer.final_layer_norm
+            att = layer.self_attn
+            _, L.h1, L.m1, L.r1 = ops.layernorm_fwd(x, ln1.weight, ln1.bias, ln1.eps)
+            L.qkv = ops.linear_fwd(L.h1, wbf16(att.in_proj.weight), att.in_proj.bias)
+            L.site_att = sites.next()
+            L.s, L.o = ops.pair_attn_fwd(L.qkv, s_prev, padding_mask if li == 0 else None, B, N, H, ld, scale, p_att, seed, L.site_att)
+            s_prev = L.s
+            L.site_o = sites.next()
+            L.x1 = ops.linear_fwd(L.o, wbf16(att.out_proj.weight), att.out_proj.bias, residual=x, out_dtype=F32, drop_p=p_res, seed=seed, site=L.site_o)
+            _, L.h2, L.m2, L.r2 = ops.layernorm_fwd(L.x1, ln2.weight, ln2.bias, ln2.eps)
+            L.u = torch.empty(M, layer.fc1.weight.shape[0], device=emb.device, dtype=BF16)
+            L.a = ops.linear_fwd(L.h2, wbf16(layer.fc1.weight), layer.fc1.bias, act=ops.ACT_GELU, aux_out=L.u)
+            L.site_f = sites.next()
+            x = ops.linear_fwd(L.a, wbf16(layer.fc2.weight), layer.fc2.bias, residual=L.x1, out_dtype=F32, drop_p=p_res, seed=seed, site=L.site_f)
+            st.layers.append(L)
+        st.x_last = x
+        if mod.final_layer_norm is not None:
+            fl = mod.final_layer_norm
+            out, _, st.f_mean, st.f_rstd = ops.layernorm_fwd(x, fl.weight, fl.bias, fl.eps, want_f32=True, want_bf16=False)
+        else:
+            out = x
+        ctx.st, ctx.mod = st, mod
+        x_last = x.view(B, N, D)
+        ctx.mark_non_differentiable(s_prev, x_last)
+        return out.view(B, N, D), s_prev, x_last
+
+    @staticmethod
+    def backward(ctx, dout, _ds_unused, _dx_unused):
+        st, mod = ctx.st, ctx.mod
+        B, N, D, H, ld, M, seed = st.B, st.N, st.D, st.H, st.ld, st.M, st.seed
+        scale = (D // H) ** -0.5
+        dout = dout.contiguous().view(M, D)
+        if mod.final_layer_norm is not None:
+            fl = mod.final_layer_norm
+            dx = ops.layernorm_bwd(dout, st.x_last, fl.weight, st.f_mean, st.f_rstd, gbuf(fl.weight), gbuf(fl.bias))
+        else:
+            dx = dout
+        G = None
+        for layer, L in zip(reversed(mod.layers), reversed(st.layers)):
+            att, ln1, ln2 = layer.self_attn, layer.self_attn_layer_norm, layer.final_layer_norm
+            # ---- FFN:  x2 = x1 + drop(fc2(gelu(fc1(LN2(x1)))))
+            dy2 = ops.cast_bf16(dx, st.p_res, seed, L.site_f)
+            _lin_bwd_params(dy2, L.a, layer.fc2.weight, layer.fc2.bias)
+            du = ops.linear_bwd_input(dy2, wbf16(layer.fc2.weight), act=ops.ACT_GELU_BWD, aux_in=L.u)
+            _lin_bwd_params(du, L.h2, layer.fc1.weight, layer.fc1.bias)
+            dh2 = ops.linear_bwd_input(du, wbf16(layer.fc1.weight))
+            dx = ops.layernorm_bwd(dh2, L.x1, ln2.weight, L.m2, L.r2, gbuf(ln2.weight), gbuf(ln2.bias), dres=dx)
+            # ---- attention:  x1 = x + drop(out_proj(attn(LN1(x))))
+            dy1 = ops.cast_bf16(dx, st.p_res, seed, L.site_o)
+            _lin_bwd_params(dy1, L.o, att.out_proj.weight, att.out_proj.bias)
+            do = ops.linear_bwd_input(dy1, wbf16(att.out_proj.weight))
+            g_zero = G is None
+            if g_zero:
+                G = torch.empty(B, H, N, ld, device=dout.device, dtype=F32)
+            dqkv = ops.pair_attn_bwd(L.qkv, L.s, do, G, B, N, H, ld, scale, g_zero, st.p_att, seed, L.site_att)
+            _lin_bwd_params(dqkv, L.h1, att.in_proj.weight, att.in_proj.bias)
+            dh1 = ops.linear_bwd_input(dqkv, wbf16(att.in_proj.weight))
+            dx = ops.layernorm_bwd(dh1, L.x, ln1.weight, L.m1, L.r1, gbuf(ln1.weight), gbuf(ln1.bias), dres=dx)
+            L.__dict__.clear()       # release this layer's activations (S_l is ~1 GB at the bench shape)
+            notify_grads_ready(layer.parameters())
+        eln = mod.emb_layer_norm
+        demb = ops.layernorm_bwd(dx, st.emb.view(M, D), eln.weight, st.emb_mean, st.emb_rstd, gbuf(eln.weight), gbuf(eln.bias),
+                                 row_zero=None if st.pad is None else st.pad.reshape(-1), drop_p=st.p_emb, seed=seed, site=st.site_emb)
+        notify_grads_ready(list(eln.parameters()) + ([] if mod.final_layer_norm is None else list(mod.final_layer_norm.parameters())))
+        if G is None:
+            G = torch.zeros(B, H, N, ld, device=dout.device, dtype=F32)
+        return demb.view(B, N, D), G, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------- Gaussian pair bias
+class PairBiasFn(torch.autograd.Function):
+    """gbf -> gbf_proj -> permute (models/mm_model.py:553-556): (dist [B,N,N] f32, edge_type [B,N,N] i64) ->
+    bias [B,H,N,ld] fp32."""
+
+    @staticmethod
+    def forward(ctx, anchor, dist, edge_type, gbf, proj, ld):
+        B, N, _ = dist.shape
+        H = proj.linear2.weight.shape[0]
+        dist, edge_type = dist.contiguous(), edge_type.contiguous()
+        args = [gbf.mul.weight.view(-1), gbf.bias.weight.view(-1), gbf.means.weight.view(-1), gbf.stds.weight.view(-1)]
+        feat = ops.gbf_features_fwd(dist, edge_type, *args)
+        u = torch.empty(feat.shape[0], proj.linear1.weight.shape[0], device=dist.device, dtype=BF16)
+        h = ops.linear_fwd(feat, wbf16(proj.linear1.weight), proj.linear1.bias, act=ops.ACT_GELU, aux_out=u)
+        o = ops.linear_fwd(h, wbf16(proj.linear2.weight), proj.linear2.bias, out_dtype=F32)
+        out = ops.pair_permute_fwd(o, B, N, H, ld)
+        ctx.st = SimpleNamespace(dist=dist, et=edge_type, feat=feat, u=u, h=h, B=B, N=N, H=H, ld=ld)
+        ctx.gbf, ctx.proj = gbf, proj
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        st, gbf, proj = ctx.st, ctx.gbf, ctx.proj
+        do = ops.pair_permute_bwd(g.contiguous(), st.B, st.N, st.H, st.ld)          # [P,H] bf16
+        _lin_bwd_params(do, st.h, proj.linear2.weight, proj.linear2.bias)
+        du = ops.linear_bwd_input(do, wbf16(proj.linear2.weight), act=ops.ACT_GELU_BWD, aux_in=st.u)
+        _lin_bwd_params(du, st.feat, proj.linear1.weight, proj.linear1.bias)
+        dfeat = ops.linear_bwd_input(du, wbf16(proj.linear1.weight))
+        ps = [gbf.mul.weight, gbf.bias.weight, gbf.means.weight, gbf.stds.weight]
+        if any(p.requires_grad for p in ps):
+            grads = [gbuf(p) if p.requires_grad else torch.zeros_like(p) for p in ps]
+            ops.gbf_features_bwd(st.dist, st.et, *[p.view(-1) for p in ps], dfeat, *[gr.view(-1) for gr in grads])
+        notify_grads_ready(list(gbf.parameters()) + list(proj.parameters()))
+        return None, None, None, None, None, None
+
+
+class EmbeddingFn(torch.autograd.Function):
+    """nn.Embedding with padding_idx (mm_model.py:439-441,552)."""
+
+    @staticmethod
+    def forward(ctx, weight, ids, padding_idx):
+        ctx.ids, ctx.w, ctx.pad = ids.contiguous(), weight, -1 if padding_idx is None else padding_idx
+        return ops.embedding_fwd(ctx.ids, weight)
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = gbuf(ctx.w)
+        if g is not None:
+            ops.embedding_bwd(ctx.ids, dout.contiguous(), g, ctx.pad)
+        notify_grads_ready([ctx.w])
+        return None, None, None
+
+
+# ------------------------------------------------------------------------------------------------- BERT-style layer
+def _bert_layer_fwd(st, s1_32, s1_16, s2_16, key_add, W, heads, p_hid, p_att, eps, seed, sites, self_attn):
+    """Post-LN BERT layer with query from s1 and key/value from s2 (HF RobertaLayer; BertCrossAttentionLayer
+    mm_module.py:615-626).  s1_32: [B*Lq,D] fp32; s1_16/s2_16 bf16; key_add [B,Lk] fp32.  Returns (out32, out16)."""
+    B, Lq, Lk, D = st.B, st.Lq, st.Lk, st.D
+    hd = D // heads
+    ld = (Lk + 7) // 8 * 8
+    L = SimpleNamespace(s1_16=s1_16, s2_16=s2_16, ld=ld, heads=heads, self_attn=self_attn, W=W, eps=eps)
+    L.q = ops.linear_fwd(s1_16, wbf16(W.q_w), W.q_b)
+    L.k = ops.linear_fwd(s2_16, wbf16(W.k_w), W.k_b)
+    L.v = ops.linear_fwd(s2_16, wbf16(W.v_w), W.v_b)
+    S = torch.empty(B, heads, Lq, ld, device=s1_32.device, dtype=F32)
+    ops.gemm(L.q, L.k, M=Lq, N=Lk, K=hd, lda=D, ldb=D, out=S, ldc=ld, batch=(B, heads), sA=(Lq * D, hd), sB=(Lk * D, hd),
+             sC=(heads * Lq * ld, Lq * ld), alpha=1.0 / math.sqrt(hd))
+    L.site_att = sites.next()
+    L.p, L.pd = ops.softmax_fwd(S, key_add, B, heads, Lq, Lk, ld, p_att, seed, L.site_att)
+    del S
+    L.ctx = torch.empty(B * Lq, D, device=s1_32.device, dtype=BF16)
+    ops.gemm(L.pd, L.v, M=Lq, N=hd, K=Lk, lda=ld, ldb=D, transB=True, out=L.ctx, ldc=D, batch=(B, heads),
+             sA=(heads * Lq * ld, Lq * ld), sB=(Lk * D, hd), sC=(Lq * D, hd))
+    L.site_o = sites.next()
+    L.y = ops.linear_fwd(L.ctx, wbf16(W.o_w), W.o_b, residual=s1_32, out_dtype=F32, drop_p=p_hid, seed=seed, site=L.site_o)
+    L.a32, L.a16, L.am, L.ar = ops.layernorm_fwd(L.y, W.ln1_w, W.ln1_b, eps, want_f32=True, want_bf16=True)
+    L.u = torch.empty(B * Lq, W.i_w.shape[0], device=s1_32.device, dtype=BF16)
+    L.i = ops.linear_fwd(L.a16, wbf16(W.i_w), W.i_b, act=ops.ACT_GELU, aux_out=L.u)
+    L.site_f = sites.next()
+    L.z = ops.linear_fwd(L.i, wbf16(W.o2_w), W.o2_b, residual=L.a32, out_dtype=F32, drop_p=p_hid, seed=seed, site=L.site_f)
+    out32, out16, L.zm, L.zr = ops.layernorm_fwd(L.z, W.ln2_w, W.ln2_b, eps, want_f32=True, want_bf16=True)
+    L.p_hid, L.p_att = p_hid, p_att
+    return L, out32, out16
+
+
+def _bert_layer_bwd(st, L, dout, seed):
+    """-> (ds1 fp32 [B*Lq,D], ds2 fp32 [B*Lk,D] or None when self_attn (then ds1 holds the sum))."""
+    B, Lq, Lk, D = st.B, st.Lq, st.Lk, st.D
+    W, heads, ld = L.W, L.heads, L.ld
+    hd = D // heads
+    dz = ops.layernorm_bwd(dout, L.z, W.ln2_w, L.zm, L.zr, gbuf(W.ln2_w), gbuf(W.ln2_b))
+    dzb = ops.cast_bf16(dz, L.p_hid, seed, L.site_f)
+    _lin_bwd_params(dzb, L.i, W.o2_w, W.o2_b)
+    du = ops.linear_bwd_input(dzb, wbf16(W.o2_w), act=ops.ACT_GELU_BWD, aux_in=L.u)
+    _lin_bwd_params(du, L.a16, W.i_w, W.i_b)
+    da = ops.linear_bwd_input(du, wbf16(W.i_w))
+    # a32 = LN1(y) feeds the FFN AND the residual add of z: both gradients go through LN1's backward
+    dy = ops.layernorm_bwd(da, L.y, W.ln1_w, L.am, L.ar, gbuf(W.ln1_w), gbuf(W.ln1_b), dy_add=dz)
+    dyb = ops.cast_bf16(dy, L.p_hid, seed, L.site_o)
+    _lin_bwd_params(dyb, L.ctx, W.o_w, W.o_b)
+    dctx = ops.linear_bwd_input(dyb, wbf16(W.o_w))
+    dev = dout.device
+    dP = torch.empty(B, heads, Lq, ld, device=dev, dtype=F32)
+    ops.gemm(dctx, L.v, M=Lq, N=Lk, K=hd, lda=D, ldb=D, out=dP, ldc=ld, batch=(B, heads), sA=(Lq * D, hd), sB=(Lk * D, hd),
+             sC=(heads * Lq * ld, Lq * ld))
+    dv = torch.empty(B * Lk, D, device=dev, dtype=BF16)
+    ops.gemm(L.pd, dctx, M=Lk, N=hd, K=Lq, lda=ld, ldb=D, transA=True, transB=True, out=dv, ldc=D, batch=(B, heads),
+             sA=(heads * Lq * ld, Lq * ld), sB=(Lq * D, hd), sC=(Lk * D, hd))
+    dS = ops.softmax_bwd(L.p, dP, B, heads, Lq, Lk, ld, 1.0 / math.sqrt(hd), L.p_att, seed, L.site_att)
+    del dP
+    dq = torch.empty(B * Lq, D, device=dev, dtype=BF16)
+    ops.gemm(dS, L.k, M=Lq, N=hd, K=Lk, lda=ld, ldb=D, transB=True, out=dq, ldc=D, batch=(B, heads),
+             sA=(heads * Lq * ld, Lq * ld), sB=(Lk * D, hd), sC=(Lq * D, hd))
+    dk = torch.empty(B * Lk, D, device=dev, dtype=BF16)
+    ops.gemm(dS, L.q, M=Lk, N=hd, K=Lq, lda=ld, ldb=D, transA=True, transB=True, out=dk, ldc=D, batch=(B, heads),
+             sA=(heads * Lq * ld, Lq * ld), sB=(Lq * D, hd), sC=(Lk * D, hd))
+    _lin_bwd_params(dq, L.s1_16, W.q_w, W.q_b)
+    _lin_bwd_params(dk, L.s2_16, W.k_w, W.k_b)
+    _lin_bwd_params(dv, L.s2_16, W.v_w, W.v_b)
+    # ds1 = dy (residual) + dq.Wq ; ds2 = dk.Wk + dv.Wv     (fp32, accumulated by the GEMM's beta=1 epilogue)
+    ds1 = dy
+    ops.gemm(dq, wbf16(W.q_w), M=B * Lq, N=D, K=D, lda=D, ldb=D, transB=True, out=ds1, ldc=D, beta=1.0)
+    if L.self_attn:
+        ops.gemm(dk, wbf16(W.k_w), M=B * Lk, N=D, K=D, lda=D, ldb=D, transB=True, out=ds1, ldc=D, beta=1.0)
+        ops.gemm(dv, wbf16(W.v_w), M=B * Lk, N=D, K=D, lda=D, ldb=D, transB=True, out=ds1, ldc=D, beta=1.0)
+        return ds1, None
+    ds2 = ops.gemm(dk, wbf16(W.k_w), M=B * Lk, N=D, K=D, lda=D, ldb=D, transB=True, out_dtype=F32)
+    ops.gemm(dv, wbf16(W.v_w), M=B * Lk, N=D, K=D, lda=D, ldb=D, transB=True, out=ds2, ldc=D, beta=1.0)
+    return ds1, ds2
+
+
+def bert_weights(layer) -> SimpleNamespace:
+    """Parameter view of an HF RobertaLayer / mm_module BertCrossAttentionLayer (identical sub-module names)."""
+    a, o = layer.attention.self, layer.attention.output
+    return SimpleNamespace(q_w=a.query.weight, q_b=a.query.bias, k_w=a.key.weight, k_b=a.key.bias, v_w=a.value.weight, v_b=a.value.bias,
+                           o_w=o.dense.weight, o_b=o.dense.bias, ln1_w=o.LayerNorm.weight, ln1_b=o.LayerNorm.bias,
+                           i_w=layer.intermediate.dense.weight, i_b=layer.intermediate.dense.bias,
+                           o2_w=layer.output.dense.weight, o2_b=layer.output.dense.bias,
+                           ln2_w=layer.output.LayerNorm.weight, ln2_b=layer.output.LayerNorm.bias)
+
+
+class RobertaEncoderFn(torch.autograd.Function):
+    """self.bert(input_ids, attention_mask)[0]  (mm_model.py:562): embeddings + L post-LN layers.
+    `mod` exposes: word/position/token_type embedding weights, emb LayerNorm, layers, cfg (heads, eps, dropouts, pad)."""
+
+    @staticmethod
+    def forward(ctx, anchor, input_ids, attention_mask, mod, training):
+        B, Lq = input_ids.shape
+        cfg = mod.cfg
+        D = mod.word.shape[1]
+        seed = dropout_state.next_seed()
+        sites = _Sites()
+        p_hid = cfg.hidden_dropout if training else 0.0
+        p_att = cfg.attn_dropout if training else 0.0
+        ids = input_ids.contiguous()
+        pos = ops.roberta_position_ids(ids, cfg.pad_idx)
+        e = ops.embedding_fwd(ids, mod.word)
+        ops.embedding_fwd(pos, mod.position, out=e, accumulate=True)
+        zeros = torch.zeros_like(ids)
+        ops.embedding_fwd(zeros, mod.token_type, out=e, accumulate=True)
+        st = SimpleNamespace(B=B, Lq=Lq, Lk=Lq, D=D, seed=seed, ids=ids, pos=pos, zeros=zeros, e=e, layers=[], p_hid=p_hid)
+        st.site_emb = sites.next()
+        x32, x16, st.em, st.er = ops.layernorm_fwd(e.view(B * Lq, D), mod.emb_ln_w, mod.emb_ln_b, cfg.ln_eps, want_f32=True, want_bf16=True,
+                                                   drop_p=p_hid, seed=seed, site=st.site_emb)
+        key_add = ((1.0 - attention_mask.to(F32)) * torch.finfo(torch.float32).min).contiguous()
+        for layer in mod.layers:
+            L, x32, x16 = _bert_layer_fwd(st, x32, x16, x16, key_add, bert_weights(layer), cfg.heads, p_hid, p_att, cfg.ln_eps, seed, sites, True)
+            st.layers.append(L)
+        ctx.st, ctx.mod = st, mod
+        return x32.view(B, Lq, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        st, mod = ctx.st, ctx.mod
+        B, Lq, D = st.B, st.Lq, st.D
+        dx = dout.contiguous().view(B * Lq, D)
+        for layer, L in zip(reversed(list(mod.layers)), reversed(st.layers)):
+            dx, _ = _bert_layer_bwd(st, L, dx, st.seed)
+            L.__dict__.clear()
+            notify_grads_ready(layer.parameters())
+        de = ops.layernorm_bwd(dx, st.e.view(B * Lq, D), mod.emb_ln_w, st.em, st.er, gbuf(mod.emb_ln_w), gbuf(mod.emb_ln_b),
+                               drop_p=st.p_hid, seed=st.seed, site=st.site_emb)
+        cfg = mod.cfg
+        for ids, w, pad in ((st.ids, mod.word, cfg.pad_idx), (st.pos, mod.position, cfg.pad_idx), (st.zeros, mod.token_type, -1)):
+            g = gbuf(w)
+            if g is not None:
+                ops.embedding_bwd(ids, de, g, pad)
+        notify_grads_ready(mod.embeddings.parameters())
+        return None, None, None, None, None
+
+
+class CrossLayerFn(torch.autograd.Function):
+    """One BertCrossEncoder layer (mm_module.py:663-677, :615-626): s1 attends to s2 under an additive key mask."""
+
+    @staticmethod
+    def forward(ctx, s1, s2, key_add, layer, cfg, training):
+        B, Lq, D = s1.shape
+        Lk = s2.shape[1]
+        seed = dropout_state.next_seed()
+        sites = _Sites()
+        p_hid = cfg.hidden_dropout if training else 0.0
+        p_att = cfg.attn_dropout if training else 0.0
+        st = SimpleNamespace(B=B, Lq=Lq, Lk=Lk, D=D, seed=seed)
+        s1c = s1.contiguous().view(B * Lq, D)
+        s1_16 = ops.cast_bf16(s1c)
+        s2_16 = ops.cast_bf16(s2.contiguous().view(B * Lk, D))
+        L, out32, _ = _bert_layer_fwd(st, s1c, s1_16, s2_16, key_add.contiguous(), bert_weights(layer), cfg.heads, p_hid, p_att, cfg.ln_eps,
+                                      seed, sites, False)
+        ctx.st, ctx.L, ctx.layer = st, L, layer
+        return out32.view(B, Lq, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        st, L = ctx.st, ctx.L
+        ds1, ds2 = _bert_layer_bwd(st, L, dout.contiguous().view(st.B * st.Lq, st.D), st.seed)
+        L.__dict__.clear()
+        notify_grads_ready(ctx.layer.parameters())
+        return ds1.view(st.B, st.Lq, st.D), ds2.view(st.B, st.Lk, st.D), None, None, None, None
+
+
+class DropoutFn(torch.autograd.Function):
+    """F.dropout on fp32 activations (mm_model.py:390-391, 79, 82)."""
+
+    @staticmethod
+    def forward(ctx, x, p, training):
+        if not training or p == 0.0:
+            ctx.p = 0.0
+            return x
+        ctx.p, ctx.seed = p, dropout_state.next_seed()
+        return ops.dropout_f32(x.contiguous(), p, ctx.seed, 1)
+
+    @staticmethod
+    def backward(ctx, d):
+        if ctx.p == 0.0:
+            return d, None, None
+        return ops.dropout_f32(d.contiguous(), ctx.p, ctx.seed, 1), None, None
+
+
+# ------------------------------------------------------------------------------------------------- InfoNCE
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+class InfoNCEFn(torch.autograd.Function):
+    """InfoNCE.forward (models/infonce.py:23-38) + info_nce (:42-98) with implicit negatives.
+
+    Under data parallelism `gather` is a callable [B_loc,2*d] -> [B_glob,2*d] (all-gather in rank order) and
+    `reduce_scatter` its adjoint; anchors of this rank are rows [row0,row0+B_loc) of the global batch and the value
+    returned is this rank's share of the global loss (the sum over ranks equals the single-process loss)."""
+
+    @staticmethod
+    def forward(ctx, query, positive, mod, training, gather, reduce_scatter, row0):
+        B, Nq, D = query.shape
+        Np = positive.shape[1]
+        d = mod.d_l
+        ldp = _pad8(d)
+        seed = dropout_state.next_seed()
+        p = mod.embed_dropout if training else 0.0
+        st = SimpleNamespace(B=B, Nq=Nq, Np=Np, D=D, d=d, ldp=ldp, seed=seed, p=p)
+        dev = query.device
+
+        def proj(x, seq, n, dropout_p, site):
+            L = SimpleNamespace()
+            L.x16 = ops.cast_bf16(x.contiguous().view(B * n, D), dropout_p, seed, site)
+            L.u = torch.empty(B * n, seq[0].weight.shape[0], device=dev, dtype=BF16)
+            L.h = ops.linear_fwd(L.x16, wbf16(seq[0].weight), seq[0].bias, act=ops.ACT_GELU, aux_out=L.u)
+            pr = torch.zeros(B * n, ldp, device=dev, dtype=BF16)
+            ops.gemm(L.h, wbf16(seq[2].weight), M=B * n, N=d, K=L.h.shape[1], lda=L.h.shape[1], ldb=seq[2].weight.shape[1], out=pr, ldc=ldp,
+                     bias=seq[2].bias)
+            L.mean = ops.seq_mean_fwd(pr, B, n, d, ldp)
+            return L
+
+        st.Lq = proj(query, mod.info_proj_query, Nq, p, 1)
+        st.Lp = proj(positive, mod.info_proj_positive, Np, 0.0, 2)
+        both = torch.cat((st.Lq.mean, st.Lp.mean), dim=1)            # [B, 2d] (tiny; one message under DDP)
+        both_all = gather(both) if gather is not None else both
+        Bg = both_all.shape[0]
+        qh, st.qinv = ops.l2norm_fwd(both_all[:, :d])
+        kh, st.kinv = ops.l2norm_fwd(both_all[:, d:])
+        loss = torch.zeros(1, device=dev, dtype=F32)
+        dqh, dkh = torch.zeros_like(qh), torch.zeros_like(kh)
+        T = mod.temperature
+        ops.infonce_dir(qh, kh, row0, B, T, loss, dqh, dkh)
+        ops.infonce_dir(kh, qh, row0, B, T, loss, dkh, dqh)
+        st.qh, st.kh, st.dqh, st.dkh, st.Bg, st.row0 = qh, kh, dqh, dkh, Bg, row0
+        ctx.st, ctx.mod, ctx.rs = st, mod, reduce_scatter
+        return (loss / (2.0 * Bg)).view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        st, mod = ctx.st, ctx.mod
+        B, d, ldp = st.B, st.d, st.ldp
+        dq = ops.l2norm_bwd(st.dqh, st.qh, st.qinv)
+        dk = ops.l2norm_bwd(st.dkh, st.kh, st.kinv)
+        dboth = torch.cat((dq, dk), dim=1)
+        if ctx.rs is not None:
+            dboth = ctx.rs(dboth)                                   # sum over ranks, keep own rows
+        dboth = (dboth * dloss).contiguous()
+
+        def proj_bwd(L, dmean, seq, n, dropout_p, site, want_dx):
+            dpr = ops.seq_mean_bwd(dmean.contiguous(), B, n, d, ldp)                       # [B*n, ldp] bf16, pad cols 0
+            gw = gbuf(seq[2].weight)
+            if gw is not None:
+                ops.linear_bwd_weight(dpr, L.h, gw)
+            gb = gbuf(seq[2].bias)
+            if gb is not None:
+                ops.colsum(dpr, gb, cols=d)
+            du = ops.gemm(dpr, wbf16(seq[2].weight), M=B * n, N=L.h.shape[1], K=d, lda=ldp, ldb=seq[2].weight.shape[1], transB=True,
+                          act=ops.ACT_GELU_BWD, aux_in=L.u)
+            _lin_bwd_params(du, L.x16, seq[0].weight, seq[0].bias)
+            if not want_dx:
+                return None
+            dx = ops.linear_bwd_input(du, wbf16(seq[0].weight), out_dtype=F32)
+            if dropout_p > 0:
+                dx = ops.dropout_f32(dx, dropout_p, st.seed, site)
+            return dx
+
+        dxq = proj_bwd(st.Lq, dboth[:, :d], mod.info_proj_query, st.Nq, st.p, 1, ctx.needs_input_grad[0])
+        dxp = proj_bwd(st.Lp, dboth[:, d:], mod.info_proj_positive, st.Np, 0.0, 2, ctx.needs_input_grad[1])
+        notify_grads_ready(mod.parameters())
+        return (None if dxq is None else dxq.view(B, st.Nq, st.D), None if dxp is None else dxp.view(B, st.Np, st.D), None, None, None, None, None)
+
+
+class InfoNCELossFn(torch.autograd.Function):
+    """info_nce(query, positive_key) on already-pooled [B,d] embeddings (models/infonce.py:42-98, implicit negatives)."""
+
+    @staticmethod
+    def forward(ctx, q, k, temperature):
+        B, d = q.shape
+        qh, qinv = ops.l2norm_fwd(q.contiguous())
+        kh, kinv = ops.l2norm_fwd(k.contiguous())
+        loss = torch.zeros(1, device=q.device, dtype=F32)
+        dqh, dkh = torch.zeros_like(qh), torch.zeros_like(kh)
+        ops.infonce_dir(qh, kh, 0, B, temperature, loss, dqh, dkh)
+        ops.infonce_dir(kh, qh, 0, B, temperature, loss, dkh, dqh)
+        ctx.sv = (qh, qinv, kh, kinv, dqh, dkh)
+        return (loss / (2.0 * B)).view(())
+
+    @staticmethod
+    def backward(ctx, dl):
+        qh, qinv, kh, kinv, dqh, dkh = ctx.sv
+        return ops.l2norm_bwd(dqh, qh, qinv) * dl, ops.l2norm_bwd(dkh, kh, kinv) * dl, None
+
+
+# ------------------------------------------------------------------------------------------------- ConR / SupCon
+class CTLossFn(torch.autograd.Function):
+    """CT_Regress / CT_Single / CT_Multi (models/contrastive.py).  Only `feature` receives a gradient (the masks built
+    from labels / predictions are not differentiable in the reference either)."""
+
+    @staticmethod
+    def forward(ctx, feature, mode, labels_f, labels_i, pred, weights, w, t, e, coef):
+        f = feature.reshape(feature.shape[0], -1).contiguous()
+        fh, inv = ops.l2norm_fwd(f)
+        loss, G = ops.ct_loss_fwd(mode, fh, labels_f=labels_f, labels_i=labels_i, pred=pred, weights=weights, w=w, t=t, e=e, coef=coef)
+        ctx.sv, ctx.t, ctx.shape = (fh, inv, G), t, feature.shape
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dl):
+        fh, inv, G = ctx.sv
+        df = ops.l2norm_bwd(ops.ct_loss_bwd(fh, G, ctx.t), fh, inv)
+        return (df * dl).view(ctx.shape), None, None, None, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------- FDS smooth / pool / head / losses
+class FDSSmoothFn(torch.autograd.Function):
+    """FDS.smooth (models/fds.py:157-190).  Out-of-place; the module wrapper copies back to keep the reference's
+    in-place aliasing visible to the caller."""
+
+    @staticmethod
+    def forward(ctx, x, bins, flags, bs, bn, m1, v1, m2, v2):
+        y, sc = ops.fds_smooth(x.contiguous(), bins, flags, bs, bn, m1, v1, m2, v2, want_scale=True)
+        ctx.sc = sc
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy * ctx.sc, None, None, None, None, None, None, None, None
+
+
+class MaskedPoolFn(torch.autograd.Function):
+    """mm_model.py:572-576: zero padded rows, concat, sum / (#atom tokens + #SMILES tokens)."""
+
+    @staticmethod
+    def forward(ctx, a, t, mask_a, mask_t):
+        ma, mt = ops._u8(mask_a), ops._u8(mask_t)
+        ctx.sv = (ma, mt, a.shape[1], t.shape[1])
+        return ops.masked_pool_fwd(a.contiguous(), t.contiguous(), ma, mt)
+
+    @staticmethod
+    def backward(ctx, dp):
+        ma, mt, Na, Nt = ctx.sv
+        da, dt = ops.masked_pool_bwd(dp.contiguous(), ma, mt, Na, Nt)
+        return da, dt, None, None
+
+
+class LinearF32Fn(torch.autograd.Function):
+    """Small fp32 Linear (+tanh) for the classification head (mm_model.py:44-84)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        x = x.contiguous()
+        y = ops.linear_f32_fwd(x, weight, bias, act)
+        ctx.sv = (x, weight, bias, y, act)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, y, act = ctx.sv
+        dx = ops.linear_f32_bwd(x, weight, y, dy.contiguous(), gbuf(weight), None if bias is None else gbuf(bias), act, want_dx=ctx.needs_input_grad[0])
+        notify_grads_ready([weight] if bias is None else [weight, bias])
+        return dx, None, None, None
+
+
+class MSELossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        loss, d = ops.mse_loss(pred.contiguous(), target.contiguous().to(F32))
+        ctx.d = d
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dl):
+        return (ctx.d * dl).view_as(ctx.d), None
+
+
+class CELossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        loss, d = ops.ce_loss(logits.contiguous(), target.contiguous().view(-1).long())
+        ctx.d = d
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dl):
+        return ctx.d * dl, None

@@ -120,12 +120,12 @@ def layernorm_fwd(x, gamma, beta, eps, *, want_f32=False, want_bf16=True, row_ze
     return y32, y16, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, *, dres=None, row_zero=None, drop_p=0.0, seed=0, site=0):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, *, dres=None, dy_add=None, row_zero=None, drop_p=0.0, seed=0, site=0):
     D = x.shape[-1]
     rows = x.numel() // D
     dx = torch.empty_like(x)
     rz = _u8(row_zero)
-    lib().mmdti_layernorm_bwd(_stream(), dy.data_ptr(), DT_BF16 if dy.dtype == BF16 else DT_F32, x.data_ptr(), gamma.data_ptr(),
+    lib().mmdti_layernorm_bwd(_stream(), dy.data_ptr(), DT_BF16 if dy.dtype == BF16 else DT_F32, _p(dy_add), x.data_ptr(), gamma.data_ptr(),
                               mean.data_ptr(), rstd.data_ptr(), rows, D, _p(dres), dx.data_ptr(), _p(dgamma), _p(dbeta), _p(rz),
                               float(drop_p), int(seed), int(site))
     return dx
@@ -188,8 +188,10 @@ def gbf_features_fwd(dist, edge_type, mul, bias, means, stds):
     _chk(dist, F32, "gbf.dist"); _chk(edge_type, torch.int64, "gbf.edge_type")
     P, K, E = dist.numel(), means.numel(), mul.numel()
     feat = torch.empty(P, K, device=dist.device, dtype=BF16)
+    t0 = kernel_timer.begin("gbf_features_fwd")
     lib().mmdti_gbf_features_fwd(_stream(), dist.data_ptr(), edge_type.data_ptr(), mul.data_ptr(), bias.data_ptr(), means.data_ptr(),
                                  stds.data_ptr(), P, K, E, feat.data_ptr())
+    kernel_timer.end("gbf_features_fwd", t0)
     return feat
 
 
@@ -225,15 +227,19 @@ def pair_attn_fwd(qkv, bias_in, key_pad, B, N, H, ld, scale, drop_p=0.0, seed=0,
     s_out = torch.empty(B, H, N, ld, device=qkv.device, dtype=F32)
     o = torch.empty(B * N, H * 8, device=qkv.device, dtype=BF16)
     kp = _u8(key_pad)
+    t0 = kernel_timer.begin("pair_attn_fwd")
     lib().mmdti_pair_attn_fwd(_stream(), qkv.data_ptr(), bias_in.data_ptr(), s_out.data_ptr(), o.data_ptr(), _p(kp), B, N, H, ld,
                               float(scale), float(drop_p), int(seed), int(site))
+    kernel_timer.end("pair_attn_fwd", t0)
     return s_out, o
 
 
 def pair_attn_bwd(qkv, s, do, g, B, N, H, ld, scale, g_in_zero, drop_p=0.0, seed=0, site=0):
     dqkv = torch.empty_like(qkv)
+    t0 = kernel_timer.begin("pair_attn_bwd")
     lib().mmdti_pair_attn_bwd(_stream(), qkv.data_ptr(), s.data_ptr(), do.data_ptr(), g.data_ptr(), dqkv.data_ptr(), B, N, H, ld,
                               float(scale), int(g_in_zero), float(drop_p), int(seed), int(site))
+    kernel_timer.end("pair_attn_bwd", t0)
     return dqkv
 
 
@@ -402,3 +408,45 @@ def probe_tr_read(stride):
     out = torch.empty(256, device="cuda", dtype=torch.int16)
     lib().mmdti_probe_tr_read(_stream(), int(stride), out.data_ptr())
     return out
+
+
+# --------------------------------------------------------------------------------------------- live kernel timing (bench.py)
+class _KernelTimer:
+    """HIP-event timing of selected kernel launches on the stream they are launched on (bench.py `roofline`)."""
+
+    def __init__(self):
+        self.names = ()
+        self.events = {}
+
+    def enable(self, names):
+        self.names = tuple(names)
+        self.events = {n: [] for n in self.names}
+
+    def disable(self):
+        self.names = ()
+
+    def begin(self, name):
+        if name not in self.names:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, name, e0):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.events[name].append((e0, e1))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for n, evs in self.events.items():
+            if evs:
+                ts = [a.elapsed_time(b) for a, b in evs]
+                out[n] = {"n": len(ts), "mean_ms": sum(ts) / len(ts), "min_ms": min(ts)}
+        return out
+
+
+kernel_timer = _KernelTimer()

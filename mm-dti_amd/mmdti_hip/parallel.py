@@ -1,0 +1,126 @@
+"""Data parallelism for the fine-tune step: one process per GPU, torch.distributed over RCCL/xGMI.
+
+The reference is single-device; the semantics below are this build's, chosen so that N ranks on a
+global batch reproduce the single-process loss and gradients:
+
+  * molecules are split across ranks (weak scaling: B_loc fixed); all weights are replicated;
+  * InfoNCE negatives are GLOBAL: each rank contributes its [B_loc, 2*50] pooled projections through ONE all-gather
+    (both towers fused into a single latency-bound message); the adjoint is a sum-reduce of the [B_glob, 100] gradient
+    from which each rank keeps its rows (all-reduce + slice: 200 KB at 8 x 256, cheaper than a reduce-scatter setup);
+  * ConR / SupCon and the task loss stay rank-local means; the step loss is the mean over ranks, so gradients are
+    all-reduced with op=AVG, except InfoNCE whose value is already this rank's share of the global loss (hence its
+    gradient is pre-multiplied by world_size before the AVG);
+  * gradients live in ONE flat fp32 arena (runtime.ParamArena): the all-reduce walks it in large buckets on a side HIP
+    stream, and is launched bucket by bucket while the backward of earlier layers is still running (tower order in the
+    arena is arranged so that buckets complete back-to-front).  xGMI is point-to-point (7 links x ~153 GB/s per GPU): a
+    ring all-reduce is bound by one link, so few large buckets (default 64 MiB) amortise the per-collective latency.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> tuple:
+    """torchrun-style env (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT) -> (rank, local_rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+class GlobalNegatives:
+    """all-gather of the pooled InfoNCE projections and its adjoint (see models/infonce.py:set_global_negatives)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def gather(self, x: torch.Tensor) -> torch.Tensor:
+        """[B_loc, C] -> [world*B_loc, C] in rank order (equal B_loc on every rank)."""
+        if self.world == 1:
+            return x
+        x = x.contiguous()
+        out = torch.empty(self.world * x.shape[0], x.shape[1], device=x.device, dtype=x.dtype)
+        dist.all_gather_into_tensor(out, x, group=self.group)
+        return out
+
+    def reduce_scatter(self, g: torch.Tensor) -> torch.Tensor:
+        """adjoint of gather: sum over ranks of [world*B_loc, C], keep own rows."""
+        if self.world == 1:
+            return g
+        g = g.contiguous()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+        b = g.shape[0] // self.world
+        return g[self.rank * b:(self.rank + 1) * b]
+
+    def row0(self, b_loc: int) -> int:
+        return self.rank * b_loc
+
+
+class ArenaReducer:
+    """Bucketed gradient all-reduce (mean) over the flat gradient arena on a side stream."""
+
+    def __init__(self, arena, bucket_bytes: int = 64 << 20, group=None):
+        self.arena, self.group = arena, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        n = arena.numel
+        per = max(1, bucket_bytes // 4)
+        self.buckets = [(s, min(n, s + per)) for s in range(0, n, per)]
+        self.stream = torch.cuda.Stream() if (self.world > 1 and arena.grad.is_cuda) else None
+        self._pending = []
+
+    def reduce_range(self, lo: int, hi: int):
+        """Launch the all-reduce of every not-yet-reduced bucket fully inside [lo, hi) -- called as soon as the backward
+        has finished writing that part of the arena."""
+        if self.world == 1:
+            return
+        for (s, e) in self.buckets:
+            if s >= lo and e <= hi and (s, e) not in self._pending:
+                self._launch(s, e)
+
+    def _launch(self, s, e):
+        view = self.arena.grad[s:e]
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            view.div_(self.world)
+        self._pending.append((s, e))
+
+    def finish(self):
+        """Reduce whatever is left and make the main stream wait for the side stream."""
+        if self.world == 1:
+            return
+        for (s, e) in self.buckets:
+            if (s, e) not in self._pending:
+                self._launch(s, e)
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self._pending = []
+
+
+def shard_batch(batch: dict, label, rank: int, world: int):
+    """Contiguous split of an already-collated GLOBAL batch.  Every shard keeps the global padded lengths, which keeps
+    the reference's unmasked InfoNCE mean (infonce.py:32-33) identical to the single-process value."""
+    B = label.shape[0]
+    assert B % world == 0, "global batch must divide evenly (drop_last on the global sampler)"
+    b = B // world
+    sl = slice(rank * b, (rank + 1) * b)
+    return {k: v[sl] for k, v in batch.items()}, label[sl]

@@ -1,0 +1,147 @@
+"""Host-side runtime plumbing: bf16 weight shadows, gradient buffers, the flat parameter arena and dropout seeds.
+
+MI355X-first layout: all trainable parameters live in ONE flat fp32 arena (plus a flat fp32 gradient arena and a flat
+bf16 shadow), so the per-step work on parameters is three streams over contiguous HBM -- zero the gradients, one
+bucketed RCCL all-reduce over slices of the gradient arena, one fused Adam pass that also refreshes the bf16 shadow --
+instead of ~350 small per-tensor launches.  ``nn.Parameter``s stay what the reference's code expects (named tensors in
+``state_dict()``); they are simply views into the arena.
+"""
+from __future__ import annotations
+
+import itertools
+from typing import Dict, Iterable, List, Optional
+
+import torch
+
+from . import ops
+
+_ALIGN = 8  # elements: 16 B for the bf16 shadow, 32 B for fp32
+
+
+class ParamArena:
+    """Flatten a module's trainable parameters into contiguous data / grad / bf16-shadow buffers."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        assert self.params, "no trainable parameters"
+        dev = self.params[0].device
+        assert dev.type == "cuda", "ParamArena needs device parameters"
+        self.offsets: Dict[int, int] = {}
+        off = 0
+        for p in self.params:
+            self.offsets[id(p)] = off
+            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.numel = off
+        self.data = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.shadow = torch.zeros(off, device=dev, dtype=torch.bfloat16)
+        for p in self.params:
+            o, n = self.offsets[id(p)], p.numel()
+            self.data[o:o + n].copy_(p.data.reshape(-1).float())
+            p.data = self.data[o:o + n].view(p.shape)
+            p.grad = self.grad[o:o + n].view(p.shape)
+            p._mmdti_arena = self
+        self.refresh_shadow()
+        self.adam_m: Optional[torch.Tensor] = None
+        self.adam_v: Optional[torch.Tensor] = None
+        self.step_count = 0
+
+    def refresh_shadow(self):
+        ops.lib().mmdti_cast_f32_bf16(ops._stream(), self.data.data_ptr(), self.shadow.data_ptr(), self.numel, 0.0, 0, 0)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p in self.params:          # re-bind in case an optimizer dropped the views (set_to_none)
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * self.offsets[id(p)]:
+                o, n = self.offsets[id(p)], p.numel()
+                p.grad = self.grad[o:o + n].view(p.shape)
+
+    def bf16(self, p: torch.nn.Parameter) -> torch.Tensor:
+        o, n = self.offsets[id(p)], p.numel()
+        return self.shadow[o:o + n].view(p.shape)
+
+    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, max_norm: Optional[float] = None):
+        """torch.optim.Adam semantics (tasks/trainer.py:160) + optional global-norm clipping (:274), one fused pass."""
+        if self.adam_m is None:
+            self.adam_m = torch.zeros_like(self.data)
+            self.adam_v = torch.zeros_like(self.data)
+        self.step_count += 1
+        scale = None
+        if max_norm is not None:
+            ss = torch.zeros(1, device=self.data.device, dtype=torch.float32)
+            ops.sumsq(self.grad, ss)
+            # clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1 (tiny scalar math; stays on device, no sync)
+            scale = torch.clamp(max_norm / (ss.sqrt() + 1e-6), max=1.0)
+        ops.adam_step(self.data, self.grad, self.adam_m, self.adam_v, self.shadow, lr, betas[0], betas[1], eps, weight_decay,
+                      self.step_count, scale)
+
+
+class _ShadowCache:
+    """bf16 copies of parameters that are not arena-managed (unit tests, ad-hoc modules): re-cast when the parameter's
+    version counter or storage changes."""
+
+    def __init__(self):
+        self._c: Dict[int, tuple] = {}
+
+    def get(self, p: torch.Tensor) -> torch.Tensor:
+        key = id(p)
+        ent = self._c.get(key)
+        ver = (p.data_ptr(), p._version)
+        if ent is None or ent[0] != ver:
+            ent = (ver, ops.cast_bf16(p.detach().contiguous()))
+            self._c[key] = ent
+        return ent[1]
+
+
+_shadow_cache = _ShadowCache()
+
+
+def wbf16(p: torch.Tensor) -> torch.Tensor:
+    """bf16 view/copy of a weight for the MFMA GEMMs."""
+    arena = getattr(p, "_mmdti_arena", None)
+    if arena is not None:
+        return arena.bf16(p)
+    return _shadow_cache.get(p)
+
+
+def gbuf(p: torch.Tensor) -> Optional[torch.Tensor]:
+    """fp32 gradient buffer of a parameter that kernels accumulate into (atomically); None if frozen."""
+    if not p.requires_grad:
+        return None
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    return p.grad
+
+
+class DropoutState:
+    """Counter-based dropout: every forward call of a module takes a fresh 64-bit seed; sites within the call are
+    numbered, and the backward regenerates the masks from (seed, site)."""
+
+    def __init__(self, seed: int = 0x5EED):
+        self.base = seed
+        self._calls = itertools.count(1)
+
+    def next_seed(self) -> int:
+        return (self.base * 0x9E3779B97F4A7C15 + next(self._calls) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+    def reseed(self, seed: int):
+        self.base = seed
+        self._calls = itertools.count(1)
+
+
+dropout_state = DropoutState()
+
+
+# ---- gradient-ready notifications (consumed by parallel.ArenaReducer to overlap the all-reduce with backward) ----
+_grad_ready_hook = None
+
+
+def set_grad_ready_hook(fn):
+    global _grad_ready_hook
+    _grad_ready_hook = fn
+
+
+def notify_grads_ready(params):
+    """Called by the backward of a module once every gradient of `params` has been enqueued on the stream."""
+    if _grad_ready_hook is not None:
+        _grad_ready_hook(params)

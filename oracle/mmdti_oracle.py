@@ -423,7 +423,7 @@ def infonce_embed(query: Tensor, positive: Tensor, P: Params, pre: str = "infonc
 
     def proj(x, name):
         h = F.gelu(linear(x, P[pre + name + ".0.weight"], P[pre + name + ".0.bias"], bf16))
-        return linear(h, P[pre + name + ".2.weight"], P[pre + name + ".2.bias"], bf16)
+        return _r(linear(h, P[pre + name + ".2.weight"], P[pre + name + ".2.bias"], bf16), bf16)   # HIP path stores the projections bf16
 
     return proj(xq, "info_proj_query").mean(dim=1), proj(positive, "info_proj_positive").mean(dim=1)
 
@@ -701,7 +701,7 @@ def mm_forward(batch, P, cfg: ModelCfg, net_target=None, weights=None, use_weigh
     feats = pooled
     if training and fds is not None and epoch >= fds.start_smooth and cfg.task == "regression":
         feats = fds.smooth(feats, net_target, epoch)            # reference aliasing: CT sees the smoothed tensor
-    logits = classification_head(feats, P, "classification_head.", cfg.unimol.pooler_dropout, training, bf16)
+    logits = classification_head(feats, P, "classification_head.", cfg.unimol.pooler_dropout, training, False)  # head runs fp32 on the HIP path
     ct = None
     if net_target is not None:
         kw = dict(w=cfg.ct_w)
@@ -813,7 +813,7 @@ def synth_batch(B: int, max_atoms: int, max_tokens: int, cfg: ModelCfg, seed: in
         if ragged:
             # clamp(round(N(48,20^2)),8,128) at max_atoms=128, scaled for smaller test shapes
             na = int(np.clip(round(rng.normal(0.375 * max_atoms, 0.16 * max_atoms)), max(2, max_atoms // 16), max_atoms))
-            nt = int(np.clip(round(1.6 * na * 0.5), 8, max_tokens))
+            nt = int(np.clip(round(1.6 * na * 0.5), min(8, max(4, max_tokens // 4)), max_tokens))
         else:
             na, nt = max_atoms, max_tokens
         a = rng.choice(u.vocab, size=na, p=elem_p)
