@@ -43,39 +43,61 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return (bf16_t)(u >> 16);
 }
 
-// ---- wave-level reductions (64 lanes) --------------------------------------
+// ---- wave-level reductions (64 lanes) on the DPP crossbar -------------------------------------------------------
+// v_*_dpp reads a neighbour lane as part of a normal VALU op (~1 issue slot) whereas __shfl_xor lowers to ds_bpermute
+// (an LDS round trip per step).  Row = 16 lanes.  Prefix-style: after row_shr 1,2,4,8 lane 15 of every row holds the
+// row total, row_bcast:15 / row_bcast:31 fold the four rows into lane 63, v_readlane broadcasts it through an SGPR.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf, bool BOUND_ZERO = true>
+__device__ __forceinline__ float dpp_f32(float old, float src) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, BANK_MASK, BOUND_ZERO));
+}
+constexpr int DPP_ROW_SHL = 0x100, DPP_ROW_SHR = 0x110, DPP_ROW_ROR = 0x120, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E;  // quad_perm [1,0,3,2] / [2,3,0,1]
+
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_f32<DPP_ROW_SHR + 1>(0.f, v);
+  v += dpp_f32<DPP_ROW_SHR + 2>(0.f, v);
+  v += dpp_f32<DPP_ROW_SHR + 4>(0.f, v);
+  v += dpp_f32<DPP_ROW_SHR + 8>(0.f, v);
+  v += dpp_f32<DPP_ROW_BCAST15, 0xa>(0.f, v);
+  v += dpp_f32<DPP_ROW_BCAST31, 0xc>(0.f, v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  const float NI = -INFINITY;  // lanes without a source keep -inf (bound_ctrl off)
+  v = fmaxf(v, dpp_f32<DPP_ROW_SHR + 1, 0xf, 0xf, false>(NI, v));
+  v = fmaxf(v, dpp_f32<DPP_ROW_SHR + 2, 0xf, 0xf, false>(NI, v));
+  v = fmaxf(v, dpp_f32<DPP_ROW_SHR + 4, 0xf, 0xf, false>(NI, v));
+  v = fmaxf(v, dpp_f32<DPP_ROW_SHR + 8, 0xf, 0xf, false>(NI, v));
+  v = fmaxf(v, dpp_f32<DPP_ROW_BCAST15, 0xa, 0xf, false>(NI, v));
+  v = fmaxf(v, dpp_f32<DPP_ROW_BCAST31, 0xc, 0xf, false>(NI, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
-// Sum 8 per-lane values over the 64 lanes; lane l (l<8) ends up holding the total of
-// value index bitrev-free index (l & 7) -- see implementation: returns total of v[lane&7].
+// Sum 8 per-lane values over the 64 lanes; every lane ends up holding the total of v[lane & 7].
+// Reduce-scatter: each exchange step halves the number of live values (xor 1, 2 by quad_perm, xor 4 by row_shl/shr:4,
+// xor 8 by row_ror:8), the last two (xor 16, 32) cross rows and go through ds_bpermute.
 __device__ __forceinline__ float wave_sum8_scatter(const float (&v)[8], int lane) {
-  // halve the value count while exchanging across lane bits 0,1,2, then all-reduce bits 3..5
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
   float a[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    float keep = (lane & 1) ? v[2 * i + 1] : v[2 * i];
-    float send = (lane & 1) ? v[2 * i] : v[2 * i + 1];
-    a[i] = keep + __shfl_xor(send, 1, 64);
-  }  // lane bit0 selects value parity: a[i] = partial of v[2i + (lane&1)]
+    const float keep = b0 ? v[2 * i + 1] : v[2 * i];
+    const float send = b0 ? v[2 * i] : v[2 * i + 1];
+    a[i] = keep + dpp_f32<DPP_QUAD_XOR1>(0.f, send);  // partial of v[2i + b0]
+  }
   float b[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    float keep = (lane & 2) ? a[2 * i + 1] : a[2 * i];
-    float send = (lane & 2) ? a[2 * i] : a[2 * i + 1];
-    b[i] = keep + __shfl_xor(send, 2, 64);
-  }  // b[i] = partial of v[4i + 2*((lane>>1)&1) + (lane&1)]
-  float keep = (lane & 4) ? b[1] : b[0];
-  float send = (lane & 4) ? b[0] : b[1];
-  float c = keep + __shfl_xor(send, 4, 64);  // partial of v[4*((lane>>2)&1) + 2*((lane>>1)&1) + (lane&1)] = v[lane&7]
-  c += __shfl_xor(c, 8, 64);
+    const float keep = b1 ? a[2 * i + 1] : a[2 * i];
+    const float send = b1 ? a[2 * i] : a[2 * i + 1];
+    b[i] = keep + dpp_f32<DPP_QUAD_XOR2>(0.f, send);  // partial of v[4i + 2*b1 + b0]
+  }
+  const float keep = b2 ? b[1] : b[0];
+  const float send = b2 ? b[0] : b[1];
+  const float up = dpp_f32<DPP_ROW_SHL + 4>(0.f, send);  // lane l <- lane l+4
+  const float dn = dpp_f32<DPP_ROW_SHR + 4>(0.f, send);  // lane l <- lane l-4
+  float c = keep + (b2 ? dn : up);                       // partial of v[lane & 7] over this 8-lane group
+  c += dpp_f32<DPP_ROW_ROR + 8>(0.f, c);                 // lane l <- lane l^8 (rotate the 16-lane row by 8)
   c += __shfl_xor(c, 16, 64);
   c += __shfl_xor(c, 32, 64);
   return c;

@@ -12,7 +12,8 @@
 // sub-tile = 4x4 v_mfma_f32_16x16x32_bf16 accumulators), LDS double-buffered,
 // one barrier per K-step.  Operands are staged global -> VGPR -> LDS in the
 // canonical [row][k] image (row stride 72 bf16 = 144 B, conflict-reducing pad);
-// an operand stored k-major (transposed) is transposed on the LDS write.
+// an operand stored k-major (transposed) keeps its order in LDS ([k][row] image, 16-byte writes) and is
+// transposed for free by ds_read_b64_tr_b16 on the way to the MFMA.
 // XCD-aware block remap keeps tiles that share an A row-panel on one XCD's L2.
 #include "common.h"
 
@@ -23,6 +24,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int LDT = BK + 8;  // LDS row stride in elements (144 B, 16-B aligned)
+constexpr int LDTR = BM + 8;  // k-major (transposed-operand) image row stride: 136 bf16 = 272 B (2-way worst case on tr reads)
+constexpr int LDC_S = BN + 4;  // fp32 epilogue staging row stride (528 B): 128*132*4 = 67,584 B <= the 73,728 B of tiles
 
 struct GemmArgs {
   const bf16_t* A;
@@ -46,6 +49,7 @@ struct GemmArgs {
   float drop_scale;
   uint64_t seed;
   uint32_t site;
+  int vec_ok;             // host-checked: every pointer/stride the vector epilogue touches is 16-byte friendly
 };
 
 // Load one 128x64 operand tile slice into registers: 4 x 16-B chunks per thread.
@@ -77,21 +81,67 @@ __device__ __forceinline__ void store_tile(const uint4 (&r)[4], bf16_t* lds, int
     if (!TR) {
       int row = c >> 3, kc = (c & 7) * 8;
       *reinterpret_cast<uint4*>(lds + row * LDT + kc) = r[i];
-    } else {
+    } else {  // k-major image [64][LDTR]: the operand keeps its memory order, fragments come out of ds_read_b64_tr_b16
       int k = c >> 4, row = (c & 15) * 8;
-      const bf16_t* e = reinterpret_cast<const bf16_t*>(&r[i]);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) lds[(row + j) * LDT + k] = e[j];
+      *reinterpret_cast<uint4*>(lds + k * LDTR + row) = r[i];
     }
+  }
+}
+
+// One MFMA 16x16x32 operand fragment (8 consecutive k of one row per lane) for the 16-row sub-tile starting at `row0`,
+// k-step kk (32 wide).
+//  !TR: [row][k] image, one ds_read_b128.
+//   TR: [k][row] image, two ds_read_b64_tr_b16: per 16-lane group g the instruction reads a 4(k) x 16(row) block and
+//       hands lane i column i -- lane 4q+p supplies the address of k-row q, columns 4p..4p+3 (guide T10; semantics
+//       pinned by tests/test_kernels_gpu.py::test_probe_tr_read_semantics).
+template <bool TR>
+__device__ __forceinline__ bf16x8 load_frag(const bf16_t* img, int row0, int kk, int lane) {
+  if (!TR) {
+    return *reinterpret_cast<const bf16x8*>(img + (row0 + (lane & 15)) * LDT + kk * 32 + (lane >> 4) * 8);
+  } else {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const bf16_t* p = img + (kk * 32 + (lane >> 4) * 8 + ((lane & 15) >> 2)) * LDTR + row0 + (lane & 3) * 4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * LDTR));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+__device__ __forceinline__ void epi_elem(const GemmArgs& a, float accv, int row, int col, bool lead, long long coff) {
+  if (row >= a.M || col >= a.N) return;
+  float v = accv * a.alpha;
+  if (a.bias && lead) v += a.bias[col];
+  if (a.act == MMDTI_ACT_GELU) {
+    if (a.aux_out) a.aux_out[(long long)row * a.ld_aux + col] = f2bf(v);
+    v = gelu_erf(v);
+  } else if (a.act == MMDTI_ACT_GELU_BWD) {
+    v *= gelu_erf_grad(bf2f(a.aux_in[(long long)row * a.ld_aux + col]));
+  }
+  if (a.drop_thresh) {
+    const bool keep = dropout_keep(a.seed, a.site, (uint64_t)row * (uint64_t)a.N + col, a.drop_thresh);
+    v = keep ? v * a.drop_scale : 0.f;
+  }
+  if (a.residual && lead) v += a.residual[(long long)row * a.ldr + col];
+  const long long ci = coff + (long long)row * a.ldc + col;
+  if (a.c_dtype == MMDTI_DT_BF16) {
+    reinterpret_cast<bf16_t*>(a.C)[ci] = f2bf(v);
+  } else if (a.c_dtype == MMDTI_DT_F32) {
+    float* c = reinterpret_cast<float*>(a.C);
+    c[ci] = (a.beta != 0.f) ? v + a.beta * c[ci] : v;
+  } else {
+    atomicAdd(reinterpret_cast<float*>(a.C) + ci, v);
   }
 }
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
-  bf16_t* sA[2] = {smem, smem + 2 * BM * LDT};
-  bf16_t* sB[2] = {smem + BM * LDT, smem + 2 * BM * LDT + BM * LDT};
+  // LDS image: [buf 0: A | B][buf 1: A | B]; addressed by integer offsets from ONE __shared__ base so that every access
+  // stays a ds_* instruction (pointer arrays indexed at run time decay to flat loads + scratch).
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+  constexpr int TILE = BM * LDT;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -100,22 +150,23 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
   // so give each XCD a contiguous chunk of the tile list (bijective form, cdna guide T1).
   const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
   const int nwg = tiles_n * tiles_m;
-  int orig = blockIdx.x;
-  int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-  int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  const int tm = wg / tiles_n, tn = wg % tiles_n;
+  const int orig = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int z = blockIdx.z;
   const int zb = z / a.splitk, ks = z - zb * a.splitk;
   const int zo = zb / a.batch_inner, zi = zb - zo * a.batch_inner;
-  const bf16_t* A = a.A + zo * a.sAo + zi * a.sAi;
-  const bf16_t* B = a.B + zo * a.sBo + zi * a.sBi;
+  const bf16_t* __restrict__ A = a.A + zo * a.sAo + zi * a.sAi;
+  const bf16_t* __restrict__ B = a.B + zo * a.sBo + zi * a.sBi;
 
   // K range of this split
   const int ktiles = (a.K + BK - 1) / BK;
   const int per = (ktiles + a.splitk - 1) / a.splitk;
   const int kt0 = ks * per, kt1 = min(ktiles, kt0 + per);
+  if (kt0 >= kt1) return;  // empty split (uniform per block): nothing to contribute
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -124,12 +175,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   uint4 ra[4], rb[4];
-  if (kt0 < kt1) {
-    load_tile<TA>(ra, A, a.lda, m0, kt0 * BK, a.M, a.K, tid);
-    load_tile<TB>(rb, B, a.ldb, n0, kt0 * BK, a.N, a.K, tid);
-    store_tile<TA>(ra, sA[0], tid);
-    store_tile<TB>(rb, sB[0], tid);
-  }
+  load_tile<TA>(ra, A, a.lda, m0, kt0 * BK, a.M, a.K, tid);
+  load_tile<TB>(rb, B, a.ldb, n0, kt0 * BK, a.N, a.K, tid);
+  store_tile<TA>(ra, smem, tid);
+  store_tile<TB>(rb, smem + TILE, tid);
   __syncthreads();
 
   int cur = 0;
@@ -139,15 +188,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
       load_tile<TA>(ra, A, a.lda, m0, (kt + 1) * BK, a.M, a.K, tid);
       load_tile<TB>(rb, B, a.ldb, n0, (kt + 1) * BK, a.N, a.K, tid);
     }
-    const bf16_t* cA = sA[cur] + (wr * 64 + (lane & 15)) * LDT + (lane >> 4) * 8;
-    const bf16_t* cB = sB[cur] + (wc * 64 + (lane & 15)) * LDT + (lane >> 4) * 8;
+    const bf16_t* imgA = smem + cur * (2 * TILE);
+    const bf16_t* imgB = imgA + TILE;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 fa[4], fb[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        fa[i] = *reinterpret_cast<const bf16x8*>(cA + i * 16 * LDT + kk * 32);
-        fb[i] = *reinterpret_cast<const bf16x8*>(cB + i * 16 * LDT + kk * 32);
+        fa[i] = load_frag<TA>(imgA, wr * 64 + i * 16, kk, lane);
+        fb[i] = load_frag<TB>(imgB, wc * 64 + i * 16, kk, lane);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -156,50 +205,109 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
     if (more) {
-      store_tile<TA>(ra, sA[cur ^ 1], tid);
-      store_tile<TB>(rb, sB[cur ^ 1], tid);
+      bf16_t* nxt = smem + (cur ^ 1) * (2 * TILE);
+      store_tile<TA>(ra, nxt, tid);
+      store_tile<TB>(rb, nxt + TILE, tid);
     }
     __syncthreads();
     cur ^= 1;
   }
-  if (kt0 >= kt1 && a.splitk > 1) return;  // empty split contributes nothing
 
-  // ---- epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + reg ----
+  // ---- epilogue.  The accumulators (C/D layout: col = lane&15, row = (lane>>4)*4 + reg) are staged through LDS as an
+  // fp32 [128][132] image so that the fused epilogue works on 8 contiguous columns per thread: bias / aux / residual
+  // come in as 16-byte loads and C leaves as one (bf16) or two (fp32) 16-byte stores per chunk.  The staging writes use
+  // literal tile indices (a rolled loop would index acc[][] dynamically and push the accumulators to scratch).
+  float* sC = reinterpret_cast<float*>(smem);
+  {
+    float* w = sC + (wr * 64 + (lane >> 4) * 4) * LDC_S + wc * 64 + (lane & 15);
+#define STG_E(I, J, R) w[((I) * 16 + (R)) * LDC_S + (J) * 16] = acc[I][J][R]
+#define STG_T(I, J) STG_E(I, J, 0); STG_E(I, J, 1); STG_E(I, J, 2); STG_E(I, J, 3)
+#define STG_R(I) STG_T(I, 0); STG_T(I, 1); STG_T(I, 2); STG_T(I, 3)
+    STG_R(0); STG_R(1); STG_R(2); STG_R(3);
+#undef STG_R
+#undef STG_T
+#undef STG_E
+  }
+  __syncthreads();
   const long long coff = zo * a.sCo + zi * a.sCi;
   const bool lead = (ks == 0);
+  if (a.c_dtype == MMDTI_DT_F32_ATOMIC || !a.vec_ok) {
+    // lane <-> column: every wave instruction touches 256 contiguous bytes of one C row (atomic-friendly shape)
+    for (int it = 0; it < (BM * BN) / 256; ++it) {
+      const int idx = tid + it * 256;
+      const int r = idx >> 7, c = idx & (BN - 1);
+      epi_elem(a, sC[r * LDC_S + c], m0 + r, n0 + c, lead, coff);
+    }
+    return;
+  }
+  for (int it = 0; it < (BM * BN) / (256 * 8); ++it) {
+    const int chunk = tid + it * 256;
+    const int r = chunk >> 4, cc = (chunk & 15) * 8;
+    const int row = m0 + r, col = n0 + cc;
+    if (row >= a.M || col >= a.N) continue;
+    if (col + 8 > a.N) {  // ragged right edge
+      for (int e = 0; e < a.N - col; ++e) epi_elem(a, sC[r * LDC_S + cc + e], row, col + e, lead, coff);
+      continue;
+    }
+    float v[8];
+    {
+      const float4 lo = *reinterpret_cast<const float4*>(sC + r * LDC_S + cc);
+      const float4 hi = *reinterpret_cast<const float4*>(sC + r * LDC_S + cc + 4);
+      v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = n0 + wc * 64 + j * 16 + (lane & 15);
-      if (col >= a.N) continue;
-      const float bv = (a.bias && lead) ? a.bias[col] : 0.f;
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int row = m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + rr;
-        if (row >= a.M) continue;
-        float v = acc[i][j][rr] * a.alpha + bv;
-        if (a.act == MMDTI_ACT_GELU) {
-          if (a.aux_out) a.aux_out[(long long)row * a.ld_aux + col] = f2bf(v);
-          v = gelu_erf(v);
-        } else if (a.act == MMDTI_ACT_GELU_BWD) {
-          v *= gelu_erf_grad(bf2f(a.aux_in[(long long)row * a.ld_aux + col]));
-        }
-        if (a.drop_thresh) {
-          bool keep = dropout_keep(a.seed, a.site, (uint64_t)row * (uint64_t)a.N + col, a.drop_thresh);
-          v = keep ? v * a.drop_scale : 0.f;
-        }
-        if (a.residual && lead) v += a.residual[(long long)row * a.ldr + col];
-        const long long ci = coff + (long long)row * a.ldc + col;
-        if (a.c_dtype == MMDTI_DT_BF16) {
-          reinterpret_cast<bf16_t*>(a.C)[ci] = f2bf(v);
-        } else if (a.c_dtype == MMDTI_DT_F32) {
-          float* c = reinterpret_cast<float*>(a.C);
-          c[ci] = (a.beta != 0.f) ? v + a.beta * c[ci] : v;
-        } else {
-          atomicAdd(reinterpret_cast<float*>(a.C) + ci, v);
-        }
+    for (int e = 0; e < 8; ++e) v[e] *= a.alpha;
+    if (a.bias && lead) {
+      const float4 b0 = *reinterpret_cast<const float4*>(a.bias + col), b1 = *reinterpret_cast<const float4*>(a.bias + col + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+    if (a.act == MMDTI_ACT_GELU) {
+      if (a.aux_out) {
+        uint4 u;
+        u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+        u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+        *reinterpret_cast<uint4*>(a.aux_out + (long long)row * a.ld_aux + col) = u;
       }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+    } else if (a.act == MMDTI_ACT_GELU_BWD) {
+      const uint4 u = *reinterpret_cast<const uint4*>(a.aux_in + (long long)row * a.ld_aux + col);
+      const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        v[e] *= gelu_erf_grad(__uint_as_float((e & 1) ? (w4[e >> 1] & 0xffff0000u) : (w4[e >> 1] << 16)));
+    }
+    if (a.drop_thresh) {  // N % 8 == 0 on this path, so the 8 elements are Philox counters idx/4 and idx/4+1
+      const uint64_t idx = (uint64_t)row * (uint64_t)a.N + col;
+      const Rand4 r0 = philox4(a.seed, a.site, idx >> 2), r1 = philox4(a.seed, a.site, (idx >> 2) + 1);
+      const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = rw[e] >= a.drop_thresh ? v[e] * a.drop_scale : 0.f;
+    }
+    if (a.residual && lead) {
+      const float* rp = a.residual + (long long)row * a.ldr + col;
+      const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+      v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+    }
+    const long long ci = coff + (long long)row * a.ldc + col;
+    if (a.c_dtype == MMDTI_DT_BF16) {
+      uint4 u;
+      u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+      u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+      u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+      u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + ci) = u;
+    } else {
+      float* c = reinterpret_cast<float*>(a.C) + ci;
+      if (a.beta != 0.f) {
+        const float4 c0 = *reinterpret_cast<const float4*>(c), c1 = *reinterpret_cast<const float4*>(c + 4);
+        v[0] += a.beta * c0.x; v[1] += a.beta * c0.y; v[2] += a.beta * c0.z; v[3] += a.beta * c0.w;
+        v[4] += a.beta * c1.x; v[5] += a.beta * c1.y; v[6] += a.beta * c1.z; v[7] += a.beta * c1.w;
+      }
+      *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
     }
   }
 }
@@ -236,6 +344,16 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
   a.act = act; a.aux_in = (const bf16_t*)aux_in; a.aux_out = (bf16_t*)aux_out; a.ld_aux = ld_aux; a.c_dtype = c_dtype;
   a.drop_thresh = dropout_thresh(drop_p); a.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   a.seed = seed; a.site = site;
+  {
+    const bool bf = c_dtype == MMDTI_DT_BF16;
+    const int cal = bf ? 8 : 4;
+    bool ok = aligned16(C) && (ldc % cal == 0) && (sCo % cal == 0) && (sCi % cal == 0) && (N % 8 == 0);
+    if (bias) ok = ok && aligned16(bias);
+    if (residual) ok = ok && aligned16(residual) && (ldr % 4 == 0);
+    if (aux_in) ok = ok && aligned16(aux_in) && (ld_aux % 8 == 0);
+    if (aux_out) ok = ok && aligned16(aux_out) && (ld_aux % 8 == 0);
+    a.vec_ok = ok ? 1 : 0;
+  }
   const int tiles = cdiv(M, BM) * cdiv(N, BN);
   dim3 grid(tiles, 1, batch_outer * batch_inner * splitk), block(256);
   MMDTI_REQUIRE(grid.z <= 65535u, "gemm: batch*splitk too large (%u)", grid.z);

@@ -9,6 +9,7 @@ instead of ~350 small per-tensor launches.  ``nn.Parameter``s stay what the refe
 from __future__ import annotations
 
 import itertools
+import weakref
 from typing import Dict, Iterable, List, Optional
 
 import torch
@@ -86,11 +87,14 @@ class _ShadowCache:
     def get(self, p: torch.Tensor) -> torch.Tensor:
         key = id(p)
         ent = self._c.get(key)
-        ver = (p.data_ptr(), p._version)
-        if ent is None or ent[0] != ver:
-            ent = (ver, ops.cast_bf16(p.detach().contiguous()))
+        ver = (p.data_ptr(), p._version, tuple(p.shape))
+        # id() values are recycled once a parameter dies: the weak reference proves the entry belongs to THIS tensor
+        if ent is None or ent[0]() is not p or ent[1] != ver:
+            if len(self._c) > 4096:
+                self._c = {k: e for k, e in self._c.items() if e[0]() is not None}
+            ent = (weakref.ref(p), ver, ops.cast_bf16(p.detach().contiguous()))
             self._c[key] = ent
-        return ent[1]
+        return ent[2]
 
 
 _shadow_cache = _ShadowCache()

@@ -147,7 +147,9 @@ def test_pair_encoder_train_mode_dropout(M):
         x, _, _ = enc.encode(e, b4.cuda().requires_grad_(), pad.cuda())
         (x * R).sum().backward()
         outs.append((x.detach().clone(), e.grad.clone()))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])      # same seed -> same masks fwd AND bwd
+    assert torch.equal(outs[0][0], outs[1][0])                                              # same seed -> same masks, bit-identical forward
+    # backward: same masks too; dK/dV and weight gradients are combined with fp32 atomics, so allow summation-order noise
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-5)
     enc.eval()
     x_eval, _, _ = enc.encode(emb.cuda(), b4.cuda(), pad.cuda())
     assert rel_l2(outs[0][0], x_eval) > 0.05                                                 # dropout really on
