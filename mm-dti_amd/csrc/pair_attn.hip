@@ -70,10 +70,28 @@ __global__ __launch_bounds__(256) void pair_attn_fwd_kernel(const bf16_t* __rest
   }
   __syncthreads();
   const float NEG_INF = -INFINITY;
+  // software pipeline over rows: the bias row of iteration i+4 is requested before row i is processed, so each wave keeps
+  // two rows of pair traffic in flight (the stream is latency-bound otherwise: one row = 3 x 256 B per wave).
+  float nb[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int j = c * 64 + lane;
+    nb[c] = (wave < N && j < N && !masked[c]) ? bias_in[((long long)bh * N + wave) * ld + j] : 0.f;
+  }
   for (int i = wave; i < N; i += 4) {
     const float4 q0 = *reinterpret_cast<const float4*>(&sq[i][0]);
     const float4 q1 = *reinterpret_cast<const float4*>(&sq[i][4]);
     const long long rowoff = ((long long)bh * N + i) * ld;
+    float cb[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) cb[c] = nb[c];
+    if (i + 4 < N) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int j = c * 64 + lane;
+        nb[c] = (j < N && !masked[c]) ? bias_in[rowoff + 4LL * ld + j] : 0.f;
+      }
+    }
     float sv[NCH];
     float m = NEG_INF;
 #pragma unroll
@@ -83,7 +101,7 @@ __global__ __launch_bounds__(256) void pair_attn_fwd_kernel(const bf16_t* __rest
       if (j < N) {
         float dot = q0.x * k[c][0] + q0.y * k[c][1] + q0.z * k[c][2] + q0.w * k[c][3] + q1.x * k[c][4] +
                     q1.y * k[c][5] + q1.z * k[c][6] + q1.w * k[c][7];
-        s = masked[c] ? NEG_INF : scale * dot + bias_in[rowoff + j];
+        s = masked[c] ? NEG_INF : scale * dot + cb[c];
         s_out[rowoff + j] = s;
       }
       sv[c] = s;
@@ -154,6 +172,15 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_kernel(const bf16_t* __rest
   }
   __syncthreads();
   const float NEG_INF = -INFINITY;
+  // software pipeline over rows (see the forward kernel): S and G of row i+4 are in flight while row i is processed
+  float ns[NCH], ng[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int j = c * 64 + lane;
+    const bool ok = wave < N && j < N;
+    ns[c] = ok ? s[((long long)bh * N + wave) * ld + j] : NEG_INF;
+    ng[c] = (ok && !g_in_zero) ? g[((long long)bh * N + wave) * ld + j] : 0.f;
+  }
   for (int i = wave; i < N; i += 4) {
     float q[8], dd[8];
     {
@@ -163,13 +190,21 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_kernel(const bf16_t* __rest
       dd[0] = b0.x; dd[1] = b0.y; dd[2] = b0.z; dd[3] = b0.w; dd[4] = b1.x; dd[5] = b1.y; dd[6] = b1.z; dd[7] = b1.w;
     }
     const long long rowoff = ((long long)bh * N + i) * ld;
-    float p[NCH], dpp[NCH], pd[NCH];
+    float p[NCH], dpp[NCH], pd[NCH], gin[NCH];
     float m = NEG_INF;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      const int j = c * 64 + lane;
-      p[c] = (j < N) ? s[rowoff + j] : NEG_INF;
+      p[c] = ns[c];
+      gin[c] = ng[c];
       m = fmaxf(m, p[c]);
+    }
+    if (i + 4 < N) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int j = c * 64 + lane;
+        ns[c] = (j < N) ? s[rowoff + 4LL * ld + j] : NEG_INF;
+        ng[c] = (j < N && !g_in_zero) ? g[rowoff + 4LL * ld + j] : 0.f;
+      }
     }
     m = wave_max(m);
     float sum = 0.f;
@@ -202,8 +237,7 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_kernel(const bf16_t* __rest
       const int j = c * 64 + lane;
       float gg = 0.f;
       if (j < N) {
-        gg = p[c] * (dpp[c] - dl);
-        if (!g_in_zero) gg += g[rowoff + j];
+        gg = p[c] * (dpp[c] - dl) + gin[c];
         g[rowoff + j] = gg;
       }
 #pragma unroll

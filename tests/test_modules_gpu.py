@@ -490,3 +490,22 @@ def test_state_dict_keys_match_reference_surface(M):
     assert model.encoder.layers[0].self_attn.in_proj.weight.shape == (192, 64)
     model2 = _tiny_model(M, "regression", 1, fds=True, seed=9)[2]
     model2.load_state_dict(model.state_dict(), strict=True)                                     # strict round trip (predict path)
+
+
+# --------------------------------------------------------------------------------------------- models/encoder.py stand-ins
+def test_split_tower_encoders_match_fused_model(M):
+    import mmdti_hip.models.encoder as enc
+    ocfg, P, model = _tiny_model(M, "classification", 2)
+    model.eval()
+    batch, label = O.synth_batch(5, 10, 14, ocfg, seed=8, ragged=True)
+    mol = M.mm.molecule_architecture()
+    mol.encoder_layers, mol.encoder_embed_dim, mol.encoder_ffn_embed_dim, mol.encoder_attention_heads = 2, 64, 128, 8
+    ue = enc.UnimolEncoder(_mol_args=mol, _gbf_K=16).cuda().eval()
+    ue.load_state_dict({k: v for k, v in model.state_dict().items() if k.startswith(("embed_tokens.", "encoder.", "gbf.", "gbf_proj."))}, strict=True)
+    rep = ue(batch["src_tokens"].cuda(), batch["src_distance"].cuda(), batch["src_edge_type"].cuda())
+    ref, _, _ = O.mm_features(batch, P, ocfg, bf16=True)
+    check(rep, ref, 3e-3, "UnimolEncoder")
+    ce = enc.ChembertaEncoder(_roberta_cfg=model.bert.cfg).cuda().eval()
+    ce.bert.load_state_dict(model.bert.state_dict(), strict=True)
+    out = ce(batch["input_ids"].cuda(), batch["attention_mask"].cuda())
+    check(out, O.roberta_encoder(batch["input_ids"], batch["attention_mask"], P, ocfg.roberta, bf16=True), 3e-3, "ChembertaEncoder")

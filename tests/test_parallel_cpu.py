@@ -1,0 +1,163 @@
+"""Multi-process (world_size 2, gloo, CPU) tests of the data-parallel host logic in mmdti_hip/parallel.py:
+global InfoNCE negatives (all-gather + its adjoint), bucketed arena all-reduce, batch sharding.
+
+No GPU and no HIP compute here: the per-rank arithmetic is the CPU oracle, which is exactly what lets these tests pin
+the SEMANTICS chosen for DDP: two ranks on a global batch reproduce the single-process loss and
+gradients."""
+import os
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _init(rank, world, initfile):
+    for p in (ROOT, os.path.join(ROOT, "mm-dti_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    dist.init_process_group("gloo", rank=rank, world_size=world, init_method=f"file://{initfile}")
+
+
+class _AllGatherFn(torch.autograd.Function):
+    """autograd wrapper used only by this test: forward = GlobalNegatives.gather, backward = its reduce_scatter."""
+
+    @staticmethod
+    def forward(ctx, x, negs):
+        ctx.negs = negs
+        return negs.gather(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.negs.reduce_scatter(g.clone()), None
+
+
+def _worker_global_negatives(rank, world, initfile, out):
+    _init(rank, world, initfile)
+    from mmdti_hip.parallel import GlobalNegatives, shard_batch
+    from oracle import mmdti_oracle as O
+    torch.manual_seed(0)
+    B, d = 8, 50
+    q_all = torch.randn(B, d)
+    k_all = torch.randn(B, d)
+    label = torch.arange(B).view(B, 1)
+    (sh, lab) = shard_batch({"q": q_all, "k": k_all}, label, rank, world)
+    assert lab[0, 0] == rank * (B // world)
+    negs = GlobalNegatives()
+    q = sh["q"].clone().requires_grad_()
+    k = sh["k"].clone().requires_grad_()
+    both = _AllGatherFn.apply(torch.cat((q, k), 1), negs)               # ONE fused message for both towers
+    qg, kg = both[:, :d], both[:, d:]
+    qh, kh = torch.nn.functional.normalize(qg, dim=-1), torch.nn.functional.normalize(kg, dim=-1)
+    logits = qh @ kh.T / 0.1
+    b = B // world
+    rows = slice(negs.row0(b), negs.row0(b) + b)
+    lse_a = torch.logsumexp(logits[rows], 1) - logits[rows].diagonal(offset=rows.start)
+    lse_b = torch.logsumexp(logits.T[rows], 1) - logits.T[rows].diagonal(offset=rows.start)
+    share = (lse_a.sum() + lse_b.sum()) / (2 * B)                        # this rank's share of the global loss
+    (share * world).backward()                                           # trainer.py: x world, then gradients are AVERAGED
+    g = torch.cat((q.grad, k.grad), 1)
+    dist.all_reduce(share)                                               # sum of shares == global loss
+    # reference: single process on the global batch
+    qr, kr = q_all.clone().requires_grad_(), k_all.clone().requires_grad_()
+    ref = O.info_nce(qr, kr, temperature=0.1)
+    ref.backward()
+    gref = torch.cat((qr.grad, kr.grad), 1)[rows]
+    torch.testing.assert_close(share, ref.detach(), rtol=1e-5, atol=1e-6)
+    # after the rank-mean of gradients, a parameter sees (1/world) * sum_r grad_r ; the embedding gradient of OWN rows is
+    # only produced on this rank, so grad_r / world must equal the single-process gradient
+    torch.testing.assert_close(g / world, gref, rtol=1e-4, atol=1e-6)
+    if rank == 0:
+        torch.save({"ok": True}, out)
+    dist.destroy_process_group()
+
+
+class _FakeArena:
+    def __init__(self, n):
+        self.numel = n
+        self.grad = torch.zeros(n)
+
+
+def _worker_reducer(rank, world, initfile, out):
+    _init(rank, world, initfile)
+    from mmdti_hip.parallel import ArenaReducer
+    n = 1000
+    arena = _FakeArena(n)
+    arena.grad.copy_(torch.arange(n, dtype=torch.float32) * (rank + 1))
+    red = ArenaReducer(arena, bucket_bytes=4 * 256)                      # 4 buckets of 256 floats
+    assert len(red.buckets) == 4 and red.buckets[-1] == (768, 1000)
+    red.reduce_range(512, 1000)                                          # "backward finished the tail of the arena first"
+    assert sorted(red._pending) == [(512, 768), (768, 1000)]
+    red.finish()
+    expect = torch.arange(n, dtype=torch.float32) * (1 + 2) / 2          # mean over the two ranks
+    torch.testing.assert_close(arena.grad, expect)
+    assert red._pending == []
+    if rank == 0:
+        torch.save({"ok": True}, out)
+    dist.destroy_process_group()
+
+
+def _worker_step_equivalence(rank, world, initfile, out):
+    """Full tiny model: rank-local oracle steps with global negatives + averaged gradients == one global step with
+    (global InfoNCE, rank-mean of local task/CT losses)."""
+    _init(rank, world, initfile)
+    from mmdti_hip.parallel import GlobalNegatives, shard_batch
+    from oracle import mmdti_oracle as O
+    cfg = O.ModelCfg(unimol=O.UniMolCfg(layers=1, dim=32, ffn=64, heads=4, K=8, vocab=31),
+                     roberta=O.RobertaCfg(layers=1, dim=32, heads=2, ffn=64, vocab=40, max_pos=40),
+                     cross=O.CrossCfg(dim=32, heads=2, ffn=64), task="classification", output_dim=2)
+    P = {k: v.requires_grad_() for k, v in O.init_params(cfg, seed=3, std=0.1).items()}
+    batch, label = O.synth_batch(4, 6, 9, cfg, seed=11, ragged=True)      # GLOBAL batch, padded to global max lengths
+    negs = GlobalNegatives()
+    sh, lab = shard_batch(batch, label, rank, world)
+    enc, bert, pooled = O.mm_features(sh, P, cfg)
+    a, b = O.infonce_embed(enc, bert, P, p=0.0)
+    both = _AllGatherFn.apply(torch.cat((a, b), 1), negs)
+    d = a.shape[1]
+    Bg, bl = both.shape[0], a.shape[0]
+    qh, kh = torch.nn.functional.normalize(both[:, :d], dim=-1), torch.nn.functional.normalize(both[:, d:], dim=-1)
+    logits = qh @ kh.T / 0.1
+    r0 = negs.row0(bl)
+    rows = slice(r0, r0 + bl)
+    share = ((torch.logsumexp(logits[rows], 1) - logits[rows].diagonal(offset=r0)).sum()
+             + (torch.logsumexp(logits.T[rows], 1) - logits.T[rows].diagonal(offset=r0)).sum()) / (2 * Bg)
+    logits_head = O.classification_head(pooled, P)
+    ct = O.ct_single(pooled, lab, logits_head)
+    loss = O.task_loss(logits_head, lab, cfg.task) + 0.1 * share * world + 0.1 * ct
+    loss.backward()
+    flat = torch.cat([p.grad.reshape(-1) if p.grad is not None else torch.zeros(p.numel()) for p in P.values()])
+    dist.all_reduce(flat)
+    flat /= world
+    # single-process reference of the same semantics
+    Pr = {k: v.detach().clone().requires_grad_() for k, v in P.items()}
+    enc, bert, pooled = O.mm_features(batch, Pr, cfg)
+    infonce = O.infonce_forward(enc, bert, Pr, p=0.0)
+    lh = O.classification_head(pooled, Pr)
+    half = label.shape[0] // world
+    tl = sum(O.task_loss(lh[i * half:(i + 1) * half], label[i * half:(i + 1) * half], cfg.task) for i in range(world)) / world
+    ctr = sum(O.ct_single(pooled[i * half:(i + 1) * half], label[i * half:(i + 1) * half], None) for i in range(world)) / world
+    (tl + 0.1 * infonce + 0.1 * ctr).backward()
+    ref = torch.cat([p.grad.reshape(-1) if p.grad is not None else torch.zeros(p.numel()) for p in Pr.values()])
+    torch.testing.assert_close(flat, ref, rtol=2e-3, atol=2e-6)
+    if rank == 0:
+        torch.save({"ok": True}, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("worker", [_worker_global_negatives, _worker_reducer, _worker_step_equivalence])
+def test_two_ranks_gloo(worker):
+    with tempfile.TemporaryDirectory() as td:
+        initfile, out = os.path.join(td, "init"), os.path.join(td, "out.pt")
+        mp.spawn(worker, args=(2, initfile, out), nprocs=2, join=True)
+        assert torch.load(out)["ok"]
+
+
+def test_shard_batch_requires_even_split():
+    sys.path.insert(0, os.path.join(ROOT, "mm-dti_amd"))
+    from mmdti_hip.parallel import shard_batch
+    with pytest.raises(AssertionError):
+        shard_batch({"x": torch.zeros(5, 2)}, torch.zeros(5, 1), 0, 2)
