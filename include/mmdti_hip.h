@@ -17,7 +17,7 @@
  *   - return value: MMDTI_OK or an error code; mmdti_last_error() gives the text
  *     (thread-local).  Argument validation happens on the host BEFORE any launch.
  *   - "atomic accumulate" outputs must be zeroed by the caller (gradient arena).
- *   - dropout: p in [0,1); mask = Philox4x32-10(seed, site, element index); the
+ *   - dropout: p in [0,1); mask = counter-based hash RNG(seed, site, element index); the
  *     backward entry regenerates the same mask from (seed, site).
  */
 #ifndef MMDTI_HIP_H

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void pair_attn_fwd_kernel(const bf16_t* __rest
       float p = sv[c] * inv;
       if (thresh) {
         const int j = c * 64 + lane;
-        bool keep = dropout_keep(seed, site, ((uint64_t)bh * N + i) * N + j, thresh);
+        bool keep = dropout_keep(seed, site, ((uint64_t)bh * N + i) * ld + j, thresh);
         p = keep ? p * dscale : 0.f;
       }
 #pragma unroll
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_kernel(const bf16_t* __rest
       float keepscale = 1.f;
       if (thresh) {
         const int j = c * 64 + lane;
-        keepscale = dropout_keep(seed, site, ((uint64_t)bh * N + i) * N + j, thresh) ? dscale : 0.f;
+        keepscale = dropout_keep(seed, site, ((uint64_t)bh * N + i) * ld + j, thresh) ? dscale : 0.f;
       }
       dpp[c] = dp * keepscale;
       pd[c] = p[c] * keepscale;
@@ -276,6 +276,125 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_kernel(const bf16_t* __rest
   }
 }
 
+// =====================================================================================================================
+// MFMA-tiled forward.  One wave owns a block of 16 queries and walks the key tiles of 16: the score tile is computed
+// TRANSPOSED, S^T[key][query] = K.Q^T, with v_mfma_f32_16x16x4_f32 (exact fp32; head_dim 8 = two K=4 steps) and the
+// bias tile as the accumulator input, so bias add, S write-out and softmax all happen on the accumulator layout
+// (lane = query column, 4 consecutive keys per lane-group in registers): pair traffic is one 16-byte load + one 16-byte
+// store per lane per tile, the row softmax needs only two cross-lane steps per query block, and P^T is already the B
+// operand of the P.V product (O^T = V^T.P^T) -- no data movement between the two matrix products.
+// Dropout element index = (bh*N + query)*ld + key (ld % 4 == 0: one RNG call per 4 keys).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int VSTR = 10;  // fp32 row stride of the V image: (4g+t)*10 + d is bank-conflict-free for the 4 lane groups
+
+__device__ __forceinline__ int dperm(int d) { return (d & 3) * 2 + (d >> 2); }  // d and d+4 adjacent: one ds_read_b64
+
+template <int NT>
+__global__ __launch_bounds__(256) void pair_attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_in,
+                                                                 float* __restrict__ s_out, bf16_t* __restrict__ o,
+                                                                 const unsigned char* __restrict__ key_pad, int N, int H, int ld,
+                                                                 float scale, uint32_t thresh, float dscale, uint64_t seed,
+                                                                 uint32_t site) {
+  constexpr int NP = NT * 16;
+  __shared__ __attribute__((aligned(16))) float sQ[NP][8];
+  __shared__ __attribute__((aligned(16))) float sK[NP][8];
+  __shared__ __attribute__((aligned(16))) float sV[NP * VSTR];
+  __shared__ __attribute__((aligned(16))) float sM[NP];
+  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  const int D = H * HD, D3 = 3 * D;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int nKB = (N + 15) >> 4;
+  const bf16_t* base = qkv + (long long)b * N * D3 + h * HD;
+  for (int t = tid; t < NP; t += blockDim.x) {
+    float q[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, vv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float msk = 1.f;
+    if (t < N) {
+      load8_bf16(base + (long long)t * D3, q);
+      load8_bf16(base + (long long)t * D3 + D, kk);
+      load8_bf16(base + (long long)t * D3 + 2 * D, vv);
+      msk = (key_pad && key_pad[b * N + t]) ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      sQ[t][dperm(d)] = q[d] * scale;
+      sK[t][dperm(d)] = kk[d];
+      sV[t * VSTR + d] = vv[d];
+    }
+    sM[t] = msk;
+  }
+  __syncthreads();
+  const int g = lane >> 4, c16 = lane & 15;
+  const float NEG_INF = -INFINITY;
+  for (int qb = wave; qb < nKB; qb += nwaves) {
+    const int qi = qb * 16 + c16;
+    const bool qvalid = qi < N;
+    const long long rowoff = ((long long)bh * N + (qvalid ? qi : 0)) * ld;
+    const float2 qv = *reinterpret_cast<const float2*>(&sQ[qb * 16 + c16][2 * g]);
+    f32x4 S[NT];
+    float m = NEG_INF;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t < nKB) {
+        const int kcol = t * 16 + 4 * g;
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        if (qvalid && kcol < N) c = *reinterpret_cast<const f32x4*>(bias_in + rowoff + kcol);
+        const float2 ka = *reinterpret_cast<const float2*>(&sK[t * 16 + c16][2 * g]);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.x, qv.x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.y, qv.y, c, 0, 0, 0);
+        const f32x4 km = *reinterpret_cast<const f32x4*>(&sM[kcol]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] = (km[r] != 0.f) ? NEG_INF : c[r];
+        if (qvalid && kcol < N) *reinterpret_cast<f32x4*>(s_out + rowoff + kcol) = c;
+        S[t] = c;
+        m = fmaxf(fmaxf(m, fmaxf(c[0], c[1])), fmaxf(c[2], c[3]));
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float lsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t < nKB) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __expf(S[t][r] - m);
+          S[t][r] = e;
+          lsum += e;
+        }
+      }
+    }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float inv = 1.0f / lsum;
+    f32x4 oacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t < nKB) {
+        f32x4 p = S[t] * inv;
+        if (thresh) {
+          const Rand4 rn = philox4(seed, site, (uint64_t)(rowoff + t * 16 + 4 * g) >> 2);
+          p[0] = rn.x >= thresh ? p[0] * dscale : 0.f;
+          p[1] = rn.y >= thresh ? p[1] * dscale : 0.f;
+          p[2] = rn.z >= thresh ? p[2] * dscale : 0.f;
+          p[3] = rn.w >= thresh ? p[3] * dscale : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float va = (c16 < 8) ? sV[(t * 16 + 4 * g + r) * VSTR + c16] : 0.f;
+          oacc = __builtin_amdgcn_mfma_f32_16x16x4f32(va, p[r], oacc, 0, 0, 0);
+        }
+      }
+    }
+    // O^T accumulator: column = query, rows d = 4g + r (valid for g < 2)
+    if (qvalid && g < 2) {
+      uint2 pk;
+      pk.x = (uint32_t)f2bf(oacc[0]) | ((uint32_t)f2bf(oacc[1]) << 16);
+      pk.y = (uint32_t)f2bf(oacc[2]) | ((uint32_t)f2bf(oacc[3]) << 16);
+      *reinterpret_cast<uint2*>(o + ((long long)b * N + qi) * D + h * HD + 4 * g) = pk;
+    }
+  }
+}
+
 }  // namespace mmdti
 using namespace mmdti;
 
@@ -298,6 +417,17 @@ extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, 
   const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   dim3 grid(B * H), block(256);
   hipStream_t s = (hipStream_t)stream;
+  if (ld % 4 == 0 && aligned16(bias_in) && aligned16(s_out)) {
+    const int nqb = (N + 15) / 16;
+    dim3 blk(nqb % 3 == 0 ? 192 : (nqb < 4 ? 64 * nqb : 256));
+#define PA_M(NT)                                                                                                     \
+  hipLaunchKernelGGL((pair_attn_fwd_mfma_kernel<NT>), grid, blk, 0, s, (const bf16_t*)qkv_bf16, bias_in, s_out,     \
+                     (bf16_t*)o_bf16, key_pad, N, H, ld, scale, th, sc, (uint64_t)seed, (uint32_t)site)
+    if (nqb <= 5) PA_M(5); else if (nqb <= 9) PA_M(9); else if (nqb <= 13) PA_M(13); else if (nqb <= 17) PA_M(17); else PA_M(20);
+#undef PA_M
+    MMDTI_LAUNCH_CHECK();
+    return MMDTI_OK;
+  }
 #define PA_F(NCH)                                                                                                   \
   hipLaunchKernelGGL((pair_attn_fwd_kernel<NCH>), grid, block, 0, s, (const bf16_t*)qkv_bf16, bias_in, s_out,      \
                      (bf16_t*)o_bf16, key_pad, N, H, ld, scale, th, sc, (uint64_t)seed, (uint32_t)site)
