@@ -330,14 +330,22 @@ __global__ __launch_bounds__(256) void pair_attn_fwd_mfma_kernel(const bf16_t* _
     const bool qvalid = qi < N;
     const long long rowoff = ((long long)bh * N + (qvalid ? qi : 0)) * ld;
     const float2 qv = *reinterpret_cast<const float2*>(&sQ[qb * 16 + c16][2 * g]);
+    // Phase 1: request every bias tile of this query block (branch-free predication, so the NT 16-byte loads are issued
+    // back to back and stay in flight together); tiles beyond N are fully masked and cost nothing but idle MFMA slots.
     f32x4 S[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int kcol = t * 16 + 4 * g;
+      const bool inrow = qvalid && kcol < N;
+      const f32x4 ld4 = *reinterpret_cast<const f32x4*>(bias_in + rowoff + (inrow ? kcol : 0));
+      S[t] = inrow ? ld4 : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     float m = NEG_INF;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      if (t < nKB) {
+      {
         const int kcol = t * 16 + 4 * g;
-        f32x4 c = {0.f, 0.f, 0.f, 0.f};
-        if (qvalid && kcol < N) c = *reinterpret_cast<const f32x4*>(bias_in + rowoff + kcol);
+        f32x4 c = S[t];
         const float2 ka = *reinterpret_cast<const float2*>(&sK[t * 16 + c16][2 * g]);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.x, qv.x, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.y, qv.y, c, 0, 0, 0);
@@ -354,7 +362,7 @@ __global__ __launch_bounds__(256) void pair_attn_fwd_mfma_kernel(const bf16_t* _
     float lsum = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      if (t < nKB) {
+      {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float e = __expf(S[t][r] - m);
@@ -369,7 +377,7 @@ __global__ __launch_bounds__(256) void pair_attn_fwd_mfma_kernel(const bf16_t* _
     f32x4 oacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      if (t < nKB) {
+      {
         f32x4 p = S[t] * inv;
         if (thresh) {
           const Rand4 rn = philox4(seed, site, (uint64_t)(rowoff + t * 16 + 4 * g) >> 2);
@@ -392,6 +400,213 @@ __global__ __launch_bounds__(256) void pair_attn_fwd_mfma_kernel(const bf16_t* _
       pk.y = (uint32_t)f2bf(oacc[2]) | ((uint32_t)f2bf(oacc[3]) << 16);
       *reinterpret_cast<uint2*>(o + ((long long)b * N + qi) * D + h * HD + 4 * g) = pk;
     }
+  }
+}
+
+// =====================================================================================================================
+// MFMA-tiled backward, same tiling as the forward: a wave owns 16 queries and sweeps the key tiles twice.
+//   sweep 1: load S^T tiles, row max / sum  ->  P^T ; dP^T = V.dO^T (MFMA) ; dropout mask (kept as 1 bit per element) ;
+//            delta = rowsum(dP' * P)
+//   sweep 2: G^T = G_in^T + P^T*(dP'^T - delta)  (16-byte load + store per lane per tile, in place) ;
+//            dQ^T += K^T.G^T (MFMA, G^T is already the B operand) ;
+//            dK += G.Qs and dV += Pd.dO contract over QUERIES (the lane axis of the accumulator layout), so each tile is
+//            transposed through a per-wave 16x16 LDS patch and fed as the A operand.
+// Each (query block, key tile) contribution to dK/dV is added to an LDS image shared by the block's waves.
+constexpr int TSTR = 20;  // fp32 row stride of the per-wave transpose patch (16-byte aligned rows)
+
+template <int NT>
+__global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ s_in,
+                                                                 const bf16_t* __restrict__ dO, const float* __restrict__ gin, float* __restrict__ gout,
+                                                                 bf16_t* __restrict__ dqkv, int N, int H, int ld, float scale,
+                                                                 int g_in_zero, uint32_t thresh, float dscale, uint64_t seed,
+                                                                 uint32_t site) {
+  constexpr int NP = NT * 16;
+  __shared__ __attribute__((aligned(16))) float sQ[NP * VSTR];   // Q * scale
+  __shared__ __attribute__((aligned(16))) float sK[NP * VSTR];
+  __shared__ __attribute__((aligned(16))) float sV[NP * VSTR];
+  __shared__ __attribute__((aligned(16))) float sD[NP * VSTR];   // dO
+  // per-wave dK / dV accumulators in MFMA accumulator order: [wave][tile][K|V][g][d][r] -- each lane owns one float4 per
+  // (tile, K|V), read as the MFMA C input and written back, so the waves never contend (LDS float atomics cost ~57
+  // cycles per wave-instruction here and were half of the kernel's time).
+  __shared__ __attribute__((aligned(16))) float redw[4 * NT * 2 * 128];
+  __shared__ __attribute__((aligned(16))) float patch[4][2][16 * TSTR];
+  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  const int D = H * HD, D3 = 3 * D;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int nKB = (N + 15) >> 4;
+  const bf16_t* base = qkv + (long long)b * N * D3 + h * HD;
+  for (int t = tid; t < NP; t += blockDim.x) {
+    float q[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, vv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (t < N) {
+      load8_bf16(base + (long long)t * D3, q);
+      load8_bf16(base + (long long)t * D3 + D, kk);
+      load8_bf16(base + (long long)t * D3 + 2 * D, vv);
+      load8_bf16(dO + ((long long)b * N + t) * D + h * HD, dd);
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      sQ[t * VSTR + d] = q[d] * scale;
+      sK[t * VSTR + d] = kk[d];
+      sV[t * VSTR + d] = vv[d];
+      sD[t * VSTR + d] = dd[d];
+    }
+  }
+  for (int t = tid; t < 4 * NT * 2 * 128; t += blockDim.x) redw[t] = 0.f;
+  __syncthreads();
+  const int g = lane >> 4, c16 = lane & 15;
+  const bool dlane = c16 < 8;
+  const float NEG_INF = -INFINITY;
+  float* pP = &patch[wave][0][0];
+  float* pG = &patch[wave][1][0];
+  for (int qb = wave; qb < nKB; qb += nwaves) {
+    const int qi = qb * 16 + c16;
+    const bool qvalid = qi < N;
+    const long long rowoff = ((long long)bh * N + (qvalid ? qi : 0)) * ld;
+    // B operand of dP^T = V.dO^T : dO[qi][g], dO[qi][g+4]
+    const float dob0 = sD[(qb * 16 + c16) * VSTR + g], dob1 = sD[(qb * 16 + c16) * VSTR + g + 4];
+    // ---- sweep 1
+    f32x4 P[NT], dPm[NT];
+    float m = NEG_INF;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      {
+        const int kcol = t * 16 + 4 * g;
+        const bool inrow = qvalid && kcol < N;
+        const f32x4 ld4 = *reinterpret_cast<const f32x4*>(s_in + rowoff + (inrow ? kcol : 0));
+        f32x4 c = inrow ? ld4 : f32x4{NEG_INF, NEG_INF, NEG_INF, NEG_INF};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] = (kcol + r < N) ? c[r] : NEG_INF;   // pad columns of the row are not data
+        P[t] = c;
+        m = fmaxf(fmaxf(m, fmaxf(c[0], c[1])), fmaxf(c[2], c[3]));
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    if (m == NEG_INF) m = 0.f;   // rows beyond N: everything is -inf, keep the arithmetic finite
+    float lsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __expf(P[t][r] - m);
+          P[t][r] = e;
+          lsum += e;
+        }
+      }
+    }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+    unsigned long long keepbits = ~0ull;
+    float dl = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      {
+        const float va0 = sV[(t * 16 + c16) * VSTR + g], va1 = sV[(t * 16 + c16) * VSTR + g + 4];
+        f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(va0, dob0, dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(va1, dob1, dp, 0, 0, 0);
+        P[t] = P[t] * inv;
+        if (thresh) {
+          const Rand4 rn = philox4(seed, site, (uint64_t)(rowoff + t * 16 + 4 * g) >> 2);
+          const bool k0 = rn.x >= thresh, k1 = rn.y >= thresh, k2 = rn.z >= thresh, k3 = rn.w >= thresh;
+          dp[0] = k0 ? dp[0] * dscale : 0.f; dp[1] = k1 ? dp[1] * dscale : 0.f;
+          dp[2] = k2 ? dp[2] * dscale : 0.f; dp[3] = k3 ? dp[3] * dscale : 0.f;
+          const unsigned long long bits = (k0 ? 1ull : 0ull) | (k1 ? 2ull : 0ull) | (k2 ? 4ull : 0ull) | (k3 ? 8ull : 0ull);
+          keepbits = (keepbits & ~(0xfull << (4 * t))) | (bits << (4 * t));
+        }
+        dPm[t] = dp;
+        dl += dp[0] * P[t][0] + dp[1] * P[t][1] + dp[2] * P[t][2] + dp[3] * P[t][3];
+      }
+    }
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    // ---- sweep 2 (branch-free per tile: G_in tiles are requested together up front, LDS operands are gathered in
+    // batches, so the compiler can keep loads in flight instead of waiting after each one)
+    f32x4 Gi[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int kcol = t * 16 + 4 * g;
+      const bool inrow = qvalid && kcol < N && !g_in_zero;
+      const f32x4 ld4 = *reinterpret_cast<const f32x4*>(gin + rowoff + (inrow ? kcol : 0));
+      Gi[t] = inrow ? ld4 : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+    const int dcol = dlane ? c16 : 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int kcol = t * 16 + 4 * g;
+      const bool inrow = qvalid && kcol < N;
+      f32x4 G;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float gv = P[t][r] * (dPm[t][r] - dl) + ((kcol + r < N) ? Gi[t][r] : 0.f);
+        G[r] = inrow ? gv : 0.f;
+      }
+      if (inrow) *reinterpret_cast<f32x4*>(gout + rowoff + kcol) = G;
+      f32x4 Pd = P[t];
+      if (thresh) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Pd[r] = ((keepbits >> (4 * t + r)) & 1ull) ? Pd[r] * dscale : 0.f;
+      }
+      if (!qvalid) Pd = f32x4{0.f, 0.f, 0.f, 0.f};
+      // transpose Pd and G through the wave's LDS patch: written [query][key], read [key][query]
+      *reinterpret_cast<f32x4*>(pP + c16 * TSTR + 4 * g) = Pd;
+      *reinterpret_cast<f32x4*>(pG + c16 * TSTR + 4 * g) = G;
+      // dQ^T += K^T . G^T   (step r: lane-group g carries key 4g + r)
+      float ka[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ka[r] = sK[(t * 16 + 4 * g + r) * VSTR + dcol];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dq = __builtin_amdgcn_mfma_f32_16x16x4f32(dlane ? ka[r] : 0.f, G[r], dq, 0, 0, 0);
+      float aP[4], aG[4], bD[4], bQ[4];
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {   // MFMA step st contracts queries 4*st + g
+        aP[st] = pP[(4 * st + g) * TSTR + c16];
+        aG[st] = pG[(4 * st + g) * TSTR + c16];
+        bD[st] = sD[(qb * 16 + 4 * st + g) * VSTR + dcol];
+        bQ[st] = sQ[(qb * 16 + 4 * st + g) * VSTR + dcol];
+      }
+      // dK / dV of key tile t: accumulator column = d (lanes c16 < 8), rows = keys 16t + 4g + r; the running sums of
+      // this wave live in LDS and pass through the MFMA as its C operand.
+      asm volatile("" ::: "memory");   // keep the LDS accumulator loads of later tiles from being hoisted (72 live VGPRs)
+      float* accK = redw + ((wave * NT + t) * 2 + 0) * 128 + (g * 8 + dcol) * 4;
+      float* accV = accK + 128;
+      f32x4 dKt = *reinterpret_cast<const f32x4*>(accK), dVt = *reinterpret_cast<const f32x4*>(accV);
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        dVt = __builtin_amdgcn_mfma_f32_16x16x4f32(aP[st], dlane ? bD[st] : 0.f, dVt, 0, 0, 0);
+        dKt = __builtin_amdgcn_mfma_f32_16x16x4f32(aG[st], dlane ? bQ[st] : 0.f, dKt, 0, 0, 0);
+      }
+      if (dlane) {
+        *reinterpret_cast<f32x4*>(accK) = dKt;
+        *reinterpret_cast<f32x4*>(accV) = dVt;
+      }
+    }
+    // dQ^T accumulator: column = query, rows d = 4g + r (valid for g < 2)
+    if (qvalid && g < 2) {
+      uint2 pk;
+      pk.x = (uint32_t)f2bf(dq[0] * scale) | ((uint32_t)f2bf(dq[1] * scale) << 16);
+      pk.y = (uint32_t)f2bf(dq[2] * scale) | ((uint32_t)f2bf(dq[3] * scale) << 16);
+      *reinterpret_cast<uint2*>(dqkv + ((long long)b * N + qi) * D3 + h * HD + 4 * g) = pk;
+    }
+  }
+  __syncthreads();
+  for (int key = tid; key < N; key += blockDim.x) {
+    const int t = key >> 4, kg = (key & 15) >> 2, r = key & 3;
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int w = 0; w < nwaves; ++w) {
+      const float* bk = redw + ((w * NT + t) * 2) * 128 + kg * 32 + r;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        a[d] += bk[d * 4];
+        c2[d] += bk[128 + d * 4];
+      }
+    }
+    bf16_t* dst = dqkv + ((long long)b * N + key) * D3 + h * HD;
+    store8_bf16(dst + D, a);
+    store8_bf16(dst + 2 * D, c2);
   }
 }
 
@@ -453,6 +668,18 @@ extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, 
   const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   dim3 grid(B * H), block(256);
   hipStream_t st = (hipStream_t)stream;
+  if (ld % 4 == 0 && aligned16(s) && aligned16(g) && N <= 16 * 13) {
+    const int nqb = (N + 15) / 16;
+    dim3 blk(nqb % 3 == 0 ? 192 : (nqb < 4 ? 64 * nqb : 256));
+#define PA_MB(NT)                                                                                                    \
+  hipLaunchKernelGGL((pair_attn_bwd_mfma_kernel<NT>), grid, blk, 0, st, (const bf16_t*)qkv_bf16, s,                 \
+                     (const bf16_t*)do_bf16, g, g, (bf16_t*)dqkv_bf16, N, H, ld, scale, g_in_zero, th, sc,         \
+                     (uint64_t)seed, (uint32_t)site)
+    if (nqb <= 5) PA_MB(5); else if (nqb <= 9) PA_MB(9); else PA_MB(13);
+#undef PA_MB
+    MMDTI_LAUNCH_CHECK();
+    return MMDTI_OK;
+  }
 #define PA_B(NCH)                                                                                                   \
   hipLaunchKernelGGL((pair_attn_bwd_kernel<NCH>), grid, block, 0, st, (const bf16_t*)qkv_bf16, s,                  \
                      (const bf16_t*)do_bf16, g, (bf16_t*)dqkv_bf16, N, H, ld, scale, g_in_zero, th, sc,            \
