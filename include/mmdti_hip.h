@@ -96,6 +96,11 @@ int mmdti_embedding_fwd(mmdti_stream_t stream, const long long* ids, const float
 /* dtable[ids[i]] += dout[i] (atomic), rows with ids==padding_idx skipped (padding_idx<0: none) */
 int mmdti_embedding_bwd(mmdti_stream_t stream, const long long* ids, const float* dout, long long n, int D,
                         int vocab, long long padding_idx, float* dtable);
+/* One-hot rows for the embedding backward: out[i, ids[i]] = 1 (bf16), everything else 0; rows with ids == padding_idx or
+ * out of range are all-zero.  out is [n, ld] with ld >= vocab, ld % 8 == 0.  dtable = onehot^T . dout is then ONE split-K
+ * MFMA GEMM (mmdti_gemm_bf16, both operands k-major) instead of n*D contended atomics on a few hundred table rows. */
+int mmdti_onehot_bf16(mmdti_stream_t stream, const long long* ids, long long n, int vocab, int ld, long long padding_idx,
+                      void* out_bf16);
 /* RoBERTa position ids: cumsum(ids!=pad)*(ids!=pad)+pad, int64, bit-exact (modeling_roberta.py:142-155) */
 int mmdti_roberta_position_ids(mmdti_stream_t stream, const long long* ids, int B, int L, long long pad_idx,
                                long long* out);

@@ -80,17 +80,36 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
   const int c0 = blockIdx.x * 256 + cc * 8;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (c0 < cols) {
-    for (int r = blockIdx.y * 8 + rl; r < rows; r += gridDim.y * 8) {
-      const bf16_t* p = x + (long long)r * ld + c0;
-      if (c0 + 8 <= cols) {
-        uint4 u = *reinterpret_cast<const uint4*>(p);
-        uint32_t w[4] = {u.x, u.y, u.z, u.w};
+    const int rstep = gridDim.y * 8;
+    int r = blockIdx.y * 8 + rl;
+    if (c0 + 8 <= cols) {
+      // 4 rows per iteration: four independent 16-byte loads in flight per lane
+      for (; r + 3 * rstep < rows; r += 4 * rstep) {
+        uint4 u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u[k] = *reinterpret_cast<const uint4*>(x + (long long)(r + k * rstep) * ld + c0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t w[4] = {u[k].x, u[k].y, u[k].z, u[k].w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc[2 * i] += __uint_as_float(w[i] << 16);
+            acc[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u);
+          }
+        }
+      }
+      for (; r < rows; r += rstep) {
+        const uint4 u = *reinterpret_cast<const uint4*>(x + (long long)r * ld + c0);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           acc[2 * i] += __uint_as_float(w[i] << 16);
           acc[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u);
         }
-      } else {
+      }
+    } else {
+      for (; r < rows; r += rstep) {
+        const bf16_t* p = x + (long long)r * ld + c0;
         for (int i = 0; i < cols - c0; ++i) acc[i] += bf2f(p[i]);
       }
     }
@@ -135,6 +154,23 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const long long* __r
     long long id = ids[i];
     if (id == padding_idx || id < 0 || id >= vocab) continue;
     atomicAdd(dtable + id * D + c, dout[t]);
+  }
+}
+
+// one-hot rows (bf16) for the embedding backward GEMM: thread per 8-column chunk
+__global__ __launch_bounds__(256) void onehot_bf16_kernel(const long long* __restrict__ ids, long long n, int vocab, int ld8,
+                                                          long long padding_idx, bf16_t* __restrict__ out) {
+  const long long total = n * ld8;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const long long i = t / ld8;
+    const int c0 = (int)(t - i * ld8) * 8;
+    const long long id = ids[i];
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    if (id != padding_idx && id >= 0 && id < vocab && id >= c0 && id < c0 + 8) {
+      const int e = (int)(id - c0);
+      w[e >> 1] = (e & 1) ? 0x3F800000u : 0x00003F80u;   // bf16(1.0) = 0x3F80
+    }
+    reinterpret_cast<uint4*>(out)[t] = make_uint4(w[0], w[1], w[2], w[3]);
   }
 }
 
@@ -375,8 +411,8 @@ extern "C" int mmdti_gelu_fwd_bf16(mmdti_stream_t stream, const void* u_bf16, vo
 extern "C" int mmdti_colsum_bf16(mmdti_stream_t stream, const void* x_bf16, int rows, int cols, int ld, float* out) {
   MMDTI_REQUIRE(x_bf16 && out && rows > 0 && cols > 0 && ld >= cols, "colsum_bf16: bad arguments");
   MMDTI_REQUIRE(ld % 8 == 0 && aligned16(x_bf16), "colsum_bf16: ld%%8 and 16-byte alignment required");
-  int gy = cdiv(rows, 8 * 16);
-  if (gy > 512) gy = 512;
+  int gy = cdiv(rows, 8 * 32);
+  if (gy > 256) gy = 256;
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(cols, 256), gy), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x_bf16, rows, cols, ld, out);
   MMDTI_LAUNCH_CHECK();
@@ -398,6 +434,16 @@ extern "C" int mmdti_embedding_bwd(mmdti_stream_t stream, const long long* ids, 
   MMDTI_REQUIRE(ids && dout && dtable && n > 0 && D > 0 && vocab > 0, "embedding_bwd: bad arguments");
   hipLaunchKernelGGL(embedding_bwd_kernel, dim3(grid_for(n * D, 256)), dim3(256), 0, (hipStream_t)stream, ids, dout,
                      n, D, vocab, padding_idx, dtable);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_onehot_bf16(mmdti_stream_t stream, const long long* ids, long long n, int vocab, int ld,
+                                 long long padding_idx, void* out_bf16) {
+  MMDTI_REQUIRE(ids && out_bf16 && n > 0 && vocab > 0 && ld >= vocab && ld % 8 == 0, "onehot_bf16: bad arguments");
+  MMDTI_REQUIRE(aligned16(out_bf16), "onehot_bf16: output must be 16-byte aligned");
+  hipLaunchKernelGGL(onehot_bf16_kernel, dim3(grid_for(n * (ld / 8), 256)), dim3(256), 0, (hipStream_t)stream, ids, n,
+                     vocab, ld / 8, padding_idx, (bf16_t*)out_bf16);
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }

@@ -196,7 +196,7 @@ class EmbeddingFn(torch.autograd.Function):
     def backward(ctx, dout):
         g = gbuf(ctx.w)
         if g is not None:
-            ops.embedding_bwd(ctx.ids, dout.contiguous(), g, ctx.pad)
+            ops.embedding_bwd_gemm(ctx.ids, ops.cast_bf16(dout.contiguous()), g, ctx.pad)
         notify_grads_ready([ctx.w])
         return None, None, None
 
@@ -331,10 +331,11 @@ class RobertaEncoderFn(torch.autograd.Function):
         de = ops.layernorm_bwd(dx, st.e.view(B * Lq, D), mod.emb_ln_w, st.em, st.er, gbuf(mod.emb_ln_w), gbuf(mod.emb_ln_b),
                                drop_p=st.p_hid, seed=st.seed, site=st.site_emb)
         cfg = mod.cfg
+        de16 = ops.cast_bf16(de)
         for ids, w, pad in ((st.ids, mod.word, cfg.pad_idx), (st.pos, mod.position, cfg.pad_idx), (st.zeros, mod.token_type, -1)):
             g = gbuf(w)
             if g is not None:
-                ops.embedding_bwd(ids, de, g, pad)
+                ops.embedding_bwd_gemm(ids, de16, g, pad)
         notify_grads_ready(mod.embeddings.parameters())
         return None, None, None, None, None
 

@@ -176,6 +176,23 @@ def embedding_bwd(ids, dout, dtable, padding_idx=-1):
     return dtable
 
 
+def embedding_bwd_gemm(ids, dout_bf16, dtable, padding_idx=-1):
+    """dtable[V,D] += onehot(ids)^T . dout  as one split-K MFMA GEMM (V == 1: a column sum)."""
+    V, D = dtable.shape
+    n = ids.numel()
+    _chk(dout_bf16, BF16, "embedding_bwd_gemm.dout")
+    if V == 1:
+        if padding_idx != 0:
+            colsum(dout_bf16.view(n, D), dtable.view(-1))
+        return dtable
+    ldv = (V + 7) // 8 * 8
+    oh = torch.empty(n, ldv, device=dtable.device, dtype=BF16)
+    lib().mmdti_onehot_bf16(_stream(), ids.data_ptr(), n, V, ldv, int(padding_idx), oh.data_ptr())
+    gemm(oh, dout_bf16.view(n, D), M=V, N=D, K=n, lda=ldv, ldb=D, transA=True, transB=True, out=dtable, ldc=D, atomic=True,
+         splitk=_splitk_for(V, D, n))
+    return dtable
+
+
 def roberta_position_ids(ids, pad_idx):
     _chk(ids, torch.int64, "position_ids.ids")
     out = torch.empty_like(ids)

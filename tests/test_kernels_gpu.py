@@ -319,6 +319,16 @@ def test_embedding_and_position_ids(ops, golden):
     tr = table.clone().requires_grad_()
     (torch.nn.functional.embedding(ids, tr, padding_idx=1) * dout).sum().backward()
     close(dt, tr.grad, 1e-5, 1e-5)
+    # same gradient as ONE one-hot MFMA GEMM (the path the modules use); dout passes through bf16 there
+    dt2 = torch.zeros(40, 32, device="cuda")
+    ops.embedding_bwd_gemm(dev(ids), dev(bf(dout)).view(-1, 32), dt2, padding_idx=1)
+    tr.grad = None
+    (torch.nn.functional.embedding(ids, tr, padding_idx=1) * rt(dout)).sum().backward()
+    close(dt2, tr.grad, 1e-4, 1e-4)
+    assert dt2[1].abs().max().item() == 0.0                                   # padding row receives nothing
+    one = torch.zeros(1, 32, device="cuda")
+    ops.embedding_bwd_gemm(dev(torch.zeros_like(ids)), dev(bf(dout)).view(-1, 32), one, padding_idx=-1)
+    close(one, rt(dout).view(-1, 32).sum(0, keepdim=True), 1e-4, 1e-3)
 
 
 # ------------------------------------------------------------------------------------------- InfoNCE (golden G1)
