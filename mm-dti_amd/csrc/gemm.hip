@@ -23,9 +23,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int LDT = BK + 8;  // LDS row stride in elements (144 B, 16-B aligned)
-constexpr int LDTR = BM + 8;  // k-major (transposed-operand) image row stride: 136 bf16 = 272 B (2-way worst case on tr reads)
-constexpr int LDC_S = BN + 4;  // fp32 epilogue staging row stride (528 B): 128*132*4 = 67,584 B <= the 73,728 B of tiles
+constexpr int LDT = BK;      // [row][k] image: unpadded 128-B rows, 16-B chunks XOR-swizzled by (row & 7) -> conflict-free ds_read_b128
+constexpr int LDTR = BM;     // [k][row] image: unpadded 256-B rows, 8-B units XOR-swizzled by k -> conflict-free ds_read_b64_tr_b16
+constexpr int LDC_S = BN + 4;  // fp32 epilogue staging row stride (528 B): 128*132*4 = 67,584 B (the tiles take 65,536 B)
 
 struct GemmArgs {
   const bf16_t* A;
@@ -73,17 +73,21 @@ __device__ __forceinline__ void load_tile(uint4 (&r)[4], const bf16_t* __restric
   }
 }
 
+// element-offset XOR for the k-major image: moves 8-byte units (4 elements) by 4*((k&3) | ((k>>3)&1)<<2) units, so the 32
+// lanes of a tr-read half-wave (k rows 8g+q and 8(g+1)+q, q = 0..3, four 8-byte units each) hit 32 distinct bank pairs.
+__device__ __forceinline__ int tr_swz(int k) { return (((k & 3) | (((k >> 3) & 1) << 2)) << 2) * 4; }
+
 template <bool TR>
 __device__ __forceinline__ void store_tile(const uint4 (&r)[4], bf16_t* lds, int tid) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int c = tid + i * 256;
     if (!TR) {
-      int row = c >> 3, kc = (c & 7) * 8;
+      int row = c >> 3, kc = ((c & 7) ^ (row & 7)) * 8;
       *reinterpret_cast<uint4*>(lds + row * LDT + kc) = r[i];
     } else {  // k-major image [64][LDTR]: the operand keeps its memory order, fragments come out of ds_read_b64_tr_b16
       int k = c >> 4, row = (c & 15) * 8;
-      *reinterpret_cast<uint4*>(lds + k * LDTR + row) = r[i];
+      *reinterpret_cast<uint4*>(lds + k * LDTR + (row ^ tr_swz(k))) = r[i];
     }
   }
 }
@@ -97,13 +101,15 @@ __device__ __forceinline__ void store_tile(const uint4 (&r)[4], bf16_t* lds, int
 template <bool TR>
 __device__ __forceinline__ bf16x8 load_frag(const bf16_t* img, int row0, int kk, int lane) {
   if (!TR) {
-    return *reinterpret_cast<const bf16x8*>(img + (row0 + (lane & 15)) * LDT + kk * 32 + (lane >> 4) * 8);
+    const int row = row0 + (lane & 15);
+    return *reinterpret_cast<const bf16x8*>(img + row * LDT + (((kk * 4 + (lane >> 4)) ^ (row & 7)) * 8));
   } else {
     typedef short s16x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-    const bf16_t* p = img + (kk * 32 + (lane >> 4) * 8 + ((lane & 15) >> 2)) * LDTR + row0 + (lane & 3) * 4;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * LDTR));
+    const int k = kk * 32 + (lane >> 4) * 8 + ((lane & 15) >> 2);
+    const int col = row0 + (lane & 3) * 4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + k * LDTR + (col ^ tr_swz(k))));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + (k + 4) * LDTR + (col ^ tr_swz(k + 4))));
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
@@ -174,44 +180,57 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  uint4 ra[4], rb[4];
-  load_tile<TA>(ra, A, a.lda, m0, kt0 * BK, a.M, a.K, tid);
-  load_tile<TB>(rb, B, a.ldb, n0, kt0 * BK, a.N, a.K, tid);
-  store_tile<TA>(ra, smem, tid);
-  store_tile<TB>(rb, smem + TILE, tid);
+  // Software pipeline, two K-tiles of global loads in flight: tile kt is being multiplied out of LDS while tile kt+1 sits
+  // in one register set (requested an iteration ago, written to the other LDS buffer at the end of this iteration) and
+  // tile kt+2 is requested into the second register set.  With one tile in flight the loop was bound by the
+  // global -> VGPR latency (~20 % of MFMA peak); the loop is unrolled by two so both register sets stay statically named.
+  uint4 ra0[4], rb0[4], ra1[4], rb1[4];
+  load_tile<TA>(ra0, A, a.lda, m0, kt0 * BK, a.M, a.K, tid);
+  load_tile<TB>(rb0, B, a.ldb, n0, kt0 * BK, a.N, a.K, tid);
+  store_tile<TA>(ra0, smem, tid);
+  store_tile<TB>(rb0, smem + TILE, tid);
+  if (kt0 + 1 < kt1) {
+    load_tile<TA>(ra0, A, a.lda, m0, (kt0 + 1) * BK, a.M, a.K, tid);
+    load_tile<TB>(rb0, B, a.ldb, n0, (kt0 + 1) * BK, a.N, a.K, tid);
+  }
   __syncthreads();
 
-  int cur = 0;
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const bool more = (kt + 1 < kt1);
-    if (more) {
-      load_tile<TA>(ra, A, a.lda, m0, (kt + 1) * BK, a.M, a.K, tid);
-      load_tile<TB>(rb, B, a.ldb, n0, (kt + 1) * BK, a.N, a.K, tid);
-    }
-    const bf16_t* imgA = smem + cur * (2 * TILE);
-    const bf16_t* imgB = imgA + TILE;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[i] = load_frag<TA>(imgA, wr * 64 + i * 16, kk, lane);
-        fb[i] = load_frag<TB>(imgB, wc * 64 + i * 16, kk, lane);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-    if (more) {
-      bf16_t* nxt = smem + (cur ^ 1) * (2 * TILE);
-      store_tile<TA>(ra, nxt, tid);
-      store_tile<TB>(rb, nxt + TILE, tid);
-    }
-    __syncthreads();
-    cur ^= 1;
+#define GEMM_COMPUTE(IMG)                                                                          \
+  {                                                                                                \
+    const bf16_t* imgA = (IMG);                                                                    \
+    const bf16_t* imgB = imgA + TILE;                                                              \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                             \
+      bf16x8 fa[4], fb[4];                                                                         \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                              \
+        fa[i] = load_frag<TA>(imgA, wr * 64 + i * 16, kk, lane);                                   \
+        fb[i] = load_frag<TB>(imgB, wc * 64 + i * 16, kk, lane);                                   \
+      }                                                                                            \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                              \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);   \
+    }                                                                                              \
   }
+  // one pipeline stage: RN = register set receiving tile kt+2, RC = register set holding tile kt+1
+#define GEMM_STAGE(KT, CUR, RNA, RNB, RCA, RCB)                                                    \
+  {                                                                                                \
+    if ((KT) + 2 < kt1) {                                                                          \
+      load_tile<TA>(RNA, A, a.lda, m0, ((KT) + 2) * BK, a.M, a.K, tid);                            \
+      load_tile<TB>(RNB, B, a.ldb, n0, ((KT) + 2) * BK, a.N, a.K, tid);                            \
+    }                                                                                              \
+    GEMM_COMPUTE(smem + (CUR) * (2 * TILE));                                                       \
+    if ((KT) + 1 < kt1) {                                                                          \
+      bf16_t* nxt = smem + ((CUR) ^ 1) * (2 * TILE);                                               \
+      store_tile<TA>(RCA, nxt, tid);                                                               \
+      store_tile<TB>(RCB, nxt + TILE, tid);                                                        \
+    }                                                                                              \
+    __syncthreads();                                                                               \
+  }
+  for (int kt = kt0; kt < kt1; kt += 2) {
+    GEMM_STAGE(kt, 0, ra1, rb1, ra0, rb0);
+    if (kt + 1 < kt1) GEMM_STAGE(kt + 1, 1, ra0, rb0, ra1, rb1);
+  }
+#undef GEMM_STAGE
+#undef GEMM_COMPUTE
 
   // ---- epilogue.  The accumulators (C/D layout: col = lane&15, row = (lane>>4)*4 + reg) are staged through LDS as an
   // fp32 [128][132] image so that the fused epilogue works on 8 contiguous columns per thread: bias / aux / residual
@@ -357,7 +376,9 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
   const int tiles = cdiv(M, BM) * cdiv(N, BN);
   dim3 grid(tiles, 1, batch_outer * batch_inner * splitk), block(256);
   MMDTI_REQUIRE(grid.z <= 65535u, "gemm: batch*splitk too large (%u)", grid.z);
-  const size_t smem = 4 * BM * LDT * sizeof(bf16_t);
+  // two (A|B) tile buffers, re-used by the epilogue as the fp32 [128][132] staging image (the larger of the two)
+  const size_t smem_tiles = 4 * (size_t)BM * LDT * sizeof(bf16_t), smem_epi = (size_t)BM * LDC_S * sizeof(float);
+  const size_t smem = smem_tiles > smem_epi ? smem_tiles : smem_epi;
   hipStream_t s = (hipStream_t)stream;
   // 72 KiB of dynamic LDS (> the 64 KiB default): opt in once per instantiation.
   static bool attr_done = false;
