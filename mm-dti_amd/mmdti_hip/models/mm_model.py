@@ -233,7 +233,8 @@ class MM_Model(nn.Module):
                            bucket_num=self.fds_num, bucket_start=self.fds_cfg.bucket_start, start_update=self.fds_cfg.start_update,
                            start_smooth=self.fds_cfg.start_smooth, kernel=self.fds_cfg.kernel, ks=self.fds_cfg.ks,
                            sigma=self.fds_cfg.sigma, momentum=self.fds_cfg.momentum)
-        self._pair_ld = None
+        self.overlap_towers = bool(params.get('overlap_towers', True))
+        self._side = None
 
     # ------------------------------------------------------------------ construction helpers
     @classmethod
@@ -256,6 +257,11 @@ class MM_Model(nn.Module):
             raise RuntimeError(f"Uni-Mol checkpoint {path} lacks {len(missing)} tower-1 parameters, e.g. {missing[:5]}")
         self.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
 
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        return self._side
+
     # ------------------------------------------------------------------ forward
     def pair_bias(self, src_distance, src_edge_type):
         """mm_model.py:553-556 fused: -> [B,H,N,ld] fp32."""
@@ -271,11 +277,25 @@ class MM_Model(nn.Module):
         # NOTE: the reference sets padding_mask=None when nothing is padded (:548-549), which costs a host sync
         # (`.any()`); the kernels treat an all-false mask identically, so no branch is needed here.
 
+        # The two towers are independent until InfoNCE: tower 2 runs on a side HIP stream so its kernels fill the CUs that
+        # tower 1's tile tails and latency-bound pair kernels leave idle (autograd replays each backward on the stream of
+        # its forward, so the overlap holds in the backward pass too).
+        side = self._side_stream() if (self.overlap_towers and src_tokens.is_cuda) else None
+        if side is not None:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                out_bert = self.bert(input_ids, attention_mask, return_dict=True)[0]
+
         x = EmbeddingFn.apply(self.embed_tokens.weight, src_tokens, self.padding_idx)
         graph_attn_bias = self.pair_bias(src_distance, src_edge_type)
         encoder_rep, _, _ = self.encoder.encode(x, graph_attn_bias, padding_mask)
 
-        out_bert = self.bert(input_ids, attention_mask, return_dict=True)[0]
+        if side is not None:
+            main.wait_stream(side)
+            out_bert.record_stream(main)
+        else:
+            out_bert = self.bert(input_ids, attention_mask, return_dict=True)[0]
 
         if return_infonce_loss:
             ct_loss = self.infonce(encoder_rep, out_bert)
