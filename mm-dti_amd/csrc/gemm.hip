@@ -52,25 +52,62 @@ struct GemmArgs {
   int vec_ok;             // host-checked: every pointer/stride the vector epilogue touches is 16-byte friendly
 };
 
-// Load one 128x64 operand tile slice into registers: 4 x 16-B chunks per thread.
+// Staging registers of one operand tile: 4 x 16-B chunks per thread, as NAMED members (an array here ends up as a
+// private-memory alloca in some instantiations and the whole pipeline then runs through scratch).
+struct Stage4 {
+  uint4 v0, v1, v2, v3;
+};
+
+// chunk c (0..1023) of a 128x64 tile:
 //  !TR: memory is [rows][k] (k contiguous): chunk = 8 consecutive k of one row.
 //   TR: memory is [k][rows] (rows contiguous): chunk = 8 consecutive rows of one k.
 template <bool TR>
-__device__ __forceinline__ void load_tile(uint4 (&r)[4], const bf16_t* __restrict__ base, int ld, int row0, int k0,
-                                          int rows, int K, int tid) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int c = tid + i * 256;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (!TR) {
-      int row = row0 + (c >> 3), k = k0 + (c & 7) * 8;
-      if (row < rows && k < K) v = *reinterpret_cast<const uint4*>(base + (long long)row * ld + k);
-    } else {
-      int k = k0 + (c >> 4), row = row0 + (c & 15) * 8;
-      if (k < K && row < rows) v = *reinterpret_cast<const uint4*>(base + (long long)k * ld + row);
-    }
-    r[i] = v;
+__device__ __forceinline__ uint4 load_chunk(const bf16_t* __restrict__ base, int ld, int row0, int k0, int rows, int K, int c) {
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (!TR) {
+    const int row = row0 + (c >> 3), k = k0 + (c & 7) * 8;
+    if (row < rows && k < K) v = *reinterpret_cast<const uint4*>(base + (long long)row * ld + k);
+  } else {
+    const int k = k0 + (c >> 4), row = row0 + (c & 15) * 8;
+    if (k < K && row < rows) v = *reinterpret_cast<const uint4*>(base + (long long)k * ld + row);
   }
+  return v;
+}
+template <bool TR>
+__device__ __forceinline__ void load_tile(Stage4& r, const bf16_t* __restrict__ base, int ld, int row0, int k0, int rows, int K, int tid) {
+  r.v0 = load_chunk<TR>(base, ld, row0, k0, rows, K, tid);
+  r.v1 = load_chunk<TR>(base, ld, row0, k0, rows, K, tid + 256);
+  r.v2 = load_chunk<TR>(base, ld, row0, k0, rows, K, tid + 512);
+  r.v3 = load_chunk<TR>(base, ld, row0, k0, rows, K, tid + 768);
+}
+
+// Fast path (K % 64 == 0, no ragged 8-row chunks): per-thread BYTE offsets of the four 16-byte chunks relative to the
+// tile's k origin are computed once; rows beyond the matrix are clamped to the last valid row/chunk (they only feed output
+// rows/columns that are never stored), so the K loop issues bare loads: wave-uniform base + 32-bit lane offset.
+struct Off4 {
+  uint32_t o0, o1, o2, o3;
+};
+template <bool TR>
+__device__ __forceinline__ uint32_t tile_offset1(int c, int ld, int row0, int rows) {
+  if (!TR) {
+    const int row = min(row0 + (c >> 3), rows - 1);
+    return (uint32_t)(((long long)row * ld + (c & 7) * 8) * 2);
+  } else {
+    const int row = min(row0 + (c & 15) * 8, rows - 8);
+    return (uint32_t)((((long long)(c >> 4)) * ld + row) * 2);
+  }
+}
+template <bool TR>
+__device__ __forceinline__ Off4 tile_offsets(int ld, int row0, int rows, int tid) {
+  return Off4{tile_offset1<TR>(tid, ld, row0, rows), tile_offset1<TR>(tid + 256, ld, row0, rows),
+              tile_offset1<TR>(tid + 512, ld, row0, rows), tile_offset1<TR>(tid + 768, ld, row0, rows)};
+}
+__device__ __forceinline__ void load_tile_fast(Stage4& r, const bf16_t* kbase, const Off4& off) {
+  const char* b = reinterpret_cast<const char*>(kbase);
+  r.v0 = *reinterpret_cast<const uint4*>(b + off.o0);
+  r.v1 = *reinterpret_cast<const uint4*>(b + off.o1);
+  r.v2 = *reinterpret_cast<const uint4*>(b + off.o2);
+  r.v3 = *reinterpret_cast<const uint4*>(b + off.o3);
 }
 
 // element-offset XOR for the k-major image: moves 8-byte units (4 elements) by 4*((k&3) | ((k>>3)&1)<<2) units, so the 32
@@ -78,18 +115,21 @@ __device__ __forceinline__ void load_tile(uint4 (&r)[4], const bf16_t* __restric
 __device__ __forceinline__ int tr_swz(int k) { return (((k & 3) | (((k >> 3) & 1) << 2)) << 2) * 4; }
 
 template <bool TR>
-__device__ __forceinline__ void store_tile(const uint4 (&r)[4], bf16_t* lds, int tid) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int c = tid + i * 256;
-    if (!TR) {
-      int row = c >> 3, kc = ((c & 7) ^ (row & 7)) * 8;
-      *reinterpret_cast<uint4*>(lds + row * LDT + kc) = r[i];
-    } else {  // k-major image [64][LDTR]: the operand keeps its memory order, fragments come out of ds_read_b64_tr_b16
-      int k = c >> 4, row = (c & 15) * 8;
-      *reinterpret_cast<uint4*>(lds + k * LDTR + (row ^ tr_swz(k))) = r[i];
-    }
+__device__ __forceinline__ void store_chunk(const uint4& v, bf16_t* lds, int c) {
+  if (!TR) {
+    const int row = c >> 3, kc = ((c & 7) ^ (row & 7)) * 8;
+    *reinterpret_cast<uint4*>(lds + row * LDT + kc) = v;
+  } else {  // k-major image [64][LDTR]: the operand keeps its memory order, fragments come out of ds_read_b64_tr_b16
+    const int k = c >> 4, row = (c & 15) * 8;
+    *reinterpret_cast<uint4*>(lds + k * LDTR + (row ^ tr_swz(k))) = v;
   }
+}
+template <bool TR>
+__device__ __forceinline__ void store_tile(const Stage4& r, bf16_t* lds, int tid) {
+  store_chunk<TR>(r.v0, lds, tid);
+  store_chunk<TR>(r.v1, lds, tid + 256);
+  store_chunk<TR>(r.v2, lds, tid + 512);
+  store_chunk<TR>(r.v3, lds, tid + 768);
 }
 
 // One MFMA 16x16x32 operand fragment (8 consecutive k of one row per lane) for the 16-row sub-tile starting at `row0`,
@@ -142,7 +182,7 @@ __device__ __forceinline__ void epi_elem(const GemmArgs& a, float accv, int row,
   }
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, bool FAST>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
   // LDS image: [buf 0: A | B][buf 1: A | B]; addressed by integer offsets from ONE __shared__ base so that every access
   // stays a ds_* instruction (pointer arrays indexed at run time decay to flat loads + scratch).
@@ -174,63 +214,72 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
   const int kt0 = ks * per, kt1 = min(ktiles, kt0 + per);
   if (kt0 >= kt1) return;  // empty split (uniform per block): nothing to contribute
 
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[4][4] = {};
 
-  // Software pipeline, two K-tiles of global loads in flight: tile kt is being multiplied out of LDS while tile kt+1 sits
-  // in one register set (requested an iteration ago, written to the other LDS buffer at the end of this iteration) and
-  // tile kt+2 is requested into the second register set.  With one tile in flight the loop was bound by the
-  // global -> VGPR latency (~20 % of MFMA peak); the loop is unrolled by two so both register sets stay statically named.
-  uint4 ra0[4], rb0[4], ra1[4], rb1[4];
-  load_tile<TA>(ra0, A, a.lda, m0, kt0 * BK, a.M, a.K, tid);
-  load_tile<TB>(rb0, B, a.ldb, n0, kt0 * BK, a.N, a.K, tid);
-  store_tile<TA>(ra0, smem, tid);
-  store_tile<TB>(rb0, smem + TILE, tid);
-  if (kt0 + 1 < kt1) {
-    load_tile<TA>(ra0, A, a.lda, m0, (kt0 + 1) * BK, a.M, a.K, tid);
-    load_tile<TB>(rb0, B, a.ldb, n0, (kt0 + 1) * BK, a.N, a.K, tid);
+  // Software pipeline: the global loads of tile kt+1 are issued before tile kt is multiplied out of LDS and land in a
+  // register set that is written to the other LDS buffer after the MFMAs; one barrier per K-step.  (A two-register-set
+  // variant with two tiles in flight measured no faster -- the loop is bound by LDS/issue bandwidth, not load latency --
+  // and hipcc turned its ping-pong register sets into scratch; see DESIGN.md.)
+  Stage4 ra, rb;
+  Off4 offA = {0, 0, 0, 0}, offB = {0, 0, 0, 0};
+  // element stride of one K-tile along the operand's k axis
+  const long long kstepA = TA ? (long long)BK * a.lda : BK, kstepB = TB ? (long long)BK * a.ldb : BK;
+  if (FAST) {
+    offA = tile_offsets<TA>(a.lda, m0, a.M, tid);
+    offB = tile_offsets<TB>(a.ldb, n0, a.N, tid);
   }
+#define GEMM_LOAD(KT)                                                    \
+  if (FAST) {                                                            \
+    load_tile_fast(ra, A + (KT) * kstepA, offA);                         \
+    load_tile_fast(rb, B + (KT) * kstepB, offB);                         \
+  } else {                                                               \
+    load_tile<TA>(ra, A, a.lda, m0, (KT) * BK, a.M, a.K, tid);           \
+    load_tile<TB>(rb, B, a.ldb, n0, (KT) * BK, a.N, a.K, tid);           \
+  }
+  GEMM_LOAD(kt0);
+  store_tile<TA>(ra, smem, tid);
+  store_tile<TB>(rb, smem + TILE, tid);
   __syncthreads();
 
-#define GEMM_COMPUTE(IMG)                                                                          \
+  // (everything that indexes acc[][] is spelled out with literal indices: a loop the optimizer declines to unroll would
+  //  turn the accumulators into a scratch array)
+#define MF(I, J) acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa##I, fb##J, acc[I][J], 0, 0, 0)
+#define GEMM_KK(IMGA, IMGB, KK)                                                                    \
   {                                                                                                \
-    const bf16_t* imgA = (IMG);                                                                    \
-    const bf16_t* imgB = imgA + TILE;                                                              \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                             \
-      bf16x8 fa[4], fb[4];                                                                         \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                              \
-        fa[i] = load_frag<TA>(imgA, wr * 64 + i * 16, kk, lane);                                   \
-        fb[i] = load_frag<TB>(imgB, wc * 64 + i * 16, kk, lane);                                   \
-      }                                                                                            \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                              \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);   \
-    }                                                                                              \
+    const bf16x8 fa0 = load_frag<TA>(IMGA, wr * 64 + 0, KK, lane), fa1 = load_frag<TA>(IMGA, wr * 64 + 16, KK, lane), \
+                 fa2 = load_frag<TA>(IMGA, wr * 64 + 32, KK, lane), fa3 = load_frag<TA>(IMGA, wr * 64 + 48, KK, lane); \
+    const bf16x8 fb0 = load_frag<TB>(IMGB, wc * 64 + 0, KK, lane), fb1 = load_frag<TB>(IMGB, wc * 64 + 16, KK, lane), \
+                 fb2 = load_frag<TB>(IMGB, wc * 64 + 32, KK, lane), fb3 = load_frag<TB>(IMGB, wc * 64 + 48, KK, lane); \
+    MF(0, 0); MF(0, 1); MF(0, 2); MF(0, 3); MF(1, 0); MF(1, 1); MF(1, 2); MF(1, 3);                \
+    MF(2, 0); MF(2, 1); MF(2, 2); MF(2, 3); MF(3, 0); MF(3, 1); MF(3, 2); MF(3, 3);                \
   }
-  // one pipeline stage: RN = register set receiving tile kt+2, RC = register set holding tile kt+1
-#define GEMM_STAGE(KT, CUR, RNA, RNB, RCA, RCB)                                                    \
-  {                                                                                                \
-    if ((KT) + 2 < kt1) {                                                                          \
-      load_tile<TA>(RNA, A, a.lda, m0, ((KT) + 2) * BK, a.M, a.K, tid);                            \
-      load_tile<TB>(RNB, B, a.ldb, n0, ((KT) + 2) * BK, a.N, a.K, tid);                            \
-    }                                                                                              \
-    GEMM_COMPUTE(smem + (CUR) * (2 * TILE));                                                       \
-    if ((KT) + 1 < kt1) {                                                                          \
-      bf16_t* nxt = smem + ((CUR) ^ 1) * (2 * TILE);                                               \
-      store_tile<TA>(RCA, nxt, tid);                                                               \
-      store_tile<TB>(RCB, nxt + TILE, tid);                                                        \
-    }                                                                                              \
-    __syncthreads();                                                                               \
+  int cur = 0;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const bool more = (kt + 1 < kt1);
+    // (the explicit zero on the last step keeps the staging registers defined on every path; without it hipcc demotes
+    //  them to a private-memory alloca on the bare-load path and the pipeline runs through scratch)
+    if (more) {
+      GEMM_LOAD(kt + 1);
+    } else {
+      const uint4 z = make_uint4(0, 0, 0, 0);
+      ra = Stage4{z, z, z, z};
+      rb = ra;
+    }
+    const bf16_t* imgA = smem + cur * (2 * TILE);
+    const bf16_t* imgB = imgA + TILE;
+    GEMM_KK(imgA, imgB, 0);
+    GEMM_KK(imgA, imgB, 1);
+    if (more) {
+      bf16_t* nxt = smem + (cur ^ 1) * (2 * TILE);
+      store_tile<TA>(ra, nxt, tid);
+      store_tile<TB>(rb, nxt + TILE, tid);
+    }
+    __syncthreads();
+    cur ^= 1;
   }
-  for (int kt = kt0; kt < kt1; kt += 2) {
-    GEMM_STAGE(kt, 0, ra1, rb1, ra0, rb0);
-    if (kt + 1 < kt1) GEMM_STAGE(kt + 1, 1, ra0, rb0, ra1, rb1);
-  }
-#undef GEMM_STAGE
-#undef GEMM_COMPUTE
+#undef GEMM_KK
+#undef MF
+#undef GEMM_LOAD
 
   // ---- epilogue.  The accumulators (C/D layout: col = lane&15, row = (lane>>4)*4 + reg) are staged through LDS as an
   // fp32 [128][132] image so that the fused epilogue works on 8 contiguous columns per thread: bias / aux / residual
@@ -380,26 +429,28 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
   const size_t smem_tiles = 4 * (size_t)BM * LDT * sizeof(bf16_t), smem_epi = (size_t)BM * LDC_S * sizeof(float);
   const size_t smem = smem_tiles > smem_epi ? smem_tiles : smem_epi;
   hipStream_t s = (hipStream_t)stream;
-  // 72 KiB of dynamic LDS (> the 64 KiB default): opt in once per instantiation.
+  // > 64 KiB of dynamic LDS: opt in once per instantiation.
+  typedef void (*kern_t)(GemmArgs);
+  static const kern_t kerns[2][2][2] = {
+      {{gemm_bf16_kernel<false, false, false>, gemm_bf16_kernel<false, false, true>},
+       {gemm_bf16_kernel<false, true, false>, gemm_bf16_kernel<false, true, true>}},
+      {{gemm_bf16_kernel<true, false, false>, gemm_bf16_kernel<true, false, true>},
+       {gemm_bf16_kernel<true, true, false>, gemm_bf16_kernel<true, true, true>}}};
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
-      set_error("gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", smem);
-      return MMDTI_ERR_LAUNCH;
+    for (int i = 0; i < 8; ++i) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[i >> 2][(i >> 1) & 1][i & 1]),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+        set_error("gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", smem);
+        return MMDTI_ERR_LAUNCH;
+      }
     }
     attr_done = true;
   }
-  if (transA) {
-    if (transB) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, smem, s, a);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, smem, s, a);
-  } else {
-    if (transB) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, smem, s, a);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, smem, s, a);
-  }
+  // bare-load fast path: no K tail, no ragged 8-row chunk on a k-major operand, offsets fit 32 bits
+  const bool fast = (K % BK == 0) && (!transA || M % 8 == 0) && (!transB || N % 8 == 0) && M >= 8 && N >= 8 &&
+                    ((long long)(transA ? BK : M) * lda * 2 < 0x7fffffffLL) && ((long long)(transB ? BK : N) * ldb * 2 < 0x7fffffffLL);
+  hipLaunchKernelGGL(kerns[transA ? 1 : 0][transB ? 1 : 0][fast ? 1 : 0], grid, block, smem, s, a);
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }
