@@ -194,8 +194,9 @@ __global__ __launch_bounds__(64) void roberta_posids_kernel(const long long* __r
 }
 
 // ---------------------------------------------------------------- row softmax over materialised scores
-// one wave per row; Lk <= 1024
-template <int NCH>
+// one wave per row, 4 consecutive keys per lane (16-byte score loads, 8-byte bf16 stores); ld % 8 == 0, ld <= 1024.
+// Dropout element index = row*ld + key (ld-based so that a lane's 4 keys share one RNG call).
+template <int NV>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ s, const float* __restrict__ key_add,
                                                           bf16_t* __restrict__ p_out, bf16_t* __restrict__ pd_out,
                                                           long long rows, int heads, int Lq, int Lk, int ld, uint32_t thresh,
@@ -205,62 +206,97 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
   if (row >= rows) return;
   const int b = (int)(row / ((long long)heads * Lq));
   const float* sr = s + row * ld;
-  float v[NCH];
+  const float* ka = key_add ? key_add + (long long)b * Lk : nullptr;
+  float v[NV][4];
   float m = -INFINITY;
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int j = c * 64 + lane;
-    v[c] = -INFINITY;
-    if (j < Lk) v[c] = sr[j] + (key_add ? key_add[(long long)b * Lk + j] : 0.f);
-    m = fmaxf(m, v[c]);
+  for (int c = 0; c < NV; ++c) {
+    const int j = (c * 64 + lane) * 4;
+    float4 t = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    if (j < ld) t = *reinterpret_cast<const float4*>(sr + j);
+    const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[c][e] = (j + e < Lk) ? tv[e] + (ka ? ka[j + e] : 0.f) : -INFINITY;
+      m = fmaxf(m, v[c][e]);
+    }
   }
   m = wave_max(m);
   float sum = 0.f;
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    v[c] = (c * 64 + lane < Lk) ? __expf(v[c] - m) : 0.f;
-    sum += v[c];
-  }
+  for (int c = 0; c < NV; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[c][e] = __expf(v[c][e] - m);   // exp(-inf) = 0 in the pad columns
+      sum += v[c][e];
+    }
   const float inv = 1.0f / wave_sum(sum);
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int j = c * 64 + lane;
+  for (int c = 0; c < NV; ++c) {
+    const int j = (c * 64 + lane) * 4;
     if (j >= ld) continue;
-    const float p = v[c] * inv;  // 0 in the pad columns [Lk, ld)
-    p_out[row * ld + j] = f2bf(p);
+    float p[4] = {v[c][0] * inv, v[c][1] * inv, v[c][2] * inv, v[c][3] * inv};
+    uint2 pk;
+    pk.x = (uint32_t)f2bf(p[0]) | ((uint32_t)f2bf(p[1]) << 16);
+    pk.y = (uint32_t)f2bf(p[2]) | ((uint32_t)f2bf(p[3]) << 16);
+    *reinterpret_cast<uint2*>(p_out + row * ld + j) = pk;
     if (pd_out != p_out) {
-      float pd = p;
-      if (thresh) pd = dropout_keep(seed, site, (uint64_t)row * Lk + j, thresh) ? p * dscale : 0.f;
-      pd_out[row * ld + j] = f2bf(j < Lk ? pd : 0.f);
+      if (thresh) {
+        const Rand4 r = philox4(seed, site, (uint64_t)(row * ld + j) >> 2);
+        p[0] = r.x >= thresh ? p[0] * dscale : 0.f; p[1] = r.y >= thresh ? p[1] * dscale : 0.f;
+        p[2] = r.z >= thresh ? p[2] * dscale : 0.f; p[3] = r.w >= thresh ? p[3] * dscale : 0.f;
+      }
+      pk.x = (uint32_t)f2bf(p[0]) | ((uint32_t)f2bf(p[1]) << 16);
+      pk.y = (uint32_t)f2bf(p[2]) | ((uint32_t)f2bf(p[3]) << 16);
+      *reinterpret_cast<uint2*>(pd_out + row * ld + j) = pk;
     }
   }
 }
 
-template <int NCH>
+template <int NV>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restrict__ p_in, const float* __restrict__ dp,
                                                           bf16_t* __restrict__ ds, long long rows, int Lk, int ld, float scale,
                                                           uint32_t thresh, float dscale, uint64_t seed, uint32_t site) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  float p[NCH], d[NCH];
+  float p[NV][4], d[NV][4];
   float dl = 0.f;
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int j = c * 64 + lane;
-    p[c] = d[c] = 0.f;
-    if (j < Lk) {
-      p[c] = bf2f(p_in[row * ld + j]);
-      d[c] = dp[row * ld + j];
-      if (thresh) d[c] = dropout_keep(seed, site, (uint64_t)row * Lk + j, thresh) ? d[c] * dscale : 0.f;
+  for (int c = 0; c < NV; ++c) {
+    const int j = (c * 64 + lane) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) p[c][e] = d[c][e] = 0.f;
+    if (j < ld) {
+      const uint2 pk = *reinterpret_cast<const uint2*>(p_in + row * ld + j);
+      const float4 t = *reinterpret_cast<const float4*>(dp + row * ld + j);
+      p[c][0] = __uint_as_float(pk.x << 16); p[c][1] = __uint_as_float(pk.x & 0xffff0000u);
+      p[c][2] = __uint_as_float(pk.y << 16); p[c][3] = __uint_as_float(pk.y & 0xffff0000u);
+      d[c][0] = t.x; d[c][1] = t.y; d[c][2] = t.z; d[c][3] = t.w;
+      if (thresh) {
+        const Rand4 r = philox4(seed, site, (uint64_t)(row * ld + j) >> 2);
+        d[c][0] = r.x >= thresh ? d[c][0] * dscale : 0.f; d[c][1] = r.y >= thresh ? d[c][1] * dscale : 0.f;
+        d[c][2] = r.z >= thresh ? d[c][2] * dscale : 0.f; d[c][3] = r.w >= thresh ? d[c][3] * dscale : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (j + e >= Lk) p[c][e] = d[c][e] = 0.f;   // pad columns of dp are not data
+        dl += p[c][e] * d[c][e];
+      }
     }
-    dl += p[c] * d[c];
   }
   dl = wave_sum(dl);
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int j = c * 64 + lane;
-    if (j < ld) ds[row * ld + j] = f2bf(j < Lk ? scale * p[c] * (d[c] - dl) : 0.f);
+  for (int c = 0; c < NV; ++c) {
+    const int j = (c * 64 + lane) * 4;
+    if (j >= ld) continue;
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = scale * p[c][e] * (d[c][e] - dl);
+    uint2 pk;
+    pk.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+    pk.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+    *reinterpret_cast<uint2*>(ds + row * ld + j) = pk;
   }
 }
 
@@ -460,17 +496,17 @@ extern "C" int mmdti_softmax_fwd(mmdti_stream_t stream, const float* s, const fl
                                  void* pd_bf16, int B, int heads, int Lq, int Lk, int ld, float drop_p,
                                  unsigned long long seed, unsigned int site) {
   MMDTI_REQUIRE(s && p_bf16 && pd_bf16 && B > 0 && heads > 0 && Lq > 0 && Lk > 0, "softmax_fwd: bad arguments");
-  MMDTI_REQUIRE(ld >= Lk && Lk <= 1024 && ld <= 1024, "softmax_fwd: need Lk <= ld <= 1024");
+  MMDTI_REQUIRE(ld >= Lk && ld <= 1024 && ld % 8 == 0, "softmax_fwd: need Lk <= ld <= 1024, ld %% 8 == 0");
+  MMDTI_REQUIRE(aligned16(s) && aligned16(p_bf16) && aligned16(pd_bf16), "softmax_fwd: 16-byte alignment required");
   DROP_SETUP("softmax_fwd");
   MMDTI_REQUIRE(drop_p == 0.f || pd_bf16 != p_bf16, "softmax_fwd: dropout needs a separate pd buffer");
   const long long rows = (long long)B * heads * Lq;
   dim3 grid(cdiv(rows, 4)), block(256);
-#define SM_F(NCH)                                                                                                  \
-  hipLaunchKernelGGL((softmax_fwd_kernel<NCH>), grid, block, 0, (hipStream_t)stream, s, key_add, (bf16_t*)p_bf16, \
+#define SM_F(NV)                                                                                                   \
+  hipLaunchKernelGGL((softmax_fwd_kernel<NV>), grid, block, 0, (hipStream_t)stream, s, key_add, (bf16_t*)p_bf16,  \
                      (bf16_t*)pd_bf16, rows, heads, Lq, Lk, ld, th, sc, (uint64_t)seed, (uint32_t)site)
-  const int nch = (ld + 63) / 64;
-  if (nch <= 1) SM_F(1); else if (nch <= 2) SM_F(2); else if (nch <= 3) SM_F(3); else if (nch <= 4) SM_F(4);
-  else if (nch <= 8) SM_F(8); else SM_F(16);
+  const int nv = (ld + 255) / 256;
+  if (nv <= 1) SM_F(1); else if (nv <= 2) SM_F(2); else SM_F(4);
 #undef SM_F
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
@@ -480,16 +516,16 @@ extern "C" int mmdti_softmax_bwd(mmdti_stream_t stream, const void* p_bf16, cons
                                  int heads, int Lq, int Lk, int ld, float scale, float drop_p,
                                  unsigned long long seed, unsigned int site) {
   MMDTI_REQUIRE(p_bf16 && dp && ds_bf16 && B > 0 && heads > 0 && Lq > 0 && Lk > 0, "softmax_bwd: bad arguments");
-  MMDTI_REQUIRE(ld >= Lk && ld <= 1024, "softmax_bwd: need Lk <= ld <= 1024");
+  MMDTI_REQUIRE(ld >= Lk && ld <= 1024 && ld % 8 == 0, "softmax_bwd: need Lk <= ld <= 1024, ld %% 8 == 0");
+  MMDTI_REQUIRE(aligned16(dp) && aligned16(p_bf16) && aligned16(ds_bf16), "softmax_bwd: 16-byte alignment required");
   DROP_SETUP("softmax_bwd");
   const long long rows = (long long)B * heads * Lq;
   dim3 grid(cdiv(rows, 4)), block(256);
-#define SM_B(NCH)                                                                                              \
-  hipLaunchKernelGGL((softmax_bwd_kernel<NCH>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)p_bf16, dp, \
+#define SM_B(NV)                                                                                              \
+  hipLaunchKernelGGL((softmax_bwd_kernel<NV>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)p_bf16, dp, \
                      (bf16_t*)ds_bf16, rows, Lk, ld, scale, th, sc, (uint64_t)seed, (uint32_t)site)
-  const int nch = (ld + 63) / 64;
-  if (nch <= 1) SM_B(1); else if (nch <= 2) SM_B(2); else if (nch <= 3) SM_B(3); else if (nch <= 4) SM_B(4);
-  else if (nch <= 8) SM_B(8); else SM_B(16);
+  const int nv = (ld + 255) / 256;
+  if (nv <= 1) SM_B(1); else if (nv <= 2) SM_B(2); else SM_B(4);
 #undef SM_B
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
