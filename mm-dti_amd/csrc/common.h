@@ -120,6 +120,16 @@ __device__ __forceinline__ Rand4 philox4(uint64_t seed, uint32_t site, uint64_t 
   const uint32_t c = mix32((uint32_t)ctr ^ k) + (uint32_t)(ctr >> 32) * 0x85EBCA6Bu;
   return Rand4{mix32(c ^ 0x68E31DA4u), mix32(c ^ 0xB5297A4Du), mix32(c ^ 0x1B56C4E9u), mix32(c + 0x9E3779B9u)};
 }
+// Cheaper variant for the pair-attention probability dropout (277 M elements per layer): TWO avalanche hashes give four
+// 16-bit uniforms, compared against a 16-bit threshold (p quantised to 1/65536: |error| < 8e-6).  ~20 integer ops per 4
+// elements.  Returns a 4-bit keep mask (bit r = element r kept).
+__device__ __forceinline__ uint32_t keep4_u16(uint64_t seed, uint32_t site, uint64_t ctr, uint32_t thresh16) {
+  const uint32_t k = mix32((uint32_t)seed ^ (site * 0x9E3779B9u)) ^ (uint32_t)(seed >> 32);
+  const uint32_t a = mix32(((uint32_t)ctr ^ k) + (uint32_t)(ctr >> 32) * 0x85EBCA6Bu);
+  const uint32_t b = mix32(a ^ 0xB5297A4Du);
+  return ((a & 0xffffu) >= thresh16 ? 1u : 0u) | ((a >> 16) >= thresh16 ? 2u : 0u) | ((b & 0xffffu) >= thresh16 ? 4u : 0u) |
+         ((b >> 16) >= thresh16 ? 8u : 0u);
+}
 // keep-mask for element index `idx` of dropout site `site`: one Philox call covers 4 consecutive
 // elements (idx>>2), lane picks word idx&3.  keep iff u32 >= thresh, thresh = p * 2^32.
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t site, uint64_t idx, uint32_t thresh) {

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void pair_attn_fwd_mfma_kernel(const bf16_t* _
   constexpr int NP = NT * 16;
   __shared__ __attribute__((aligned(16))) float sQ[NP][8];
   __shared__ __attribute__((aligned(16))) float sK[NP][8];
-  __shared__ __attribute__((aligned(16))) float sV[NP * VSTR];
+  __shared__ __attribute__((aligned(16))) float sV[NP * VSTR + 8];   // +8: lanes d >= 8 read past the last row (unused rows of O^T)
   __shared__ __attribute__((aligned(16))) float sM[NP];
   const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
   const int D = H * HD, D3 = 3 * D;
@@ -380,17 +380,14 @@ __global__ __launch_bounds__(256) void pair_attn_fwd_mfma_kernel(const bf16_t* _
       {
         f32x4 p = S[t] * inv;
         if (thresh) {
-          const Rand4 rn = philox4(seed, site, (uint64_t)(rowoff + t * 16 + 4 * g) >> 2);
-          p[0] = rn.x >= thresh ? p[0] * dscale : 0.f;
-          p[1] = rn.y >= thresh ? p[1] * dscale : 0.f;
-          p[2] = rn.z >= thresh ? p[2] * dscale : 0.f;
-          p[3] = rn.w >= thresh ? p[3] * dscale : 0.f;
-        }
+          const uint32_t kb = keep4_u16(seed, site, (uint64_t)(rowoff + t * 16 + 4 * g) >> 2, thresh >> 16);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float va = (c16 < 8) ? sV[(t * 16 + 4 * g + r) * VSTR + c16] : 0.f;
-          oacc = __builtin_amdgcn_mfma_f32_16x16x4f32(va, p[r], oacc, 0, 0, 0);
+          for (int r = 0; r < 4; ++r) p[r] = (kb >> r) & 1u ? p[r] * dscale : 0.f;
         }
+        // A operand rows d >= 8 (lanes c16 >= 8) read whatever follows in LDS: those rows of O^T are never used
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          oacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sV[(t * 16 + 4 * g + r) * VSTR + c16], p[r], oacc, 0, 0, 0);
       }
     }
     // O^T accumulator: column = query, rows d = 4g + r (valid for g < 2)
@@ -421,10 +418,10 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* _
                                                                  int g_in_zero, uint32_t thresh, float dscale, uint64_t seed,
                                                                  uint32_t site) {
   constexpr int NP = NT * 16;
-  __shared__ __attribute__((aligned(16))) float sQ[NP * VSTR];   // Q * scale
-  __shared__ __attribute__((aligned(16))) float sK[NP * VSTR];
-  __shared__ __attribute__((aligned(16))) float sV[NP * VSTR];
-  __shared__ __attribute__((aligned(16))) float sD[NP * VSTR];   // dO
+  __shared__ __attribute__((aligned(16))) float sQ[NP * VSTR + 8];   // Q * scale
+  __shared__ __attribute__((aligned(16))) float sK[NP * VSTR + 8];
+  __shared__ __attribute__((aligned(16))) float sV[NP * VSTR + 8];
+  __shared__ __attribute__((aligned(16))) float sD[NP * VSTR + 8];   // dO
   // per-wave dK / dV accumulators in MFMA accumulator order: [wave][tile][K|V][g][d][r] -- each lane owns one float4 per
   // (tile, K|V), read as the MFMA C input and written back, so the waves never contend (LDS float atomics cost ~57
   // cycles per wave-instruction here and were half of the kernel's time).
@@ -498,7 +495,7 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* _
     lsum += __shfl_xor(lsum, 16, 64);
     lsum += __shfl_xor(lsum, 32, 64);
     const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
-    unsigned long long keepbits = ~0ull;
+    // dropped elements are remembered in the SIGN of P (P >= 0): |P| feeds the softmax gradient, P > 0 selects dropout(P)
     float dl = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -507,17 +504,21 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* _
         f32x4 dp = {0.f, 0.f, 0.f, 0.f};
         dp = __builtin_amdgcn_mfma_f32_16x16x4f32(va0, dob0, dp, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_16x16x4f32(va1, dob1, dp, 0, 0, 0);
-        P[t] = P[t] * inv;
+        f32x4 pr = P[t] * inv;
         if (thresh) {
-          const Rand4 rn = philox4(seed, site, (uint64_t)(rowoff + t * 16 + 4 * g) >> 2);
-          const bool k0 = rn.x >= thresh, k1 = rn.y >= thresh, k2 = rn.z >= thresh, k3 = rn.w >= thresh;
-          dp[0] = k0 ? dp[0] * dscale : 0.f; dp[1] = k1 ? dp[1] * dscale : 0.f;
-          dp[2] = k2 ? dp[2] * dscale : 0.f; dp[3] = k3 ? dp[3] * dscale : 0.f;
-          const unsigned long long bits = (k0 ? 1ull : 0ull) | (k1 ? 2ull : 0ull) | (k2 ? 4ull : 0ull) | (k3 ? 8ull : 0ull);
-          keepbits = (keepbits & ~(0xfull << (4 * t))) | (bits << (4 * t));
+          const uint32_t kb = keep4_u16(seed, site, (uint64_t)(rowoff + t * 16 + 4 * g) >> 2, thresh >> 16);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool kp = (kb >> r) & 1u;
+            dp[r] = kp ? dp[r] * dscale : 0.f;
+            dl += dp[r] * pr[r];
+            pr[r] = kp ? pr[r] : -pr[r];
+          }
+        } else {
+          dl += dp[0] * pr[0] + dp[1] * pr[1] + dp[2] * pr[2] + dp[3] * pr[3];
         }
+        P[t] = pr;
         dPm[t] = dp;
-        dl += dp[0] * P[t][0] + dp[1] * P[t][1] + dp[2] * P[t][2] + dp[3] * P[t][3];
       }
     }
     dl += __shfl_xor(dl, 16, 64);
@@ -540,33 +541,34 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* _
       const bool inrow = qvalid && kcol < N;
       f32x4 G;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float gv = P[t][r] * (dPm[t][r] - dl) + ((kcol + r < N) ? Gi[t][r] : 0.f);
-        G[r] = inrow ? gv : 0.f;
-      }
-      if (inrow) *reinterpret_cast<f32x4*>(gout + rowoff + kcol) = G;
-      f32x4 Pd = P[t];
-      if (thresh) {
+      for (int r = 0; r < 4; ++r) G[r] = fabsf(P[t][r]) * (dPm[t][r] - dl) + Gi[t][r];
+      if (t * 16 + 16 > N) {   // only the last key tile has columns beyond N (uniform branch): their G must be exactly 0
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Pd[r] = ((keepbits >> (4 * t + r)) & 1ull) ? Pd[r] * dscale : 0.f;
+        for (int r = 0; r < 4; ++r) G[r] = (kcol + r < N) ? G[r] : 0.f;
       }
+      if (!qvalid) G = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (inrow) *reinterpret_cast<f32x4*>(gout + rowoff + kcol) = G;
+      f32x4 Pd;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Pd[r] = P[t][r] > 0.f ? P[t][r] * dscale : 0.f;   // dscale == 1 without dropout
       if (!qvalid) Pd = f32x4{0.f, 0.f, 0.f, 0.f};
       // transpose Pd and G through the wave's LDS patch: written [query][key], read [key][query]
       *reinterpret_cast<f32x4*>(pP + c16 * TSTR + 4 * g) = Pd;
       *reinterpret_cast<f32x4*>(pG + c16 * TSTR + 4 * g) = G;
       // dQ^T += K^T . G^T   (step r: lane-group g carries key 4g + r)
+      // (operand lanes with d >= 8 read past their row: the matching output rows / columns are never stored)
       float ka[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ka[r] = sK[(t * 16 + 4 * g + r) * VSTR + dcol];
+      for (int r = 0; r < 4; ++r) ka[r] = sK[(t * 16 + 4 * g + r) * VSTR + c16];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dq = __builtin_amdgcn_mfma_f32_16x16x4f32(dlane ? ka[r] : 0.f, G[r], dq, 0, 0, 0);
+      for (int r = 0; r < 4; ++r) dq = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[r], G[r], dq, 0, 0, 0);
       float aP[4], aG[4], bD[4], bQ[4];
 #pragma unroll
       for (int st = 0; st < 4; ++st) {   // MFMA step st contracts queries 4*st + g
         aP[st] = pP[(4 * st + g) * TSTR + c16];
         aG[st] = pG[(4 * st + g) * TSTR + c16];
-        bD[st] = sD[(qb * 16 + 4 * st + g) * VSTR + dcol];
-        bQ[st] = sQ[(qb * 16 + 4 * st + g) * VSTR + dcol];
+        bD[st] = sD[(qb * 16 + 4 * st + g) * VSTR + c16];
+        bQ[st] = sQ[(qb * 16 + 4 * st + g) * VSTR + c16];
       }
       // dK / dV of key tile t: accumulator column = d (lanes c16 < 8), rows = keys 16t + 4g + r; the running sums of
       // this wave live in LDS and pass through the MFMA as its C operand.
@@ -576,8 +578,8 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* _
       f32x4 dKt = *reinterpret_cast<const f32x4*>(accK), dVt = *reinterpret_cast<const f32x4*>(accV);
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
-        dVt = __builtin_amdgcn_mfma_f32_16x16x4f32(aP[st], dlane ? bD[st] : 0.f, dVt, 0, 0, 0);
-        dKt = __builtin_amdgcn_mfma_f32_16x16x4f32(aG[st], dlane ? bQ[st] : 0.f, dKt, 0, 0, 0);
+        dVt = __builtin_amdgcn_mfma_f32_16x16x4f32(aP[st], bD[st], dVt, 0, 0, 0);
+        dKt = __builtin_amdgcn_mfma_f32_16x16x4f32(aG[st], bQ[st], dKt, 0, 0, 0);
       }
       if (dlane) {
         *reinterpret_cast<f32x4*>(accK) = dKt;
@@ -632,13 +634,14 @@ extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, 
   const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   dim3 grid(B * H), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (ld % 4 == 0 && aligned16(bias_in) && aligned16(s_out)) {
+  // (same eligibility rule as the backward: the two MFMA kernels share one dropout-mask generator)
+  if (ld % 4 == 0 && aligned16(bias_in) && aligned16(s_out) && N <= 16 * 13) {
     const int nqb = (N + 15) / 16;
     dim3 blk(nqb % 3 == 0 ? 192 : (nqb < 4 ? 64 * nqb : 256));
 #define PA_M(NT)                                                                                                     \
   hipLaunchKernelGGL((pair_attn_fwd_mfma_kernel<NT>), grid, blk, 0, s, (const bf16_t*)qkv_bf16, bias_in, s_out,     \
                      (bf16_t*)o_bf16, key_pad, N, H, ld, scale, th, sc, (uint64_t)seed, (uint32_t)site)
-    if (nqb <= 5) PA_M(5); else if (nqb <= 9) PA_M(9); else if (nqb <= 13) PA_M(13); else if (nqb <= 17) PA_M(17); else PA_M(20);
+    if (nqb <= 5) PA_M(5); else if (nqb <= 9) PA_M(9); else PA_M(13);
 #undef PA_M
     MMDTI_LAUNCH_CHECK();
     return MMDTI_OK;
