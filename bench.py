@@ -37,10 +37,10 @@ def build_model(task="classification", output_dim=2):
     return model, rcfg
 
 
-def synth(B, atoms, tokens, seed, task="classification"):
+def synth(B, atoms, tokens, seed, task="classification", ragged=False):
     from oracle import mmdti_oracle as O          # synthetic-batch generator only (seeded numpy); no oracle compute here
     cfg = O.ModelCfg(task=task, output_dim=2 if task == "classification" else 1)
-    batch, label = O.synth_batch(B, atoms, tokens, cfg, seed=seed, ragged=False)
+    batch, label = O.synth_batch(B, atoms, tokens, cfg, seed=seed, ragged=ragged)
     return cfg, batch, label
 
 
@@ -69,6 +69,22 @@ def cpu_baseline(atoms, tokens, sample_B=8, iters=2):
                       f"tokens, same architecture, dropout on; {dt:.2f} s/step"}
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of `kernel_prefix` from the committed PMC summary (profiles/r01_bench_pmc_hbm_traffic.csv:
+    separate FETCH_SIZE / WRITE_SIZE rocprofv3 passes of this same command, gfx950 units already applied there).  PMC
+    counters cannot be collected from inside the timed run, so this is the recorded value or null."""
+    path = os.path.join(ROOT, "profiles", "r01_bench_pmc_hbm_traffic.csv")
+    try:
+        import csv
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if row["kernel"].startswith(kernel_prefix):
+                    return int(float(row["hbm_bytes_per_launch"]))
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,11 +95,12 @@ def main():
     ap.add_argument("--tokens", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8)
+    ap.add_argument("--ragged", action="store_true", help="molecules of mixed length padded to the batch maximum (not the headline workload)")
     args = ap.parse_args()
 
     from mmdti_hip import parallel, ops
     from mmdti_hip.trainer import FineTuner
-    rank, local, world = parallel.init_from_env()
+    rank, local, world = parallel.init_from_env(force=os.environ.get("MMDTI_FORCE_DDP") == "1")
     if world != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run for N>1", file=sys.stderr)
@@ -95,8 +112,8 @@ def main():
 
     model, rcfg = build_model()
     model = model.to(dev).train()
-    tuner = FineTuner(model, "classification", total_steps=10_000, distributed=world > 1)
-    _, batch, label = synth(args.batch, args.atoms, args.tokens, seed=1234 + rank)
+    tuner = FineTuner(model, "classification", total_steps=10_000, distributed=(world > 1 or os.environ.get("MMDTI_FORCE_DDP") == "1"))
+    _, batch, label = synth(args.batch, args.atoms, args.tokens, seed=1234 + rank, ragged=args.ragged)
     batch = {k: v.to(dev) for k, v in batch.items()}
     label = label.to(dev)
 
@@ -123,7 +140,7 @@ def main():
     losses = {"loss": float(out.loss), "task": float(out.task_loss), "infonce": float(out.infonce_loss), "ct": float(out.ct_loss)}
 
     if rank == 0:
-        N = args.atoms + 2
+        N = int(batch["src_tokens"].shape[1])
         H = 64
         timers = ops.kernel_timer.summary()
         # dominant HBM-bound kernel: pair attention backward.  Algorithmic bytes per launch (DESIGN.md "roofline"):
@@ -135,8 +152,8 @@ def main():
         roofline = None
         if ms:
             ach = pa_bytes / (ms * 1e-3) / 1e9
-            roofline = {"kernel": "pair_attn_bwd_kernel<3>", "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
-                        "frac": round(ach / 8000.0, 4), "traffic": None, "algorithmic_bytes_per_launch": pa_bytes,
+            roofline = {"kernel": "pair_attn_bwd_mfma_kernel<9>", "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(ach / 8000.0, 4), "traffic": pmc_traffic("pair_attn_bwd_mfma_kernel"), "algorithmic_bytes_per_launch": pa_bytes,
                         "mean_launch_ms": round(ms, 4), "launches_timed": timers["pair_attn_bwd"]["n"], "other_kernels_ms": {k: round(v["mean_ms"], 4) for k, v in timers.items()}}
         cpu = None
         if not args.no_cpu_baseline:
@@ -153,7 +170,7 @@ def main():
             "losses_last_step": losses, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -24,14 +24,15 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: Optional[str] = None) -> tuple:
+def init_from_env(backend: Optional[str] = None, force: bool = False) -> tuple:
     """torchrun-style env (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT) -> (rank, local_rank, world)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -42,6 +43,12 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     return rank, local, world
 
 
+def _collectives_active(world: int) -> bool:
+    """Collectives run when there is more than one rank -- or, for single-GPU rehearsal of the RCCL code path, when
+    MMDTI_FORCE_DDP=1 and a (1-rank) process group exists."""
+    return dist.is_initialized() and (world > 1 or os.environ.get("MMDTI_FORCE_DDP") == "1")
+
+
 class GlobalNegatives:
     """all-gather of the pooled InfoNCE projections and its adjoint (see models/infonce.py:set_global_negatives)."""
 
@@ -49,10 +56,11 @@ class GlobalNegatives:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.active = _collectives_active(self.world)
 
     def gather(self, x: torch.Tensor) -> torch.Tensor:
         """[B_loc, C] -> [world*B_loc, C] in rank order (equal B_loc on every rank)."""
-        if self.world == 1:
+        if not self.active:
             return x
         x = x.contiguous()
         out = torch.empty(self.world * x.shape[0], x.shape[1], device=x.device, dtype=x.dtype)
@@ -61,7 +69,7 @@ class GlobalNegatives:
 
     def reduce_scatter(self, g: torch.Tensor) -> torch.Tensor:
         """adjoint of gather: sum over ranks of [world*B_loc, C], keep own rows."""
-        if self.world == 1:
+        if not self.active:
             return g
         g = g.contiguous()
         dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
@@ -78,16 +86,17 @@ class ArenaReducer:
     def __init__(self, arena, bucket_bytes: int = 64 << 20, group=None):
         self.arena, self.group = arena, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = _collectives_active(self.world)
         n = arena.numel
         per = max(1, bucket_bytes // 4)
         self.buckets = [(s, min(n, s + per)) for s in range(0, n, per)]
-        self.stream = torch.cuda.Stream() if (self.world > 1 and arena.grad.is_cuda) else None
+        self.stream = torch.cuda.Stream() if (self.active and arena.grad.is_cuda) else None
         self._pending = []
 
     def reduce_range(self, lo: int, hi: int):
         """Launch the all-reduce of every not-yet-reduced bucket fully inside [lo, hi) -- called as soon as the backward
         has finished writing that part of the arena."""
-        if self.world == 1:
+        if not self.active:
             return
         for (s, e) in self.buckets:
             if s >= lo and e <= hi and (s, e) not in self._pending:
@@ -95,18 +104,22 @@ class ArenaReducer:
 
     def _launch(self, s, e):
         view = self.arena.grad[s:e]
+        # SUM + scale rather than ReduceOp.AVG: identical result, no dependence on the collective library's AVG support
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
-                dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                if self.world > 1:
+                    view.mul_(1.0 / self.world)
         else:
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
-            view.div_(self.world)
+            if self.world > 1:
+                view.mul_(1.0 / self.world)
         self._pending.append((s, e))
 
     def finish(self):
         """Reduce whatever is left and make the main stream wait for the side stream."""
-        if self.world == 1:
+        if not self.active:
             return
         for (s, e) in self.buckets:
             if (s, e) not in self._pending:

@@ -64,7 +64,7 @@ class FineTuner:
 
     # ------------------------------------------------------------------
     def _bind_global_negatives(self, b_loc: int):
-        if self.world > 1 and self._b_loc != b_loc:
+        if self.negs.active and self._b_loc != b_loc:
             self.model.infonce.set_global_negatives(self.negs.gather, self.negs.reduce_scatter, self.negs.row0(b_loc))
             self._b_loc = b_loc
 
@@ -72,7 +72,7 @@ class FineTuner:
         """optimizer.zero_grad(); model(...); loss; loss.backward()  (+ gradient all-reduce under DDP)."""
         model = self.model
         self.arena.zero_grad()
-        if self.world > 1:
+        if self.reducer is not None:
             self._bind_global_negatives(net_target.shape[0])
         logits, infonce, ct = model(**net_input, return_infonce_loss=True, return_ct_loss=True, net_target=net_target, use_weight=use_weight,
                                     epoch=epoch)

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Turn the raw rocprofv3 output of one bench.py run into the small summaries committed under profiles/.
+
+  python profiles/summarize.py stats  <rocprof-dir> profiles/r01_bench_kernel_stats.csv
+  python profiles/summarize.py pmc    <fetch-dir> <write-dir> profiles/r01_bench_pmc_hbm_traffic.csv
+
+`stats`: the *_kernel_stats.csv of `rocprofv3 --kernel-trace --stats`, template arguments kept, top 40 rows.
+`pmc`:   per-kernel means of FETCH_SIZE and WRITE_SIZE (two separate passes, TCC has no room for both) converted to HBM
+         bytes per launch as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE (KB) is doubled (128-B requests are
+         tallied at 64 B), WRITE_SIZE (KB) is taken as is.
+"""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def find(d, pat):
+    hits = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True), key=os.path.getsize)
+    if not hits:
+        sys.exit(f"no {pat} under {d}")
+    return hits[-1]
+
+
+def short(name):
+    name = re.sub(r"\(.*$", "", name)            # drop the argument list, keep template args
+    return name.replace("void ", "").strip()
+
+
+def stats(src, dst):
+    rows = list(csv.DictReader(open(find(src, "*kernel_stats.csv"))))
+    rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+    with open(dst, "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline (7 steps in the trace)\n")
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_ms", "avg_us", "percent", "min_us", "max_us"])
+        for r in rows[:40]:
+            w.writerow([short(r["Name"]), r["Calls"], f'{float(r["TotalDurationNs"]) / 1e6:.3f}', f'{float(r["AverageNs"]) / 1e3:.2f}',
+                        f'{float(r["Percentage"]):.2f}', f'{float(r["MinNs"]) / 1e3:.2f}', f'{float(r["MaxNs"]) / 1e3:.2f}'])
+
+
+def counter_means(d, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    per_dispatch = defaultdict(float)
+    names = {}
+    for r in csv.DictReader(open(find(d, "*counter_collection.csv"))):
+        if r["Counter_Name"] != counter:
+            continue
+        key = (r.get("Dispatch_Id") or r.get("Correlation_Id"))
+        per_dispatch[key] += float(r["Counter_Value"])
+        names[key] = short(r["Kernel_Name"])
+    for key, v in per_dispatch.items():
+        a = acc[names[key]]
+        a[0] += v
+        a[1] += 1
+    return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
+
+
+def pmc(fetch_dir, write_dir, dst):
+    fe, wr = counter_means(fetch_dir, "FETCH_SIZE"), counter_means(write_dir, "WRITE_SIZE")
+    rows = []
+    for k in fe:
+        f_kb, n = fe[k]
+        w_kb = wr.get(k, (0.0, 0))[0]
+        rows.append((k, n, f_kb, w_kb, 2 * f_kb * 1024 + w_kb * 1024))
+    rows.sort(key=lambda r: -r[4] * r[1])
+    with open(dst, "w") as f:
+        f.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python bench.py --steps 1 --warmup 1 "
+                "--no-cpu-baseline; hbm_bytes_per_launch = 2*FETCH_SIZE_KB*1024 + WRITE_SIZE_KB*1024 (gfx950 correction of MI355X_MICROARCH.md)\n")
+        w = csv.writer(f)
+        w.writerow(["kernel", "launches", "FETCH_SIZE_KB_mean", "WRITE_SIZE_KB_mean", "hbm_bytes_per_launch"])
+        for r in rows[:30]:
+            w.writerow([r[0], r[1], f"{r[2]:.1f}", f"{r[3]:.1f}", f"{r[4]:.0f}"])
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3])
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4])

@@ -1,0 +1,89 @@
+"""GPU tests of the step engine (mmdti_hip/trainer.py): the reference's step semantics (tasks/trainer.py:177-306) on the
+parameter arena -- loss composition, Adam + clipping + warm-up schedule vs torch.optim, FDS epoch pass, train-mode step."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mmdti_oracle as O
+
+
+def _model(task, odim, **kw):
+    from mmdti_hip.models import mm_model as mm
+    mol = mm.molecule_architecture()
+    mol.encoder_layers, mol.encoder_embed_dim, mol.encoder_ffn_embed_dim, mol.encoder_attention_heads = 2, 64, 128, 8
+    cross = mm.crossmodal_config()
+    cross.hidden_size, cross.num_attention_heads, cross.intermediate_size = 64, 4, 128
+    rcfg = SimpleNamespace(layers=2, dim=64, heads=4, ffn=128, vocab=40, max_pos=40, type_vocab=1, pad_idx=1, ln_eps=1e-12, hidden_dropout=0.1, attn_dropout=0.1)
+    torch.manual_seed(0)
+    return mm.MM_Model.from_configs(odim, task, mol_args=mol, roberta_cfg=rcfg, cross_cfg=cross, gbf_K=16, **kw).cuda()
+
+
+def _ocfg(task, odim):
+    return O.ModelCfg(unimol=O.UniMolCfg(layers=2, dim=64, ffn=128, heads=8, K=16, vocab=31), roberta=O.RobertaCfg(layers=2, dim=64, heads=4, ffn=128, vocab=40, max_pos=40),
+                      cross=O.CrossCfg(dim=64, heads=4, ffn=128), task=task, output_dim=odim)
+
+
+def test_step_matches_torch_adam_and_clip():
+    """One eval-mode (dropout off) step through FineTuner == autograd grads -> clip_grad_norm_(5.0) -> torch Adam(eps 1e-6)
+    with the HF warm-up schedule, on a copy of the same model."""
+    from mmdti_hip.trainer import FineTuner, linear_warmup_lr
+    ocfg = _ocfg("classification", 2)
+    batch, label = O.synth_batch(8, 10, 14, ocfg, seed=3, ragged=True)
+    dev = {k: v.cuda() for k, v in batch.items()}
+    m1, m2 = _model("classification", 2).eval(), _model("classification", 2).eval()
+    m2.load_state_dict(m1.state_dict())
+    tuner = FineTuner(m1, "classification", learning_rate=1e-3, warmup_ratio=0.5, total_steps=4, max_norm=5.0)
+    params2 = [p for p in m2.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params2, lr=1e-3, eps=1e-6)
+    for step in range(3):
+        out = tuner.step(dev, label.cuda())
+        for p in params2:
+            p.grad = None
+        lg, inf, ct = m2(**dev, return_infonce_loss=True, return_ct_loss=True, net_target=label.cuda())
+        from mmdti_hip.functional import CELossFn
+        loss = CELossFn.apply(lg, label.cuda()) + 0.1 * inf + 0.1 * ct
+        assert abs(float(loss) - float(out.loss)) <= 2e-4 * abs(float(loss)) + 1e-6
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params2, 5.0)
+        for gi in opt.param_groups:
+            gi["lr"] = linear_warmup_lr(1e-3, step, 2, 4)
+        opt.step()
+        worst = 0.0
+        for (n, a), b in zip(m1.named_parameters(), m2.parameters()):
+            if a.requires_grad:
+                worst = max(worst, float((a - b).abs().max()))
+        # Adam's first steps move every weight by ~lr regardless of gradient scale, so a sign flip of a noise-level
+        # gradient shows up as 2*lr; bound by a few lr and require near-equality on average
+        assert worst <= 3e-3, (step, worst)
+    tot = sum(float((a - b).abs().sum()) for a, b in zip(m1.parameters(), m2.parameters()) if a.requires_grad)
+    cnt = sum(a.numel() for a in m1.parameters() if a.requires_grad)
+    assert tot / cnt < 2e-5
+    # the bf16 shadow follows the fp32 masters
+    p = next(iter(m1.parameters()))
+    from mmdti_hip.runtime import wbf16
+    assert torch.equal(wbf16(p), p.detach().to(torch.bfloat16))
+
+
+def test_training_reduces_loss_and_fds_pass():
+    from mmdti_hip.trainer import FineTuner
+    ocfg = _ocfg("regression", 1)
+    batch, label = O.synth_batch(16, 10, 14, ocfg, seed=4, ragged=True)
+    dev = {k: v.cuda() for k, v in batch.items()}
+    lab = label.cuda()
+    model = _model("regression", 1, fds=True, fds_num=6, _fds_raw_values=label.numpy().reshape(-1), use_scaler=False).train()
+    tuner = FineTuner(model, "regression", learning_rate=2e-3, warmup_ratio=0.0, total_steps=100)
+    losses = []
+    for epoch in range(2):
+        for _ in range(12):
+            out = tuner.step(dev, lab, epoch=epoch)
+            losses.append(float(out.task_loss))
+        tuner.fds_epoch_pass([(dev, lab)], epoch)                       # tasks/trainer.py:288-306
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-4:]) < 0.7 * np.mean(losses[:4]), losses
+    assert float(model.FDS.epoch) == 1.0 and float(model.FDS.num_samples_tracked.sum()) == 32.0
+    sd = model.state_dict()
+    assert torch.isfinite(sd["FDS.running_mean"]).all() and float(sd["FDS.running_var"].min()) >= 0
