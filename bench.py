@@ -78,7 +78,7 @@ def pmc_traffic(kernel_prefix):
         import csv
         with open(path) as f:
             for row in csv.DictReader(f):
-                if row["kernel"].startswith(kernel_prefix):
+                if kernel_prefix in row["kernel"]:
                     return int(float(row["hbm_bytes_per_launch"]))
     except (OSError, KeyError, ValueError):
         pass
