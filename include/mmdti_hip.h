@@ -142,6 +142,21 @@ int mmdti_softmax_bwd(mmdti_stream_t stream, const void* p_bf16, const float* dp
                       int Lq, int Lk, int ld, float scale, float drop_p, unsigned long long seed,
                       unsigned int site);
 
+/* ---- Fused multi-head attention (HF eager_attention_forward modeling_roberta.py:158-183 via mm_model.py:562;
+ * BertCoAttention mm_module.py:470-514): softmax(q.k^T * scale + key_add) -> dropout -> . v without materialising the
+ * [B,heads,Lq,Lk] scores.  q: rows b*Lq+i, head h at columns [h*head_dim, (h+1)*head_dim), row stride ldq (elements);
+ * k, v: rows b*Lk+j, stride ldk; ctx: [B*Lq, ldo] bf16; key_add: [B,Lk] fp32 additive mask or null.
+ * stats: [B,heads,Lq,2] fp32 (row max, 1/row sum) saved for the backward.  head_dim 32 or 64; Lq, Lk <= 256. */
+int mmdti_attn_fwd(mmdti_stream_t stream, const void* q_bf16, const void* k_bf16, const void* v_bf16,
+                   const float* key_add, void* ctx_bf16, float* stats, int B, int heads, int Lq, int Lk, int head_dim,
+                   int ldq, int ldk, int ldo, float scale, float drop_p, unsigned long long seed, unsigned int site);
+/* dq/dk/dv (bf16, strides lddq / lddk / lddk) from dctx (stride ldo); drow: [B,heads,Lq] fp32 scratch that receives
+ * sum_j dP'_ij p_ij.  Same (seed, site) as the forward call regenerates the dropout mask. */
+int mmdti_attn_bwd(mmdti_stream_t stream, const void* q_bf16, const void* k_bf16, const void* v_bf16,
+                   const float* key_add, const void* dctx_bf16, const float* stats, float* drow, void* dq_bf16,
+                   void* dk_bf16, void* dv_bf16, int B, int heads, int Lq, int Lk, int head_dim, int ldq, int ldk, int ldo,
+                   int lddq, int lddk, float scale, float drop_p, unsigned long long seed, unsigned int site);
+
 /* ---- GELU on bf16 (kept for un-fused call sites) ------------------------------------------- */
 int mmdti_gelu_fwd_bf16(mmdti_stream_t stream, const void* u_bf16, void* y_bf16, long long n);
 

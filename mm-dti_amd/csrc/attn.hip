@@ -1,0 +1,477 @@
+// Fused BERT-style multi-head attention for gfx950 (head_dim 32 or 64, up to 256 queries x 256 keys per head).
+//
+// Replaces, for the ChemBERTa tower (HF eager_attention_forward, modeling_roberta.py:158-183, called through
+// mm_model.py:562) and the cross-modal layers (BertCoAttention, mm_module.py:470-514), the chain
+//   scores GEMM -> row softmax (+ key mask, + dropout) -> context GEMM                     (forward)
+//   dP GEMM, dV GEMM, softmax backward, dQ GEMM, dK GEMM                                   (backward)
+// which moves the [B, heads, Lq, Lk] score tensor through HBM eight times per layer.  Here the scores never leave
+// registers: one workgroup (8 waves) owns one (molecule, head), keeps that head's K and V (or Q and dO) rows in LDS, and
+// each wave walks 16-row tiles.
+//
+// Layout trick shared by all three kernels: the score tile is produced with the CONTRACTED index of the next product on
+// the accumulator's register/row axis, so that two consecutive 16x16 accumulator tiles ARE one 16x16x32 bf16 MFMA
+// operand (k-slot 8g+j <-> tile row 4g+j of the first / second tile).  The other operand of that product is read from
+// the row-major LDS image with ds_read_b64_tr_b16, which hands each lane the matching four rows of one column.  No
+// shuffles, no LDS round trip between the two matrix products.
+//   forward / dQ kernel : S^T[key][query] = K.Q^T   (lane = query, 4 consecutive keys per register quad)
+//   dK/dV kernel        : S[query][key]   = Q.K^T   (lane = key,   4 consecutive queries per register quad)
+//
+// Numerics (same rounding points as the unfused path and the oracle's bf16 mode): bf16 operands, fp32 accumulate,
+// fp32 scale/mask/softmax over the WHOLE row (two passes in registers -- not an online softmax), probabilities and dS
+// rounded to bf16 only as MFMA operands.  The backward recomputes the probabilities from the saved row statistics
+// (max, 1/sum) in fp32, and the row term sum_j dP'_ij p_ij exactly in registers (no O.dO shortcut).
+// Dropout: per-element hash of (seed, site, head, query, key) -- the same function in all three kernels.
+#include "common.h"
+
+namespace mmdti {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// row stride (elements) of the LDS images: head_dim + 16 -> 160-B / 96-B rows, conflict-free for both the row-major
+// ds_read_b128 fragments (4 x 16-lane groups) and the ds_read_b64_tr_b16 fragments (2 x 32-lane halves).
+template <int HD>
+struct AttnShape {
+  static constexpr int STR = HD + 16;
+  static constexpr int KC = HD / 32;  // 32-wide k chunks of a head_dim contraction
+  static constexpr int NB = HD / 16;  // 16-wide head_dim blocks of an output
+};
+
+__device__ __forceinline__ uint32_t attn_rng_key(uint64_t seed, uint32_t site, uint32_t bh) {
+  return mix32((mix32((uint32_t)seed ^ (site * 0x9E3779B9u)) ^ (uint32_t)(seed >> 32)) + bh * 0x85EBCA6Bu);
+}
+// keep iff a 16-bit uniform >= thresh16 (p quantised to 1/65536).  idx = query * key_stride + key.
+__device__ __forceinline__ bool attn_keep(uint32_t key, uint32_t idx, uint32_t thresh16) {
+  uint32_t h = (idx * 0x9E3779B1u) ^ key;
+  h ^= h >> 16;
+  h *= 0x7FEB352Du;
+  h ^= h >> 15;
+  return (h >> 16) >= thresh16;
+}
+
+template <int HD>
+__device__ __forceinline__ void attn_fill_rows(bf16_t* lds, const bf16_t* g, int L, int rows, int ld, int tid, int nthreads) {
+  constexpr int CPR = HD / 8, STR = AttnShape<HD>::STR;
+  for (int c = tid; c < rows * CPR; c += nthreads) {
+    const int row = c / CPR, col = (c % CPR) * 8;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (row < L) v = *reinterpret_cast<const uint4*>(g + (long long)row * ld + col);
+    *reinterpret_cast<uint4*>(lds + row * STR + col) = v;
+  }
+}
+// rows row0..row0+15 as an MFMA operand (lane = row, 8 consecutive k): one ds_read_b128
+template <int HD>
+__device__ __forceinline__ bf16x8 attn_frag_rm(const bf16_t* lds, int row0, int c, int lane) {
+  return *reinterpret_cast<const bf16x8*>(lds + (row0 + (lane & 15)) * AttnShape<HD>::STR + 32 * c + 8 * (lane >> 4));
+}
+// columns n0..n0+15 as an MFMA operand (lane = column) whose k-slots 8g+j are rows r0+4g+j (j<4) and r1+4g+(j-4)
+template <int HD>
+__device__ __forceinline__ bf16x8 attn_frag_tr(const bf16_t* lds, int r0, int r1, int n0, int lane) {
+  constexpr int STR = AttnShape<HD>::STR;
+  const int off = (4 * (lane >> 4) + ((lane & 15) >> 2)) * STR + n0 + 4 * (lane & 3);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + r0 * STR + off));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + r1 * STR + off));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+template <int HD>
+__device__ __forceinline__ bf16x8 attn_frag_global(const bf16_t* base, bool valid, int c, int lane) {
+  bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (valid) z = *reinterpret_cast<const bf16x8*>(base + 32 * c + 8 * (lane >> 4));
+  return z;
+}
+__device__ __forceinline__ bf16x8 attn_pack(const f32x4& a, const f32x4& b) {
+  bf16x8 r;
+  r[0] = (__bf16)a[0]; r[1] = (__bf16)a[1]; r[2] = (__bf16)a[2]; r[3] = (__bf16)a[3];
+  r[4] = (__bf16)b[0]; r[5] = (__bf16)b[1]; r[6] = (__bf16)b[2]; r[7] = (__bf16)b[3];
+  return r;
+}
+__device__ __forceinline__ void attn_store4(bf16_t* dst, const f32x4& a) {
+  uint2 pk;
+  pk.x = (uint32_t)f2bf(a[0]) | ((uint32_t)f2bf(a[1]) << 16);
+  pk.y = (uint32_t)f2bf(a[2]) | ((uint32_t)f2bf(a[3]) << 16);
+  *reinterpret_cast<uint2*>(dst) = pk;
+}
+#define ATTN_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C, 0, 0, 0)
+
+// ------------------------------------------------------------------------------------------------------ forward
+template <int HD, int NT>
+__global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                       const bf16_t* __restrict__ v, const float* __restrict__ key_add,
+                                                       bf16_t* __restrict__ ctx, float* __restrict__ stats, int heads, int Lq,
+                                                       int Lk, int ldq, int ldk, int ldo, float scale, uint32_t thresh16,
+                                                       float dscale, uint64_t seed, uint32_t site) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
+  constexpr int STR = AttnShape<HD>::STR, KC = AttnShape<HD>::KC, NB = AttnShape<HD>::NB, NP = NT * 16;
+  bf16_t* sK = reinterpret_cast<bf16_t*>(attn_smem);
+  bf16_t* sV = sK + NP * STR;
+  float* sKA = reinterpret_cast<float*>(sV + NP * STR);
+  const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  attn_fill_rows<HD>(sK, k + (long long)b * Lk * ldk + h * HD, Lk, NP, ldk, tid, blockDim.x);
+  attn_fill_rows<HD>(sV, v + (long long)b * Lk * ldk + h * HD, Lk, NP, ldk, tid, blockDim.x);
+  for (int t = tid; t < NP; t += blockDim.x) sKA[t] = t < Lk ? (key_add ? key_add[(long long)b * Lk + t] : 0.f) : -INFINITY;
+  __syncthreads();
+  const uint32_t rkey = attn_rng_key(seed, site, (uint32_t)bh);
+  const int g = lane >> 4, i = lane & 15;
+  const int nqt = (Lq + 15) >> 4;
+  for (int qt = wave; qt < nqt; qt += nw) {
+    const int qi = qt * 16 + i;
+    const bool qv = qi < Lq;
+    const bf16_t* qrow = q + ((long long)b * Lq + (qv ? qi : 0)) * ldq + h * HD;
+    bf16x8 qf[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) qf[c] = attn_frag_global<HD>(qrow, qv, c, lane);
+    f32x4 S[NT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < KC; ++c) acc = ATTN_MFMA(attn_frag_rm<HD>(sK, t * 16, c, lane), qf[c], acc);
+      const f32x4 ka = *reinterpret_cast<const f32x4*>(&sKA[t * 16 + 4 * g]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = acc[r] * scale + ka[r];
+      m = fmaxf(fmaxf(m, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
+      S[t] = acc;
+      __builtin_amdgcn_sched_barrier(0);  // keep the unrolled tiles in order: hoisted LDS fragments would spill
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float lsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(S[t][r] - m);
+        S[t][r] = e;
+        lsum += e;
+      }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float inv = 1.0f / lsum;
+    if (g == 0 && qv) *reinterpret_cast<float2*>(stats + ((long long)bh * Lq + qi) * 2) = make_float2(m, inv);
+    f32x4 o[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) o[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NT / 2; ++u) {
+      f32x4 p0 = S[2 * u] * inv, p1 = S[2 * u + 1] * inv;
+      if (thresh16) {
+        const uint32_t i0 = (uint32_t)qi * NP + (2 * u) * 16 + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p0[r] = attn_keep(rkey, i0 + r, thresh16) ? p0[r] * dscale : 0.f;
+          p1[r] = attn_keep(rkey, i0 + 16 + r, thresh16) ? p1[r] * dscale : 0.f;
+        }
+      }
+      const bf16x8 pf = attn_pack(p0, p1);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) o[nb] = ATTN_MFMA(attn_frag_tr<HD>(sV, 32 * u, 32 * u + 16, nb * 16, lane), pf, o[nb]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (qv) {
+      bf16_t* dst = ctx + ((long long)b * Lq + qi) * ldo + h * HD + 4 * g;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) attn_store4(dst + nb * 16, o[nb]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------ backward: dQ
+template <int HD, int NT>
+__global__ __launch_bounds__(512) void attn_bwd_q_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                         const bf16_t* __restrict__ v, const float* __restrict__ key_add,
+                                                         const bf16_t* __restrict__ dout, const float* __restrict__ stats,
+                                                         bf16_t* __restrict__ dq, float* __restrict__ drow, int heads, int Lq,
+                                                         int Lk, int ldq, int ldk, int ldo, int lddq, float scale,
+                                                         uint32_t thresh16, float dscale, uint64_t seed, uint32_t site) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
+  constexpr int STR = AttnShape<HD>::STR, KC = AttnShape<HD>::KC, NB = AttnShape<HD>::NB, NP = NT * 16;
+  bf16_t* sK = reinterpret_cast<bf16_t*>(attn_smem);
+  bf16_t* sV = sK + NP * STR;
+  float* sKA = reinterpret_cast<float*>(sV + NP * STR);
+  const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  attn_fill_rows<HD>(sK, k + (long long)b * Lk * ldk + h * HD, Lk, NP, ldk, tid, blockDim.x);
+  attn_fill_rows<HD>(sV, v + (long long)b * Lk * ldk + h * HD, Lk, NP, ldk, tid, blockDim.x);
+  for (int t = tid; t < NP; t += blockDim.x) sKA[t] = t < Lk ? (key_add ? key_add[(long long)b * Lk + t] : 0.f) : -INFINITY;
+  __syncthreads();
+  const uint32_t rkey = attn_rng_key(seed, site, (uint32_t)bh);
+  const int g = lane >> 4, i = lane & 15;
+  const int nqt = (Lq + 15) >> 4;
+  for (int qt = wave; qt < nqt; qt += nw) {
+    const int qi = qt * 16 + i;
+    const bool qv = qi < Lq;
+    const bf16_t* qrow = q + ((long long)b * Lq + (qv ? qi : 0)) * ldq + h * HD;
+    const bf16_t* orow = dout + ((long long)b * Lq + (qv ? qi : 0)) * ldo + h * HD;
+    bf16x8 qf[KC], dof[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      qf[c] = attn_frag_global<HD>(qrow, qv, c, lane);
+      dof[c] = attn_frag_global<HD>(orow, qv, c, lane);
+    }
+    float2 st = make_float2(0.f, 0.f);
+    if (qv) st = *reinterpret_cast<const float2*>(stats + ((long long)bh * Lq + qi) * 2);
+    // sweep 1: probabilities (kept in registers, sign bit = "dropped") and the row term D = sum_j dP'_ij p_ij
+    f32x4 P[NT];
+    float dsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, dacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        acc = ATTN_MFMA(attn_frag_rm<HD>(sK, t * 16, c, lane), qf[c], acc);
+        dacc = ATTN_MFMA(attn_frag_rm<HD>(sV, t * 16, c, lane), dof[c], dacc);
+      }
+      const f32x4 ka = *reinterpret_cast<const f32x4*>(&sKA[t * 16 + 4 * g]);
+      const uint32_t i0 = (uint32_t)qi * NP + t * 16 + 4 * g;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf(acc[r] * scale + ka[r] - st.x) * st.y;
+        const bool keep = !thresh16 || attn_keep(rkey, i0 + r, thresh16);
+        dsum += keep ? dacc[r] * p : 0.f;
+        acc[r] = keep ? p : -p;
+      }
+      P[t] = acc;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    dsum *= dscale;
+    dsum += __shfl_xor(dsum, 16, 64);
+    dsum += __shfl_xor(dsum, 32, 64);
+    if (g == 0 && qv) drow[(long long)bh * Lq + qi] = dsum;
+    // sweep 2: dP again (two MFMAs per tile are cheaper than 64 more live registers), dS, dQ^T += K^T.dS^T
+    f32x4 da[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) da[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NT / 2; ++u) {
+      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        s0 = ATTN_MFMA(attn_frag_rm<HD>(sV, 32 * u, c, lane), dof[c], s0);
+        s1 = ATTN_MFMA(attn_frag_rm<HD>(sV, 32 * u + 16, c, lane), dof[c], s1);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p0 = P[2 * u][r], p1 = P[2 * u + 1][r];
+        s0[r] = fabsf(p0) * ((__float_as_uint(p0) >> 31 ? 0.f : s0[r] * dscale) - dsum) * scale;
+        s1[r] = fabsf(p1) * ((__float_as_uint(p1) >> 31 ? 0.f : s1[r] * dscale) - dsum) * scale;
+      }
+      const bf16x8 sf = attn_pack(s0, s1);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) da[nb] = ATTN_MFMA(attn_frag_tr<HD>(sK, 32 * u, 32 * u + 16, nb * 16, lane), sf, da[nb]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (qv) {
+      bf16_t* dst = dq + ((long long)b * Lq + qi) * lddq + h * HD + 4 * g;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) attn_store4(dst + nb * 16, da[nb]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------ backward: dK, dV
+template <int HD>
+__global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                          const bf16_t* __restrict__ v, const float* __restrict__ key_add,
+                                                          const bf16_t* __restrict__ dout, const float* __restrict__ stats,
+                                                          const float* __restrict__ drow, bf16_t* __restrict__ dk,
+                                                          bf16_t* __restrict__ dv, int heads, int Lq, int Lk, int ldq, int ldk,
+                                                          int ldo, int lddk, float scale, uint32_t thresh16, float dscale,
+                                                          uint64_t seed, uint32_t site, int key_stride) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
+  constexpr int STR = AttnShape<HD>::STR, KC = AttnShape<HD>::KC, NB = AttnShape<HD>::NB;
+  const int LQP = ((Lq + 31) >> 5) << 5;
+  bf16_t* sQ = reinterpret_cast<bf16_t*>(attn_smem);
+  bf16_t* sO = sQ + LQP * STR;
+  float* sM = reinterpret_cast<float*>(sO + LQP * STR);
+  float* sI = sM + LQP;
+  float* sD = sI + LQP;
+  const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  attn_fill_rows<HD>(sQ, q + (long long)b * Lq * ldq + h * HD, Lq, LQP, ldq, tid, blockDim.x);
+  attn_fill_rows<HD>(sO, dout + (long long)b * Lq * ldo + h * HD, Lq, LQP, ldo, tid, blockDim.x);
+  for (int t = tid; t < LQP; t += blockDim.x) {
+    float2 st = make_float2(0.f, 0.f);
+    float d = 0.f;
+    if (t < Lq) {
+      st = *reinterpret_cast<const float2*>(stats + ((long long)bh * Lq + t) * 2);
+      d = drow[(long long)bh * Lq + t];
+    }
+    sM[t] = st.x;
+    sI[t] = st.y;
+    sD[t] = d;
+  }
+  __syncthreads();
+  const uint32_t rkey = attn_rng_key(seed, site, (uint32_t)bh);
+  const int g = lane >> 4, i = lane & 15;
+  const int nkt = (Lk + 15) >> 4;
+  for (int kt = wave; kt < nkt; kt += nw) {
+    const int key = kt * 16 + i;
+    const bool kv = key < Lk;
+    const bf16_t* krow = k + ((long long)b * Lk + (kv ? key : 0)) * ldk + h * HD;
+    const bf16_t* vrow = v + ((long long)b * Lk + (kv ? key : 0)) * ldk + h * HD;
+    bf16x8 kf[KC], vf[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      kf[c] = attn_frag_global<HD>(krow, kv, c, lane);
+      vf[c] = attn_frag_global<HD>(vrow, kv, c, lane);
+    }
+    const float ka = kv ? (key_add ? key_add[(long long)b * Lk + key] : 0.f) : -INFINITY;
+    f32x4 dka[NB], dva[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      dka[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dva[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll 1
+    for (int up = 0; up < (LQP >> 5); ++up) {
+      f32x4 pd[2], ds[2];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int r0 = up * 32 + hf * 16;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, dacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          acc = ATTN_MFMA(attn_frag_rm<HD>(sQ, r0, c, lane), kf[c], acc);
+          dacc = ATTN_MFMA(attn_frag_rm<HD>(sO, r0, c, lane), vf[c], dacc);
+        }
+        const f32x4 m4 = *reinterpret_cast<const f32x4*>(&sM[r0 + 4 * g]);
+        const f32x4 i4 = *reinterpret_cast<const f32x4*>(&sI[r0 + 4 * g]);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(&sD[r0 + 4 * g]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __expf(acc[r] * scale + ka - m4[r]) * i4[r];
+          float w = dacc[r], pk = p;
+          if (thresh16) {
+            const bool keep = attn_keep(rkey, (uint32_t)(r0 + 4 * g + r) * key_stride + key, thresh16);
+            w = keep ? w * dscale : 0.f;
+            pk = keep ? p * dscale : 0.f;
+          }
+          pd[hf][r] = pk;
+          ds[hf][r] = p * (w - d4[r]) * scale;
+        }
+      }
+      const bf16x8 pf = attn_pack(pd[0], pd[1]), sf = attn_pack(ds[0], ds[1]);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        dva[nb] = ATTN_MFMA(attn_frag_tr<HD>(sO, up * 32, up * 32 + 16, nb * 16, lane), pf, dva[nb]);
+        dka[nb] = ATTN_MFMA(attn_frag_tr<HD>(sQ, up * 32, up * 32 + 16, nb * 16, lane), sf, dka[nb]);
+      }
+    }
+    if (kv) {
+      bf16_t* dkd = dk + ((long long)b * Lk + key) * lddk + h * HD + 4 * g;
+      bf16_t* dvd = dv + ((long long)b * Lk + key) * lddk + h * HD + 4 * g;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        attn_store4(dkd + nb * 16, dka[nb]);
+        attn_store4(dvd + nb * 16, dva[nb]);
+      }
+    }
+  }
+}
+
+static inline uint32_t thresh16_of(float p) { return p > 0.f ? (uint32_t)((double)p * 65536.0) : 0u; }
+static inline int attn_nt(int Lk) { return Lk <= 160 ? 10 : 16; }
+// largest dynamic LDS any launch of these kernels asks for: 2 x 256 rows x (64+16) bf16 + 3 x 256 floats
+constexpr size_t smem_max = (size_t)2 * 256 * 80 * 2 + 3 * 256 * 4;
+
+template <typename K>
+static int attn_set_smem(K kern, size_t smem) {
+  if (smem <= 65536) return MMDTI_OK;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+    set_error("attn: hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", smem);
+    return MMDTI_ERR_LAUNCH;
+  }
+  return MMDTI_OK;
+}
+
+static int attn_check(const char* name, const void* q, const void* k, const void* v, int B, int heads, int Lq, int Lk, int hd,
+                      int ldq, int ldk, float drop_p) {
+  MMDTI_REQUIRE(q && k && v && B > 0 && heads > 0 && Lq > 0 && Lk > 0, "%s: bad arguments", name);
+  MMDTI_REQUIRE(hd == 32 || hd == 64, "%s: head_dim must be 32 or 64 (got %d)", name, hd);
+  MMDTI_REQUIRE(Lq <= 256 && Lk <= 256, "%s: at most 256 queries / keys per head (got %d / %d)", name, Lq, Lk);
+  MMDTI_REQUIRE(ldq >= heads * hd && ldk >= heads * hd && ldq % 8 == 0 && ldk % 8 == 0, "%s: row strides must cover heads*head_dim and be multiples of 8", name);
+  MMDTI_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v), "%s: 16-byte alignment required", name);
+  MMDTI_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "%s: dropout p out of range", name);
+  return MMDTI_OK;
+}
+
+}  // namespace mmdti
+using namespace mmdti;
+
+extern "C" int mmdti_attn_fwd(mmdti_stream_t stream, const void* q_bf16, const void* k_bf16, const void* v_bf16,
+                              const float* key_add, void* ctx_bf16, float* stats, int B, int heads, int Lq, int Lk,
+                              int head_dim, int ldq, int ldk, int ldo, float scale, float drop_p, unsigned long long seed,
+                              unsigned int site) {
+  if (int e = attn_check("attn_fwd", q_bf16, k_bf16, v_bf16, B, heads, Lq, Lk, head_dim, ldq, ldk, drop_p)) return e;
+  MMDTI_REQUIRE(ctx_bf16 && stats && ldo >= heads * head_dim && ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(ctx_bf16) & 7) == 0 &&
+                    (reinterpret_cast<uintptr_t>(stats) & 7) == 0, "attn_fwd: bad output arguments");
+  const uint32_t th = thresh16_of(drop_p);
+  const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const int nt = attn_nt(Lk);
+  const size_t smem = (size_t)2 * nt * 16 * (head_dim + 16) * 2 + (size_t)nt * 16 * 4;
+#define ATTN_F(HD, NT)                                                                                                   \
+  do {                                                                                                                   \
+    static bool attr_done = false;                                                                                       \
+    if (!attr_done) { if (int e = attn_set_smem(attn_fwd_kernel<HD, NT>, smem_max)) return e; attr_done = true; }        \
+    hipLaunchKernelGGL((attn_fwd_kernel<HD, NT>), dim3(B * heads), dim3(512), smem, (hipStream_t)stream,                 \
+                       (const bf16_t*)q_bf16, (const bf16_t*)k_bf16, (const bf16_t*)v_bf16, key_add, (bf16_t*)ctx_bf16,  \
+                       stats, heads, Lq, Lk, ldq, ldk, ldo, scale, th, sc, (uint64_t)seed, (uint32_t)site);              \
+  } while (0)
+  if (head_dim == 64) { if (nt == 10) ATTN_F(64, 10); else ATTN_F(64, 16); }
+  else                { if (nt == 10) ATTN_F(32, 10); else ATTN_F(32, 16); }
+#undef ATTN_F
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_attn_bwd(mmdti_stream_t stream, const void* q_bf16, const void* k_bf16, const void* v_bf16,
+                              const float* key_add, const void* dctx_bf16, const float* stats, float* drow, void* dq_bf16,
+                              void* dk_bf16, void* dv_bf16, int B, int heads, int Lq, int Lk, int head_dim, int ldq, int ldk,
+                              int ldo, int lddq, int lddk, float scale, float drop_p, unsigned long long seed,
+                              unsigned int site) {
+  if (int e = attn_check("attn_bwd", q_bf16, k_bf16, v_bf16, B, heads, Lq, Lk, head_dim, ldq, ldk, drop_p)) return e;
+  MMDTI_REQUIRE(dctx_bf16 && stats && drow && dq_bf16 && dk_bf16 && dv_bf16, "attn_bwd: null argument");
+  MMDTI_REQUIRE(ldo >= heads * head_dim && ldo % 8 == 0 && aligned16(dctx_bf16), "attn_bwd: dctx stride/alignment");
+  MMDTI_REQUIRE(lddq >= heads * head_dim && lddk >= heads * head_dim && lddq % 4 == 0 && lddk % 4 == 0 &&
+                    (reinterpret_cast<uintptr_t>(dq_bf16) & 7) == 0 && (reinterpret_cast<uintptr_t>(dk_bf16) & 7) == 0 &&
+                    (reinterpret_cast<uintptr_t>(dv_bf16) & 7) == 0 && (reinterpret_cast<uintptr_t>(stats) & 7) == 0,
+                "attn_bwd: output stride/alignment");
+  const uint32_t th = thresh16_of(drop_p);
+  const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const int nt = attn_nt(Lk);
+  const size_t smem_q = (size_t)2 * nt * 16 * (head_dim + 16) * 2 + (size_t)nt * 16 * 4;
+  const int lqp = ((Lq + 31) / 32) * 32;
+  const size_t smem_kv = (size_t)2 * lqp * (head_dim + 16) * 2 + (size_t)3 * lqp * 4;
+#define ATTN_BQ(HD, NT)                                                                                                    \
+  do {                                                                                                                     \
+    static bool attr_done = false;                                                                                         \
+    if (!attr_done) { if (int e = attn_set_smem(attn_bwd_q_kernel<HD, NT>, smem_max)) return e; attr_done = true; }        \
+    hipLaunchKernelGGL((attn_bwd_q_kernel<HD, NT>), dim3(B * heads), dim3(512), smem_q, (hipStream_t)stream,               \
+                       (const bf16_t*)q_bf16, (const bf16_t*)k_bf16, (const bf16_t*)v_bf16, key_add,                       \
+                       (const bf16_t*)dctx_bf16, stats, (bf16_t*)dq_bf16, drow, heads, Lq, Lk, ldq, ldk, ldo, lddq, scale, \
+                       th, sc, (uint64_t)seed, (uint32_t)site);                                                            \
+  } while (0)
+#define ATTN_BKV(HD)                                                                                                       \
+  do {                                                                                                                     \
+    static bool attr_done = false;                                                                                         \
+    if (!attr_done) { if (int e = attn_set_smem(attn_bwd_kv_kernel<HD>, smem_max)) return e; attr_done = true; }           \
+    hipLaunchKernelGGL((attn_bwd_kv_kernel<HD>), dim3(B * heads), dim3(512), smem_kv, (hipStream_t)stream,                 \
+                       (const bf16_t*)q_bf16, (const bf16_t*)k_bf16, (const bf16_t*)v_bf16, key_add,                       \
+                       (const bf16_t*)dctx_bf16, stats, drow, (bf16_t*)dk_bf16, (bf16_t*)dv_bf16, heads, Lq, Lk, ldq, ldk, \
+                       ldo, lddk, scale, th, sc, (uint64_t)seed, (uint32_t)site, nt * 16);                                 \
+  } while (0)
+  if (head_dim == 64) { if (nt == 10) ATTN_BQ(64, 10); else ATTN_BQ(64, 16); }
+  else                { if (nt == 10) ATTN_BQ(32, 10); else ATTN_BQ(32, 16); }
+  MMDTI_LAUNCH_CHECK();
+  if (head_dim == 64) ATTN_BKV(64); else ATTN_BKV(32);
+#undef ATTN_BQ
+#undef ATTN_BKV
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}

@@ -212,15 +212,20 @@ def _bert_layer_fwd(st, s1_32, s1_16, s2_16, key_add, W, heads, p_hid, p_att, ep
     L.q = ops.linear_fwd(s1_16, wbf16(W.q_w), W.q_b)
     L.k = ops.linear_fwd(s2_16, wbf16(W.k_w), W.k_b)
     L.v = ops.linear_fwd(s2_16, wbf16(W.v_w), W.v_b)
-    S = torch.empty(B, heads, Lq, ld, device=s1_32.device, dtype=F32)
-    ops.gemm(L.q, L.k, M=Lq, N=Lk, K=hd, lda=D, ldb=D, out=S, ldc=ld, batch=(B, heads), sA=(Lq * D, hd), sB=(Lk * D, hd),
-             sC=(heads * Lq * ld, Lq * ld), alpha=1.0 / math.sqrt(hd))
     L.site_att = sites.next()
-    L.p, L.pd = ops.softmax_fwd(S, key_add, B, heads, Lq, Lk, ld, p_att, seed, L.site_att)
-    del S
-    L.ctx = torch.empty(B * Lq, D, device=s1_32.device, dtype=BF16)
-    ops.gemm(L.pd, L.v, M=Lq, N=hd, K=Lk, lda=ld, ldb=D, transB=True, out=L.ctx, ldc=D, batch=(B, heads),
-             sA=(heads * Lq * ld, Lq * ld), sB=(Lk * D, hd), sC=(Lq * D, hd))
+    L.key_add, L.fused = key_add, ops.attn_eligible(Lq, Lk, hd, D)
+    if L.fused:
+        # scores, softmax, dropout and context in one kernel: the [B,heads,Lq,Lk] tensor never reaches HBM
+        L.ctx, L.stats = ops.attn_fwd(L.q, L.k, L.v, key_add, B, heads, Lq, Lk, 1.0 / math.sqrt(hd), p_att, seed, L.site_att)
+    else:
+        S = torch.empty(B, heads, Lq, ld, device=s1_32.device, dtype=F32)
+        ops.gemm(L.q, L.k, M=Lq, N=Lk, K=hd, lda=D, ldb=D, out=S, ldc=ld, batch=(B, heads), sA=(Lq * D, hd), sB=(Lk * D, hd),
+                 sC=(heads * Lq * ld, Lq * ld), alpha=1.0 / math.sqrt(hd))
+        L.p, L.pd = ops.softmax_fwd(S, key_add, B, heads, Lq, Lk, ld, p_att, seed, L.site_att)
+        del S
+        L.ctx = torch.empty(B * Lq, D, device=s1_32.device, dtype=BF16)
+        ops.gemm(L.pd, L.v, M=Lq, N=hd, K=Lk, lda=ld, ldb=D, transB=True, out=L.ctx, ldc=D, batch=(B, heads),
+                 sA=(heads * Lq * ld, Lq * ld), sB=(Lk * D, hd), sC=(Lq * D, hd))
     L.site_o = sites.next()
     L.y = ops.linear_fwd(L.ctx, wbf16(W.o_w), W.o_b, residual=s1_32, out_dtype=F32, drop_p=p_hid, seed=seed, site=L.site_o)
     L.a32, L.a16, L.am, L.ar = ops.layernorm_fwd(L.y, W.ln1_w, W.ln1_b, eps, want_f32=True, want_bf16=True)
@@ -250,20 +255,23 @@ def _bert_layer_bwd(st, L, dout, seed):
     _lin_bwd_params(dyb, L.ctx, W.o_w, W.o_b)
     dctx = ops.linear_bwd_input(dyb, wbf16(W.o_w))
     dev = dout.device
-    dP = torch.empty(B, heads, Lq, ld, device=dev, dtype=F32)
-    ops.gemm(dctx, L.v, M=Lq, N=Lk, K=hd, lda=D, ldb=D, out=dP, ldc=ld, batch=(B, heads), sA=(Lq * D, hd), sB=(Lk * D, hd),
-             sC=(heads * Lq * ld, Lq * ld))
-    dv = torch.empty(B * Lk, D, device=dev, dtype=BF16)
-    ops.gemm(L.pd, dctx, M=Lk, N=hd, K=Lq, lda=ld, ldb=D, transA=True, transB=True, out=dv, ldc=D, batch=(B, heads),
-             sA=(heads * Lq * ld, Lq * ld), sB=(Lq * D, hd), sC=(Lk * D, hd))
-    dS = ops.softmax_bwd(L.p, dP, B, heads, Lq, Lk, ld, 1.0 / math.sqrt(hd), L.p_att, seed, L.site_att)
-    del dP
-    dq = torch.empty(B * Lq, D, device=dev, dtype=BF16)
-    ops.gemm(dS, L.k, M=Lq, N=hd, K=Lk, lda=ld, ldb=D, transB=True, out=dq, ldc=D, batch=(B, heads),
-             sA=(heads * Lq * ld, Lq * ld), sB=(Lk * D, hd), sC=(Lq * D, hd))
-    dk = torch.empty(B * Lk, D, device=dev, dtype=BF16)
-    ops.gemm(dS, L.q, M=Lk, N=hd, K=Lq, lda=ld, ldb=D, transA=True, transB=True, out=dk, ldc=D, batch=(B, heads),
-             sA=(heads * Lq * ld, Lq * ld), sB=(Lq * D, hd), sC=(Lk * D, hd))
+    if L.fused:
+        dq, dk, dv = ops.attn_bwd(L.q, L.k, L.v, L.key_add, dctx, L.stats, B, heads, Lq, Lk, 1.0 / math.sqrt(hd), L.p_att, seed, L.site_att)
+    else:
+        dP = torch.empty(B, heads, Lq, ld, device=dev, dtype=F32)
+        ops.gemm(dctx, L.v, M=Lq, N=Lk, K=hd, lda=D, ldb=D, out=dP, ldc=ld, batch=(B, heads), sA=(Lq * D, hd), sB=(Lk * D, hd),
+                 sC=(heads * Lq * ld, Lq * ld))
+        dv = torch.empty(B * Lk, D, device=dev, dtype=BF16)
+        ops.gemm(L.pd, dctx, M=Lk, N=hd, K=Lq, lda=ld, ldb=D, transA=True, transB=True, out=dv, ldc=D, batch=(B, heads),
+                 sA=(heads * Lq * ld, Lq * ld), sB=(Lq * D, hd), sC=(Lk * D, hd))
+        dS = ops.softmax_bwd(L.p, dP, B, heads, Lq, Lk, ld, 1.0 / math.sqrt(hd), L.p_att, seed, L.site_att)
+        del dP
+        dq = torch.empty(B * Lq, D, device=dev, dtype=BF16)
+        ops.gemm(dS, L.k, M=Lq, N=hd, K=Lk, lda=ld, ldb=D, transB=True, out=dq, ldc=D, batch=(B, heads),
+                 sA=(heads * Lq * ld, Lq * ld), sB=(Lk * D, hd), sC=(Lq * D, hd))
+        dk = torch.empty(B * Lk, D, device=dev, dtype=BF16)
+        ops.gemm(dS, L.q, M=Lk, N=hd, K=Lq, lda=ld, ldb=D, transA=True, transB=True, out=dk, ldc=D, batch=(B, heads),
+                 sA=(heads * Lq * ld, Lq * ld), sB=(Lq * D, hd), sC=(Lk * D, hd))
     _lin_bwd_params(dq, L.s1_16, W.q_w, W.q_b)
     _lin_bwd_params(dk, L.s2_16, W.k_w, W.k_b)
     _lin_bwd_params(dv, L.s2_16, W.v_w, W.v_b)

@@ -277,6 +277,43 @@ def softmax_bwd(p, dp, B, heads, Lq, Lk, ld, scale, drop_p=0.0, seed=0, site=0):
     return ds
 
 
+# --------------------------------------------------------------------------------------------- fused attention
+FUSED_ATTN = True      # tests flip this to exercise the materialised-scores path that longer sequences take
+
+
+def attn_eligible(Lq, Lk, hd, D):
+    return FUSED_ATTN and hd in (32, 64) and Lq <= 256 and Lk <= 256 and D % 8 == 0
+
+
+def attn_fwd(q, k, v, key_add, B, heads, Lq, Lk, scale, drop_p=0.0, seed=0, site=0):
+    """q [B*Lq, D], k/v [B*Lk, D] bf16 -> (ctx [B*Lq, D] bf16, stats [B,heads,Lq,2] fp32)."""
+    for t_, n_ in ((q, "attn.q"), (k, "attn.k"), (v, "attn.v")):
+        _chk(t_, BF16, n_, contiguous=False)
+        if t_.stride(1) != 1:
+            raise MMDTIError(f"{n_}: unit column stride required")
+    D = q.shape[1]
+    hd = D // heads
+    ctx = torch.empty(B * Lq, D, device=q.device, dtype=BF16)
+    stats = torch.empty(B, heads, Lq, 2, device=q.device, dtype=F32)
+    lib().mmdti_attn_fwd(_stream(), q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(key_add), ctx.data_ptr(), stats.data_ptr(), B, heads, Lq, Lk,
+                         hd, q.stride(0), k.stride(0), D, float(scale), float(drop_p), int(seed), int(site))
+    return ctx, stats
+
+
+def attn_bwd(q, k, v, key_add, dctx, stats, B, heads, Lq, Lk, scale, drop_p=0.0, seed=0, site=0):
+    _chk(dctx, BF16, "attn.dctx")
+    D = q.shape[1]
+    hd = D // heads
+    dq = torch.empty(B * Lq, D, device=q.device, dtype=BF16)
+    dk = torch.empty(B * Lk, D, device=q.device, dtype=BF16)
+    dv = torch.empty(B * Lk, D, device=q.device, dtype=BF16)
+    drow = torch.empty(B, heads, Lq, device=q.device, dtype=F32)
+    lib().mmdti_attn_bwd(_stream(), q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(key_add), dctx.data_ptr(), stats.data_ptr(), drow.data_ptr(),
+                         dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, heads, Lq, Lk, hd, q.stride(0), k.stride(0), dctx.stride(0), D, D,
+                         float(scale), float(drop_p), int(seed), int(site))
+    return dq, dk, dv
+
+
 # --------------------------------------------------------------------------------------------- InfoNCE pieces
 def seq_mean_fwd(x, B, S, D, ld):
     out = torch.empty(B, D, device=x.device, dtype=F32)

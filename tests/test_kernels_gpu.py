@@ -535,3 +535,98 @@ def test_probe_tr_read_semantics(ops):
         g, i = lane // 16, lane % 16
         exp = [(4 * g + q) * stride + i for q in range(4)]
         assert out[lane].tolist() == exp, (lane, out[lane].tolist(), exp)
+
+
+# ------------------------------------------------------------------------------------------- fused attention
+def _attn_ref(q, k, v, add, heads, scale, keep=None, p_drop=0.0):
+    """fp32 torch restatement on bf16-rounded operands (oracle mha, mmdti_oracle.py:320-338, minus the Linears)."""
+    B, Lq, D = q.shape
+    Lk = k.shape[1]
+    hd = D // heads
+    qh, kh, vh = (t.view(B, -1, heads, hd).transpose(1, 2) for t in (q, k, v))
+    s = torch.matmul(qh, kh.transpose(-1, -2)) * scale
+    if add is not None:
+        s = s + add.view(B, 1, 1, Lk)
+    p = torch.softmax(s, -1)
+    if keep is not None:
+        p = p * keep / (1.0 - p_drop)
+    pr = p + (rt(p) - p).detach()                       # bf16 operand rounding, straight-through
+    return torch.matmul(pr, vh).transpose(1, 2).reshape(B, Lq, D), p
+
+
+@pytest.mark.parametrize("B,heads,Lq,Lk,hd", [(2, 8, 256, 256, 64), (2, 3, 37, 50, 64), (3, 16, 130, 256, 32), (2, 16, 256, 130, 32),
+                                              (1, 2, 1, 1, 32), (2, 4, 161, 161, 64), (1, 2, 16, 160, 32)])
+def test_attn_fused_matches_reference(ops, B, heads, Lq, Lk, hd):
+    D = heads * hd
+    scale = 1.0 / math.sqrt(hd)
+    q, k, v, do = (rt(torch.randn(B, L, D, generator=G(s)) * 1.5) for L, s in ((Lq, 1), (Lk, 2), (Lk, 3), (Lq, 4)))
+    mask = torch.ones(B, Lk)
+    if Lk > 2:
+        mask[0, Lk - Lk // 3:] = 0
+    add = (1 - mask) * torch.finfo(torch.float32).min
+    qg, kg, vg = (t.clone().requires_grad_() for t in (q, k, v))
+    ref, _ = _attn_ref(qg, kg, vg, add, heads, scale)
+    ref.backward(do)
+    flat = lambda t, L: dev(bf(t.reshape(B * L, D)))
+    ctx, stats = ops.attn_fwd(flat(q, Lq), flat(k, Lk), flat(v, Lk), dev(add), B, heads, Lq, Lk, scale)
+    close(ctx.view(B, Lq, D), ref, 2e-2, 2e-2)
+    assert float((ctx.view(B, Lq, D).float().cpu() - ref.detach()).abs().mean()) < 3e-3
+    dq, dk, dv = ops.attn_bwd(flat(q, Lq), flat(k, Lk), flat(v, Lk), dev(add), flat(do, Lq), stats, B, heads, Lq, Lk, scale)
+    for got, want, L in ((dq, qg.grad, Lq), (dk, kg.grad, Lk), (dv, vg.grad, Lk)):
+        w = want.reshape(B * L, D)
+        tol = 2e-2 * float(w.abs().max()) + 1e-3
+        assert float((got.float().cpu() - w).abs().max()) < tol, float((got.float().cpu() - w).abs().max())
+        assert float((got.float().cpu() - w).abs().mean()) < 0.01 * float(w.abs().mean()) + 1e-4
+    # masked keys receive exactly zero gradient
+    if Lk > 2:
+        assert (dk.view(B, Lk, D)[0, Lk - Lk // 3:] == 0).all() and (dv.view(B, Lk, D)[0, Lk - Lk // 3:] == 0).all()
+
+
+@pytest.mark.parametrize("Lq,Lk,hd", [(70, 96, 64), (130, 256, 32)])
+def test_attn_fused_dropout_mask_consistent(ops, Lq, Lk, hd):
+    """The keep mask is recovered from the forward itself (indicator V columns); with that mask plugged into the torch
+    reference, forward and all three gradients must agree -- i.e. the three kernels regenerate the SAME mask."""
+    B, heads, p_drop = 2, 4, 0.1
+    D = heads * hd
+    scale = 1.0 / math.sqrt(hd)
+    q, k, v, do = (rt(torch.randn(B, L, D, generator=G(s))) for L, s in ((Lq, 11), (Lk, 12), (Lk, 13), (Lq, 14)))
+    flat = lambda t, L: dev(bf(t.reshape(B * L, D)))
+    seed, site = 987654321, 3
+    pd = torch.zeros(B, heads, Lq, Lk)
+    for c0 in range(0, Lk, hd):                                # V = indicator of keys [c0, c0+hd): ctx column c = pd[.., c0+c]
+        vi = torch.zeros(B, Lk, heads, hd)
+        for c in range(min(hd, Lk - c0)):
+            vi[:, c0 + c, :, c] = 1.0
+        ctx, _ = ops.attn_fwd(flat(q, Lq), flat(k, Lk), flat(vi.view(B, Lk, D), Lk), None, B, heads, Lq, Lk, scale, p_drop, seed, site)
+        got = ctx.view(B, Lq, heads, hd).float().cpu().permute(0, 2, 1, 3)
+        n = min(hd, Lk - c0)
+        pd[..., c0:c0 + n] = got[..., :n]
+    keep = (pd != 0).float()
+    rate = float(keep.mean())
+    assert abs(rate - (1 - p_drop)) < 0.01, rate
+    # rows and columns are not systematically correlated
+    assert float(keep.mean(-1).std()) < 0.06 and float(keep.mean(-2).std()) < 0.06
+    qg, kg, vg = (t.clone().requires_grad_() for t in (q, k, v))
+    ref, p = _attn_ref(qg, kg, vg, None, heads, scale, keep, p_drop)
+    close(pd, rt(p.detach()), 1e-2, 1e-4)
+    ref.backward(do)
+    ctx, stats = ops.attn_fwd(flat(q, Lq), flat(k, Lk), flat(v, Lk), None, B, heads, Lq, Lk, scale, p_drop, seed, site)
+    close(ctx.view(B, Lq, D), ref, 2e-2, 2e-2)
+    dq, dk, dv = ops.attn_bwd(flat(q, Lq), flat(k, Lk), flat(v, Lk), None, flat(do, Lq), stats, B, heads, Lq, Lk, scale, p_drop, seed, site)
+    for got, want, L in ((dq, qg.grad, Lq), (dk, kg.grad, Lk), (dv, vg.grad, Lk)):
+        w = want.reshape(B * L, D)
+        assert float((got.float().cpu() - w).abs().max()) < 2e-2 * float(w.abs().max()) + 1e-3
+        assert float((got.float().cpu() - w).abs().mean()) < 0.01 * float(w.abs().mean()) + 1e-4
+    # a different site gives a different mask
+    ctx2, _ = ops.attn_fwd(flat(q, Lq), flat(k, Lk), flat(v, Lk), None, B, heads, Lq, Lk, scale, p_drop, seed, site + 1)
+    assert not torch.equal(ctx, ctx2)
+
+
+def test_attn_fused_rejects_unsupported_shapes(ops):
+    from mmdti_hip._abi import MMDTIError
+    q = torch.zeros(300, 128, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(MMDTIError):
+        ops.attn_fwd(q, q, q, None, 1, 2, 300, 300, 0.125)                # more than 256 keys
+    q2 = torch.zeros(16, 96, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(MMDTIError):
+        ops.attn_fwd(q2, q2, q2, None, 1, 2, 16, 16, 0.1)                  # head_dim 48

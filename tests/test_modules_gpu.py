@@ -262,6 +262,36 @@ def test_roberta_tower_golden(M, golden, impl):
     assert tower.pooler.dense.weight.grad is None                           # pooler: no gradient, as in the reference
 
 
+@pytest.mark.parametrize("heads,fused", [(2, True), (4, True), (2, False)])
+def test_roberta_tower_fused_attention_vs_oracle(M, heads, fused):
+    """head_dim 64 / 32 take the fused attention kernels; the same weights through the materialised-scores path (the one
+    sequences longer than 256 take) and through the oracle must agree."""
+    from mmdti_hip import ops
+    cfg = SimpleNamespace(layers=2, dim=128, heads=heads, ffn=256, vocab=60, max_pos=80, type_vocab=1, pad_idx=1, ln_eps=1e-12,
+                          hidden_dropout=0.1, attn_dropout=0.1)
+    torch.manual_seed(5)
+    tower = M.bl.RobertaTower(cfg).cuda().eval()
+    P = {"bert." + k: v.detach().cpu().clone().requires_grad_() for k, v in tower.state_dict().items()}
+    gen = torch.Generator().manual_seed(3)
+    ids = torch.randint(4, 60, (3, 70), generator=gen)
+    am = torch.ones(3, 70, dtype=torch.long)
+    ids[1, 50:], am[1, 50:] = 1, 0
+    ids[2, 9:], am[2, 9:] = 1, 0
+    old = ops.FUSED_ATTN
+    ops.FUSED_ATTN = fused
+    try:
+        out = tower(ids.cuda(), am.cuda(), return_dict=True)[0]
+        ocfg = O.RobertaCfg(layers=2, dim=128, heads=heads, ffn=256, vocab=60, max_pos=80, pad_idx=1)
+        ob = O.roberta_encoder(ids, am, P, ocfg, bf16=True)
+        check(out, ob, 2e-3, "roberta out vs bf16-contract oracle")
+        gout = torch.randn(out.shape, generator=gen)
+        (out * gout.cuda()).sum().backward()
+        (ob * gout).sum().backward()
+    finally:
+        ops.FUSED_ATTN = old
+    compare_param_grads(grads_of(tower, "bert."), P, 5e-2, skip=("pooler", "key.bias"))
+
+
 # --------------------------------------------------------------------------------------------- cross-modal (golden G5)
 @pytest.mark.parametrize("tag", ["d64h4", "d128h4"])
 def test_cross_encoder_golden(M, golden, tag):
