@@ -25,7 +25,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int LDT = BK;      // [row][k] image: unpadded 128-B rows, 16-B chunks XOR-swizzled by (row & 7) -> conflict-free ds_read_b128
 constexpr int LDTR = BM;     // [k][row] image: unpadded 256-B rows, 8-B units XOR-swizzled by k -> conflict-free ds_read_b64_tr_b16
-constexpr int LDC_S = BN + 4;  // fp32 epilogue staging row stride (528 B): 128*132*4 = 67,584 B (the tiles take 65,536 B)
 
 struct GemmArgs {
   const bf16_t* A;
@@ -182,8 +181,76 @@ __device__ __forceinline__ void epi_elem(const GemmArgs& a, float accv, int row,
   }
 }
 
+constexpr int LDC_W = 68;  // fp32 row stride of a wave's 16x64 epilogue patch (68 = 4 mod 8: conflict-free C-layout writes)
+
+constexpr int LDC_S = BN + 4;  // fp32 row stride of the epilogue's staging image (528 B)
+
+// Fused epilogue on 8 consecutive columns of one row, read from the LDS staging image.  N % 8 == 0, col % 8 == 0 here.
+__device__ __forceinline__ void epilogue_oct(const GemmArgs& a, const float* src, int row, int col, bool lead, long long coff) {
+  float v[8];
+  {
+    const float4 lo = *reinterpret_cast<const float4*>(src);
+    const float4 hi = *reinterpret_cast<const float4*>(src + 4);
+    v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] *= a.alpha;
+  if (a.bias && lead) {
+    const float4 b0 = *reinterpret_cast<const float4*>(a.bias + col), b1 = *reinterpret_cast<const float4*>(a.bias + col + 4);
+    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+  }
+  if (a.act == MMDTI_ACT_GELU) {
+    if (a.aux_out) {
+      uint4 u;
+      u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+      u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+      u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+      u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+      *reinterpret_cast<uint4*>(a.aux_out + (long long)row * a.ld_aux + col) = u;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+  } else if (a.act == MMDTI_ACT_GELU_BWD) {
+    const uint4 u = *reinterpret_cast<const uint4*>(a.aux_in + (long long)row * a.ld_aux + col);
+    const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      v[e] *= gelu_erf_grad(__uint_as_float((e & 1) ? (w4[e >> 1] & 0xffff0000u) : (w4[e >> 1] << 16)));
+  }
+  if (a.drop_thresh) {  // N % 8 == 0 on this path, so the 8 elements are Philox counters idx/4 and idx/4+1
+    const uint64_t idx = (uint64_t)row * (uint64_t)a.N + col;
+    const Rand4 r0 = philox4(a.seed, a.site, idx >> 2), r1 = philox4(a.seed, a.site, (idx >> 2) + 1);
+    const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = rw[e] >= a.drop_thresh ? v[e] * a.drop_scale : 0.f;
+  }
+  if (a.residual && lead) {
+    const float* rp = a.residual + (long long)row * a.ldr + col;
+    const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+    v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+  }
+  const long long ci = coff + (long long)row * a.ldc + col;
+  if (a.c_dtype == MMDTI_DT_BF16) {
+    uint4 u;
+    u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+    u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + ci) = u;
+  } else {
+    float* c = reinterpret_cast<float*>(a.C) + ci;
+    if (a.beta != 0.f) {
+      const float4 c0 = *reinterpret_cast<const float4*>(c), c1 = *reinterpret_cast<const float4*>(c + 4);
+      v[0] += a.beta * c0.x; v[1] += a.beta * c0.y; v[2] += a.beta * c0.z; v[3] += a.beta * c0.w;
+      v[4] += a.beta * c1.x; v[5] += a.beta * c1.y; v[6] += a.beta * c1.z; v[7] += a.beta * c1.w;
+    }
+    *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+
 template <bool TA, bool TB, bool FAST>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
+__global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(GemmArgs a) {
   // LDS image: [buf 0: A | B][buf 1: A | B]; addressed by integer offsets from ONE __shared__ base so that every access
   // stays a ds_* instruction (pointer arrays indexed at run time decay to flat loads + scratch).
   extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
@@ -243,7 +310,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
 
   // (everything that indexes acc[][] is spelled out with literal indices: a loop the optimizer declines to unroll would
   //  turn the accumulators into a scratch array)
-#define MF(I, J) acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa##I, fb##J, acc[I][J], 0, 0, 0)
+// operands swapped (B fragment first): the accumulator then holds C^T tiles, i.e. lane = output ROW (lane&15) and the 4
+  // registers = 4 consecutive output COLUMNS (4*(lane>>4)+r) -- the epilogue stores 8/16 contiguous bytes per lane
+  // straight from registers, no LDS transpose.
+#define MF(I, J) acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb##J, fa##I, acc[I][J], 0, 0, 0)
 #define GEMM_KK(IMGA, IMGB, KK)                                                                    \
   {                                                                                                \
     const bf16x8 fa0 = load_frag<TA>(IMGA, wr * 64 + 0, KK, lane), fa1 = load_frag<TA>(IMGA, wr * 64 + 16, KK, lane), \
@@ -253,7 +323,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
     MF(0, 0); MF(0, 1); MF(0, 2); MF(0, 3); MF(1, 0); MF(1, 1); MF(1, 2); MF(1, 3);                \
     MF(2, 0); MF(2, 1); MF(2, 2); MF(2, 3); MF(3, 0); MF(3, 1); MF(3, 2); MF(3, 3);                \
   }
-  int cur = 0;
   for (int kt = kt0; kt < kt1; ++kt) {
     const bool more = (kt + 1 < kt1);
     // (the explicit zero on the last step keeps the staging registers defined on every path; without it hipcc demotes
@@ -265,119 +334,68 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
       ra = Stage4{z, z, z, z};
       rb = ra;
     }
-    const bf16_t* imgA = smem + cur * (2 * TILE);
-    const bf16_t* imgB = imgA + TILE;
-    GEMM_KK(imgA, imgB, 0);
-    GEMM_KK(imgA, imgB, 1);
+    GEMM_KK(smem, smem + TILE, 0);
+    GEMM_KK(smem, smem + TILE, 1);
+    __syncthreads();  // every wave has read tile kt
     if (more) {
-      bf16_t* nxt = smem + (cur ^ 1) * (2 * TILE);
-      store_tile<TA>(ra, nxt, tid);
-      store_tile<TB>(rb, nxt + TILE, tid);
+      store_tile<TA>(ra, smem, tid);
+      store_tile<TB>(rb, smem + TILE, tid);
+      __syncthreads();
     }
-    __syncthreads();
-    cur ^= 1;
   }
 #undef GEMM_KK
 #undef MF
 #undef GEMM_LOAD
 
-  // ---- epilogue.  The accumulators (C/D layout: col = lane&15, row = (lane>>4)*4 + reg) are staged through LDS as an
-  // fp32 [128][132] image so that the fused epilogue works on 8 contiguous columns per thread: bias / aux / residual
-  // come in as 16-byte loads and C leaves as one (bf16) or two (fp32) 16-byte stores per chunk.  The staging writes use
-  // literal tile indices (a rolled loop would index acc[][] dynamically and push the accumulators to scratch).
-  float* sC = reinterpret_cast<float*>(smem);
-  {
-    float* w = sC + (wr * 64 + (lane >> 4) * 4) * LDC_S + wc * 64 + (lane & 15);
-#define STG_E(I, J, R) w[((I) * 16 + (R)) * LDC_S + (J) * 16] = acc[I][J][R]
-#define STG_T(I, J) STG_E(I, J, 0); STG_E(I, J, 1); STG_E(I, J, 2); STG_E(I, J, 3)
-#define STG_R(I) STG_T(I, 0); STG_T(I, 1); STG_T(I, 2); STG_T(I, 3)
-    STG_R(0); STG_R(1); STG_R(2); STG_R(3);
-#undef STG_R
-#undef STG_T
-#undef STG_E
-  }
-  __syncthreads();
+  // ---- epilogue.  Accumulator tile (I, J) of this wave: lane -> row m0 + wr*64 + I*16 + (lane&15), registers -> columns
+  // n0 + wc*64 + J*16 + 4*(lane>>4) + {0..3}.  Vector path: bias / aux / residual arrive as 8- or 16-byte loads and C
+  // leaves as one 8-byte (bf16) or 16-byte (fp32) store per lane, straight from registers.  Atomic (split-K) and
+  // unaligned outputs go through a private 16 x 68 fp32 LDS patch per wave so that a wave instruction covers 256
+  // contiguous bytes of one C row.  Literal accumulator indices throughout (a rolled loop would index acc[][]
+  // dynamically and push it to scratch).  The K-loop ends on a barrier, so the patches may overwrite the tiles.
   const long long coff = zo * a.sCo + zi * a.sCi;
   const bool lead = (ks == 0);
-  if (a.c_dtype == MMDTI_DT_F32_ATOMIC || !a.vec_ok) {
-    // lane <-> column: every wave instruction touches 256 contiguous bytes of one C row (atomic-friendly shape)
-    for (int it = 0; it < (BM * BN) / 256; ++it) {
-      const int idx = tid + it * 256;
-      const int r = idx >> 7, c = idx & (BN - 1);
-      epi_elem(a, sC[r * LDC_S + c], m0 + r, n0 + c, lead, coff);
+  const int g4 = (lane >> 4) * 4, l15 = lane & 15;
+  if (a.c_dtype != MMDTI_DT_F32_ATOMIC && a.vec_ok) {
+    // two half-tiles of 64 rows through a [64][132] fp32 LDS image (33,792 B -- no more than the K-loop's tiles): the
+    // waves of row-half h park their accumulators (16-byte LDS writes), then all 256 threads run the fused epilogue on
+    // 8 contiguous columns each: every wave instruction moves full 128-byte lines of C / residual / aux.
+    float* sC = reinterpret_cast<float*>(smem);
+#define STG_Q(I, J) *reinterpret_cast<f32x4*>(sC + ((I) * 16 + l15) * LDC_S + wc * 64 + (J) * 16 + g4) = acc[I][J]
+#define STG_R(I) STG_Q(I, 0); STG_Q(I, 1); STG_Q(I, 2); STG_Q(I, 3)
+#define EPI_HALF(H)                                                        \
+    if (wr == (H)) { STG_R(0); STG_R(1); STG_R(2); STG_R(3); }             \
+    __syncthreads();                                                       \
+    for (int it = 0; it < 4; ++it) {                                       \
+      const int chunk = tid + it * 256;                                    \
+      const int r = chunk >> 4, cc = (chunk & 15) * 8;                     \
+      const int row = m0 + (H) * 64 + r, col = n0 + cc;                    \
+      if (row < a.M && col < a.N) epilogue_oct(a, sC + r * LDC_S + cc, row, col, lead, coff); \
     }
+    EPI_HALF(0)
+    __syncthreads();
+    EPI_HALF(1)
+#undef EPI_HALF
+#undef STG_R
+#undef STG_Q
     return;
   }
-  for (int it = 0; it < (BM * BN) / (256 * 8); ++it) {
-    const int chunk = tid + it * 256;
-    const int r = chunk >> 4, cc = (chunk & 15) * 8;
-    const int row = m0 + r, col = n0 + cc;
-    if (row >= a.M || col >= a.N) continue;
-    if (col + 8 > a.N) {  // ragged right edge
-      for (int e = 0; e < a.N - col; ++e) epi_elem(a, sC[r * LDC_S + cc + e], row, col + e, lead, coff);
-      continue;
-    }
-    float v[8];
-    {
-      const float4 lo = *reinterpret_cast<const float4*>(sC + r * LDC_S + cc);
-      const float4 hi = *reinterpret_cast<const float4*>(sC + r * LDC_S + cc + 4);
-      v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] *= a.alpha;
-    if (a.bias && lead) {
-      const float4 b0 = *reinterpret_cast<const float4*>(a.bias + col), b1 = *reinterpret_cast<const float4*>(a.bias + col + 4);
-      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-    }
-    if (a.act == MMDTI_ACT_GELU) {
-      if (a.aux_out) {
-        uint4 u;
-        u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-        u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-        u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
-        *reinterpret_cast<uint4*>(a.aux_out + (long long)row * a.ld_aux + col) = u;
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-    } else if (a.act == MMDTI_ACT_GELU_BWD) {
-      const uint4 u = *reinterpret_cast<const uint4*>(a.aux_in + (long long)row * a.ld_aux + col);
-      const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        v[e] *= gelu_erf_grad(__uint_as_float((e & 1) ? (w4[e >> 1] & 0xffff0000u) : (w4[e >> 1] << 16)));
-    }
-    if (a.drop_thresh) {  // N % 8 == 0 on this path, so the 8 elements are Philox counters idx/4 and idx/4+1
-      const uint64_t idx = (uint64_t)row * (uint64_t)a.N + col;
-      const Rand4 r0 = philox4(a.seed, a.site, idx >> 2), r1 = philox4(a.seed, a.site, (idx >> 2) + 1);
-      const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = rw[e] >= a.drop_thresh ? v[e] * a.drop_scale : 0.f;
-    }
-    if (a.residual && lead) {
-      const float* rp = a.residual + (long long)row * a.ldr + col;
-      const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
-      v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-    }
-    const long long ci = coff + (long long)row * a.ldc + col;
-    if (a.c_dtype == MMDTI_DT_BF16) {
-      uint4 u;
-      u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-      u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-      u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-      u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
-      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + ci) = u;
-    } else {
-      float* c = reinterpret_cast<float*>(a.C) + ci;
-      if (a.beta != 0.f) {
-        const float4 c0 = *reinterpret_cast<const float4*>(c), c1 = *reinterpret_cast<const float4*>(c + 4);
-        v[0] += a.beta * c0.x; v[1] += a.beta * c0.y; v[2] += a.beta * c0.z; v[3] += a.beta * c0.w;
-        v[4] += a.beta * c1.x; v[5] += a.beta * c1.y; v[6] += a.beta * c1.z; v[7] += a.beta * c1.w;
-      }
-      *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-      *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
-    }
+  float* sW = reinterpret_cast<float*>(smem) + wave * (16 * LDC_W);
+#define STG_T(I, J) *reinterpret_cast<f32x4*>(sW + l15 * LDC_W + (J) * 16 + g4) = acc[I][J]
+#define EPI_PASS(I)                                                                                  \
+  {                                                                                                  \
+    STG_T(I, 0); STG_T(I, 1); STG_T(I, 2); STG_T(I, 3);                                              \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                           \
+    __builtin_amdgcn_wave_barrier();                                                                 \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                           \
+    for (int r = 0; r < 16; ++r)                                                                     \
+      epi_elem(a, sW[r * LDC_W + lane], m0 + wr * 64 + (I) * 16 + r, n0 + wc * 64 + lane, lead, coff); \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                           \
+    __builtin_amdgcn_wave_barrier();                                                                 \
   }
+  EPI_PASS(0) EPI_PASS(1) EPI_PASS(2) EPI_PASS(3)
+#undef EPI_PASS
+#undef STG_T
 }
 
 }  // namespace mmdti
@@ -425,9 +443,9 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
   const int tiles = cdiv(M, BM) * cdiv(N, BN);
   dim3 grid(tiles, 1, batch_outer * batch_inner * splitk), block(256);
   MMDTI_REQUIRE(grid.z <= 65535u, "gemm: batch*splitk too large (%u)", grid.z);
-  // two (A|B) tile buffers, re-used by the epilogue as the fp32 [128][132] staging image (the larger of the two)
-  const size_t smem_tiles = 4 * (size_t)BM * LDT * sizeof(bf16_t), smem_epi = (size_t)BM * LDC_S * sizeof(float);
-  const size_t smem = smem_tiles > smem_epi ? smem_tiles : smem_epi;
+  // two (A|B) tile buffers, re-used by the epilogue's per-wave patches
+  // one (A|B) tile pair (32,768 B), re-used by the epilogue's [64][132] fp32 staging image (33,792 B)
+  const size_t smem = (size_t)64 * LDC_S * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   // > 64 KiB of dynamic LDS: opt in once per instantiation.
   typedef void (*kern_t)(GemmArgs);
