@@ -447,8 +447,10 @@ extern "C" int mmdti_gelu_fwd_bf16(mmdti_stream_t stream, const void* u_bf16, vo
 extern "C" int mmdti_colsum_bf16(mmdti_stream_t stream, const void* x_bf16, int rows, int cols, int ld, float* out) {
   MMDTI_REQUIRE(x_bf16 && out && rows > 0 && cols > 0 && ld >= cols, "colsum_bf16: bad arguments");
   MMDTI_REQUIRE(ld % 8 == 0 && aligned16(x_bf16), "colsum_bf16: ld%%8 and 16-byte alignment required");
-  int gy = cdiv(rows, 8 * 32);
-  if (gy > 256) gy = 256;
+  // 8 rows per thread (two rounds of four 16-byte loads): enough workgroups to fill 256 CUs several times over --
+  // the reduction is latency-bound at one workgroup per CU
+  int gy = cdiv(rows, 8 * 8);
+  if (gy > 1024) gy = 1024;
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(cols, 256), gy), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x_bf16, rows, cols, ld, out);
   MMDTI_LAUNCH_CHECK();

@@ -85,8 +85,10 @@ def linear_bwd_input(dy, w, *, act=ACT_NONE, aux_in=None, out_dtype=BF16, K_vali
 def _splitk_for(M, N, K):
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     ktiles = (K + 63) // 64
-    sk = max(1, min(ktiles, (512 + tiles - 1) // tiles))
-    return sk
+    # measured on MI355X (scratch/dw_sweep.py): about one workgroup per CU for few-tile outputs, 8 splits from 48 tiles up
+    # -- every extra split is another atomic pass over the fp32 output
+    sk = max(256 // tiles, min(8, max(1, 2048 // tiles)))
+    return max(1, min(ktiles, sk))
 
 
 def linear_bwd_weight(dy, x, dw, *, rows=None):
