@@ -72,10 +72,12 @@ int mmdti_layernorm_fwd(mmdti_stream_t stream, const float* x, const float* gamm
 /* dx = dres + LN'(dy + dy_add) ; dgamma/dbeta atomic accumulate.  dy is fp32 (dy_dtype=MMDTI_DT_F32) or bf16;
  * dy_add (fp32, nullable) is a second upstream gradient of the LN OUTPUT (post-LN residual: a = LN(y) feeds both the FFN
  * and the next residual add); dres (fp32, nullable) is a gradient of the LN INPUT that bypasses the LN (pre-LN residual). */
+/* dx_bf16 (nullable): a second copy of dx for the next backward GEMM, with the dropout-backward of site2 (probability
+ * drop2_p, same seed) applied and rounded to bf16 -- saves the separate cast pass over dx. */
 int mmdti_layernorm_bwd(mmdti_stream_t stream, const void* dy, int dy_dtype, const float* dy_add, const float* x, const float* gamma,
                         const float* mean, const float* rstd, int rows, int D, const float* dres, float* dx,
                         float* dgamma, float* dbeta, const unsigned char* row_zero, float drop_p,
-                        unsigned long long seed, unsigned int site);
+                        unsigned long long seed, unsigned int site, void* dx_bf16, float drop2_p, unsigned int site2);
 
 /* ---- small utilities ------------------------------------------------------------------------ */
 /* out[c] += sum_r x[r,c]  (bias gradients of every Linear) */

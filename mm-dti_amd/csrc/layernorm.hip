@@ -80,7 +80,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ dres, float* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      const unsigned char* __restrict__ row_zero, uint32_t thresh,
-                                                     float dscale, uint64_t seed, uint32_t site) {
+                                                     float dscale, uint64_t seed, uint32_t site,
+                                                     bf16_t* __restrict__ dx_bf16, uint32_t thresh2, float dscale2,
+                                                     uint32_t site2) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [2][4][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = D >> 2;
@@ -141,6 +143,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
       }
       reinterpret_cast<float4*>(dx + (long long)row * D)[c] = o;
+      if (dx_bf16) {  // the next GEMM's operand: dropout-backward of ANOTHER site applied to dx, rounded to bf16
+        if (thresh2) {
+          const Rand4 r = philox4(seed, site2, ((uint64_t)row * D + (uint64_t)c * 4) >> 2);
+          o.x = r.x >= thresh2 ? o.x * dscale2 : 0.f; o.y = r.y >= thresh2 ? o.y * dscale2 : 0.f;
+          o.z = r.z >= thresh2 ? o.z * dscale2 : 0.f; o.w = r.w >= thresh2 ? o.w * dscale2 : 0.f;
+        }
+        uint2 pk;
+        pk.x = (uint32_t)f2bf(o.x) | ((uint32_t)f2bf(o.y) << 16);
+        pk.y = (uint32_t)f2bf(o.z) | ((uint32_t)f2bf(o.w) << 16);
+        reinterpret_cast<uint2*>(dx_bf16 + (long long)row * D)[c] = pk;
+      }
     }
   }
   // cross-wave reduction of dgamma/dbeta partials
@@ -198,19 +211,23 @@ extern "C" int mmdti_layernorm_bwd(mmdti_stream_t stream, const void* dy, int dy
                                    const float* gamma, const float* mean, const float* rstd, int rows, int D,
                                    const float* dres, float* dx, float* dgamma, float* dbeta,
                                    const unsigned char* row_zero, float drop_p, unsigned long long seed,
-                                   unsigned int site) {
+                                   unsigned int site, void* dx_bf16, float drop2_p, unsigned int site2) {
   MMDTI_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 2048, "layernorm_bwd: need rows>0, D%%4==0, D<=2048 (D=%d)", D);
   MMDTI_REQUIRE(dy && x && gamma && mean && rstd && dx, "layernorm_bwd: null pointer");
   MMDTI_REQUIRE(dy_dtype == MMDTI_DT_F32 || dy_dtype == MMDTI_DT_BF16, "layernorm_bwd: bad dy dtype");
   MMDTI_REQUIRE(aligned16(x) && aligned16(gamma) && aligned16(dx) && aligned16(dy), "layernorm_bwd: alignment");
+  MMDTI_REQUIRE(drop_p >= 0.f && drop_p < 1.f && drop2_p >= 0.f && drop2_p < 1.f, "layernorm_bwd: dropout p out of range");
+  MMDTI_REQUIRE(!dx_bf16 || (reinterpret_cast<uintptr_t>(dx_bf16) & 7) == 0, "layernorm_bwd: dx_bf16 alignment");
   const uint32_t th = dropout_thresh(drop_p);
   const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const uint32_t th2 = dropout_thresh(drop2_p);
+  const float sc2 = drop2_p > 0.f ? 1.f / (1.f - drop2_p) : 1.f;
   dim3 grid(cdiv(rows, 4 * LN_BWD_ROWS_PER_WAVE)), block(256);
   const size_t smem = 8 * (size_t)D * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
 #define LN_B(NV, BF)                                                                                               \
   hipLaunchKernelGGL((ln_bwd_kernel<NV, BF>), grid, block, smem, s, dy, dy_add, x, gamma, mean, rstd, rows, D, dres, dx,  \
-                     dgamma, dbeta, row_zero, th, sc, (uint64_t)seed, (uint32_t)site)
+                     dgamma, dbeta, row_zero, th, sc, (uint64_t)seed, (uint32_t)site, (bf16_t*)dx_bf16, th2, sc2, (uint32_t)site2)
   const bool bf = dy_dtype == MMDTI_DT_BF16;
   switch (ln_nv(D)) {
     case 1: if (bf) LN_B(1, true); else LN_B(1, false); break;

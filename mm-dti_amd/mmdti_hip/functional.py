@@ -113,21 +113,25 @@ class PairEncoderFn(torch.autograd.Function):
         dout = dout.contiguous().view(M, D)
         if mod.final_layer_norm is not None:
             fl = mod.final_layer_norm
-            dx = ops.layernorm_bwd(dout, st.x_last, fl.weight, st.f_mean, st.f_rstd, gbuf(fl.weight), gbuf(fl.bias))
+            nxt = (st.p_res, st.layers[-1].site_f) if st.layers else None
+            dx = ops.layernorm_bwd(dout, st.x_last, fl.weight, st.f_mean, st.f_rstd, gbuf(fl.weight), gbuf(fl.bias), bf16_copy=nxt)
+            dx, dx16 = dx if nxt is not None else (dx, None)
         else:
-            dx = dout
+            dx, dx16 = dout, None
         G = None
-        for layer, L in zip(reversed(mod.layers), reversed(st.layers)):
+        below = [Lb.site_f for Lb in st.layers[:-1]]      # site of the FFN dropout of the layer UNDER each layer
+        for li, layer, L in zip(range(len(st.layers) - 1, -1, -1), reversed(mod.layers), reversed(st.layers)):
             att, ln1, ln2 = layer.self_attn, layer.self_attn_layer_norm, layer.final_layer_norm
             # ---- FFN:  x2 = x1 + drop(fc2(gelu(fc1(LN2(x1)))))
-            dy2 = ops.cast_bf16(dx, st.p_res, seed, L.site_f)
+            # (dx16 = bf16 dropout-backward copy of dx, written by the LayerNorm backward that produced dx)
+            dy2 = dx16 if dx16 is not None else ops.cast_bf16(dx, st.p_res, seed, L.site_f)
             _lin_bwd_params(dy2, L.a, layer.fc2.weight, layer.fc2.bias)
             du = ops.linear_bwd_input(dy2, wbf16(layer.fc2.weight), act=ops.ACT_GELU_BWD, aux_in=L.u)
             _lin_bwd_params(du, L.h2, layer.fc1.weight, layer.fc1.bias)
             dh2 = ops.linear_bwd_input(du, wbf16(layer.fc1.weight))
-            dx = ops.layernorm_bwd(dh2, L.x1, ln2.weight, L.m2, L.r2, gbuf(ln2.weight), gbuf(ln2.bias), dres=dx)
+            dx, dy1 = ops.layernorm_bwd(dh2, L.x1, ln2.weight, L.m2, L.r2, gbuf(ln2.weight), gbuf(ln2.bias), dres=dx,
+                                        bf16_copy=(st.p_res, L.site_o))
             # ---- attention:  x1 = x + drop(out_proj(attn(LN1(x))))
-            dy1 = ops.cast_bf16(dx, st.p_res, seed, L.site_o)
             _lin_bwd_params(dy1, L.o, att.out_proj.weight, att.out_proj.bias)
             do = ops.linear_bwd_input(dy1, wbf16(att.out_proj.weight))
             g_zero = G is None
@@ -136,7 +140,11 @@ class PairEncoderFn(torch.autograd.Function):
             dqkv = ops.pair_attn_bwd(L.qkv, L.s, do, G, B, N, H, ld, scale, g_zero, st.p_att, seed, L.site_att)
             _lin_bwd_params(dqkv, L.h1, att.in_proj.weight, att.in_proj.bias)
             dh1 = ops.linear_bwd_input(dqkv, wbf16(att.in_proj.weight))
-            dx = ops.layernorm_bwd(dh1, L.x, ln1.weight, L.m1, L.r1, gbuf(ln1.weight), gbuf(ln1.bias), dres=dx)
+            if li > 0:
+                dx, dx16 = ops.layernorm_bwd(dh1, L.x, ln1.weight, L.m1, L.r1, gbuf(ln1.weight), gbuf(ln1.bias), dres=dx,
+                                             bf16_copy=(st.p_res, below[li - 1]))
+            else:
+                dx, dx16 = ops.layernorm_bwd(dh1, L.x, ln1.weight, L.m1, L.r1, gbuf(ln1.weight), gbuf(ln1.bias), dres=dx), None
             L.__dict__.clear()       # release this layer's activations (S_l is ~1 GB at the bench shape)
             notify_grads_ready(layer.parameters())
         eln = mod.emb_layer_norm
@@ -243,15 +251,13 @@ def _bert_layer_bwd(st, L, dout, seed):
     B, Lq, Lk, D = st.B, st.Lq, st.Lk, st.D
     W, heads, ld = L.W, L.heads, L.ld
     hd = D // heads
-    dz = ops.layernorm_bwd(dout, L.z, W.ln2_w, L.zm, L.zr, gbuf(W.ln2_w), gbuf(W.ln2_b))
-    dzb = ops.cast_bf16(dz, L.p_hid, seed, L.site_f)
+    dz, dzb = ops.layernorm_bwd(dout, L.z, W.ln2_w, L.zm, L.zr, gbuf(W.ln2_w), gbuf(W.ln2_b), bf16_copy=(L.p_hid, L.site_f))
     _lin_bwd_params(dzb, L.i, W.o2_w, W.o2_b)
     du = ops.linear_bwd_input(dzb, wbf16(W.o2_w), act=ops.ACT_GELU_BWD, aux_in=L.u)
     _lin_bwd_params(du, L.a16, W.i_w, W.i_b)
     da = ops.linear_bwd_input(du, wbf16(W.i_w))
     # a32 = LN1(y) feeds the FFN AND the residual add of z: both gradients go through LN1's backward
-    dy = ops.layernorm_bwd(da, L.y, W.ln1_w, L.am, L.ar, gbuf(W.ln1_w), gbuf(W.ln1_b), dy_add=dz)
-    dyb = ops.cast_bf16(dy, L.p_hid, seed, L.site_o)
+    dy, dyb = ops.layernorm_bwd(da, L.y, W.ln1_w, L.am, L.ar, gbuf(W.ln1_w), gbuf(W.ln1_b), dy_add=dz, bf16_copy=(L.p_hid, L.site_o))
     _lin_bwd_params(dyb, L.ctx, W.o_w, W.o_b)
     dctx = ops.linear_bwd_input(dyb, wbf16(W.o_w))
     dev = dout.device

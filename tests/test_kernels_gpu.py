@@ -171,6 +171,19 @@ def test_layernorm_dropout_consistency(ops):
     close(db, (mask.float() / 0.9).sum(0), 1e-5, 1e-4)
 
 
+def test_layernorm_bwd_fused_bf16_copy(ops):
+    """The optional second output equals the separate cast kernel applied to dx (same dropout site): bit-exact."""
+    rows, D = 70, 512
+    x = torch.randn(rows, D, generator=G(1)); g = torch.randn(D, generator=G(2)); dy = torch.randn(rows, D, generator=G(3))
+    _, _, mean, rstd = ops.layernorm_fwd(dev(x), dev(g), dev(torch.zeros(D)), 1e-5, want_f32=True, want_bf16=False)
+    dg, db = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    for p in (0.0, 0.1):
+        dx, dx16 = ops.layernorm_bwd(dev(dy), dev(x), dev(g), mean, rstd, dg, db, bf16_copy=(p, 7), seed=11)
+        ref = ops.cast_bf16(dx, p, 11, 7)
+        assert torch.equal(dx16, ref)
+        assert torch.equal(dx, ops.layernorm_bwd(dev(dy), dev(x), dev(g), mean, rstd, dg, db))
+
+
 # ------------------------------------------------------------------------------------------- pair attention
 def _pair_ref(qkv, bias, key_pad, H, scale, dO=None, g_in=None):
     """oracle core of unimol_layer's attention on given (bf16-rounded) qkv.  Returns S,O and grads."""
