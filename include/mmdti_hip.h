@@ -114,6 +114,13 @@ int mmdti_gbf_features_fwd(mmdti_stream_t stream, const float* dist, const long 
 int mmdti_gbf_features_bwd(mmdti_stream_t stream, const float* dist, const long long* edge_type, const float* mul,
                            const float* bias, const float* means, const float* stds, long long P, int K, int E,
                            const void* dfeat_bf16, float* dmul, float* dbias, float* dmeans, float* dstds);
+/* gbf -> gbf_proj (Linear+GELU+Linear, NonLinearHead mm_model.py:190-208) -> permute (mm_model.py:553-556) in one kernel:
+ * out[b,h,i,j] (fp32, [B,H,N,ld], pad columns j >= N written 0).  w1: [F,K] bf16, w2: [H,F] bf16; built for K=128, F=128,
+ * H=64.  feat/u/h (nullable, together): the [B*N*N, 128] bf16 basis / pre-activation / hidden rows for the backward. */
+int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, const long long* edge_type, const float* mul,
+                       const float* bias, const float* means, const float* stds, const void* w1_bf16, const float* b1,
+                       const void* w2_bf16, const float* b2, int B, int N, int ld, int K, int F, int H, int E, float* out,
+                       void* feat_bf16, void* u_bf16, void* h_bf16);
 /* [B,N,N,H] fp32 -> [B,H,N,ld] fp32 (mm_model.py:555-556 permute(0,3,1,2).contiguous()) and its gradient
  * [B,H,N,ld] fp32 -> [B,N,N,H] bf16 */
 int mmdti_pair_permute_fwd(mmdti_stream_t stream, const float* x, float* out, int B, int N, int H, int ld);

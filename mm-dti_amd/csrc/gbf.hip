@@ -167,6 +167,153 @@ __global__ __launch_bounds__(256) void pair_permute_bwd_kernel(const float* __re
   }
 }
 
+// =====================================================================================================================
+// Fused pair bias:  dist, edge type -> Gaussian basis (128) -> Linear(128,128) + GELU -> Linear(128,64) -> [B,H,N,ld]
+// (mm_model.py:553-556: gbf, gbf_proj (NonLinearHead), permute) in ONE kernel.  The unfused chain writes and re-reads
+// three [P,128] bf16 tensors and a [P,64] fp32 one (P = B*N*N pairs); here a wave keeps a tile of 16 pairs in
+// registers from the distance to the 64 head values and both weight matrices sit in LDS.
+//
+// Same operand trick as attn.hip: everything is computed TRANSPOSED (lane = pair, accumulator rows = features), so the
+// basis is generated directly in MFMA-operand form, and two consecutive accumulator tiles of GELU(hidden)^T are one
+// K=32 operand of the second product; W2 is stored in LDS with its columns pre-permuted to that k-slot order.
+// Pairs are enumerated over the padded [N][ld] plane of each molecule (q = i*ld + j): 16 consecutive q are 64
+// contiguous bytes of every head plane.  Pad columns (j >= N) are written as 0.
+// Optionally saves the three intermediates the unfused backward consumes (basis, pre-activation, hidden; [P,128] bf16,
+// row = (b*N+i)*N+j) -- same values, same bf16 rounding points as the unfused chain.
+typedef __bf16 gbf16x8 __attribute__((ext_vector_type(8)));
+typedef float gf32x4 __attribute__((ext_vector_type(4)));
+constexpr int GBF_K = 128, GBF_F = 128, GBF_H = 64;
+constexpr int GBF_WS = 136;  // LDS row stride (elements) of the weight images: 272-B rows, conflict-free ds_read_b128 fragments
+
+__device__ __forceinline__ gbf16x8 gbf_pack8(const float* v) {
+  gbf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = (__bf16)v[e];
+  return r;
+}
+__device__ __forceinline__ uint2 gbf_pack4(const gf32x4& a) {
+  uint2 pk;
+  pk.x = (uint32_t)f2bf(a[0]) | ((uint32_t)f2bf(a[1]) << 16);
+  pk.y = (uint32_t)f2bf(a[2]) | ((uint32_t)f2bf(a[3]) << 16);
+  return pk;
+}
+
+template <bool SAVE>
+__global__ __launch_bounds__(256) void gbf_bias_fwd_kernel(const float* __restrict__ dist, const long long* __restrict__ et,
+                                                           const float* __restrict__ mul, const float* __restrict__ bias,
+                                                           const float* __restrict__ means, const float* __restrict__ stds,
+                                                           const bf16_t* __restrict__ W1, const float* __restrict__ b1,
+                                                           const bf16_t* __restrict__ W2, const float* __restrict__ b2,
+                                                           float* __restrict__ out, bf16_t* __restrict__ feat_out,
+                                                           bf16_t* __restrict__ u_out, bf16_t* __restrict__ h_out, int B, int N,
+                                                           int ld, int E, int tpm) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gbf_smem[];
+  bf16_t* sW1 = reinterpret_cast<bf16_t*>(gbf_smem);       // [128][136]   W1[f][k]
+  bf16_t* sW2 = sW1 + GBF_F * GBF_WS;                       // [64][136]    W2[h][f], f in k-slot order
+  float* sMu = reinterpret_cast<float*>(sW2 + GBF_H * GBF_WS);  // [128] means, [128] 1/sigma, [128] 1/(a*sigma), [128] b1, [64] b2
+  float* sIs = sMu + GBF_K;
+  float* sCf = sIs + GBF_K;
+  float* sB1 = sCf + GBF_K;
+  float* sB2 = sB1 + GBF_F;
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int c = tid; c < GBF_F * (GBF_K / 8); c += 256) {
+    const int row = c >> 4, col = (c & 15) * 8;
+    *reinterpret_cast<uint4*>(sW1 + row * GBF_WS + col) = *reinterpret_cast<const uint4*>(W1 + row * GBF_K + col);
+  }
+  for (int c = tid; c < GBF_H * 32; c += 256) {  // 8-byte pieces: slot 32u+8g+4hf.. <- feature 32u+16hf+4g..
+    const int row = c >> 5, pc = c & 31, u = pc >> 3, g = (pc >> 1) & 3, hf = pc & 1;
+    *reinterpret_cast<uint2*>(sW2 + row * GBF_WS + 32 * u + 8 * g + 4 * hf) =
+        *reinterpret_cast<const uint2*>(W2 + row * GBF_F + 32 * u + 16 * hf + 4 * g);
+  }
+  if (tid < GBF_K) {
+    const float sg = fabsf(stds[tid]) + 1e-5f;
+    sMu[tid] = means[tid];
+    sIs[tid] = 1.0f / sg;
+    sCf[tid] = 1.0f / (GBF_A * sg);
+    sB1[tid] = b1[tid];
+    if (tid < GBF_H) sB2[tid] = b2[tid];
+  }
+  __syncthreads();
+  const int g = lane >> 4, i = lane & 15;
+  const long long ntiles = (long long)B * tpm;
+  const long long nwaves = (long long)gridDim.x * 4;
+  const long long plane = (long long)N * ld;
+  for (long long tile = (long long)blockIdx.x * 4 + (tid >> 6); tile < ntiles; tile += nwaves) {
+    const int b = (int)(tile / tpm);
+    const int q = (int)(tile - (long long)b * tpm) * 16 + i;
+    const int ii = q / ld, jj = q - ii * ld;
+    const bool inplane = q < plane, valid = inplane && jj < N;
+    const long long p = ((long long)b * N + (valid ? ii : 0)) * N + (valid ? jj : 0);
+    float y = 0.f;
+    {
+      long long e = et[p];
+      e = e < 0 ? 0 : (e >= E ? E - 1 : e);
+      y = mul[e] * dist[p] + bias[e];
+    }
+    // Gaussian basis in B-operand form: lane (g, pair i) holds k = 32c + 8g + 0..7
+    gbf16x8 fB[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k0 = 32 * c + 8 * g;
+      float v[8];
+      const gf32x4 m0 = *reinterpret_cast<const gf32x4*>(sMu + k0), m1 = *reinterpret_cast<const gf32x4*>(sMu + k0 + 4);
+      const gf32x4 s0 = *reinterpret_cast<const gf32x4*>(sIs + k0), s1 = *reinterpret_cast<const gf32x4*>(sIs + k0 + 4);
+      const gf32x4 c0 = *reinterpret_cast<const gf32x4*>(sCf + k0), c1 = *reinterpret_cast<const gf32x4*>(sCf + k0 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float z0 = (y - m0[e]) * s0[e], z1 = (y - m1[e]) * s1[e];
+        v[e] = __expf(-0.5f * z0 * z0) * c0[e];
+        v[4 + e] = __expf(-0.5f * z1 * z1) * c1[e];
+      }
+      fB[c] = gbf_pack8(v);
+      if (SAVE && valid) *reinterpret_cast<gbf16x8*>(feat_out + p * GBF_K + k0) = fB[c];
+    }
+    // hidden^T = W1 . basis^T (+ b1), GELU; pairs of accumulator tiles become the K=32 operands of the second product
+    gbf16x8 hB[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      gf32x4 hv[2];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int ft = 2 * u + hf;
+        gf32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const gbf16x8 wf = *reinterpret_cast<const gbf16x8*>(sW1 + (16 * ft + i) * GBF_WS + 32 * c + 8 * g);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, fB[c], acc, 0, 0, 0);
+        }
+        const gf32x4 bb = *reinterpret_cast<const gf32x4*>(sB1 + 16 * ft + 4 * g);
+        acc += bb;
+        if (SAVE && valid) *reinterpret_cast<uint2*>(u_out + p * GBF_F + 16 * ft + 4 * g) = gbf_pack4(acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = gelu_erf(acc[r]);
+        if (SAVE && valid) *reinterpret_cast<uint2*>(h_out + p * GBF_F + 16 * ft + 4 * g) = gbf_pack4(acc);
+        hv[hf] = acc;
+        __builtin_amdgcn_sched_barrier(0);  // keep the unrolled tiles in order: hoisted weight fragments would eat the register file
+      }
+      float v[8] = {hv[0][0], hv[0][1], hv[0][2], hv[0][3], hv[1][0], hv[1][1], hv[1][2], hv[1][3]};
+      hB[u] = gbf_pack8(v);
+    }
+    // bias^T = W2 . hidden^T (+ b2): accumulator rows = heads 16*ht + 4g + r, column = pair
+    float* ob = out + (long long)b * GBF_H * plane + q;
+#pragma unroll
+    for (int ht = 0; ht < 4; ++ht) {
+      gf32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const gbf16x8 wf = *reinterpret_cast<const gbf16x8*>(sW2 + (16 * ht + i) * GBF_WS + 32 * u + 8 * g);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hB[u], acc, 0, 0, 0);
+      }
+      const gf32x4 bb = *reinterpret_cast<const gf32x4*>(sB2 + 16 * ht + 4 * g);
+      if (inplane) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ob[(long long)(16 * ht + 4 * g + r) * plane] = valid ? acc[r] + bb[r] : 0.f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 }  // namespace mmdti
 using namespace mmdti;
 
@@ -222,6 +369,33 @@ extern "C" int mmdti_pair_permute_bwd(mmdti_stream_t stream, const float* g, voi
   MMDTI_REQUIRE(smem <= 64 * 1024, "pair_permute_bwd: N*H too large for the LDS tile (N=%d,H=%d)", N, H);
   hipLaunchKernelGGL(pair_permute_bwd_kernel, dim3(B * N), dim3(256), smem, (hipStream_t)stream, g, (bf16_t*)out_bf16,
                      N, H, ld);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, const long long* edge_type, const float* mul,
+                                  const float* bias, const float* means, const float* stds, const void* w1_bf16,
+                                  const float* b1, const void* w2_bf16, const float* b2, int B, int N, int ld, int K, int F,
+                                  int H, int E, float* out, void* feat_bf16, void* u_bf16, void* h_bf16) {
+  MMDTI_REQUIRE(dist && edge_type && mul && bias && means && stds && w1_bf16 && b1 && w2_bf16 && b2 && out, "gbf_bias_fwd: null argument");
+  MMDTI_REQUIRE(K == GBF_K && F == GBF_F && H == GBF_H, "gbf_bias_fwd: built for %d gaussians, %d hidden, %d heads (got %d,%d,%d)",
+                GBF_K, GBF_F, GBF_H, K, F, H);
+  MMDTI_REQUIRE(B > 0 && N > 0 && ld >= N && ld % 4 == 0 && E > 0, "gbf_bias_fwd: bad shape");
+  MMDTI_REQUIRE(aligned16(w1_bf16) && aligned16(w2_bf16) && aligned16(out), "gbf_bias_fwd: 16-byte alignment required");
+  const bool save = feat_bf16 || u_bf16 || h_bf16;
+  MMDTI_REQUIRE(!save || (feat_bf16 && u_bf16 && h_bf16 && aligned16(feat_bf16) && aligned16(u_bf16) && aligned16(h_bf16)),
+                "gbf_bias_fwd: the three saved intermediates come together, 16-byte aligned");
+  const int tpm = cdiv((long long)N * ld, 16);
+  const long long ntiles = (long long)B * tpm;
+  const int grid = (int)(ntiles / 4 + 1 < 2048 ? ntiles / 4 + 1 : 2048);
+  const size_t smem = (size_t)(GBF_F + GBF_H) * GBF_WS * 2 + (size_t)(3 * GBF_K + GBF_F + GBF_H) * 4;
+  if (save)
+    hipLaunchKernelGGL((gbf_bias_fwd_kernel<true>), dim3(grid), dim3(256), smem, (hipStream_t)stream, dist, edge_type, mul, bias, means,
+                       stds, (const bf16_t*)w1_bf16, b1, (const bf16_t*)w2_bf16, b2, out, (bf16_t*)feat_bf16, (bf16_t*)u_bf16,
+                       (bf16_t*)h_bf16, B, N, ld, E, tpm);
+  else
+    hipLaunchKernelGGL((gbf_bias_fwd_kernel<false>), dim3(grid), dim3(256), smem, (hipStream_t)stream, dist, edge_type, mul, bias, means,
+                       stds, (const bf16_t*)w1_bf16, b1, (const bf16_t*)w2_bf16, b2, out, nullptr, nullptr, nullptr, B, N, ld, E, tpm);
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }

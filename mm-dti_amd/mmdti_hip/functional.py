@@ -167,11 +167,16 @@ class PairBiasFn(torch.autograd.Function):
         H = proj.linear2.weight.shape[0]
         dist, edge_type = dist.contiguous(), edge_type.contiguous()
         args = [gbf.mul.weight.view(-1), gbf.bias.weight.view(-1), gbf.means.weight.view(-1), gbf.stds.weight.view(-1)]
-        feat = ops.gbf_features_fwd(dist, edge_type, *args)
-        u = torch.empty(feat.shape[0], proj.linear1.weight.shape[0], device=dist.device, dtype=BF16)
-        h = ops.linear_fwd(feat, wbf16(proj.linear1.weight), proj.linear1.bias, act=ops.ACT_GELU, aux_out=u)
-        o = ops.linear_fwd(h, wbf16(proj.linear2.weight), proj.linear2.bias, out_dtype=F32)
-        out = ops.pair_permute_fwd(o, B, N, H, ld)
+        if ops.gbf_bias_eligible(args[2].numel(), proj.linear1.weight.shape[0], H, ld):
+            # one kernel from distances to the [B,H,N,ld] bias; the three [P,128] intermediates are saved for the backward
+            out, (feat, u, h) = ops.gbf_bias_fwd(dist, edge_type, *args, wbf16(proj.linear1.weight), proj.linear1.bias,
+                                                 wbf16(proj.linear2.weight), proj.linear2.bias, ld, save=True)
+        else:
+            feat = ops.gbf_features_fwd(dist, edge_type, *args)
+            u = torch.empty(feat.shape[0], proj.linear1.weight.shape[0], device=dist.device, dtype=BF16)
+            h = ops.linear_fwd(feat, wbf16(proj.linear1.weight), proj.linear1.bias, act=ops.ACT_GELU, aux_out=u)
+            o = ops.linear_fwd(h, wbf16(proj.linear2.weight), proj.linear2.bias, out_dtype=F32)
+            out = ops.pair_permute_fwd(o, B, N, H, ld)
         ctx.st = SimpleNamespace(dist=dist, et=edge_type, feat=feat, u=u, h=h, B=B, N=N, H=H, ld=ld)
         ctx.gbf, ctx.proj = gbf, proj
         return out

@@ -225,6 +225,26 @@ def gbf_features_bwd(dist, edge_type, mul, bias, means, stds, dfeat, dmul, dbias
                                  dstds.data_ptr())
 
 
+def gbf_bias_fwd(dist, edge_type, mul, bias, means, stds, w1, b1, w2, b2, ld, save=True):
+    """Fused gbf + gbf_proj + permute -> (out [B,H,N,ld] fp32, (feat, u, h) [P,128] bf16 or None)."""
+    _chk(dist, F32, "gbf.dist"); _chk(edge_type, torch.int64, "gbf.edge_type"); _chk(w1, BF16, "gbf.w1"); _chk(w2, BF16, "gbf.w2")
+    B, N, _ = dist.shape
+    Hh, Fh = w2.shape
+    K = w1.shape[1]
+    out = torch.empty(B, Hh, N, ld, device=dist.device, dtype=F32)
+    saved = tuple(torch.empty(B * N * N, 128, device=dist.device, dtype=BF16) for _ in range(3)) if save else None
+    t0 = kernel_timer.begin("gbf_features_fwd")
+    lib().mmdti_gbf_bias_fwd(_stream(), dist.data_ptr(), edge_type.data_ptr(), mul.data_ptr(), bias.data_ptr(), means.data_ptr(), stds.data_ptr(),
+                             w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), B, N, ld, K, Fh, Hh, mul.numel(), out.data_ptr(),
+                             *([t.data_ptr() for t in saved] if save else [0, 0, 0]))
+    kernel_timer.end("gbf_features_fwd", t0)
+    return out, saved
+
+
+def gbf_bias_eligible(K, Fh, Hh, ld):
+    return K == 128 and Fh == 128 and Hh == 64 and ld % 4 == 0
+
+
 def pair_ld(N):
     """row stride of the internal [B,H,N,ld] pair tensors (16-byte aligned rows)."""
     return (N + 3) // 4 * 4

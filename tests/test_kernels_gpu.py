@@ -550,6 +550,43 @@ def test_probe_tr_read_semantics(ops):
         assert out[lane].tolist() == exp, (lane, out[lane].tolist(), exp)
 
 
+@pytest.mark.parametrize("B,N", [(3, 13), (2, 130), (1, 1), (2, 37)])
+def test_gbf_bias_fused_matches_unfused_chain(ops, B, N):
+    """gbf -> Linear+GELU -> Linear -> permute in one kernel vs the four-kernel chain it replaces (same bf16 rounding
+    points, so the saved intermediates agree to an ulp of bf16 and the bias to fp32 accumulation order)."""
+    K, Fh, H, E = 128, 128, 64, 31 * 31
+    ld = ops.pair_ld(N)
+    gen = G(7)
+    dist = torch.rand(B, N, N, generator=gen) * 8
+    et = torch.randint(0, E, (B, N, N), generator=gen)
+    mul, bias = 1 + 0.1 * torch.randn(E, generator=gen), 0.1 * torch.randn(E, generator=gen)
+    means, stds = torch.rand(K, generator=gen) * 3, torch.rand(K, generator=gen) * 3 - 1.5
+    w1, b1 = torch.randn(Fh, K, generator=gen) * 0.2, torch.randn(Fh, generator=gen) * 0.1
+    w2, b2 = torch.randn(H, Fh, generator=gen) * 0.2, torch.randn(H, generator=gen) * 0.1
+    d = [dev(t) for t in (dist, et, mul, bias, means, stds)]
+    feat = ops.gbf_features_fwd(*d)
+    u = torch.empty(B * N * N, Fh, device="cuda", dtype=torch.bfloat16)
+    h = ops.linear_fwd(feat, dev(bf(w1)), dev(b1), act=ops.ACT_GELU, aux_out=u)
+    o = ops.linear_fwd(h, dev(bf(w2)), dev(b2), out_dtype=torch.float32)
+    ref = ops.pair_permute_fwd(o, B, N, H, ld)
+    out, (f2, u2, h2) = ops.gbf_bias_fwd(*d, dev(bf(w1)), dev(b1), dev(bf(w2)), dev(b2), ld, save=True)
+    close(f2, feat, 1e-2, 1e-6)
+    close(u2, u, 1e-2, 2e-2)
+    close(h2, h, 1e-2, 2e-2)
+    close(out[..., :N], ref[..., :N], 2e-2, 3e-2)
+    assert float((out[..., :N] - ref[..., :N]).abs().mean()) < 2e-3 * float(ref[..., :N].abs().mean()) + 1e-5
+    assert (out[..., N:] == 0).all()
+    out2, none = ops.gbf_bias_fwd(*d, dev(bf(w1)), dev(b1), dev(bf(w2)), dev(b2), ld, save=False)
+    assert none is None and torch.equal(out2, out)
+    # and against the fp32 oracle of the same chain
+    P = {"gbf.means.weight": means.view(1, K), "gbf.stds.weight": stds.view(1, K), "gbf.mul.weight": mul.view(E, 1), "gbf.bias.weight": bias.view(E, 1)}
+    g = O.gaussian_layer(dist, et, P) if hasattr(O, "gaussian_layer") else None
+    if g is not None:
+        hid = torch.nn.functional.gelu(rt(g) @ rt(w1).T + b1)
+        want = (rt(hid) @ rt(w2).T + b2).permute(0, 3, 1, 2)
+        close(out[..., :N], want, 3e-2, 5e-2)
+
+
 # ------------------------------------------------------------------------------------------- fused attention
 def _attn_ref(q, k, v, add, heads, scale, keep=None, p_drop=0.0):
     """fp32 torch restatement on bf16-rounded operands (oracle mha, mmdti_oracle.py:320-338, minus the Linears)."""
