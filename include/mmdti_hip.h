@@ -179,10 +179,11 @@ int mmdti_l2norm_fwd(mmdti_stream_t stream, const float* x, int B, int D, int ld
 int mmdti_l2norm_bwd(mmdti_stream_t stream, const float* dxhat, const float* xhat, const float* inv_norm, int B,
                      int D, int ldx, float* dx);
 /* One direction of the symmetric CE (infonce.py:93-98) for anchors rows [row0,row0+Bl) of qh_all against all
- * Bg keys kh_all (global negatives under DDP).  loss_sum += sum_i CE_i (atomic), dq rows written,
- * dk accumulated atomically.  Gradients are of (1/(2*Bg)) * sum_i CE_i. */
+ * Bg keys kh_all (global negatives under DDP).  loss_sum += sum_i CE_i (atomic); dq_all rows [row0,row0+Bl) and all
+ * Bg rows of dk_all are accumulated (+=, caller zero-initialises).  Gradients are of (1/(2*Bg)) * sum_i CE_i.
+ * scratch: Bl*Bg floats (the logit-gradient matrix handed from the row pass to the column pass). */
 int mmdti_infonce_dir(mmdti_stream_t stream, const float* qh_all, const float* kh_all, int Bg, int D, int row0,
-                      int Bl, float temperature, float* loss_sum, float* dq_all, float* dk_all);
+                      int Bl, float temperature, float* loss_sum, float* dq_all, float* dk_all, float* scratch);
 
 /* ---- ConR / SupCon (models/contrastive.py:3-59, 62-112, 114-169) --------------------------- */
 /* fhat: L2-normalised features [B,D].  labels_f: [B] fp32 (regress: mean target; single: class id as float);

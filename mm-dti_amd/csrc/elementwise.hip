@@ -301,46 +301,68 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restri
 }
 
 // ---------------------------------------------------------------- masked pooling (mm_model.py:572-576)
+// pooled[b] = mean over the unmasked rows of [a[b]; t[b]].  grid (B, D/64): a block owns 64 columns (16 float4 lanes) and
+// spreads the Na+Nt rows over 16 row groups -- 8x the workgroups of a block-per-molecule layout, 16-byte loads.
+__device__ __forceinline__ int masked_pool_count(const unsigned char* ma, const unsigned char* mt, int Na, int Nt, int* cnt) {
+  if (threadIdx.x == 0) *cnt = 0;
+  __syncthreads();
+  int c = 0;
+  for (int i = threadIdx.x; i < Na + Nt; i += 256) c += (i < Na ? ma[i] : mt[i - Na]) ? 1 : 0;
+  if (c) atomicAdd(cnt, c);
+  __syncthreads();
+  return *cnt;
+}
+
 __global__ __launch_bounds__(256) void masked_pool_fwd_kernel(const float* __restrict__ a, const float* __restrict__ t,
                                                               const unsigned char* __restrict__ ma, const unsigned char* __restrict__ mt,
                                                               int Na, int Nt, int D, float* __restrict__ pooled) {
   const int b = blockIdx.x;
   __shared__ int cnt;
-  if (threadIdx.x == 0) {
-    int c = 0;
-    for (int i = 0; i < Na; ++i) c += ma[b * Na + i] ? 1 : 0;
-    for (int i = 0; i < Nt; ++i) c += mt[b * Nt + i] ? 1 : 0;
-    cnt = c;
+  __shared__ float4 red[16][16];
+  const int n = masked_pool_count(ma + (long long)b * Na, mt + (long long)b * Nt, Na, Nt, &cnt);
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int col = blockIdx.y * 64 + cl * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col < D) {
+    for (int i = rg; i < Na + Nt; i += 16) {
+      const bool in_a = i < Na;
+      const bool on = in_a ? ma[(long long)b * Na + i] : mt[(long long)b * Nt + (i - Na)];
+      if (!on) continue;
+      const float* src = in_a ? a + ((long long)b * Na + i) * D : t + ((long long)b * Nt + (i - Na)) * D;
+      const float4 v = *reinterpret_cast<const float4*>(src + col);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   }
+  red[rg][cl] = s;
   __syncthreads();
-  for (int d = threadIdx.x; d < D; d += 256) {
-    float s = 0.f;
-    for (int i = 0; i < Na; ++i)
-      if (ma[b * Na + i]) s += a[((long long)b * Na + i) * D + d];
-    for (int i = 0; i < Nt; ++i)
-      if (mt[b * Nt + i]) s += t[((long long)b * Nt + i) * D + d];
-    pooled[(long long)b * D + d] = s / (float)cnt;
+  if (rg == 0 && col < D) {
+#pragma unroll
+    for (int r = 1; r < 16; ++r) {
+      const float4 v = red[r][cl];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const float inv = 1.0f / (float)n;
+    *reinterpret_cast<float4*>(pooled + (long long)b * D + col) = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
   }
 }
 
+// grid (B, 8): block (b, y) writes rows y, y+8, ... of da / dt, one float4 per thread per step
 __global__ __launch_bounds__(256) void masked_pool_bwd_kernel(const float* __restrict__ dp, const unsigned char* __restrict__ ma,
                                                               const unsigned char* __restrict__ mt, int Na, int Nt, int D,
                                                               float* __restrict__ da, float* __restrict__ dt) {
   const int b = blockIdx.x;
   __shared__ int cnt;
-  if (threadIdx.x == 0) {
-    int c = 0;
-    for (int i = 0; i < Na; ++i) c += ma[b * Na + i] ? 1 : 0;
-    for (int i = 0; i < Nt; ++i) c += mt[b * Nt + i] ? 1 : 0;
-    cnt = c;
-  }
-  __syncthreads();
-  const float inv = 1.0f / (float)cnt;
-  for (int t = threadIdx.x; t < (Na + Nt) * D; t += 256) {
-    const int i = t / D, d = t - i * D;
-    const float g = dp[(long long)b * D + d] * inv;
-    if (i < Na) da[((long long)b * Na + i) * D + d] = ma[b * Na + i] ? g : 0.f;
-    else dt[((long long)b * Nt + (i - Na)) * D + d] = mt[b * Nt + (i - Na)] ? g : 0.f;
+  const float inv = 1.0f / (float)masked_pool_count(ma + (long long)b * Na, mt + (long long)b * Nt, Na, Nt, &cnt);
+  const int nv = D >> 2;
+  for (int i = blockIdx.y; i < Na + Nt; i += gridDim.y) {
+    const bool in_a = i < Na;
+    const bool on = in_a ? ma[(long long)b * Na + i] : mt[(long long)b * Nt + (i - Na)];
+    float* dst = in_a ? da + ((long long)b * Na + i) * D : dt + ((long long)b * Nt + (i - Na)) * D;
+    for (int c = threadIdx.x; c < nv; c += 256) {
+      float4 g = *reinterpret_cast<const float4*>(dp + (long long)b * D + c * 4);
+      g = on ? make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv) : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(dst + c * 4) = g;
+    }
   }
 }
 
@@ -537,7 +559,8 @@ extern "C" int mmdti_masked_pool_fwd(mmdti_stream_t stream, const float* a, cons
                                      const unsigned char* mask_a, const unsigned char* mask_t, int B, int Na, int Nt,
                                      int D, float* pooled) {
   MMDTI_REQUIRE(a && t && mask_a && mask_t && pooled && B > 0 && Na > 0 && Nt > 0 && D > 0, "masked_pool_fwd: bad arguments");
-  hipLaunchKernelGGL(masked_pool_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a, t, mask_a, mask_t, Na, Nt, D, pooled);
+  MMDTI_REQUIRE(D % 4 == 0 && aligned16(a) && aligned16(t) && aligned16(pooled), "masked_pool_fwd: D%%4 and 16-byte alignment required");
+  hipLaunchKernelGGL(masked_pool_fwd_kernel, dim3(B, cdiv(D, 64)), dim3(256), 0, (hipStream_t)stream, a, t, mask_a, mask_t, Na, Nt, D, pooled);
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }
@@ -545,7 +568,8 @@ extern "C" int mmdti_masked_pool_fwd(mmdti_stream_t stream, const float* a, cons
 extern "C" int mmdti_masked_pool_bwd(mmdti_stream_t stream, const float* dpooled, const unsigned char* mask_a,
                                      const unsigned char* mask_t, int B, int Na, int Nt, int D, float* da, float* dt) {
   MMDTI_REQUIRE(dpooled && mask_a && mask_t && da && dt && B > 0 && Na > 0 && Nt > 0 && D > 0, "masked_pool_bwd: bad arguments");
-  hipLaunchKernelGGL(masked_pool_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dpooled, mask_a, mask_t, Na, Nt, D, da, dt);
+  MMDTI_REQUIRE(D % 4 == 0 && aligned16(dpooled) && aligned16(da) && aligned16(dt), "masked_pool_bwd: D%%4 and 16-byte alignment required");
+  hipLaunchKernelGGL(masked_pool_bwd_kernel, dim3(B, 8), dim3(256), 0, (hipStream_t)stream, dpooled, mask_a, mask_t, Na, Nt, D, da, dt);
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }

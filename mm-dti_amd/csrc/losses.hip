@@ -59,17 +59,19 @@ __global__ __launch_bounds__(64) void l2norm_bwd_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------- InfoNCE, one direction (infonce.py:93-98)
-// block per anchor row i (global index row0+i): logits_j = <q_i, k_j>/T over all Bg keys; CE with label i.
-__global__ __launch_bounds__(256) void infonce_dir_kernel(const float* __restrict__ q, const float* __restrict__ k, int Bg, int D, int row0,
-                                                          float invT, float* __restrict__ loss_sum, float* __restrict__ dq,
-                                                          float* __restrict__ dk) {
-  extern __shared__ float sm[];  // qrow[D] | logits[Bg] | red[4] | dqrow[D]
+// Two small kernels, no atomics on the gradients:
+//  rows: block per anchor i (global index row0+i): logits_j = <q_i, k_j>/T over all Bg keys, CE with label i; writes the
+//        logit-gradient row gl[i][:] to scratch and dq_i += sum_j gl_ij k_j (thread = feature column).
+//  cols: block per key j: dk_j += sum_i gl_ij q_i.
+__global__ __launch_bounds__(256) void infonce_rows_kernel(const float* __restrict__ q, const float* __restrict__ k, int Bg, int D, int row0,
+                                                           float invT, float* __restrict__ loss_sum, float* __restrict__ dq,
+                                                           float* __restrict__ gl_out) {
+  extern __shared__ float sm[];  // qrow[D] | logits[Bg] | red[4]
   float* qrow = sm;
   float* lg = sm + D;
   float* red = lg + Bg;
-  float* dqrow = red + 4;
-  const int i = row0 + blockIdx.x;
-  for (int d = threadIdx.x; d < D; d += 256) { qrow[d] = q[(long long)i * D + d]; dqrow[d] = 0.f; }
+  const int il = blockIdx.x, i = row0 + il;
+  for (int d = threadIdx.x; d < D; d += 256) qrow[d] = q[(long long)i * D + d];
   __syncthreads();
   float m = -INFINITY;
   for (int j = threadIdx.x; j < Bg; j += 256) {
@@ -86,15 +88,28 @@ __global__ __launch_bounds__(256) void infonce_dir_kernel(const float* __restric
   const float lse = m + __logf(se);
   if (threadIdx.x == 0) atomicAdd(loss_sum, lse - lg[i]);
   const float gscale = 0.5f / (float)Bg;  // d[(CE_a + CE_b)/2 mean over Bg]/d CE_i
+  __syncthreads();
   for (int j = threadIdx.x; j < Bg; j += 256) {
     const float gl = (__expf(lg[j] - lse) - (j == i ? 1.f : 0.f)) * gscale * invT;
-    for (int d = 0; d < D; ++d) {
-      atomicAdd(&dqrow[d], gl * k[(long long)j * D + d]);
-      atomicAdd(dk + (long long)j * D + d, gl * qrow[d]);
-    }
+    lg[j] = gl;
+    gl_out[(long long)il * Bg + j] = gl;
   }
   __syncthreads();
-  for (int d = threadIdx.x; d < D; d += 256) atomicAdd(dq + (long long)i * D + d, dqrow[d]);
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float acc = 0.f;
+    for (int j = 0; j < Bg; ++j) acc += lg[j] * k[(long long)j * D + d];
+    dq[(long long)i * D + d] += acc;
+  }
+}
+
+__global__ __launch_bounds__(64) void infonce_cols_kernel(const float* __restrict__ q, const float* __restrict__ gl, int Bg, int D, int row0,
+                                                          int Bl, float* __restrict__ dk) {
+  const int j = blockIdx.x;
+  for (int d = threadIdx.x; d < D; d += 64) {
+    float acc = 0.f;
+    for (int il = 0; il < Bl; ++il) acc += gl[(long long)il * Bg + j] * q[(long long)(row0 + il) * D + d];
+    dk[(long long)j * D + d] += acc;
+  }
 }
 
 // ---------------------------------------------------------------- ConR / SupCon
@@ -406,14 +421,16 @@ extern "C" int mmdti_l2norm_bwd(mmdti_stream_t stream, const float* dxhat, const
   return MMDTI_OK;
 }
 extern "C" int mmdti_infonce_dir(mmdti_stream_t stream, const float* qh_all, const float* kh_all, int Bg, int D, int row0, int Bl,
-                                 float temperature, float* loss_sum, float* dq_all, float* dk_all) {
-  MMDTI_REQUIRE(qh_all && kh_all && loss_sum && dq_all && dk_all, "infonce_dir: null pointer");
+                                 float temperature, float* loss_sum, float* dq_all, float* dk_all, float* scratch) {
+  MMDTI_REQUIRE(qh_all && kh_all && loss_sum && dq_all && dk_all && scratch, "infonce_dir: null pointer");
   MMDTI_REQUIRE(Bg > 0 && D > 0 && row0 >= 0 && Bl > 0 && row0 + Bl <= Bg, "infonce_dir: bad sizes (Bg=%d row0=%d Bl=%d)", Bg, row0, Bl);
   MMDTI_REQUIRE(temperature > 0.f, "infonce_dir: temperature must be positive");
-  const size_t smem = (2 * (size_t)D + Bg + 4) * sizeof(float);
+  const size_t smem = ((size_t)D + Bg + 4) * sizeof(float);
   MMDTI_REQUIRE(smem <= 64 * 1024, "infonce_dir: global batch %d too large for the LDS logits row", Bg);
-  hipLaunchKernelGGL(infonce_dir_kernel, dim3(Bl), dim3(256), smem, (hipStream_t)stream, qh_all, kh_all, Bg, D, row0,
-                     1.0f / temperature, loss_sum, dq_all, dk_all);
+  hipLaunchKernelGGL(infonce_rows_kernel, dim3(Bl), dim3(256), smem, (hipStream_t)stream, qh_all, kh_all, Bg, D, row0,
+                     1.0f / temperature, loss_sum, dq_all, scratch);
+  MMDTI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(infonce_cols_kernel, dim3(Bg), dim3(64), 0, (hipStream_t)stream, qh_all, scratch, Bg, D, row0, Bl, dk_all);
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }

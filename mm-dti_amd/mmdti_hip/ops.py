@@ -371,8 +371,9 @@ def l2norm_bwd(dxh, xh, inv):
 
 def infonce_dir(qh_all, kh_all, row0, Bl, temperature, loss_sum, dq_all, dk_all):
     Bg, D = qh_all.shape
+    scratch = torch.empty(Bl, Bg, device=qh_all.device, dtype=F32)
     lib().mmdti_infonce_dir(_stream(), qh_all.data_ptr(), kh_all.data_ptr(), Bg, D, row0, Bl, float(temperature), loss_sum.data_ptr(),
-                            dq_all.data_ptr(), dk_all.data_ptr())
+                            dq_all.data_ptr(), dk_all.data_ptr(), scratch.data_ptr())
 
 
 # --------------------------------------------------------------------------------------------- ConR / SupCon

@@ -37,7 +37,7 @@ def test_argument_validation_happens_before_any_launch():
     with pytest.raises(_abi.MMDTIError, match="exceeds"):
         lib.mmdti_pair_attn_fwd(0, 16, 16, 16, 16, 0, 1, 400, 8, 400, 0.35, 0.0, 0, 0)
     with pytest.raises(_abi.MMDTIError, match="temperature"):
-        lib.mmdti_infonce_dir(0, 16, 16, 4, 50, 0, 4, 0.0, 16, 16, 16)
+        lib.mmdti_infonce_dir(0, 16, 16, 4, 50, 0, 4, 0.0, 16, 16, 16, 16)
 
 
 def test_product_path_has_no_cpu_fallback():
