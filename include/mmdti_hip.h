@@ -116,15 +116,17 @@ int mmdti_gbf_features_bwd(mmdti_stream_t stream, const float* dist, const long 
                            const void* dfeat_bf16, float* dmul, float* dbias, float* dmeans, float* dstds);
 /* gbf -> gbf_proj (Linear+GELU+Linear, NonLinearHead mm_model.py:190-208) -> permute (mm_model.py:553-556) in one kernel:
  * out[b,h,i,j] (fp32, [B,H,N,ld], pad columns j >= N written 0).  w1: [F,K] bf16, w2: [H,F] bf16; built for K=128, F=128,
- * H=64.  feat/u/h (nullable, together): the [B*N*N, 128] bf16 basis / pre-activation / hidden rows for the backward. */
+ * H=64.  feat/u/h (nullable, together): the [B*N*N, 128] bf16 basis / pre-activation / hidden rows for the backward.
+ * tiled != 0: out is [B,H,nt,nt,256] (nt = ceil(N/16); 16x16 tiles in MFMA accumulator order, the layout the pair-attention
+ * kernels stream -- see mmdti_pair_attn_fwd) and every pad slot (query or key >= N) is written -inf. */
 int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, const long long* edge_type, const float* mul,
                        const float* bias, const float* means, const float* stds, const void* w1_bf16, const float* b1,
                        const void* w2_bf16, const float* b2, int B, int N, int ld, int K, int F, int H, int E, float* out,
-                       void* feat_bf16, void* u_bf16, void* h_bf16);
+                       void* feat_bf16, void* u_bf16, void* h_bf16, int tiled);
 /* [B,N,N,H] fp32 -> [B,H,N,ld] fp32 (mm_model.py:555-556 permute(0,3,1,2).contiguous()) and its gradient
- * [B,H,N,ld] fp32 -> [B,N,N,H] bf16 */
+ * [B,H,N,ld] fp32 (or, tiled != 0, the [B,H,nt,nt,256] tile layout of mmdti_gbf_bias_fwd) -> [B,N,N,H] bf16 */
 int mmdti_pair_permute_fwd(mmdti_stream_t stream, const float* x, float* out, int B, int N, int H, int ld);
-int mmdti_pair_permute_bwd(mmdti_stream_t stream, const float* g, void* out_bf16, int B, int N, int H, int ld);
+int mmdti_pair_permute_bwd(mmdti_stream_t stream, const float* g, void* out_bf16, int B, int N, int H, int ld, int tiled);
 
 /* ---- Pair-bias attention, head_dim 8 (unicore SelfMultiheadAttention + softmax_dropout with
  * return_attn=True, reached from transformers.py:137-139; key-padding merge :122-135) ------------
@@ -132,12 +134,12 @@ int mmdti_pair_permute_bwd(mmdti_stream_t stream, const float* g, void* out_bf16
  * O = dropout(softmax(S)).v.   qkv: [B,N,3*H*8] bf16 (q|k|v);  bias_in/s_out: [B,H,N,ld] fp32. */
 int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, const float* bias_in, float* s_out,
                         void* o_bf16, const unsigned char* key_pad, int B, int N, int H, int ld, float scale,
-                        float drop_p, unsigned long long seed, unsigned int site);
+                        float drop_p, unsigned long long seed, unsigned int site, int tiled);
 /* g (in/out, [B,H,N,ld] fp32): on entry dL/dS_l from the layers above (ignored if g_in_zero), on exit
  * dL/dS_l total = dL/d(bias_in).  dqkv: [B,N,3*H*8] bf16. */
 int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, const float* s, const void* do_bf16, float* g,
                         void* dqkv_bf16, int B, int N, int H, int ld, float scale, int g_in_zero, float drop_p,
-                        unsigned long long seed, unsigned int site);
+                        unsigned long long seed, unsigned int site, int tiled);
 
 /* ---- Row softmax over materialised scores (HF eager_attention_forward :158-183; BertCoAttention
  * mm_module.py:497-514) ------------------------------------------------------------------------

@@ -151,13 +151,16 @@ __global__ __launch_bounds__(256) void pair_permute_fwd_kernel(const float* __re
 
 // [B,H,N,ld] fp32 -> [B,N,N,H] bf16
 __global__ __launch_bounds__(256) void pair_permute_bwd_kernel(const float* __restrict__ g, bf16_t* __restrict__ out,
-                                                               int N, int H, int ld) {
+                                                               int N, int H, int ld, int tiled) {
   extern __shared__ float tile[];  // [H][NP], NP odd
   const int bi = blockIdx.x, b = bi / N, i = bi - b * N;
   const int NP = N | 1;
+  const int nt = (N + 15) >> 4;
   for (int t = threadIdx.x; t < H * N; t += 256) {
     const int h = t / N, j = t - h * N;
-    tile[h * NP + j] = g[(((long long)b * H + h) * N + i) * ld + j];
+    const long long off = tiled ? ((long long)(b * H + h) * nt * nt + (i >> 4) * nt + (j >> 4)) * 256 + (((j & 15) >> 2) * 16 + (i & 15)) * 4 + (j & 3)
+                                : (((long long)b * H + h) * N + i) * ld + j;
+    tile[h * NP + j] = g[off];
   }
   __syncthreads();
   bf16_t* dst = out + (long long)bi * N * H;
@@ -198,7 +201,7 @@ __device__ __forceinline__ uint2 gbf_pack4(const gf32x4& a) {
   return pk;
 }
 
-template <bool SAVE>
+template <bool SAVE, bool TILED>
 __global__ __launch_bounds__(256) void gbf_bias_fwd_kernel(const float* __restrict__ dist, const long long* __restrict__ et,
                                                            const float* __restrict__ mul, const float* __restrict__ bias,
                                                            const float* __restrict__ means, const float* __restrict__ stds,
@@ -237,12 +240,37 @@ __global__ __launch_bounds__(256) void gbf_bias_fwd_kernel(const float* __restri
   const int g = lane >> 4, i = lane & 15;
   const long long ntiles = (long long)B * tpm;
   const long long nwaves = (long long)gridDim.x * 4;
-  const long long plane = (long long)N * ld;
+  // Pair tiles of 16.  Row-major planes: 16 consecutive q = i*ld + j (64 contiguous bytes of every head plane).  Tiled
+  // planes ([nt][nt][256], 16x16 tiles in MFMA accumulator order -- the layout the pair-attention kernels stream): a
+  // 4x4 (query, key) block, which is again 64 contiguous bytes; blocks past N are visited too so that EVERY pad slot of
+  // the plane holds -inf (the attention kernels then need no masking of pad keys / rows).
+  const int nt = (N + 15) >> 4, nblk = nt * 4;
+  const long long plane = TILED ? (long long)nt * nt * 256 : (long long)N * ld;
   for (long long tile = (long long)blockIdx.x * 4 + (tid >> 6); tile < ntiles; tile += nwaves) {
     const int b = (int)(tile / tpm);
-    const int q = (int)(tile - (long long)b * tpm) * 16 + i;
-    const int ii = q / ld, jj = q - ii * ld;
-    const bool inplane = q < plane, valid = inplane && jj < N;
+    const int tq = (int)(tile - (long long)b * tpm);
+    int q, ii, jj;
+    bool inplane, past = false;
+    if (TILED) {
+      const int rb = tq / nblk, cb = tq - rb * nblk;
+      past = 4 * rb >= N || 4 * cb >= N;   // whole block past N (the same for every lane of the wave)
+      ii = 4 * rb + (i >> 2);
+      jj = 4 * cb + (i & 3);
+      q = ((rb >> 2) * nt + (cb >> 2)) * 256 + (cb & 3) * 64 + (rb & 3) * 16 + i;
+      inplane = true;
+    } else {
+      q = tq * 16 + i;
+      ii = q / ld;
+      jj = q - ii * ld;
+      inplane = q < plane;
+    }
+    const bool valid = ii < N && jj < N;
+    const float padv = TILED ? -INFINITY : 0.f;
+    float* ob = out + (long long)b * GBF_H * plane + q;
+    if (TILED && past) {
+      for (int hh = 0; hh < GBF_H; ++hh) ob[(long long)hh * plane] = padv;
+      continue;
+    }
     const long long p = ((long long)b * N + (valid ? ii : 0)) * N + (valid ? jj : 0);
     float y = 0.f;
     {
@@ -295,7 +323,6 @@ __global__ __launch_bounds__(256) void gbf_bias_fwd_kernel(const float* __restri
       hB[u] = gbf_pack8(v);
     }
     // bias^T = W2 . hidden^T (+ b2): accumulator rows = heads 16*ht + 4g + r, column = pair
-    float* ob = out + (long long)b * GBF_H * plane + q;
 #pragma unroll
     for (int ht = 0; ht < 4; ++ht) {
       gf32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -307,7 +334,7 @@ __global__ __launch_bounds__(256) void gbf_bias_fwd_kernel(const float* __restri
       const gf32x4 bb = *reinterpret_cast<const gf32x4*>(sB2 + 16 * ht + 4 * g);
       if (inplane) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ob[(long long)(16 * ht + 4 * g + r) * plane] = valid ? acc[r] + bb[r] : 0.f;
+        for (int r = 0; r < 4; ++r) ob[(long long)(16 * ht + 4 * g + r) * plane] = valid ? acc[r] + bb[r] : padv;
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -363,12 +390,12 @@ extern "C" int mmdti_pair_permute_fwd(mmdti_stream_t stream, const float* x, flo
 }
 
 extern "C" int mmdti_pair_permute_bwd(mmdti_stream_t stream, const float* g, void* out_bf16, int B, int N, int H,
-                                      int ld) {
+                                      int ld, int tiled) {
   MMDTI_REQUIRE(g && out_bf16 && B > 0 && N > 0 && H > 0 && ld >= N, "pair_permute_bwd: bad arguments");
   const size_t smem = (size_t)H * (N | 1) * sizeof(float);
   MMDTI_REQUIRE(smem <= 64 * 1024, "pair_permute_bwd: N*H too large for the LDS tile (N=%d,H=%d)", N, H);
   hipLaunchKernelGGL(pair_permute_bwd_kernel, dim3(B * N), dim3(256), smem, (hipStream_t)stream, g, (bf16_t*)out_bf16,
-                     N, H, ld);
+                     N, H, ld, tiled);
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }
@@ -376,7 +403,7 @@ extern "C" int mmdti_pair_permute_bwd(mmdti_stream_t stream, const float* g, voi
 extern "C" int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, const long long* edge_type, const float* mul,
                                   const float* bias, const float* means, const float* stds, const void* w1_bf16,
                                   const float* b1, const void* w2_bf16, const float* b2, int B, int N, int ld, int K, int F,
-                                  int H, int E, float* out, void* feat_bf16, void* u_bf16, void* h_bf16) {
+                                  int H, int E, float* out, void* feat_bf16, void* u_bf16, void* h_bf16, int tiled) {
   MMDTI_REQUIRE(dist && edge_type && mul && bias && means && stds && w1_bf16 && b1 && w2_bf16 && b2 && out, "gbf_bias_fwd: null argument");
   MMDTI_REQUIRE(K == GBF_K && F == GBF_F && H == GBF_H, "gbf_bias_fwd: built for %d gaussians, %d hidden, %d heads (got %d,%d,%d)",
                 GBF_K, GBF_F, GBF_H, K, F, H);
@@ -385,17 +412,18 @@ extern "C" int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, cons
   const bool save = feat_bf16 || u_bf16 || h_bf16;
   MMDTI_REQUIRE(!save || (feat_bf16 && u_bf16 && h_bf16 && aligned16(feat_bf16) && aligned16(u_bf16) && aligned16(h_bf16)),
                 "gbf_bias_fwd: the three saved intermediates come together, 16-byte aligned");
-  const int tpm = cdiv((long long)N * ld, 16);
+  const int nt = (N + 15) / 16;
+  const int tpm = tiled ? 16 * nt * nt : cdiv((long long)N * ld, 16);
   const long long ntiles = (long long)B * tpm;
   const int grid = (int)(ntiles / 4 + 1 < 2048 ? ntiles / 4 + 1 : 2048);
   const size_t smem = (size_t)(GBF_F + GBF_H) * GBF_WS * 2 + (size_t)(3 * GBF_K + GBF_F + GBF_H) * 4;
-  if (save)
-    hipLaunchKernelGGL((gbf_bias_fwd_kernel<true>), dim3(grid), dim3(256), smem, (hipStream_t)stream, dist, edge_type, mul, bias, means,
-                       stds, (const bf16_t*)w1_bf16, b1, (const bf16_t*)w2_bf16, b2, out, (bf16_t*)feat_bf16, (bf16_t*)u_bf16,
-                       (bf16_t*)h_bf16, B, N, ld, E, tpm);
-  else
-    hipLaunchKernelGGL((gbf_bias_fwd_kernel<false>), dim3(grid), dim3(256), smem, (hipStream_t)stream, dist, edge_type, mul, bias, means,
-                       stds, (const bf16_t*)w1_bf16, b1, (const bf16_t*)w2_bf16, b2, out, nullptr, nullptr, nullptr, B, N, ld, E, tpm);
+#define GBF_L(SAVE, TILED)                                                                                                          \
+  hipLaunchKernelGGL((gbf_bias_fwd_kernel<SAVE, TILED>), dim3(grid), dim3(256), smem, (hipStream_t)stream, dist, edge_type, mul, bias, \
+                     means, stds, (const bf16_t*)w1_bf16, b1, (const bf16_t*)w2_bf16, b2, out, (bf16_t*)feat_bf16, (bf16_t*)u_bf16, \
+                     (bf16_t*)h_bf16, B, N, ld, E, tpm)
+  if (save) { if (tiled) GBF_L(true, true); else GBF_L(true, false); }
+  else      { if (tiled) GBF_L(false, true); else GBF_L(false, false); }
+#undef GBF_L
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }

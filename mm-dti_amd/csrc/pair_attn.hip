@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void pair_attn_fwd_mfma_kernel(const bf16_t* _
                                                                  float* __restrict__ s_out, bf16_t* __restrict__ o,
                                                                  const unsigned char* __restrict__ key_pad, int N, int H, int ld,
                                                                  float scale, uint32_t thresh, float dscale, uint64_t seed,
-                                                                 uint32_t site) {
+                                                                 uint32_t site, int tiled) {
   constexpr int NP = NT * 16;
   __shared__ __attribute__((aligned(16))) float sQ[NP][8];
   __shared__ __attribute__((aligned(16))) float sK[NP][8];
@@ -330,6 +330,10 @@ __global__ __launch_bounds__(256) void pair_attn_fwd_mfma_kernel(const bf16_t* _
     const bool qvalid = qi < N;
     const long long rowoff = ((long long)bh * N + (qvalid ? qi : 0)) * ld;
     const float2 qv = *reinterpret_cast<const float2*>(&sQ[qb * 16 + c16][2 * g]);
+    // element offset of this lane's float4 of key tile T: row-major [N][ld] planes, or the tiled layout in which every
+    // 16x16 tile is stored in accumulator order (1 KB contiguous per wave access; see ops.pair_tile)
+    const long long tbase = ((long long)bh * nKB + qb) * nKB * 256 + lane * 4;
+#define PA_OFF(T) (tiled ? tbase + (T) * 256 : rowoff + (T) * 16 + 4 * g)
     // Phase 1: request every bias tile of this query block (branch-free predication, so the NT 16-byte loads are issued
     // back to back and stay in flight together); tiles beyond N are fully masked and cost nothing but idle MFMA slots.
     f32x4 S[NT];
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(256) void pair_attn_fwd_mfma_kernel(const bf16_t* _
     for (int t = 0; t < NT; ++t) {
       const int kcol = t * 16 + 4 * g;
       const bool inrow = qvalid && kcol < N;
-      const f32x4 ld4 = *reinterpret_cast<const f32x4*>(bias_in + rowoff + (inrow ? kcol : 0));
+      const f32x4 ld4 = *reinterpret_cast<const f32x4*>(bias_in + (inrow ? PA_OFF(t) : PA_OFF(0)));
       S[t] = inrow ? ld4 : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     float m = NEG_INF;
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(256) void pair_attn_fwd_mfma_kernel(const bf16_t* _
         const f32x4 km = *reinterpret_cast<const f32x4*>(&sM[kcol]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) c[r] = (km[r] != 0.f) ? NEG_INF : c[r];
-        if (qvalid && kcol < N) *reinterpret_cast<f32x4*>(s_out + rowoff + kcol) = c;
+        if (qvalid && kcol < N) *reinterpret_cast<f32x4*>(s_out + PA_OFF(t)) = c;
         S[t] = c;
         m = fmaxf(fmaxf(m, fmaxf(c[0], c[1])), fmaxf(c[2], c[3]));
       }
@@ -397,6 +401,7 @@ __global__ __launch_bounds__(256) void pair_attn_fwd_mfma_kernel(const bf16_t* _
       pk.y = (uint32_t)f2bf(oacc[2]) | ((uint32_t)f2bf(oacc[3]) << 16);
       *reinterpret_cast<uint2*>(o + ((long long)b * N + qi) * D + h * HD + 4 * g) = pk;
     }
+#undef PA_OFF
   }
 }
 
@@ -416,7 +421,7 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* _
                                                                  const bf16_t* __restrict__ dO, const float* __restrict__ gin, float* __restrict__ gout,
                                                                  bf16_t* __restrict__ dqkv, int N, int H, int ld, float scale,
                                                                  int g_in_zero, uint32_t thresh, float dscale, uint64_t seed,
-                                                                 uint32_t site) {
+                                                                 uint32_t site, int tiled) {
   constexpr int NP = NT * 16;
   __shared__ __attribute__((aligned(16))) float sQ[NP * VSTR + 8];   // Q * scale
   __shared__ __attribute__((aligned(16))) float sK[NP * VSTR + 8];
@@ -459,6 +464,8 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* _
     const int qi = qb * 16 + c16;
     const bool qvalid = qi < N;
     const long long rowoff = ((long long)bh * N + (qvalid ? qi : 0)) * ld;
+    const long long tbase = ((long long)bh * nKB + qb) * nKB * 256 + lane * 4;
+#define PA_OFF(T) (tiled ? tbase + (T) * 256 : rowoff + (T) * 16 + 4 * g)
     // B operand of dP^T = V.dO^T : dO[qi][g], dO[qi][g+4]
     const float dob0 = sD[(qb * 16 + c16) * VSTR + g], dob1 = sD[(qb * 16 + c16) * VSTR + g + 4];
     // ---- sweep 1
@@ -469,7 +476,7 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* _
       {
         const int kcol = t * 16 + 4 * g;
         const bool inrow = qvalid && kcol < N;
-        const f32x4 ld4 = *reinterpret_cast<const f32x4*>(s_in + rowoff + (inrow ? kcol : 0));
+        const f32x4 ld4 = *reinterpret_cast<const f32x4*>(s_in + (inrow ? PA_OFF(t) : PA_OFF(0)));
         f32x4 c = inrow ? ld4 : f32x4{NEG_INF, NEG_INF, NEG_INF, NEG_INF};
 #pragma unroll
         for (int r = 0; r < 4; ++r) c[r] = (kcol + r < N) ? c[r] : NEG_INF;   // pad columns of the row are not data
@@ -530,7 +537,7 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* _
     for (int t = 0; t < NT; ++t) {
       const int kcol = t * 16 + 4 * g;
       const bool inrow = qvalid && kcol < N && !g_in_zero;
-      const f32x4 ld4 = *reinterpret_cast<const f32x4*>(gin + rowoff + (inrow ? kcol : 0));
+      const f32x4 ld4 = *reinterpret_cast<const f32x4*>(gin + (inrow ? PA_OFF(t) : PA_OFF(0)));
       Gi[t] = inrow ? ld4 : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     f32x4 dq = {0.f, 0.f, 0.f, 0.f};
@@ -547,7 +554,7 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* _
         for (int r = 0; r < 4; ++r) G[r] = (kcol + r < N) ? G[r] : 0.f;
       }
       if (!qvalid) G = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (inrow) *reinterpret_cast<f32x4*>(gout + rowoff + kcol) = G;
+      if (inrow) *reinterpret_cast<f32x4*>(gout + PA_OFF(t)) = G;
       f32x4 Pd;
 #pragma unroll
       for (int r = 0; r < 4; ++r) Pd[r] = P[t][r] > 0.f ? P[t][r] * dscale : 0.f;   // dscale == 1 without dropout
@@ -593,6 +600,7 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* _
       pk.y = (uint32_t)f2bf(dq[2] * scale) | ((uint32_t)f2bf(dq[3] * scale) << 16);
       *reinterpret_cast<uint2*>(dqkv + ((long long)b * N + qi) * D3 + h * HD + 4 * g) = pk;
     }
+#undef PA_OFF
   }
   __syncthreads();
   for (int key = tid; key < N; key += blockDim.x) {
@@ -625,8 +633,9 @@ static int check_common(const char* fn, int B, int N, int H, int ld) {
 
 extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, const float* bias_in, float* s_out,
                                    void* o_bf16, const unsigned char* key_pad, int B, int N, int H, int ld,
-                                   float scale, float drop_p, unsigned long long seed, unsigned int site) {
+                                   float scale, float drop_p, unsigned long long seed, unsigned int site, int tiled) {
   if (int e = check_common("pair_attn_fwd", B, N, H, ld)) return e;
+  MMDTI_REQUIRE(!tiled || (ld % 4 == 0 && N <= 16 * 13), "pair_attn_fwd: the tiled pair layout needs ld %% 4 == 0 and N <= 208");
   MMDTI_REQUIRE(qkv_bf16 && bias_in && s_out && o_bf16, "pair_attn_fwd: null pointer");
   MMDTI_REQUIRE(aligned16(qkv_bf16), "pair_attn_fwd: qkv must be 16-byte aligned");
   MMDTI_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "pair_attn_fwd: dropout p out of range");
@@ -640,7 +649,7 @@ extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, 
     dim3 blk(nqb % 3 == 0 ? 192 : (nqb < 4 ? 64 * nqb : 256));
 #define PA_M(NT)                                                                                                     \
   hipLaunchKernelGGL((pair_attn_fwd_mfma_kernel<NT>), grid, blk, 0, s, (const bf16_t*)qkv_bf16, bias_in, s_out,     \
-                     (bf16_t*)o_bf16, key_pad, N, H, ld, scale, th, sc, (uint64_t)seed, (uint32_t)site)
+                     (bf16_t*)o_bf16, key_pad, N, H, ld, scale, th, sc, (uint64_t)seed, (uint32_t)site, tiled)
     if (nqb <= 5) PA_M(5); else if (nqb <= 9) PA_M(9); else PA_M(13);
 #undef PA_M
     MMDTI_LAUNCH_CHECK();
@@ -663,8 +672,9 @@ extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, 
 
 extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, const float* s, const void* do_bf16,
                                    float* g, void* dqkv_bf16, int B, int N, int H, int ld, float scale,
-                                   int g_in_zero, float drop_p, unsigned long long seed, unsigned int site) {
+                                   int g_in_zero, float drop_p, unsigned long long seed, unsigned int site, int tiled) {
   if (int e = check_common("pair_attn_bwd", B, N, H, ld)) return e;
+  MMDTI_REQUIRE(!tiled || (ld % 4 == 0 && N <= 16 * 13), "pair_attn_bwd: the tiled pair layout needs ld %% 4 == 0 and N <= 208");
   MMDTI_REQUIRE(qkv_bf16 && s && do_bf16 && g && dqkv_bf16, "pair_attn_bwd: null pointer");
   MMDTI_REQUIRE(aligned16(qkv_bf16) && aligned16(do_bf16) && aligned16(dqkv_bf16), "pair_attn_bwd: alignment");
   const uint32_t th = dropout_thresh(drop_p);
@@ -677,7 +687,7 @@ extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, 
 #define PA_MB(NT)                                                                                                    \
   hipLaunchKernelGGL((pair_attn_bwd_mfma_kernel<NT>), grid, blk, 0, st, (const bf16_t*)qkv_bf16, s,                 \
                      (const bf16_t*)do_bf16, g, g, (bf16_t*)dqkv_bf16, N, H, ld, scale, g_in_zero, th, sc,         \
-                     (uint64_t)seed, (uint32_t)site)
+                     (uint64_t)seed, (uint32_t)site, tiled)
     if (nqb <= 5) PA_MB(5); else if (nqb <= 9) PA_MB(9); else PA_MB(13);
 #undef PA_MB
     MMDTI_LAUNCH_CHECK();

@@ -59,7 +59,8 @@ class PairEncoderFn(torch.autograd.Function):
     def forward(ctx, emb, bias, padding_mask, mod, training):
         B, N, D = emb.shape
         H = mod.attention_heads
-        ld = bias.shape[-1]
+        tiled = ops.pair_is_tiled(bias)        # [B,H,nt,nt,256] tile layout (see ops.pair_tile) or row-major [B,H,N,ld]
+        ld = ops.pair_ld(N) if tiled else bias.shape[-1]
         M = B * N
         p_emb = mod.emb_dropout if training else 0.0
         p_res = mod.dropout if training else 0.0
@@ -77,6 +78,7 @@ class PairEncoderFn(torch.autograd.Function):
                                                            drop_p=p_emb, seed=seed, site=st.site_emb)
         scale = (D // H) ** -0.5
         s_prev = bias.contiguous()
+        st.bias0 = s_prev if not mod.layers else None     # only needed to shape a zero gradient when there is no layer
         for li, layer in enumerate(mod.layers):
             L = SimpleNamespace(x=x)
             ln1, ln2 = layer.self_attn_layer_norm, layer.final_layer_norm
@@ -136,7 +138,7 @@ class PairEncoderFn(torch.autograd.Function):
             do = ops.linear_bwd_input(dy1, wbf16(att.out_proj.weight))
             g_zero = G is None
             if g_zero:
-                G = torch.empty(B, H, N, ld, device=dout.device, dtype=F32)
+                G = torch.empty_like(L.s)
             dqkv = ops.pair_attn_bwd(L.qkv, L.s, do, G, B, N, H, ld, scale, g_zero, st.p_att, seed, L.site_att)
             _lin_bwd_params(dqkv, L.h1, att.in_proj.weight, att.in_proj.bias)
             dh1 = ops.linear_bwd_input(dqkv, wbf16(att.in_proj.weight))
@@ -152,7 +154,7 @@ class PairEncoderFn(torch.autograd.Function):
                                  row_zero=None if st.pad is None else st.pad.reshape(-1), drop_p=st.p_emb, seed=seed, site=st.site_emb)
         notify_grads_ready(list(eln.parameters()) + ([] if mod.final_layer_norm is None else list(mod.final_layer_norm.parameters())))
         if G is None:
-            G = torch.zeros(B, H, N, ld, device=dout.device, dtype=F32)
+            G = torch.zeros_like(st.bias0)
         return demb.view(B, N, D), G, None, None, None
 
 
@@ -169,8 +171,9 @@ class PairBiasFn(torch.autograd.Function):
         args = [gbf.mul.weight.view(-1), gbf.bias.weight.view(-1), gbf.means.weight.view(-1), gbf.stds.weight.view(-1)]
         if ops.gbf_bias_eligible(args[2].numel(), proj.linear1.weight.shape[0], H, ld):
             # one kernel from distances to the [B,H,N,ld] bias; the three [P,128] intermediates are saved for the backward
+            # (tiled pair layout whenever the MFMA pair-attention kernels can take it: their loads become contiguous KiBs)
             out, (feat, u, h) = ops.gbf_bias_fwd(dist, edge_type, *args, wbf16(proj.linear1.weight), proj.linear1.bias,
-                                                 wbf16(proj.linear2.weight), proj.linear2.bias, ld, save=True)
+                                                 wbf16(proj.linear2.weight), proj.linear2.bias, ld, save=True, tiled=ops.pair_tiled_ok(N))
         else:
             feat = ops.gbf_features_fwd(dist, edge_type, *args)
             u = torch.empty(feat.shape[0], proj.linear1.weight.shape[0], device=dist.device, dtype=BF16)

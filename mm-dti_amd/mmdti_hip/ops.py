@@ -225,18 +225,18 @@ def gbf_features_bwd(dist, edge_type, mul, bias, means, stds, dfeat, dmul, dbias
                                  dstds.data_ptr())
 
 
-def gbf_bias_fwd(dist, edge_type, mul, bias, means, stds, w1, b1, w2, b2, ld, save=True):
-    """Fused gbf + gbf_proj + permute -> (out [B,H,N,ld] fp32, (feat, u, h) [P,128] bf16 or None)."""
+def gbf_bias_fwd(dist, edge_type, mul, bias, means, stds, w1, b1, w2, b2, ld, save=True, tiled=False):
+    """Fused gbf + gbf_proj + permute -> (out [B,H,N,ld] fp32 -- or the tiled pair layout --, (feat, u, h) [P,128] bf16 or None)."""
     _chk(dist, F32, "gbf.dist"); _chk(edge_type, torch.int64, "gbf.edge_type"); _chk(w1, BF16, "gbf.w1"); _chk(w2, BF16, "gbf.w2")
     B, N, _ = dist.shape
     Hh, Fh = w2.shape
     K = w1.shape[1]
-    out = torch.empty(B, Hh, N, ld, device=dist.device, dtype=F32)
+    out = pair_empty(B, Hh, N, dist.device, tiled) if tiled else torch.empty(B, Hh, N, ld, device=dist.device, dtype=F32)
     saved = tuple(torch.empty(B * N * N, 128, device=dist.device, dtype=BF16) for _ in range(3)) if save else None
     t0 = kernel_timer.begin("gbf_features_fwd")
     lib().mmdti_gbf_bias_fwd(_stream(), dist.data_ptr(), edge_type.data_ptr(), mul.data_ptr(), bias.data_ptr(), means.data_ptr(), stds.data_ptr(),
                              w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), B, N, ld, K, Fh, Hh, mul.numel(), out.data_ptr(),
-                             *([t.data_ptr() for t in saved] if save else [0, 0, 0]))
+                             *([t.data_ptr() for t in saved] if save else [0, 0, 0]), int(tiled))
     kernel_timer.end("gbf_features_fwd", t0)
     return out, saved
 
@@ -260,28 +260,77 @@ def pair_permute_fwd(x, B, N, H, ld):
 def pair_permute_bwd(g, B, N, H, ld):
     _chk(g, F32, "pair_permute_bwd.g")
     out = torch.empty(B * N * N, H, device=g.device, dtype=BF16)
-    lib().mmdti_pair_permute_bwd(_stream(), g.data_ptr(), out.data_ptr(), B, N, H, ld)
+    lib().mmdti_pair_permute_bwd(_stream(), g.data_ptr(), out.data_ptr(), B, N, H, ld, int(pair_is_tiled(g)))
     return out
 
 
 # --------------------------------------------------------------------------------------------- pair-bias attention
+# Pair tensors (attention bias, per-layer logits S_l, their gradient G) come in two layouts:
+#   standard  [B, H, N, ld]            row-major planes (ld = pair_ld(N))
+#   tiled     [B, H, nt, nt, 256]      nt = ceil(N/16): every 16x16 (query, key) tile stored in MFMA accumulator order, element
+#             (q, k) of a tile at ((k%16)//4 * 16 + q%16) * 4 + k%4 -- a wave's access to a tile is ONE contiguous KiB.
+# The tiled form is what the hot path uses (N <= 208); pair_tile / pair_untile convert at the boundary (tests, aux outputs).
+def pair_is_tiled(t):
+    return t.dim() == 5
+
+
+def pair_tiles(N):
+    return (N + 15) // 16
+
+
+def pair_tiled_ok(N):
+    return N <= 208
+
+
+def pair_empty(B, H, N, device, tiled, zero=False):
+    nt = pair_tiles(N)
+    shape = (B, H, nt, nt, 256) if tiled else (B, H, N, pair_ld(N))
+    return (torch.zeros if zero else torch.empty)(shape, device=device, dtype=F32)
+
+
+def _tile_index(N, device):
+    nt = pair_tiles(N)
+    q = torch.arange(N, device=device).view(N, 1)
+    k = torch.arange(N, device=device).view(1, N)
+    return ((q // 16) * nt + k // 16) * 256 + ((k % 16) // 4 * 16 + q % 16) * 4 + k % 4          # [N, N] flat offsets
+
+
+def pair_tile(x, N):
+    """standard [B,H,N,>=N] -> tiled (layout glue for tests / API boundaries; pad slots are 0)."""
+    B, H = x.shape[:2]
+    nt = pair_tiles(N)
+    out = torch.zeros(B, H, nt * nt * 256, device=x.device, dtype=x.dtype)
+    out[:, :, _tile_index(N, x.device).reshape(-1)] = x[..., :N, :N].reshape(B, H, N * N)
+    return out.view(B, H, nt, nt, 256)
+
+
+def pair_untile(t, N):
+    """tiled -> standard [B,H,N,N]."""
+    B, H = t.shape[:2]
+    return t.reshape(B, H, -1)[:, :, _tile_index(N, t.device).reshape(-1)].view(B, H, N, N)
+
+
 def pair_attn_fwd(qkv, bias_in, key_pad, B, N, H, ld, scale, drop_p=0.0, seed=0, site=0):
     _chk(qkv, BF16, "pair_attn.qkv"); _chk(bias_in, F32, "pair_attn.bias")
-    s_out = torch.empty(B, H, N, ld, device=qkv.device, dtype=F32)
+    tiled = pair_is_tiled(bias_in)
+    s_out = torch.empty_like(bias_in) if tiled else torch.empty(B, H, N, ld, device=qkv.device, dtype=F32)
     o = torch.empty(B * N, H * 8, device=qkv.device, dtype=BF16)
     kp = _u8(key_pad)
     t0 = kernel_timer.begin("pair_attn_fwd")
     lib().mmdti_pair_attn_fwd(_stream(), qkv.data_ptr(), bias_in.data_ptr(), s_out.data_ptr(), o.data_ptr(), _p(kp), B, N, H, ld,
-                              float(scale), float(drop_p), int(seed), int(site))
+                              float(scale), float(drop_p), int(seed), int(site), int(tiled))
     kernel_timer.end("pair_attn_fwd", t0)
     return s_out, o
 
 
 def pair_attn_bwd(qkv, s, do, g, B, N, H, ld, scale, g_in_zero, drop_p=0.0, seed=0, site=0):
     dqkv = torch.empty_like(qkv)
+    tiled = pair_is_tiled(s)
+    if pair_is_tiled(g) != tiled:
+        raise MMDTIError("pair_attn_bwd: S and G must share one pair layout")
     t0 = kernel_timer.begin("pair_attn_bwd")
     lib().mmdti_pair_attn_bwd(_stream(), qkv.data_ptr(), s.data_ptr(), do.data_ptr(), g.data_ptr(), dqkv.data_ptr(), B, N, H, ld,
-                              float(scale), int(g_in_zero), float(drop_p), int(seed), int(site))
+                              float(scale), int(g_in_zero), float(drop_p), int(seed), int(site), int(tiled))
     kernel_timer.end("pair_attn_bwd", t0)
     return dqkv
 

@@ -210,36 +210,53 @@ def _pair_ref(qkv, bias, key_pad, H, scale, dO=None, g_in=None):
     return S, Oo, qkv.grad, bias.grad
 
 
+@pytest.mark.parametrize("tiled", [False, True])
 @pytest.mark.parametrize("B,N,H", [(2, 7, 8), (3, 70, 4), (2, 130, 64), (1, 200, 2)])
-def test_pair_attn(ops, B, N, H):
+def test_pair_attn(ops, B, N, H, tiled):
+    """Both pair layouts: row-major [B,H,N,ld] planes and the tiled [B,H,nt,nt,256] form the hot path streams."""
     D = H * 8
     ld = ops.pair_ld(N)
     scale = 8 ** -0.5
+    up = (lambda t: ops.pair_tile(dev(t), N)) if tiled else dev                      # host standard -> device layout
+    down = (lambda t: ops.pair_untile(t, N).cpu()) if tiled else (lambda t: t.cpu()[..., :N])
     qkv = rt(torch.randn(B, N, 3 * D, generator=G(1)))
     bias = torch.randn(B, H, N, N, generator=G(2))
     key_pad = torch.zeros(B, N, dtype=torch.bool)
     key_pad[0, N - max(1, N // 3):] = True
     bias_ld = torch.zeros(B, H, N, ld); bias_ld[..., :N] = bias
-    s_out, o = ops.pair_attn_fwd(dev(bf(qkv)).view(B * N, 3 * D), dev(bias_ld), dev(key_pad), B, N, H, ld, scale)
+    s_out, o = ops.pair_attn_fwd(dev(bf(qkv)).view(B * N, 3 * D), up(bias_ld), dev(key_pad), B, N, H, ld, scale)
+    assert ops.pair_is_tiled(s_out) == tiled
     dO = rt(torch.randn(B, N, D, generator=G(3)))
     g_in = torch.randn(B, H, N, N, generator=G(4)).masked_fill(key_pad.view(B, 1, 1, N), 0.0)   # G is 0 at -inf entries
     S, Oref, dqkv_ref, dbias_ref = _pair_ref(qkv, bias, key_pad, H, scale, dO, g_in)
-    s_cpu = s_out.cpu()[..., :N]
+    s_cpu = down(s_out)
     assert torch.equal(torch.isinf(s_cpu), torch.isinf(S.detach()))        # masked columns are exactly -inf
     fin = torch.isfinite(S.detach())
     close(s_cpu[fin], S.detach()[fin], 1e-5, 1e-5)
     close(o.view(B, N, D), rt(Oref), 1e-2, 1e-2)
     g = torch.zeros(B, H, N, ld); g[..., :N] = g_in
-    g = dev(g)
+    g = up(g)
     dqkv = ops.pair_attn_bwd(dev(bf(qkv)).view(B * N, 3 * D), s_out, dev(bf(dO)).view(B * N, D), g, B, N, H, ld, scale, False)
-    close(g.cpu()[..., :N][fin], (dbias_ref + 0)[fin], 1e-4, 1e-4)
+    close(down(g)[fin], (dbias_ref + 0)[fin], 1e-4, 1e-4)
     close(dqkv.view(B, N, 3 * D), rt(dqkv_ref), 2e-2, 2e-2)
     # g_in_zero path == g_in of zeros
-    g2 = dev(torch.full((B, H, N, ld), 7.0))
+    g2 = up(torch.full((B, H, N, ld), 7.0))
     dq2 = ops.pair_attn_bwd(dev(bf(qkv)).view(B * N, 3 * D), s_out, dev(bf(dO)).view(B * N, D), g2, B, N, H, ld, scale, True)
     _, _, dqkv0, dbias0 = _pair_ref(qkv, bias, key_pad, H, scale, dO, None)
-    close(g2.cpu()[..., :N][fin], dbias0[fin], 1e-4, 1e-4)
+    close(down(g2)[fin], dbias0[fin], 1e-4, 1e-4)
     close(dq2.view(B, N, 3 * D), rt(dqkv0), 2e-2, 2e-2)
+    if tiled:   # the two layouts run the same arithmetic: identical bits
+        s_std, o_std = ops.pair_attn_fwd(dev(bf(qkv)).view(B * N, 3 * D), dev(bias_ld), dev(key_pad), B, N, H, ld, scale)
+        assert torch.equal(o_std, o) and torch.equal(s_std.cpu()[..., :N], s_cpu)
+
+
+def test_pair_tile_roundtrip(ops):
+    N = 37
+    x = torch.randn(2, 3, N, N, generator=G(1))
+    t = ops.pair_tile(dev(x), N)
+    assert t.shape == (2, 3, 3, 3, 256) and torch.equal(ops.pair_untile(t, N).cpu(), x)
+    # element (q, k) of tile (q//16, k//16) sits at ((k%16)//4*16 + q%16)*4 + k%4  (MFMA accumulator order)
+    assert t[1, 2, 1, 2, ((35 % 16) // 4 * 16 + 20 % 16) * 4 + 35 % 4].item() == x[1, 2, 20, 35].item()
 
 
 def test_pair_attn_dropout(ops):
@@ -289,6 +306,8 @@ def test_pair_permute(ops):
     g = torch.randn(B, H, N, ld, generator=G(2))
     back = ops.pair_permute_bwd(dev(g), B, N, H, ld)
     assert torch.equal(back.float().cpu().view(B, N, N, H), rt(g[..., :N].permute(0, 2, 3, 1)))
+    back_t = ops.pair_permute_bwd(ops.pair_tile(dev(g), N), B, N, H, ld)                 # same gradient from the tiled layout
+    assert torch.equal(back_t, back)
 
 
 # ------------------------------------------------------------------------------------------- softmax
@@ -578,6 +597,11 @@ def test_gbf_bias_fused_matches_unfused_chain(ops, B, N):
     assert (out[..., N:] == 0).all()
     out2, none = ops.gbf_bias_fwd(*d, dev(bf(w1)), dev(b1), dev(bf(w2)), dev(b2), ld, save=False)
     assert none is None and torch.equal(out2, out)
+    # tiled output: same numbers in the tile layout, every pad slot -inf
+    out_t, _ = ops.gbf_bias_fwd(*d, dev(bf(w1)), dev(b1), dev(bf(w2)), dev(b2), ld, save=False, tiled=True)
+    assert torch.equal(ops.pair_untile(out_t, N), out[..., :N])
+    nt = ops.pair_tiles(N)
+    assert int(torch.isinf(out_t).sum()) == B * H * (nt * nt * 256 - N * N)
     # and against the fp32 oracle of the same chain
     P = {"gbf.means.weight": means.view(1, K), "gbf.stds.weight": stds.view(1, K), "gbf.mul.weight": mul.view(E, 1), "gbf.bias.weight": bias.view(E, 1)}
     g = O.gaussian_layer(dist, et, P) if hasattr(O, "gaussian_layer") else None
