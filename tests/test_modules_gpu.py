@@ -234,6 +234,42 @@ def test_pair_bias_vs_oracle(M):
     compare_param_grads(got, P, 4e-2)
 
 
+def test_unimol_tower_hot_path_layout_vs_oracle(M):
+    """Reference-sized head count / basis (64 heads, 128 Gaussians, 128 hidden): the path the benchmark takes -- fused
+    gbf -> MLP -> TILED pair bias, pair attention streaming the tiled layout, tiled G back into the gbf backward."""
+    from mmdti_hip.functional import PairBiasFn
+    from mmdti_hip import ops
+    B, N, D, H, K, V = 2, 21, 512, 64, 128, 31
+    ucfg = O.UniMolCfg(layers=2, dim=D, ffn=128, heads=H, K=K, vocab=V)
+    cfg = O.ModelCfg(unimol=ucfg, roberta=O.RobertaCfg(layers=1, dim=64, heads=4, ffn=128, vocab=40, max_pos=40), cross=O.CrossCfg(dim=64, heads=4, ffn=128))
+    P = {k: v.requires_grad_() for k, v in O.init_params(cfg, seed=2, std=0.06).items()}
+    g = torch.Generator().manual_seed(5)
+    emb, dist = torch.randn(B, N, D, generator=g), torch.rand(B, N, N, generator=g) * 6
+    et = torch.randint(0, V * V, (B, N, N), generator=g)
+    pad = torch.zeros(B, N, dtype=torch.bool); pad[1, N - 4:] = True
+    dx = torch.randn(B, N, D, generator=g)
+    # oracle
+    er = emb.clone().requires_grad_()
+    bias_o = O.pair_bias(dist, et, P, bf16=True).reshape(B * H, N, N)
+    xo, *_ = O.unimol_encoder(er, bias_o, pad, P, ucfg, bf16=True)
+    (xo * dx).sum().backward()
+    # HIP
+    enc = M.tr.TransformerEncoderWithPair(encoder_layers=2, embed_dim=D, ffn_embed_dim=128, attention_heads=H, no_final_head_layer_norm=True).cuda().eval()
+    gbf, proj = M.mm.GaussianLayer(K, V * V).cuda(), M.mm.NonLinearHead(K, H, "gelu").cuda()
+    load_params(enc, P, "encoder."); load_params(gbf, P, "gbf."); load_params(proj, P, "gbf_proj.")
+    e = emb.cuda().requires_grad_()
+    bias = PairBiasFn.apply(gbf.means.weight, dist.cuda(), et.cuda(), gbf, proj, ops.pair_ld(N))
+    assert ops.pair_is_tiled(bias)
+    x, s_last, _ = enc.encode(e, bias, pad.cuda())
+    assert ops.pair_is_tiled(s_last)
+    check(x, xo, 2e-3, "encoder output (tiled path)")
+    (x * dx.cuda()).sum().backward()
+    check(e.grad, er.grad, 3e-2, "d emb")
+    got = {**grads_of(enc, "encoder."), **grads_of(gbf, "gbf."), **grads_of(proj, "gbf_proj.")}
+    # linear2.bias shifts every key of a (query, head) row alike: softmax-invariant, its gradient is analytically zero
+    compare_param_grads(got, P, 5e-2, skip=("gbf_proj.linear2.bias",))
+
+
 # --------------------------------------------------------------------------------------------- tower 2 (golden G6)
 @pytest.mark.parametrize("impl", ["eager", "sdpa"])
 def test_roberta_tower_golden(M, golden, impl):
