@@ -12,6 +12,8 @@
 //
 // Backward recomputes P from the saved S and carries the running pair gradient G in place:
 //     G_l = G_{l+1} + softmax'(S_l)    dq = scale * G_l k,  dk = scale * G_l^T q,  dv = Pd^T dO
+#include <type_traits>
+
 #include "common.h"
 
 namespace mmdti {
@@ -289,12 +291,12 @@ constexpr int VSTR = 10;  // fp32 row stride of the V image: (4g+t)*10 + d is ba
 
 __device__ __forceinline__ int dperm(int d) { return (d & 3) * 2 + (d >> 2); }  // d and d+4 adjacent: one ds_read_b64
 
-template <int NT>
+template <int NT, bool TILED, bool FULL>
 __global__ __launch_bounds__(256) void pair_attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_in,
                                                                  float* __restrict__ s_out, bf16_t* __restrict__ o,
                                                                  const unsigned char* __restrict__ key_pad, int N, int H, int ld,
                                                                  float scale, uint32_t thresh, float dscale, uint64_t seed,
-                                                                 uint32_t site, int tiled) {
+                                                                 uint32_t site) {
   constexpr int NP = NT * 16;
   __shared__ __attribute__((aligned(16))) float sQ[NP][8];
   __shared__ __attribute__((aligned(16))) float sK[NP][8];
@@ -325,24 +327,39 @@ __global__ __launch_bounds__(256) void pair_attn_fwd_mfma_kernel(const bf16_t* _
   __syncthreads();
   const int g = lane >> 4, c16 = lane & 15;
   const float NEG_INF = -INFINITY;
-  for (int qb = wave; qb < nKB; qb += nwaves) {
+  // Layouts (TILED): row-major [N][ld] planes, or [nKB][nKB][256] planes whose 16x16 tiles are stored in accumulator
+  // order -- a wave's access to a tile is then one contiguous KiB at a compile-time offset from the query block's base,
+  // and, because every pad slot of a tiled tensor holds -inf (written by mmdti_gbf_bias_fwd, preserved by every S
+  // store), interior tiles need no predicate and no pad masking at all.  Only the last query block (EDGE) and the last
+  // key tile keep per-lane predicates.  FULL: nKB == NT, so "last tile" is a compile-time index.
+  const int nlast = nKB - 1;
+  const bool colok = 4 * g < N - 16 * nlast;
+  auto body = [&](int qb, auto edge_c) {
+    constexpr bool EDGE = decltype(edge_c)::value;
     const int qi = qb * 16 + c16;
-    const bool qvalid = qi < N;
-    const long long rowoff = ((long long)bh * N + (qvalid ? qi : 0)) * ld;
+    const bool qvalid = EDGE ? qi < N : true;
+    const long long rowoff = ((long long)bh * N + (qvalid ? qi : 0)) * ld;   // (also the dropout counter base)
     const float2 qv = *reinterpret_cast<const float2*>(&sQ[qb * 16 + c16][2 * g]);
-    // element offset of this lane's float4 of key tile T: row-major [N][ld] planes, or the tiled layout in which every
-    // 16x16 tile is stored in accumulator order (1 KB contiguous per wave access; see ops.pair_tile)
     const long long tbase = ((long long)bh * nKB + qb) * nKB * 256 + lane * 4;
-#define PA_OFF(T) (tiled ? tbase + (T) * 256 : rowoff + (T) * 16 + 4 * g)
-    // Phase 1: request every bias tile of this query block (branch-free predication, so the NT 16-byte loads are issued
-    // back to back and stay in flight together); tiles beyond N are fully masked and cost nothing but idle MFMA slots.
+    const float* bin = bias_in + (TILED ? tbase : rowoff + 4 * g);
+    float* sout = s_out + (TILED ? tbase : rowoff + 4 * g);
+    constexpr int TSTEP = TILED ? 256 : 16;
+#define PA_PRED(T) (!TILED ? (qvalid && (T) * 16 + 4 * g < N) \
+                           : (qvalid && (FULL ? ((T) < NT - 1 || colok) : ((T) < nlast || ((T) == nlast && colok)))))
+    // Phase 1: request every bias tile of this query block (the NT 16-byte loads are issued back to back and stay in
+    // flight together).  Slots that are not loaded: -inf (pad keys), or 0 in a pad ROW (keeps that row's softmax finite;
+    // nothing of it is stored).
+    const float fillv = (TILED && qvalid) ? -INFINITY : 0.f;
     f32x4 S[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int kcol = t * 16 + 4 * g;
-      const bool inrow = qvalid && kcol < N;
-      const f32x4 ld4 = *reinterpret_cast<const f32x4*>(bias_in + (inrow ? PA_OFF(t) : PA_OFF(0)));
-      S[t] = inrow ? ld4 : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (TILED && !EDGE && (FULL ? t < NT - 1 : false)) {
+        S[t] = *reinterpret_cast<const f32x4*>(bin + t * TSTEP);
+      } else {
+        const bool pr = PA_PRED(t);
+        const f32x4 ld4 = *reinterpret_cast<const f32x4*>(bin + (pr ? t * TSTEP : 0));
+        S[t] = pr ? ld4 : f32x4{fillv, fillv, fillv, fillv};
+      }
     }
     float m = NEG_INF;
 #pragma unroll
@@ -353,10 +370,16 @@ __global__ __launch_bounds__(256) void pair_attn_fwd_mfma_kernel(const bf16_t* _
         const float2 ka = *reinterpret_cast<const float2*>(&sK[t * 16 + c16][2 * g]);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.x, qv.x, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.y, qv.y, c, 0, 0, 0);
-        const f32x4 km = *reinterpret_cast<const f32x4*>(&sM[kcol]);
+        if (!TILED || key_pad) {   // (tiled tensors carry -inf in their pad keys already: only a real padding mask is left)
+          const f32x4 km = *reinterpret_cast<const f32x4*>(&sM[kcol]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) c[r] = (km[r] != 0.f) ? NEG_INF : c[r];
-        if (qvalid && kcol < N) *reinterpret_cast<f32x4*>(s_out + PA_OFF(t)) = c;
+          for (int r = 0; r < 4; ++r) c[r] = (km[r] != 0.f) ? NEG_INF : c[r];
+        }
+        if (TILED && !EDGE && (FULL ? t < NT - 1 : false)) {
+          *reinterpret_cast<f32x4*>(sout + t * TSTEP) = c;
+        } else if (PA_PRED(t)) {
+          *reinterpret_cast<f32x4*>(sout + t * TSTEP) = c;
+        }
         S[t] = c;
         m = fmaxf(fmaxf(m, fmaxf(c[0], c[1])), fmaxf(c[2], c[3]));
       }
@@ -401,7 +424,11 @@ __global__ __launch_bounds__(256) void pair_attn_fwd_mfma_kernel(const bf16_t* _
       pk.y = (uint32_t)f2bf(oacc[2]) | ((uint32_t)f2bf(oacc[3]) << 16);
       *reinterpret_cast<uint2*>(o + ((long long)b * N + qi) * D + h * HD + 4 * g) = pk;
     }
-#undef PA_OFF
+#undef PA_PRED
+  };
+  for (int qb = wave; qb < nKB; qb += nwaves) {
+    if (TILED && qb * 16 + 16 <= N) body(qb, std::false_type{});
+    else body(qb, std::true_type{});
   }
 }
 
@@ -416,12 +443,12 @@ __global__ __launch_bounds__(256) void pair_attn_fwd_mfma_kernel(const bf16_t* _
 // Each (query block, key tile) contribution to dK/dV is added to an LDS image shared by the block's waves.
 constexpr int TSTR = 20;  // fp32 row stride of the per-wave transpose patch (16-byte aligned rows)
 
-template <int NT>
+template <int NT, bool TILED, bool FULL>
 __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ s_in,
                                                                  const bf16_t* __restrict__ dO, const float* __restrict__ gin, float* __restrict__ gout,
                                                                  bf16_t* __restrict__ dqkv, int N, int H, int ld, float scale,
                                                                  int g_in_zero, uint32_t thresh, float dscale, uint64_t seed,
-                                                                 uint32_t site, int tiled) {
+                                                                 uint32_t site) {
   constexpr int NP = NT * 16;
   __shared__ __attribute__((aligned(16))) float sQ[NP * VSTR + 8];   // Q * scale
   __shared__ __attribute__((aligned(16))) float sK[NP * VSTR + 8];
@@ -460,12 +487,23 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* _
   const float NEG_INF = -INFINITY;
   float* pP = &patch[wave][0][0];
   float* pG = &patch[wave][1][0];
-  for (int qb = wave; qb < nKB; qb += nwaves) {
+  // (layouts, TILED / FULL / EDGE: see the forward kernel.  In a tiled S every pad slot is -inf and in a tiled G every pad
+  //  slot is 0 -- both are preserved by the stores below --, so interior tiles run without predicates or pad masking.)
+  const int nlast = nKB - 1;
+  const bool colok = 4 * g < N - 16 * nlast;
+  auto body = [&](int qb, auto edge_c) {
+    constexpr bool EDGE = decltype(edge_c)::value;
     const int qi = qb * 16 + c16;
-    const bool qvalid = qi < N;
-    const long long rowoff = ((long long)bh * N + (qvalid ? qi : 0)) * ld;
+    const bool qvalid = EDGE ? qi < N : true;
+    const long long rowoff = ((long long)bh * N + (qvalid ? qi : 0)) * ld;   // (also the dropout counter base)
     const long long tbase = ((long long)bh * nKB + qb) * nKB * 256 + lane * 4;
-#define PA_OFF(T) (tiled ? tbase + (T) * 256 : rowoff + (T) * 16 + 4 * g)
+    const float* sin_p = s_in + (TILED ? tbase : rowoff + 4 * g);
+    const float* gin_p = gin + (TILED ? tbase : rowoff + 4 * g);
+    float* gout_p = gout + (TILED ? tbase : rowoff + 4 * g);
+    constexpr int TSTEP = TILED ? 256 : 16;
+#define PA_PRED(T) (!TILED ? (qvalid && (T) * 16 + 4 * g < N) \
+                           : (qvalid && (FULL ? ((T) < NT - 1 || colok) : ((T) < nlast || ((T) == nlast && colok)))))
+#define PA_FAST(T) (TILED && !EDGE && (FULL ? (T) < NT - 1 : false))
     // B operand of dP^T = V.dO^T : dO[qi][g], dO[qi][g+4]
     const float dob0 = sD[(qb * 16 + c16) * VSTR + g], dob1 = sD[(qb * 16 + c16) * VSTR + g + 4];
     // ---- sweep 1
@@ -475,11 +513,18 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* _
     for (int t = 0; t < NT; ++t) {
       {
         const int kcol = t * 16 + 4 * g;
-        const bool inrow = qvalid && kcol < N;
-        const f32x4 ld4 = *reinterpret_cast<const f32x4*>(s_in + (inrow ? PA_OFF(t) : PA_OFF(0)));
-        f32x4 c = inrow ? ld4 : f32x4{NEG_INF, NEG_INF, NEG_INF, NEG_INF};
+        f32x4 c;
+        if (PA_FAST(t)) {
+          c = *reinterpret_cast<const f32x4*>(sin_p + t * TSTEP);
+        } else {
+          const bool inrow = PA_PRED(t);
+          const f32x4 ld4 = *reinterpret_cast<const f32x4*>(sin_p + (inrow ? t * TSTEP : 0));
+          c = inrow ? ld4 : f32x4{NEG_INF, NEG_INF, NEG_INF, NEG_INF};
+        }
+        if (!TILED) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) c[r] = (kcol + r < N) ? c[r] : NEG_INF;   // pad columns of the row are not data
+          for (int r = 0; r < 4; ++r) c[r] = (kcol + r < N) ? c[r] : NEG_INF;   // pad columns of the row are not data
+        }
         P[t] = c;
         m = fmaxf(fmaxf(m, fmaxf(c[0], c[1])), fmaxf(c[2], c[3]));
       }
@@ -535,30 +580,37 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* _
     f32x4 Gi[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int kcol = t * 16 + 4 * g;
-      const bool inrow = qvalid && kcol < N && !g_in_zero;
-      const f32x4 ld4 = *reinterpret_cast<const f32x4*>(gin + (inrow ? PA_OFF(t) : PA_OFF(0)));
-      Gi[t] = inrow ? ld4 : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (PA_FAST(t)) {
+        const f32x4 ld4 = *reinterpret_cast<const f32x4*>(gin_p + (g_in_zero ? 0 : t * TSTEP));
+        Gi[t] = g_in_zero ? f32x4{0.f, 0.f, 0.f, 0.f} : ld4;
+      } else {
+        const bool inrow = PA_PRED(t) && !g_in_zero;
+        const f32x4 ld4 = *reinterpret_cast<const f32x4*>(gin_p + (inrow ? t * TSTEP : 0));
+        Gi[t] = inrow ? ld4 : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
     f32x4 dq = {0.f, 0.f, 0.f, 0.f};
     const int dcol = dlane ? c16 : 0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int kcol = t * 16 + 4 * g;
-      const bool inrow = qvalid && kcol < N;
       f32x4 G;
 #pragma unroll
       for (int r = 0; r < 4; ++r) G[r] = fabsf(P[t][r]) * (dPm[t][r] - dl) + Gi[t][r];
-      if (t * 16 + 16 > N) {   // only the last key tile has columns beyond N (uniform branch): their G must be exactly 0
+      if (!TILED && t * 16 + 16 > N) {   // only the last key tile has columns beyond N (uniform branch): their G must be exactly 0
 #pragma unroll
         for (int r = 0; r < 4; ++r) G[r] = (kcol + r < N) ? G[r] : 0.f;
       }
-      if (!qvalid) G = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (inrow) *reinterpret_cast<f32x4*>(gout + PA_OFF(t)) = G;
+      if (EDGE && !qvalid) G = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (PA_FAST(t)) {
+        *reinterpret_cast<f32x4*>(gout_p + t * TSTEP) = G;
+      } else if (PA_PRED(t)) {
+        *reinterpret_cast<f32x4*>(gout_p + t * TSTEP) = G;
+      }
       f32x4 Pd;
 #pragma unroll
       for (int r = 0; r < 4; ++r) Pd[r] = P[t][r] > 0.f ? P[t][r] * dscale : 0.f;   // dscale == 1 without dropout
-      if (!qvalid) Pd = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (EDGE && !qvalid) Pd = f32x4{0.f, 0.f, 0.f, 0.f};
       // transpose Pd and G through the wave's LDS patch: written [query][key], read [key][query]
       *reinterpret_cast<f32x4*>(pP + c16 * TSTR + 4 * g) = Pd;
       *reinterpret_cast<f32x4*>(pG + c16 * TSTR + 4 * g) = G;
@@ -600,7 +652,12 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* _
       pk.y = (uint32_t)f2bf(dq[2] * scale) | ((uint32_t)f2bf(dq[3] * scale) << 16);
       *reinterpret_cast<uint2*>(dqkv + ((long long)b * N + qi) * D3 + h * HD + 4 * g) = pk;
     }
-#undef PA_OFF
+#undef PA_PRED
+#undef PA_FAST
+  };
+  for (int qb = wave; qb < nKB; qb += nwaves) {
+    if (TILED && qb * 16 + 16 <= N) body(qb, std::false_type{});
+    else body(qb, std::true_type{});
   }
   __syncthreads();
   for (int key = tid; key < N; key += blockDim.x) {
@@ -647,10 +704,17 @@ extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, 
   if (ld % 4 == 0 && aligned16(bias_in) && aligned16(s_out) && N <= 16 * 13) {
     const int nqb = (N + 15) / 16;
     dim3 blk(nqb % 3 == 0 ? 192 : (nqb < 4 ? 64 * nqb : 256));
-#define PA_M(NT)                                                                                                     \
-  hipLaunchKernelGGL((pair_attn_fwd_mfma_kernel<NT>), grid, blk, 0, s, (const bf16_t*)qkv_bf16, bias_in, s_out,     \
-                     (bf16_t*)o_bf16, key_pad, N, H, ld, scale, th, sc, (uint64_t)seed, (uint32_t)site, tiled)
-    if (nqb <= 5) PA_M(5); else if (nqb <= 9) PA_M(9); else PA_M(13);
+#define PA_M(NT, TL, FL)                                                                                                    \
+  hipLaunchKernelGGL((pair_attn_fwd_mfma_kernel<NT, TL, FL>), grid, blk, 0, s, (const bf16_t*)qkv_bf16, bias_in, s_out,         \
+                     (bf16_t*)o_bf16, key_pad, N, H, ld, scale, th, sc, (uint64_t)seed, (uint32_t)site)
+#define PA_MT(NT)                                                                           \
+  do {                                                                                      \
+    if (!tiled) PA_M(NT, false, false);                                                     \
+    else if (nqb == NT) PA_M(NT, true, true);                                               \
+    else PA_M(NT, true, false);                                                             \
+  } while (0)
+    if (nqb <= 5) PA_MT(5); else if (nqb <= 9) PA_MT(9); else PA_MT(13);
+#undef PA_MT
 #undef PA_M
     MMDTI_LAUNCH_CHECK();
     return MMDTI_OK;
@@ -684,11 +748,18 @@ extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, 
   if (ld % 4 == 0 && aligned16(s) && aligned16(g) && N <= 16 * 13) {
     const int nqb = (N + 15) / 16;
     dim3 blk(nqb % 3 == 0 ? 192 : (nqb < 4 ? 64 * nqb : 256));
-#define PA_MB(NT)                                                                                                    \
-  hipLaunchKernelGGL((pair_attn_bwd_mfma_kernel<NT>), grid, blk, 0, st, (const bf16_t*)qkv_bf16, s,                 \
-                     (const bf16_t*)do_bf16, g, g, (bf16_t*)dqkv_bf16, N, H, ld, scale, g_in_zero, th, sc,         \
-                     (uint64_t)seed, (uint32_t)site, tiled)
-    if (nqb <= 5) PA_MB(5); else if (nqb <= 9) PA_MB(9); else PA_MB(13);
+#define PA_MB(NT, TL, FL)                                                                                                  \
+  hipLaunchKernelGGL((pair_attn_bwd_mfma_kernel<NT, TL, FL>), grid, blk, 0, st, (const bf16_t*)qkv_bf16, s,                  \
+                     (const bf16_t*)do_bf16, g, g, (bf16_t*)dqkv_bf16, N, H, ld, scale, g_in_zero, th, sc,                   \
+                     (uint64_t)seed, (uint32_t)site)
+#define PA_MBT(NT)                                                                          \
+  do {                                                                                      \
+    if (!tiled) PA_MB(NT, false, false);                                                    \
+    else if (nqb == NT) PA_MB(NT, true, true);                                              \
+    else PA_MB(NT, true, false);                                                            \
+  } while (0)
+    if (nqb <= 5) PA_MBT(5); else if (nqb <= 9) PA_MBT(9); else PA_MBT(13);
+#undef PA_MBT
 #undef PA_MB
     MMDTI_LAUNCH_CHECK();
     return MMDTI_OK;

@@ -295,11 +295,12 @@ def _tile_index(N, device):
     return ((q // 16) * nt + k // 16) * 256 + ((k % 16) // 4 * 16 + q % 16) * 4 + k % 4          # [N, N] flat offsets
 
 
-def pair_tile(x, N):
-    """standard [B,H,N,>=N] -> tiled (layout glue for tests / API boundaries; pad slots are 0)."""
+def pair_tile(x, N, pad=float("-inf")):
+    """standard [B,H,N,>=N] -> tiled (layout glue for tests / API boundaries).  Pad slots: -inf for logits-like tensors
+    (the invariant the attention kernels rely on), pass pad=0 for gradients."""
     B, H = x.shape[:2]
     nt = pair_tiles(N)
-    out = torch.zeros(B, H, nt * nt * 256, device=x.device, dtype=x.dtype)
+    out = torch.full((B, H, nt * nt * 256), pad, device=x.device, dtype=x.dtype)
     out[:, :, _tile_index(N, x.device).reshape(-1)] = x[..., :N, :N].reshape(B, H, N * N)
     return out.view(B, H, nt, nt, 256)
 

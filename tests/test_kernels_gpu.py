@@ -217,7 +217,7 @@ def test_pair_attn(ops, B, N, H, tiled):
     D = H * 8
     ld = ops.pair_ld(N)
     scale = 8 ** -0.5
-    up = (lambda t: ops.pair_tile(dev(t), N)) if tiled else dev                      # host standard -> device layout
+    up = (lambda t, pad=float("-inf"): ops.pair_tile(dev(t), N, pad)) if tiled else (lambda t, pad=None: dev(t))   # host standard -> device layout
     down = (lambda t: ops.pair_untile(t, N).cpu()) if tiled else (lambda t: t.cpu()[..., :N])
     qkv = rt(torch.randn(B, N, 3 * D, generator=G(1)))
     bias = torch.randn(B, H, N, N, generator=G(2))
@@ -235,16 +235,37 @@ def test_pair_attn(ops, B, N, H, tiled):
     close(s_cpu[fin], S.detach()[fin], 1e-5, 1e-5)
     close(o.view(B, N, D), rt(Oref), 1e-2, 1e-2)
     g = torch.zeros(B, H, N, ld); g[..., :N] = g_in
-    g = up(g)
+    g = up(g, 0.0)
     dqkv = ops.pair_attn_bwd(dev(bf(qkv)).view(B * N, 3 * D), s_out, dev(bf(dO)).view(B * N, D), g, B, N, H, ld, scale, False)
     close(down(g)[fin], (dbias_ref + 0)[fin], 1e-4, 1e-4)
     close(dqkv.view(B, N, 3 * D), rt(dqkv_ref), 2e-2, 2e-2)
     # g_in_zero path == g_in of zeros
-    g2 = up(torch.full((B, H, N, ld), 7.0))
+    g2 = up(torch.full((B, H, N, ld), 7.0), 0.0)
     dq2 = ops.pair_attn_bwd(dev(bf(qkv)).view(B * N, 3 * D), s_out, dev(bf(dO)).view(B * N, D), g2, B, N, H, ld, scale, True)
     _, _, dqkv0, dbias0 = _pair_ref(qkv, bias, key_pad, H, scale, dO, None)
     close(down(g2)[fin], dbias0[fin], 1e-4, 1e-4)
     close(dq2.view(B, N, 3 * D), rt(dqkv0), 2e-2, 2e-2)
+    # no padding mask at all: the structural pads (keys / queries >= N) must take care of themselves in both layouts
+    s_np, o_np = ops.pair_attn_fwd(dev(bf(qkv)).view(B * N, 3 * D), up(bias_ld), None, B, N, H, ld, scale)
+    qkv_n = qkv.clone()
+    S_np, O_np, dqkv_np, dbias_np = _pair_ref(qkv_n, bias.clone(), None, H, scale, dO, None)
+    close(down(s_np), S_np.detach(), 1e-5, 1e-5)
+    close(o_np.view(B, N, D), rt(O_np), 1e-2, 1e-2)
+    g3 = up(torch.full((B, H, N, ld), 3.0), 0.0)
+    dq3 = ops.pair_attn_bwd(dev(bf(qkv)).view(B * N, 3 * D), s_np, dev(bf(dO)).view(B * N, D), g3, B, N, H, ld, scale, True)
+    close(down(g3), dbias_np, 1e-4, 1e-4)
+    close(dq3.view(B, N, 3 * D), rt(dqkv_np), 2e-2, 2e-2)
+    if tiled:   # pads of a tiled S stay -inf, pads of a tiled G stay 0 (what the next layer's unpredicated loads rely on)
+        nt = ops.pair_tiles(N)
+        assert int(torch.isinf(s_np).sum()) >= 0
+        s_pads = s_np.reshape(B, H, -1).clone(); g_pads = g3.reshape(B, H, -1).clone()
+        idx = ops._tile_index(N, s_np.device).reshape(-1)
+        s_pads[:, :, idx] = float("-inf"); g_pads[:, :, idx] = 0.0
+        full_q = (N // 16) * 16                                  # rows of complete query blocks: every slot of their tiles is defined
+        tiles = s_pads.view(B, H, nt, nt, 256)[:, :, :N // 16] if N >= 16 else None
+        if tiles is not None and tiles.numel():
+            lastcol_ok = torch.isinf(tiles[:, :, :, nt - 1].reshape(B, H, -1, 4, 16, 4)[..., :max(1, (N - 16 * (nt - 1) + 3) // 4), :, :]).all()
+            assert lastcol_ok
     if tiled:   # the two layouts run the same arithmetic: identical bits
         s_std, o_std = ops.pair_attn_fwd(dev(bf(qkv)).view(B * N, 3 * D), dev(bias_ld), dev(key_pad), B, N, H, ld, scale)
         assert torch.equal(o_std, o) and torch.equal(s_std.cpu()[..., :N], s_cpu)
@@ -306,7 +327,7 @@ def test_pair_permute(ops):
     g = torch.randn(B, H, N, ld, generator=G(2))
     back = ops.pair_permute_bwd(dev(g), B, N, H, ld)
     assert torch.equal(back.float().cpu().view(B, N, N, H), rt(g[..., :N].permute(0, 2, 3, 1)))
-    back_t = ops.pair_permute_bwd(ops.pair_tile(dev(g), N), B, N, H, ld)                 # same gradient from the tiled layout
+    back_t = ops.pair_permute_bwd(ops.pair_tile(dev(g), N, 0.0), B, N, H, ld)                 # same gradient from the tiled layout
     assert torch.equal(back_t, back)
 
 
