@@ -574,12 +574,16 @@ class LinearF32Fn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, act):
         x = x.contiguous()
         y = ops.linear_f32_fwd(x, weight, bias, act)
-        ctx.sv = (x, weight, bias, y, act)
+        # y is this node's OUTPUT: it must go through save_for_backward -- kept as a plain attribute it closes a reference
+        # cycle (node -> y -> grad_fn -> node) that keeps the whole step's graph alive until the cyclic GC runs
+        ctx.save_for_backward(y)
+        ctx.sv = (x, weight, bias, act)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, bias, y, act = ctx.sv
+        x, weight, bias, act = ctx.sv
+        (y,) = ctx.saved_tensors
         dx = ops.linear_f32_bwd(x, weight, y, dy.contiguous(), gbuf(weight), None if bias is None else gbuf(bias), act, want_dx=ctx.needs_input_grad[0])
         notify_grads_ready([weight] if bias is None else [weight, bias])
         return dx, None, None, None

@@ -87,3 +87,33 @@ def test_training_reduces_loss_and_fds_pass():
     assert float(model.FDS.epoch) == 1.0 and float(model.FDS.num_samples_tracked.sum()) == 32.0
     sd = model.state_dict()
     assert torch.isfinite(sd["FDS.running_mean"]).all() and float(sd["FDS.running_var"].min()) >= 0
+
+
+@pytest.mark.parametrize("task,odim", [("classification", 2), ("regression", 1)])
+def test_step_leaves_no_reference_cycles(task, odim):
+    """A step must free its whole autograd graph by reference counting.  A node that keeps one of its own OUTPUT tensors
+    as a plain attribute closes a cycle (node -> tensor -> grad_fn -> node); the graph -- gigabytes of saved activations
+    at the benchmark shape -- then survives until Python's cyclic collector runs and the caching allocator thrashes."""
+    import gc
+    from mmdti_hip.trainer import FineTuner
+    ocfg = _ocfg(task, odim)
+    batch, label = O.synth_batch(6, 9, 12, ocfg, seed=1, ragged=True)
+    dev = {k: v.cuda() for k, v in batch.items()}
+    tuner = FineTuner(_model(task, odim).train(), task, total_steps=10)
+    tuner.step(dev, label.cuda(), epoch=0)
+    gc.collect()
+    base = torch.cuda.memory_allocated()
+    gc.disable()
+    try:
+        for _ in range(3):
+            tuner.step(dev, label.cuda(), epoch=0)
+        grown = torch.cuda.memory_allocated() - base
+        gc.set_debug(gc.DEBUG_SAVEALL)
+        gc.collect()
+        leaked = [o for o in gc.garbage if isinstance(o, torch.Tensor)]
+    finally:
+        gc.set_debug(0)
+        gc.garbage.clear()
+        gc.enable()
+    assert not leaked, f"{len(leaked)} tensors were only reachable through reference cycles"
+    assert grown < (1 << 20), f"device memory grew by {grown} bytes over 3 steps"
