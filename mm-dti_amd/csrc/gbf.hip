@@ -341,6 +341,33 @@ __global__ __launch_bounds__(256) void gbf_bias_fwd_kernel(const float* __restri
   }
 }
 
+// Tiled G ([B,H,nt,nt,256], tiles in accumulator order) -> [B,N,N,H] bf16.  One block per (molecule, query block, key
+// tile): the 64 head tiles are 64 contiguous KiB reads; the 16x16 pairs x H heads are regrouped in LDS so that each of
+// the 16 query rows leaves as one contiguous run of 16 keys x H heads.
+__global__ __launch_bounds__(256) void pair_untile_bwd_kernel(const float* __restrict__ g, bf16_t* __restrict__ out, int N, int H,
+                                                              int nt) {
+  extern __shared__ bf16_t ptile[];  // [256 pairs][H + 2]
+  const int HP = H + 2;
+  const int t = blockIdx.x % nt, qb = (blockIdx.x / nt) % nt, b = blockIdx.x / (nt * nt);
+  const long long plane = (long long)nt * nt * 256;
+  const float* src = g + (long long)b * H * plane + ((long long)qb * nt + t) * 256;
+  for (int e = threadIdx.x; e < H * 64; e += 256) {      // one float4 (4 keys of one query) per step
+    const int h = e >> 6, l = e & 63;
+    const float4 v = *reinterpret_cast<const float4*>(src + (long long)h * plane + l * 4);
+    const int q = l & 15, k0 = (l >> 4) * 4;
+    bf16_t* d = ptile + (q * 16 + k0) * HP + h;
+    d[0] = f2bf(v.x); d[HP] = f2bf(v.y); d[2 * HP] = f2bf(v.z); d[3 * HP] = f2bf(v.w);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 256 * (H / 2); e += 256) {   // two heads (4 bytes) per step
+    const int pr = e / (H / 2), h2 = e - pr * (H / 2);
+    const int i = qb * 16 + (pr >> 4), j = t * 16 + (pr & 15);
+    if (i < N && j < N)
+      *reinterpret_cast<uint32_t*>(out + (((long long)b * N + i) * N + j) * H + 2 * h2) =
+          *reinterpret_cast<const uint32_t*>(ptile + pr * HP + 2 * h2);
+  }
+}
+
 }  // namespace mmdti
 using namespace mmdti;
 
@@ -392,6 +419,13 @@ extern "C" int mmdti_pair_permute_fwd(mmdti_stream_t stream, const float* x, flo
 extern "C" int mmdti_pair_permute_bwd(mmdti_stream_t stream, const float* g, void* out_bf16, int B, int N, int H,
                                       int ld, int tiled) {
   MMDTI_REQUIRE(g && out_bf16 && B > 0 && N > 0 && H > 0 && ld >= N, "pair_permute_bwd: bad arguments");
+  if (tiled && H % 2 == 0 && (size_t)256 * (H + 2) * 2 <= 64 * 1024 && aligned16(g)) {
+    const int nt = (N + 15) / 16;
+    hipLaunchKernelGGL(pair_untile_bwd_kernel, dim3(B * nt * nt), dim3(256), (size_t)256 * (H + 2) * 2, (hipStream_t)stream, g,
+                       (bf16_t*)out_bf16, N, H, nt);
+    MMDTI_LAUNCH_CHECK();
+    return MMDTI_OK;
+  }
   const size_t smem = (size_t)H * (N | 1) * sizeof(float);
   MMDTI_REQUIRE(smem <= 64 * 1024, "pair_permute_bwd: N*H too large for the LDS tile (N=%d,H=%d)", N, H);
   hipLaunchKernelGGL(pair_permute_bwd_kernel, dim3(B * N), dim3(256), smem, (hipStream_t)stream, g, (bf16_t*)out_bf16,
