@@ -341,6 +341,176 @@ __global__ __launch_bounds__(256) void gbf_bias_fwd_kernel(const float* __restri
   }
 }
 
+// =====================================================================================================================
+// Fused pair-bias backward, the per-pair half (mm_model.py:553-556 backward):
+//   dO = bf16(G)                                  [P,64]   -> written (A operand of dW2 = dO^T.hidden, and db2)
+//   du = bf16((dO.W2) * gelu'(u))                 [P,128]  -> written (A operand of dW1 = du^T.basis, and db1)
+//   dbasis = bf16(du.W1) -> Gaussian backward -> d mul/bias (LDS histogram over edge types), d means/stds
+// in ONE pass over G: replaces the G re-layout, two dX GEMMs over P = 4.3 M rows and the Gaussian-backward kernel, and
+// the [P,128] dbasis tensor never exists.  Same transposed-operand scheme and pair enumeration as the forward kernel;
+// the two weight-gradient GEMMs (contraction over the 4.3 M pairs) stay on the GEMM kernel.
+constexpr int GBF_W2S = 72;   // LDS row stride of W2^T [128 f][64 h]: 144-B rows, conflict-free ds_read_b128 fragments
+
+template <bool TILED>
+__global__ __launch_bounds__(256) void gbf_bias_bwd_kernel(const float* __restrict__ gsrc, const float* __restrict__ dist,
+                                                           const long long* __restrict__ et, const float* __restrict__ mul,
+                                                           const float* __restrict__ bias, const float* __restrict__ means,
+                                                           const float* __restrict__ stds, const bf16_t* __restrict__ W1,
+                                                           const bf16_t* __restrict__ W2, const bf16_t* __restrict__ u_in,
+                                                           bf16_t* __restrict__ do_out, bf16_t* __restrict__ du_out,
+                                                           float* __restrict__ dmul, float* __restrict__ dbias,
+                                                           float* __restrict__ dmeans, float* __restrict__ dstds, int B, int N, int ld,
+                                                           int E, int tpm) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gbf_smem[];
+  bf16_t* sW1T = reinterpret_cast<bf16_t*>(gbf_smem);   // [128 k][136]  W1^T[k][f], f in k-slot order
+  bf16_t* sW2T = sW1T + GBF_K * GBF_WS;                  // [128 f][72]   W2^T[f][h]
+  float* sMu = reinterpret_cast<float*>(sW2T + GBF_F * GBF_W2S);
+  float* sIs = sMu + GBF_K;
+  float* sCf = sIs + GBF_K;
+  float* hist = sCf + GBF_K;                             // [2][E]
+  const int tid = threadIdx.x, lane = tid & 63;
+  // W1^T with the feature (contraction) axis in k-slot order: slot 32u+8g+4hf+e <- feature 32u+16hf+4g+e
+  for (int c = tid; c < GBF_K * GBF_F; c += 256) {
+    const int f = c >> 7, k = c & 127;                   // coalesced read of W1[f][k]
+    const int u = f >> 5, hf = (f >> 4) & 1, g = (f >> 2) & 3, e = f & 3;
+    sW1T[k * GBF_WS + 32 * u + 8 * g + 4 * hf + e] = W1[c];
+  }
+  for (int c = tid; c < GBF_H * GBF_F; c += 256) {
+    const int h = c >> 7, f = c & 127;
+    sW2T[f * GBF_W2S + h] = W2[c];
+  }
+  if (tid < GBF_K) {
+    const float sg = fabsf(stds[tid]) + 1e-5f;
+    sMu[tid] = means[tid];
+    sIs[tid] = 1.0f / sg;
+    sCf[tid] = 1.0f / (GBF_A * sg);
+  }
+  for (int c = tid; c < 2 * E; c += 256) hist[c] = 0.f;
+  __syncthreads();
+  const int g = lane >> 4, i = lane & 15;
+  const long long ntiles = (long long)B * tpm;
+  const long long nwaves = (long long)gridDim.x * 4;
+  const int nt = (N + 15) >> 4, nblk = nt * 4;
+  const long long plane = TILED ? (long long)nt * nt * 256 : (long long)N * ld;
+  // d means / d stds partial sums of this lane: k = 16*kt + 4g + r
+  gf32x4 amu[8], asg[8];
+#pragma unroll
+  for (int kt = 0; kt < 8; ++kt) amu[kt] = asg[kt] = gf32x4{0.f, 0.f, 0.f, 0.f};
+  for (long long tile = (long long)blockIdx.x * 4 + (tid >> 6); tile < ntiles; tile += nwaves) {
+    const int b = (int)(tile / tpm);
+    const int tq = (int)(tile - (long long)b * tpm);
+    int q, ii, jj;
+    if (TILED) {
+      const int rb = tq / nblk, cb = tq - rb * nblk;
+      if (4 * rb >= N || 4 * cb >= N) continue;          // whole block past N (the same for every lane of the wave)
+      ii = 4 * rb + (i >> 2);
+      jj = 4 * cb + (i & 3);
+      q = ((rb >> 2) * nt + (cb >> 2)) * 256 + (cb & 3) * 64 + (rb & 3) * 16 + i;
+    } else {
+      q = tq * 16 + i;
+      ii = q / ld;
+      jj = q - ii * ld;
+    }
+    const bool valid = ii < N && jj < N;
+    const long long p = ((long long)b * N + (valid ? ii : 0)) * N + (valid ? jj : 0);
+    long long e = et[p];
+    e = e < 0 ? 0 : (e >= E ? E - 1 : e);
+    const float d = dist[p];
+    const float y = mul[e] * d + bias[e];
+    // dO^T in B-operand form: lane (g, pair i) holds heads 32c + 8g + 0..7
+    const float* gp = gsrc + (long long)b * GBF_H * plane + (valid ? q : 0);
+    gbf16x8 oB[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = valid ? gp[(long long)(32 * c + 8 * g + j) * plane] : 0.f;
+      oB[c] = gbf_pack8(v);
+      if (valid) *reinterpret_cast<gbf16x8*>(do_out + p * GBF_H + 32 * c + 8 * g) = oB[c];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // du^T = (W2^T . dO^T) * gelu'(u): accumulator rows = features 16*ft + 4g + r
+    gbf16x8 uB[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      gf32x4 dv[2];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int ft = 2 * u + hf;
+        gf32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const gbf16x8 wf = *reinterpret_cast<const gbf16x8*>(sW2T + (16 * ft + i) * GBF_W2S + 32 * c + 8 * g);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, oB[c], acc, 0, 0, 0);
+        }
+        uint2 up = make_uint2(0u, 0u);
+        if (valid) up = *reinterpret_cast<const uint2*>(u_in + p * GBF_F + 16 * ft + 4 * g);
+        acc[0] *= gelu_erf_grad(__uint_as_float(up.x << 16));
+        acc[1] *= gelu_erf_grad(__uint_as_float(up.x & 0xffff0000u));
+        acc[2] *= gelu_erf_grad(__uint_as_float(up.y << 16));
+        acc[3] *= gelu_erf_grad(__uint_as_float(up.y & 0xffff0000u));
+        if (valid) *reinterpret_cast<uint2*>(du_out + p * GBF_F + 16 * ft + 4 * g) = gbf_pack4(acc);
+        dv[hf] = acc;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      float v[8] = {dv[0][0], dv[0][1], dv[0][2], dv[0][3], dv[1][0], dv[1][1], dv[1][2], dv[1][3]};
+      uB[u] = gbf_pack8(v);
+    }
+    // dbasis^T = W1^T . du^T: rows = Gaussian kernels 16*kt + 4g + r; Gaussian backward on the accumulator layout
+    float dy = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+      gf32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const gbf16x8 wf = *reinterpret_cast<const gbf16x8*>(sW1T + (16 * kt + i) * GBF_WS + 32 * u + 8 * g);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, uB[u], acc, 0, 0, 0);
+      }
+      const gf32x4 mu = *reinterpret_cast<const gf32x4*>(sMu + 16 * kt + 4 * g);
+      const gf32x4 is = *reinterpret_cast<const gf32x4*>(sIs + 16 * kt + 4 * g);
+      const gf32x4 cf = *reinterpret_cast<const gf32x4*>(sCf + 16 * kt + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float dvr = __uint_as_float(((uint32_t)f2bf(acc[r])) << 16);   // dbasis passes through bf16 like the unfused chain
+        const float z = (y - mu[r]) * is[r];
+        const float val = __expf(-0.5f * z * z) * cf[r];
+        const float t = valid ? dvr * val : 0.f;
+        const float zs = z * is[r];
+        dy -= t * zs;
+        amu[kt][r] += t * zs;
+        asg[kt][r] += t * (z * zs - is[r]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    dy += __shfl_xor(dy, 16, 64);
+    dy += __shfl_xor(dy, 32, 64);
+    if (g == 0 && valid) {
+      atomicAdd(&hist[e], dy * d);
+      atomicAdd(&hist[E + e], dy);
+    }
+  }
+  // d means / d stds: sum over the 16 pair lanes of each lane group, one atomic per (wave, k)
+#pragma unroll
+  for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float a = amu[kt][r], sgv = asg[kt][r];
+      a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64); a += __shfl_xor(a, 8, 64);
+      sgv += __shfl_xor(sgv, 1, 64); sgv += __shfl_xor(sgv, 2, 64); sgv += __shfl_xor(sgv, 4, 64); sgv += __shfl_xor(sgv, 8, 64);
+      if (i == 0) {
+        const int k = 16 * kt + 4 * g + r;
+        atomicAdd(dmeans + k, a);
+        atomicAdd(dstds + k, stds[k] < 0.f ? -sgv : sgv);   // d|std|/dstd
+      }
+    }
+  __syncthreads();
+  for (int c = tid; c < E; c += 256) {
+    const float a = hist[c], bb = hist[E + c];
+    if (a != 0.f) atomicAdd(dmul + c, a);
+    if (bb != 0.f) atomicAdd(dbias + c, bb);
+  }
+}
+
 // Tiled G ([B,H,nt,nt,256], tiles in accumulator order) -> [B,N,N,H] bf16.  One block per (molecule, query block, key
 // tile): the 64 head tiles are 64 contiguous KiB reads; the 16x16 pairs x H heads are regrouped in LDS so that each of
 // the 16 query rows leaves as one contiguous run of 16 keys x H heads.
@@ -458,6 +628,41 @@ extern "C" int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, cons
   if (save) { if (tiled) GBF_L(true, true); else GBF_L(true, false); }
   else      { if (tiled) GBF_L(false, true); else GBF_L(false, false); }
 #undef GBF_L
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_gbf_bias_bwd(mmdti_stream_t stream, const float* g, const float* dist, const long long* edge_type,
+                                  const float* mul, const float* bias, const float* means, const float* stds,
+                                  const void* w1_bf16, const void* w2_bf16, const void* u_bf16, int B, int N, int ld, int K,
+                                  int F, int H, int E, int tiled, void* do_bf16, void* du_bf16, float* dmul, float* dbias,
+                                  float* dmeans, float* dstds) {
+  MMDTI_REQUIRE(g && dist && edge_type && mul && bias && means && stds && w1_bf16 && w2_bf16 && u_bf16 && do_bf16 && du_bf16 && dmul &&
+                    dbias && dmeans && dstds, "gbf_bias_bwd: null argument");
+  MMDTI_REQUIRE(K == GBF_K && F == GBF_F && H == GBF_H, "gbf_bias_bwd: built for %d gaussians, %d hidden, %d heads (got %d,%d,%d)",
+                GBF_K, GBF_F, GBF_H, K, F, H);
+  MMDTI_REQUIRE(B > 0 && N > 0 && ld >= N && ld % 4 == 0 && E > 0 && E <= GBF_MAXE, "gbf_bias_bwd: bad shape (E <= %d)", GBF_MAXE);
+  MMDTI_REQUIRE(aligned16(u_bf16) && aligned16(do_bf16) && aligned16(du_bf16), "gbf_bias_bwd: 16-byte alignment required");
+  const int nt = (N + 15) / 16;
+  const int tpm = tiled ? 16 * nt * nt : cdiv((long long)N * ld, 16);
+  const long long ntiles = (long long)B * tpm;
+  const int grid = (int)(ntiles / 4 + 1 < 1024 ? ntiles / 4 + 1 : 1024);
+  const size_t smem = (size_t)GBF_K * GBF_WS * 2 + (size_t)GBF_F * GBF_W2S * 2 + (size_t)(3 * GBF_K + 2 * E) * 4;
+  static bool attr_done = false;
+  if (!attr_done && smem > 65536) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gbf_bias_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gbf_bias_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
+      set_error("gbf_bias_bwd: hipFuncSetAttribute failed");
+      return MMDTI_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+#define GBF_B(TILED)                                                                                                          \
+  hipLaunchKernelGGL((gbf_bias_bwd_kernel<TILED>), dim3(grid), dim3(256), smem, (hipStream_t)stream, g, dist, edge_type, mul, bias, \
+                     means, stds, (const bf16_t*)w1_bf16, (const bf16_t*)w2_bf16, (const bf16_t*)u_bf16, (bf16_t*)do_bf16,    \
+                     (bf16_t*)du_bf16, dmul, dbias, dmeans, dstds, B, N, ld, E, tpm)
+  if (tiled) GBF_B(true); else GBF_B(false);
+#undef GBF_B
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }

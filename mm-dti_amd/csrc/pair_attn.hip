@@ -341,9 +341,12 @@ __global__ __launch_bounds__(256) void pair_attn_fwd_mfma_kernel(const bf16_t* _
     const long long rowoff = ((long long)bh * N + (qvalid ? qi : 0)) * ld;   // (also the dropout counter base)
     const float2 qv = *reinterpret_cast<const float2*>(&sQ[qb * 16 + c16][2 * g]);
     const long long tbase = ((long long)bh * nKB + qb) * nKB * 256 + lane * 4;
-    const float* bin = bias_in + (TILED ? tbase : rowoff + 4 * g);
-    float* sout = s_out + (TILED ? tbase : rowoff + 4 * g);
+    // (row-major: the lane's 4 keys of tile t start at rowoff + 16t + 4g; a lane whose predicate is off reads the row's
+    //  first 16 bytes instead -- always inside the tensor, unlike "tile 0 + 4g" when ld < 16)
+    const float* bin = bias_in + (TILED ? tbase : rowoff);
+    float* sout = s_out + (TILED ? tbase : rowoff);
     constexpr int TSTEP = TILED ? 256 : 16;
+    const int goff = TILED ? 0 : 4 * g;
 #define PA_PRED(T) (!TILED ? (qvalid && (T) * 16 + 4 * g < N) \
                            : (qvalid && (FULL ? ((T) < NT - 1 || colok) : ((T) < nlast || ((T) == nlast && colok)))))
     // Phase 1: request every bias tile of this query block (the NT 16-byte loads are issued back to back and stay in
@@ -354,10 +357,10 @@ __global__ __launch_bounds__(256) void pair_attn_fwd_mfma_kernel(const bf16_t* _
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       if (TILED && !EDGE && (FULL ? t < NT - 1 : false)) {
-        S[t] = *reinterpret_cast<const f32x4*>(bin + t * TSTEP);
+        S[t] = *reinterpret_cast<const f32x4*>(bin + t * TSTEP + goff);
       } else {
         const bool pr = PA_PRED(t);
-        const f32x4 ld4 = *reinterpret_cast<const f32x4*>(bin + (pr ? t * TSTEP : 0));
+        const f32x4 ld4 = *reinterpret_cast<const f32x4*>(bin + (pr ? t * TSTEP + goff : 0));
         S[t] = pr ? ld4 : f32x4{fillv, fillv, fillv, fillv};
       }
     }
@@ -376,9 +379,9 @@ __global__ __launch_bounds__(256) void pair_attn_fwd_mfma_kernel(const bf16_t* _
           for (int r = 0; r < 4; ++r) c[r] = (km[r] != 0.f) ? NEG_INF : c[r];
         }
         if (TILED && !EDGE && (FULL ? t < NT - 1 : false)) {
-          *reinterpret_cast<f32x4*>(sout + t * TSTEP) = c;
+          *reinterpret_cast<f32x4*>(sout + t * TSTEP + goff) = c;
         } else if (PA_PRED(t)) {
-          *reinterpret_cast<f32x4*>(sout + t * TSTEP) = c;
+          *reinterpret_cast<f32x4*>(sout + t * TSTEP + goff) = c;
         }
         S[t] = c;
         m = fmaxf(fmaxf(m, fmaxf(c[0], c[1])), fmaxf(c[2], c[3]));
@@ -497,10 +500,11 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* _
     const bool qvalid = EDGE ? qi < N : true;
     const long long rowoff = ((long long)bh * N + (qvalid ? qi : 0)) * ld;   // (also the dropout counter base)
     const long long tbase = ((long long)bh * nKB + qb) * nKB * 256 + lane * 4;
-    const float* sin_p = s_in + (TILED ? tbase : rowoff + 4 * g);
-    const float* gin_p = gin + (TILED ? tbase : rowoff + 4 * g);
-    float* gout_p = gout + (TILED ? tbase : rowoff + 4 * g);
+    const float* sin_p = s_in + (TILED ? tbase : rowoff);     // (predicate-off lanes read the row's first 16 bytes: in bounds)
+    const float* gin_p = gin + (TILED ? tbase : rowoff);
+    float* gout_p = gout + (TILED ? tbase : rowoff);
     constexpr int TSTEP = TILED ? 256 : 16;
+    const int goff = TILED ? 0 : 4 * g;
 #define PA_PRED(T) (!TILED ? (qvalid && (T) * 16 + 4 * g < N) \
                            : (qvalid && (FULL ? ((T) < NT - 1 || colok) : ((T) < nlast || ((T) == nlast && colok)))))
 #define PA_FAST(T) (TILED && !EDGE && (FULL ? (T) < NT - 1 : false))
@@ -515,10 +519,10 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* _
         const int kcol = t * 16 + 4 * g;
         f32x4 c;
         if (PA_FAST(t)) {
-          c = *reinterpret_cast<const f32x4*>(sin_p + t * TSTEP);
+          c = *reinterpret_cast<const f32x4*>(sin_p + t * TSTEP + goff);
         } else {
           const bool inrow = PA_PRED(t);
-          const f32x4 ld4 = *reinterpret_cast<const f32x4*>(sin_p + (inrow ? t * TSTEP : 0));
+          const f32x4 ld4 = *reinterpret_cast<const f32x4*>(sin_p + (inrow ? t * TSTEP + goff : 0));
           c = inrow ? ld4 : f32x4{NEG_INF, NEG_INF, NEG_INF, NEG_INF};
         }
         if (!TILED) {
@@ -581,11 +585,11 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* _
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       if (PA_FAST(t)) {
-        const f32x4 ld4 = *reinterpret_cast<const f32x4*>(gin_p + (g_in_zero ? 0 : t * TSTEP));
+        const f32x4 ld4 = *reinterpret_cast<const f32x4*>(gin_p + (g_in_zero ? 0 : t * TSTEP + goff));
         Gi[t] = g_in_zero ? f32x4{0.f, 0.f, 0.f, 0.f} : ld4;
       } else {
         const bool inrow = PA_PRED(t) && !g_in_zero;
-        const f32x4 ld4 = *reinterpret_cast<const f32x4*>(gin_p + (inrow ? t * TSTEP : 0));
+        const f32x4 ld4 = *reinterpret_cast<const f32x4*>(gin_p + (inrow ? t * TSTEP + goff : 0));
         Gi[t] = inrow ? ld4 : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
@@ -603,9 +607,9 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* _
       }
       if (EDGE && !qvalid) G = f32x4{0.f, 0.f, 0.f, 0.f};
       if (PA_FAST(t)) {
-        *reinterpret_cast<f32x4*>(gout_p + t * TSTEP) = G;
+        *reinterpret_cast<f32x4*>(gout_p + t * TSTEP + goff) = G;
       } else if (PA_PRED(t)) {
-        *reinterpret_cast<f32x4*>(gout_p + t * TSTEP) = G;
+        *reinterpret_cast<f32x4*>(gout_p + t * TSTEP + goff) = G;
       }
       f32x4 Pd;
 #pragma unroll

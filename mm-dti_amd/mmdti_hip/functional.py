@@ -169,7 +169,8 @@ class PairBiasFn(torch.autograd.Function):
         H = proj.linear2.weight.shape[0]
         dist, edge_type = dist.contiguous(), edge_type.contiguous()
         args = [gbf.mul.weight.view(-1), gbf.bias.weight.view(-1), gbf.means.weight.view(-1), gbf.stds.weight.view(-1)]
-        if ops.gbf_bias_eligible(args[2].numel(), proj.linear1.weight.shape[0], H, ld):
+        fused = ops.gbf_bias_eligible(args[2].numel(), proj.linear1.weight.shape[0], H, ld)
+        if fused:
             # one kernel from distances to the [B,H,N,ld] bias; the three [P,128] intermediates are saved for the backward
             # (tiled pair layout whenever the MFMA pair-attention kernels can take it: their loads become contiguous KiBs)
             out, (feat, u, h) = ops.gbf_bias_fwd(dist, edge_type, *args, wbf16(proj.linear1.weight), proj.linear1.bias,
@@ -180,22 +181,31 @@ class PairBiasFn(torch.autograd.Function):
             h = ops.linear_fwd(feat, wbf16(proj.linear1.weight), proj.linear1.bias, act=ops.ACT_GELU, aux_out=u)
             o = ops.linear_fwd(h, wbf16(proj.linear2.weight), proj.linear2.bias, out_dtype=F32)
             out = ops.pair_permute_fwd(o, B, N, H, ld)
-        ctx.st = SimpleNamespace(dist=dist, et=edge_type, feat=feat, u=u, h=h, B=B, N=N, H=H, ld=ld)
+        ctx.st = SimpleNamespace(dist=dist, et=edge_type, feat=feat, u=u, h=h, B=B, N=N, H=H, ld=ld, fused=fused)
         ctx.gbf, ctx.proj = gbf, proj
         return out
 
     @staticmethod
     def backward(ctx, g):
         st, gbf, proj = ctx.st, ctx.gbf, ctx.proj
-        do = ops.pair_permute_bwd(g.contiguous(), st.B, st.N, st.H, st.ld)          # [P,H] bf16
-        _lin_bwd_params(do, st.h, proj.linear2.weight, proj.linear2.bias)
-        du = ops.linear_bwd_input(do, wbf16(proj.linear2.weight), act=ops.ACT_GELU_BWD, aux_in=st.u)
-        _lin_bwd_params(du, st.feat, proj.linear1.weight, proj.linear1.bias)
-        dfeat = ops.linear_bwd_input(du, wbf16(proj.linear1.weight))
         ps = [gbf.mul.weight, gbf.bias.weight, gbf.means.weight, gbf.stds.weight]
-        if any(p.requires_grad for p in ps):
+        if st.fused and ps[0].numel() <= 4096:
+            # one pass over G: re-layout, both dX products, GELU' and the Gaussian backward; only the two weight-gradient
+            # GEMMs (contraction over all pairs) and their column sums remain
             grads = [gbuf(p) if p.requires_grad else torch.zeros_like(p) for p in ps]
-            ops.gbf_features_bwd(st.dist, st.et, *[p.view(-1) for p in ps], dfeat, *[gr.view(-1) for gr in grads])
+            do, du = ops.gbf_bias_bwd(g.contiguous(), st.dist, st.et, *[p.view(-1) for p in ps], wbf16(proj.linear1.weight),
+                                      wbf16(proj.linear2.weight), st.u, st.ld, *[gr.view(-1) for gr in grads])
+            _lin_bwd_params(do, st.h, proj.linear2.weight, proj.linear2.bias)
+            _lin_bwd_params(du, st.feat, proj.linear1.weight, proj.linear1.bias)
+        else:
+            do = ops.pair_permute_bwd(g.contiguous(), st.B, st.N, st.H, st.ld)          # [P,H] bf16
+            _lin_bwd_params(do, st.h, proj.linear2.weight, proj.linear2.bias)
+            du = ops.linear_bwd_input(do, wbf16(proj.linear2.weight), act=ops.ACT_GELU_BWD, aux_in=st.u)
+            _lin_bwd_params(du, st.feat, proj.linear1.weight, proj.linear1.bias)
+            dfeat = ops.linear_bwd_input(du, wbf16(proj.linear1.weight))
+            if any(p.requires_grad for p in ps):
+                grads = [gbuf(p) if p.requires_grad else torch.zeros_like(p) for p in ps]
+                ops.gbf_features_bwd(st.dist, st.et, *[p.view(-1) for p in ps], dfeat, *[gr.view(-1) for gr in grads])
         notify_grads_ready(list(gbf.parameters()) + list(proj.parameters()))
         return None, None, None, None, None, None
 
@@ -359,6 +369,16 @@ class RobertaEncoderFn(torch.autograd.Function):
             if g is not None:
                 ops.embedding_bwd_gemm(ids, de16, g, pad)
         notify_grads_ready(mod.embeddings.parameters())
+        # This tower may be running on a side stream (MM_Model overlaps the two towers) and writes its parameter gradients
+        # itself, so autograd sees no leaf on this stream and would not join it at the end of backward(): queue the join.
+        here = torch.cuda.current_stream()
+
+        def _join(stream=here):
+            cur = torch.cuda.current_stream()
+            if cur != stream:
+                cur.wait_stream(stream)
+
+        torch.autograd.Variable._execution_engine.queue_callback(_join)
         return None, None, None, None, None
 
 

@@ -241,6 +241,20 @@ def gbf_bias_fwd(dist, edge_type, mul, bias, means, stds, w1, b1, w2, b2, ld, sa
     return out, saved
 
 
+def gbf_bias_bwd(g, dist, edge_type, mul, bias, means, stds, w1, w2, u, ld, dmul, dbias, dmeans, dstds):
+    """Per-pair half of the fused pair-bias backward -> (do [P,64] bf16, du [P,128] bf16); Gaussian grads accumulated."""
+    B, N, _ = dist.shape
+    Hh, Fh = w2.shape
+    P = B * N * N
+    do = torch.empty(P, Hh, device=g.device, dtype=BF16)
+    du = torch.empty(P, Fh, device=g.device, dtype=BF16)
+    lib().mmdti_gbf_bias_bwd(_stream(), g.data_ptr(), dist.data_ptr(), edge_type.data_ptr(), mul.data_ptr(), bias.data_ptr(), means.data_ptr(),
+                             stds.data_ptr(), w1.data_ptr(), w2.data_ptr(), u.data_ptr(), B, N, ld, w1.shape[1], Fh, Hh, mul.numel(),
+                             int(pair_is_tiled(g)), do.data_ptr(), du.data_ptr(), dmul.data_ptr(), dbias.data_ptr(), dmeans.data_ptr(),
+                             dstds.data_ptr())
+    return do, du
+
+
 def gbf_bias_eligible(K, Fh, Hh, ld):
     return K == 128 and Fh == 128 and Hh == 64 and ld % 4 == 0
 
