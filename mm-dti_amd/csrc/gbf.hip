@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void gbf_bias_fwd_kernel(const float* __restri
 constexpr int GBF_W2S = 72;   // LDS row stride of W2^T [128 f][64 h]: 144-B rows, conflict-free ds_read_b128 fragments
 
 template <bool TILED>
-__global__ __launch_bounds__(256) void gbf_bias_bwd_kernel(const float* __restrict__ gsrc, const float* __restrict__ dist,
+__global__ __launch_bounds__(256, 2) void gbf_bias_bwd_kernel(const float* __restrict__ gsrc, const float* __restrict__ dist,
                                                            const long long* __restrict__ et, const float* __restrict__ mul,
                                                            const float* __restrict__ bias, const float* __restrict__ means,
                                                            const float* __restrict__ stds, const bf16_t* __restrict__ W1,
@@ -368,7 +368,13 @@ __global__ __launch_bounds__(256) void gbf_bias_bwd_kernel(const float* __restri
   float* sIs = sMu + GBF_K;
   float* sCf = sIs + GBF_K;
   float* hist = sCf + GBF_K;                             // [2][E]
+  float* sMul = hist + 2 * E;                            // [E] mul, [E] bias (the per-pair affine of the Gaussian layer)
+  float* sBia = sMul + E;
   const int tid = threadIdx.x, lane = tid & 63;
+  for (int c = tid; c < E; c += 256) {
+    sMul[c] = mul[c];
+    sBia[c] = bias[c];
+  }
   // W1^T with the feature (contraction) axis in k-slot order: slot 32u+8g+4hf+e <- feature 32u+16hf+4g+e
   for (int c = tid; c < GBF_K * GBF_F; c += 256) {
     const int f = c >> 7, k = c & 127;                   // coalesced read of W1[f][k]
@@ -396,13 +402,22 @@ __global__ __launch_bounds__(256) void gbf_bias_bwd_kernel(const float* __restri
   gf32x4 amu[8], asg[8];
 #pragma unroll
   for (int kt = 0; kt < 8; ++kt) amu[kt] = asg[kt] = gf32x4{0.f, 0.f, 0.f, 0.f};
-  for (long long tile = (long long)blockIdx.x * 4 + (tid >> 6); tile < ntiles; tile += nwaves) {
+  // Software pipeline over pair tiles: the index math and every global load of tile t+1 (edge type, distance, the 16 head
+  // values of G, the 8 saved pre-activation quads) are issued before tile t is computed -- at 2 waves per SIMD nothing
+  // else hides the ~2 us round trips.
+  auto fetch = [&](long long tile, bool& act, bool& valid, long long& p, int& e, float& d, float (&gv)[16], uint2 (&up)[8]) {
+    act = false;
+    valid = false;
+    p = 0;
+    e = 0;
+    d = 0.f;
+    if (tile >= ntiles) return;
     const int b = (int)(tile / tpm);
     const int tq = (int)(tile - (long long)b * tpm);
     int q, ii, jj;
     if (TILED) {
       const int rb = tq / nblk, cb = tq - rb * nblk;
-      if (4 * rb >= N || 4 * cb >= N) continue;          // whole block past N (the same for every lane of the wave)
+      if (4 * rb >= N || 4 * cb >= N) return;            // whole block past N (the same for every lane of the wave)
       ii = 4 * rb + (i >> 2);
       jj = 4 * cb + (i & 3);
       q = ((rb >> 2) * nt + (cb >> 2)) * 256 + (cb & 3) * 64 + (rb & 3) * 16 + i;
@@ -411,23 +426,40 @@ __global__ __launch_bounds__(256) void gbf_bias_bwd_kernel(const float* __restri
       ii = q / ld;
       jj = q - ii * ld;
     }
-    const bool valid = ii < N && jj < N;
-    const long long p = ((long long)b * N + (valid ? ii : 0)) * N + (valid ? jj : 0);
-    long long e = et[p];
-    e = e < 0 ? 0 : (e >= E ? E - 1 : e);
-    const float d = dist[p];
-    const float y = mul[e] * d + bias[e];
-    // dO^T in B-operand form: lane (g, pair i) holds heads 32c + 8g + 0..7
+    act = true;
+    valid = ii < N && jj < N;
+    p = ((long long)b * N + (valid ? ii : 0)) * N + (valid ? jj : 0);
+    long long e64 = et[p];
+    e = (int)(e64 < 0 ? 0 : (e64 >= E ? E - 1 : e64));
+    d = dist[p];
     const float* gp = gsrc + (long long)b * GBF_H * plane + (valid ? q : 0);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gv[c * 8 + j] = valid ? gp[(long long)(32 * c + 8 * g + j) * plane] : 0.f;
+#pragma unroll
+    for (int ft = 0; ft < 8; ++ft) {
+      up[ft] = make_uint2(0u, 0u);
+      if (valid) up[ft] = *reinterpret_cast<const uint2*>(u_in + p * GBF_F + 16 * ft + 4 * g);
+    }
+  };
+  bool act, valid, n_act, n_valid;
+  long long p, n_p;
+  int e, n_e;
+  float d, n_d, gv[16], n_gv[16];
+  uint2 upre[8], n_up[8];
+  long long tile = (long long)blockIdx.x * 4 + (tid >> 6);
+  fetch(tile, act, valid, p, e, d, gv, upre);
+  for (; tile < ntiles; tile += nwaves) {
+    fetch(tile + nwaves, n_act, n_valid, n_p, n_e, n_d, n_gv, n_up);
+    if (act) {
+    const float y = sMul[e] * d + sBia[e];
+    // dO^T in B-operand form: lane (g, pair i) holds heads 32c + 8g + 0..7
     gbf16x8 oB[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = valid ? gp[(long long)(32 * c + 8 * g + j) * plane] : 0.f;
-      oB[c] = gbf_pack8(v);
+      oB[c] = gbf_pack8(gv + 8 * c);
       if (valid) *reinterpret_cast<gbf16x8*>(do_out + p * GBF_H + 32 * c + 8 * g) = oB[c];
-      __builtin_amdgcn_sched_barrier(0);
     }
     // du^T = (W2^T . dO^T) * gelu'(u): accumulator rows = features 16*ft + 4g + r
     gbf16x8 uB[4];
@@ -443,8 +475,7 @@ __global__ __launch_bounds__(256) void gbf_bias_bwd_kernel(const float* __restri
           const gbf16x8 wf = *reinterpret_cast<const gbf16x8*>(sW2T + (16 * ft + i) * GBF_W2S + 32 * c + 8 * g);
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, oB[c], acc, 0, 0, 0);
         }
-        uint2 up = make_uint2(0u, 0u);
-        if (valid) up = *reinterpret_cast<const uint2*>(u_in + p * GBF_F + 16 * ft + 4 * g);
+        const uint2 up = upre[ft];
         acc[0] *= gelu_erf_grad(__uint_as_float(up.x << 16));
         acc[1] *= gelu_erf_grad(__uint_as_float(up.x & 0xffff0000u));
         acc[2] *= gelu_erf_grad(__uint_as_float(up.y << 16));
@@ -488,6 +519,12 @@ __global__ __launch_bounds__(256) void gbf_bias_bwd_kernel(const float* __restri
       atomicAdd(&hist[e], dy * d);
       atomicAdd(&hist[E + e], dy);
     }
+    }  // act
+    act = n_act; valid = n_valid; p = n_p; e = n_e; d = n_d;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) gv[j] = n_gv[j];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) upre[j] = n_up[j];
   }
   // d means / d stds: sum over the 16 pair lanes of each lane group, one atomic per (wave, k)
 #pragma unroll
@@ -647,9 +684,10 @@ extern "C" int mmdti_gbf_bias_bwd(mmdti_stream_t stream, const float* g, const f
   const int tpm = tiled ? 16 * nt * nt : cdiv((long long)N * ld, 16);
   const long long ntiles = (long long)B * tpm;
   const int grid = (int)(ntiles / 4 + 1 < 1024 ? ntiles / 4 + 1 : 1024);
-  const size_t smem = (size_t)GBF_K * GBF_WS * 2 + (size_t)GBF_F * GBF_W2S * 2 + (size_t)(3 * GBF_K + 2 * E) * 4;
+  const size_t smem = (size_t)GBF_K * GBF_WS * 2 + (size_t)GBF_F * GBF_W2S * 2 + (size_t)(3 * GBF_K + 4 * E) * 4;
+  MMDTI_REQUIRE(smem <= 96 * 1024, "gbf_bias_bwd: %d edge types do not fit the LDS tables", E);
   static bool attr_done = false;
-  if (!attr_done && smem > 65536) {
+  if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gbf_bias_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(gbf_bias_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
       set_error("gbf_bias_bwd: hipFuncSetAttribute failed");

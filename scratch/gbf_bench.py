@@ -19,3 +19,13 @@ w1=(torch.randn(Fh,K,generator=g)*0.2).cuda().bfloat16(); b1=(torch.randn(Fh,gen
 w2=(torch.randn(H,Fh,generator=g)*0.2).cuda().bfloat16(); b2=(torch.randn(H,generator=g)*0.1).cuda()
 bench("fused save=True", lambda: ops.gbf_bias_fwd(dist,et,mul,bias,means,stds,w1,b1,w2,b2,ld,save=True))
 bench("fused save=False", lambda: ops.gbf_bias_fwd(dist,et,mul,bias,means,stds,w1,b1,w2,b2,ld,save=False))
+out,(feat,u,h)=ops.gbf_bias_fwd(dist,et,mul,bias,means,stds,w1,b1,w2,b2,ld,save=True,tiled=True)
+G=torch.randn_like(out); G[torch.isinf(out)]=0
+gr=[torch.zeros_like(t) for t in (mul,bias,means,stds)]
+bench("fused bwd per-pair", lambda: ops.gbf_bias_bwd(G,dist,et,mul,bias,means,stds,w1,w2,u,ld,*gr))
+def old():
+    do=ops.pair_permute_bwd(G,B,N,H,ld)
+    du=ops.linear_bwd_input(do,w2,act=ops.ACT_GELU_BWD,aux_in=u)
+    df=ops.linear_bwd_input(du,w1)
+    ops.gbf_features_bwd(dist,et,mul,bias,means,stds,df,*gr)
+bench("unfused chain (same outputs)", old)

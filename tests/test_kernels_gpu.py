@@ -632,6 +632,40 @@ def test_gbf_bias_fused_matches_unfused_chain(ops, B, N):
         close(out[..., :N], want, 3e-2, 5e-2)
 
 
+@pytest.mark.parametrize("tiled", [False, True])
+@pytest.mark.parametrize("B,N", [(2, 13), (2, 37), (1, 130)])
+def test_gbf_bias_bwd_fused_matches_unfused_chain(ops, B, N, tiled):
+    """One pass over G vs (re-layout, dX GEMM with GELU', dX GEMM, Gaussian backward): same bf16 rounding points."""
+    K, Fh, H, E = 128, 128, 64, 31 * 31
+    ld = ops.pair_ld(N)
+    gen = G(11)
+    dist = torch.rand(B, N, N, generator=gen) * 8
+    et = torch.randint(0, E, (B, N, N), generator=gen)
+    mul, bias = 1 + 0.1 * torch.randn(E, generator=gen), 0.1 * torch.randn(E, generator=gen)
+    means, stds = torch.rand(K, generator=gen) * 3, torch.rand(K, generator=gen) * 3 - 1.5
+    w1, w2 = dev(bf(torch.randn(Fh, K, generator=gen) * 0.2)), dev(bf(torch.randn(H, Fh, generator=gen) * 0.2))
+    b1, b2 = dev(torch.randn(Fh, generator=gen) * 0.1), dev(torch.randn(H, generator=gen) * 0.1)
+    d = [dev(t) for t in (dist, et, mul, bias, means, stds)]
+    _, (feat, u, h) = ops.gbf_bias_fwd(*d, w1, b1, w2, b2, ld, save=True, tiled=tiled)
+    g_std = torch.zeros(B, H, N, ld); g_std[..., :N] = torch.randn(B, H, N, N, generator=gen)
+    g = ops.pair_tile(dev(g_std), N, 0.0) if tiled else dev(g_std)
+    # unfused chain
+    do_r = ops.pair_permute_bwd(g, B, N, H, ld)
+    du_r = ops.linear_bwd_input(do_r, w2, act=ops.ACT_GELU_BWD, aux_in=u)
+    df_r = ops.linear_bwd_input(du_r, w1)
+    gr_r = [torch.zeros_like(t) for t in d[2:]]
+    ops.gbf_features_bwd(*d, df_r, *gr_r)
+    # fused
+    gr = [torch.zeros_like(t) for t in d[2:]]
+    do, du = ops.gbf_bias_bwd(g, *d, w1, w2, u, ld, *gr)
+    assert torch.equal(do, do_r)
+    close(du, du_r, 1e-2, 1e-3)
+    assert float((du.float() - du_r.float()).abs().mean()) < 2e-3 * float(du_r.float().abs().mean()) + 1e-6
+    for a, b_, name in zip(gr, gr_r, ("dmul", "dbias", "dmeans", "dstds")):
+        r = float((a - b_).norm() / (b_.norm() + 1e-12))
+        assert r < 2e-2, (name, r)
+
+
 # ------------------------------------------------------------------------------------------- fused attention
 def _attn_ref(q, k, v, add, heads, scale, keep=None, p_drop=0.0):
     """fp32 torch restatement on bf16-rounded operands (oracle mha, mmdti_oracle.py:320-338, minus the Linears)."""
