@@ -35,13 +35,9 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 
 // ---- bf16 <-> f32 ----------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even; NaN stays NaN, +-inf stays inf.
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// round-to-nearest-even; NaN stays NaN, +-inf stays inf.  gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32):
+// one instruction instead of the six of the integer formulation.
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 
 // ---- wave-level reductions (64 lanes) on the DPP crossbar -------------------------------------------------------
 // v_*_dpp reads a neighbour lane as part of a normal VALU op (~1 issue slot) whereas __shfl_xor lowers to ds_bpermute
@@ -148,7 +144,7 @@ static inline uint32_t dropout_thresh(float p) {
 // FMAs instead of ocml's branchy erff (~40 instructions) -- the GELU epilogue was costing 40 % of the fc1 GEMM.
 __device__ __forceinline__ float fast_erf(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);   // v_rcp_f32 (1 ulp); __frcp_rn expands to a 10-instruction IEEE divide
   const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
   const float r = 1.0f - poly * __expf(-ax * ax);
   return copysignf(r, x);
