@@ -150,9 +150,15 @@ __device__ __forceinline__ float fast_erf(float x) {
   return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
+// gelu'(x) = Phi(x) + x*phi(x); the Gaussian exp(-x^2/2) is the same exponential the erf approximation evaluates
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float kInvSqrt2Pi = 0.39894228040143267794f;
-  return 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f)) + x * kInvSqrt2Pi * __expf(-0.5f * x * x);
+  const float ax = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+  const float e = __expf(-ax * ax);
+  const float erfv = copysignf(1.0f - poly * e, x);
+  return 0.5f * (1.0f + erfv) + x * kInvSqrt2Pi * e;
 }
 
 }  // namespace mmdti
