@@ -73,11 +73,13 @@ int mmdti_layernorm_fwd(mmdti_stream_t stream, const float* x, const float* gamm
  * dy_add (fp32, nullable) is a second upstream gradient of the LN OUTPUT (post-LN residual: a = LN(y) feeds both the FFN
  * and the next residual add); dres (fp32, nullable) is a gradient of the LN INPUT that bypasses the LN (pre-LN residual). */
 /* dx_bf16 (nullable): a second copy of dx for the next backward GEMM, with the dropout-backward of site2 (probability
- * drop2_p, same seed) applied and rounded to bf16 -- saves the separate cast pass over dx. */
+ * drop2_p, same seed) applied and rounded to bf16 -- saves the separate cast pass over dx.  dx_colsum (nullable, [D] fp32,
+ * +=): column sums of that bf16 copy = the bias gradient of the Linear whose output gradient it is. */
 int mmdti_layernorm_bwd(mmdti_stream_t stream, const void* dy, int dy_dtype, const float* dy_add, const float* x, const float* gamma,
                         const float* mean, const float* rstd, int rows, int D, const float* dres, float* dx,
                         float* dgamma, float* dbeta, const unsigned char* row_zero, float drop_p,
-                        unsigned long long seed, unsigned int site, void* dx_bf16, float drop2_p, unsigned int site2);
+                        unsigned long long seed, unsigned int site, void* dx_bf16, float drop2_p, unsigned int site2,
+                        float* dx_colsum);
 
 /* ---- small utilities ------------------------------------------------------------------------ */
 /* out[c] += sum_r x[r,c]  (bias gradients of every Linear) */

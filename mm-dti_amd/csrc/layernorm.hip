@@ -82,13 +82,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const unsigned char* __restrict__ row_zero, uint32_t thresh,
                                                      float dscale, uint64_t seed, uint32_t site,
                                                      bf16_t* __restrict__ dx_bf16, uint32_t thresh2, float dscale2,
-                                                     uint32_t site2) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [2][4][D]
+                                                     uint32_t site2, float* __restrict__ dx_colsum) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [3][4][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = D >> 2;
-  float4 ag[NV], ab[NV];
+  float4 ag[NV], ab[NV], ac[NV];   // dgamma, dbeta, column sums of the bf16 copy (the next Linear's bias gradient)
 #pragma unroll
-  for (int i = 0; i < NV; ++i) ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < NV; ++i) ag[i] = ab[i] = ac[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   const int row_base = (blockIdx.x * 4 + wave) * LN_BWD_ROWS_PER_WAVE;
   for (int rr = 0; rr < LN_BWD_ROWS_PER_WAVE; ++rr) {
     const int row = row_base + rr;
@@ -153,6 +153,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         pk.x = (uint32_t)f2bf(o.x) | ((uint32_t)f2bf(o.y) << 16);
         pk.y = (uint32_t)f2bf(o.z) | ((uint32_t)f2bf(o.w) << 16);
         reinterpret_cast<uint2*>(dx_bf16 + (long long)row * D)[c] = pk;
+        if (dx_colsum) {   // sums the ROUNDED values: exactly what a column-sum pass over dx_bf16 would add up
+          ac[i].x += __uint_as_float(pk.x << 16); ac[i].y += __uint_as_float(pk.x & 0xffff0000u);
+          ac[i].z += __uint_as_float(pk.y << 16); ac[i].w += __uint_as_float(pk.y & 0xffff0000u);
+        }
       }
     }
   }
@@ -167,12 +171,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
       reinterpret_cast<float4*>(rb)[c] = ab[i];
     }
   }
+  if (dx_colsum) {
+    float* rc = red + 8 * D + wave * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int c = lane + i * 64;
+      if (c < nvec) reinterpret_cast<float4*>(rc)[c] = ac[i];
+    }
+  }
   __syncthreads();
   for (int c = threadIdx.x; c < D; c += 256) {
     float g = red[c] + red[D + c] + red[2 * D + c] + red[3 * D + c];
     float b = red[4 * D + c] + red[5 * D + c] + red[6 * D + c] + red[7 * D + c];
     if (dgamma) atomicAdd(dgamma + c, g);
     if (dbeta) atomicAdd(dbeta + c, b);
+    if (dx_colsum) atomicAdd(dx_colsum + c, red[8 * D + c] + red[9 * D + c] + red[10 * D + c] + red[11 * D + c]);
   }
 }
 
@@ -211,7 +224,7 @@ extern "C" int mmdti_layernorm_bwd(mmdti_stream_t stream, const void* dy, int dy
                                    const float* gamma, const float* mean, const float* rstd, int rows, int D,
                                    const float* dres, float* dx, float* dgamma, float* dbeta,
                                    const unsigned char* row_zero, float drop_p, unsigned long long seed,
-                                   unsigned int site, void* dx_bf16, float drop2_p, unsigned int site2) {
+                                   unsigned int site, void* dx_bf16, float drop2_p, unsigned int site2, float* dx_colsum) {
   MMDTI_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 2048, "layernorm_bwd: need rows>0, D%%4==0, D<=2048 (D=%d)", D);
   MMDTI_REQUIRE(dy && x && gamma && mean && rstd && dx, "layernorm_bwd: null pointer");
   MMDTI_REQUIRE(dy_dtype == MMDTI_DT_F32 || dy_dtype == MMDTI_DT_BF16, "layernorm_bwd: bad dy dtype");
@@ -223,11 +236,12 @@ extern "C" int mmdti_layernorm_bwd(mmdti_stream_t stream, const void* dy, int dy
   const uint32_t th2 = dropout_thresh(drop2_p);
   const float sc2 = drop2_p > 0.f ? 1.f / (1.f - drop2_p) : 1.f;
   dim3 grid(cdiv(rows, 4 * LN_BWD_ROWS_PER_WAVE)), block(256);
-  const size_t smem = 8 * (size_t)D * sizeof(float);
+  MMDTI_REQUIRE(!dx_colsum || dx_bf16, "layernorm_bwd: dx_colsum sums the bf16 copy, which was not requested");
+  const size_t smem = 12 * (size_t)D * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
 #define LN_B(NV, BF)                                                                                               \
   hipLaunchKernelGGL((ln_bwd_kernel<NV, BF>), grid, block, smem, s, dy, dy_add, x, gamma, mean, rstd, rows, D, dres, dx,  \
-                     dgamma, dbeta, row_zero, th, sc, (uint64_t)seed, (uint32_t)site, (bf16_t*)dx_bf16, th2, sc2, (uint32_t)site2)
+                     dgamma, dbeta, row_zero, th, sc, (uint64_t)seed, (uint32_t)site, (bf16_t*)dx_bf16, th2, sc2, (uint32_t)site2, dx_colsum)
   const bool bf = dy_dtype == MMDTI_DT_BF16;
   switch (ln_nv(D)) {
     case 1: if (bf) LN_B(1, true); else LN_B(1, false); break;

@@ -23,12 +23,13 @@ from .runtime import wbf16, gbuf, dropout_state, notify_grads_ready
 
 
 # ------------------------------------------------------------------------------------------------- helpers
-def _lin_bwd_params(dy_bf16, x_bf16, weight, bias, rows=None):
-    """dW += dy^T x ; db += colsum(dy)   (atomic accumulation into param.grad)."""
+def _lin_bwd_params(dy_bf16, x_bf16, weight, bias, rows=None, bias_done=False):
+    """dW += dy^T x ; db += colsum(dy)   (atomic accumulation into param.grad).  bias_done: the kernel that produced dy
+    already accumulated its column sums (LayerNorm backward's bf16 copy)."""
     gw = gbuf(weight)
     if gw is not None:
         ops.linear_bwd_weight(dy_bf16, x_bf16, gw, rows=rows)
-    if bias is not None:
+    if bias is not None and not bias_done:
         gb = gbuf(bias)
         if gb is not None:
             ops.colsum(dy_bf16, gb, cols=bias.numel())
@@ -115,7 +116,7 @@ class PairEncoderFn(torch.autograd.Function):
         dout = dout.contiguous().view(M, D)
         if mod.final_layer_norm is not None:
             fl = mod.final_layer_norm
-            nxt = (st.p_res, st.layers[-1].site_f) if st.layers else None
+            nxt = (st.p_res, st.layers[-1].site_f, gbuf(mod.layers[-1].fc2.bias)) if st.layers else None
             dx = ops.layernorm_bwd(dout, st.x_last, fl.weight, st.f_mean, st.f_rstd, gbuf(fl.weight), gbuf(fl.bias), bf16_copy=nxt)
             dx, dx16 = dx if nxt is not None else (dx, None)
         else:
@@ -127,14 +128,14 @@ class PairEncoderFn(torch.autograd.Function):
             # ---- FFN:  x2 = x1 + drop(fc2(gelu(fc1(LN2(x1)))))
             # (dx16 = bf16 dropout-backward copy of dx, written by the LayerNorm backward that produced dx)
             dy2 = dx16 if dx16 is not None else ops.cast_bf16(dx, st.p_res, seed, L.site_f)
-            _lin_bwd_params(dy2, L.a, layer.fc2.weight, layer.fc2.bias)
+            _lin_bwd_params(dy2, L.a, layer.fc2.weight, layer.fc2.bias, bias_done=dx16 is not None)
             du = ops.linear_bwd_input(dy2, wbf16(layer.fc2.weight), act=ops.ACT_GELU_BWD, aux_in=L.u)
             _lin_bwd_params(du, L.h2, layer.fc1.weight, layer.fc1.bias)
             dh2 = ops.linear_bwd_input(du, wbf16(layer.fc1.weight))
             dx, dy1 = ops.layernorm_bwd(dh2, L.x1, ln2.weight, L.m2, L.r2, gbuf(ln2.weight), gbuf(ln2.bias), dres=dx,
-                                        bf16_copy=(st.p_res, L.site_o))
+                                        bf16_copy=(st.p_res, L.site_o, gbuf(att.out_proj.bias)))
             # ---- attention:  x1 = x + drop(out_proj(attn(LN1(x))))
-            _lin_bwd_params(dy1, L.o, att.out_proj.weight, att.out_proj.bias)
+            _lin_bwd_params(dy1, L.o, att.out_proj.weight, att.out_proj.bias, bias_done=True)
             do = ops.linear_bwd_input(dy1, wbf16(att.out_proj.weight))
             g_zero = G is None
             if g_zero:
@@ -144,7 +145,7 @@ class PairEncoderFn(torch.autograd.Function):
             dh1 = ops.linear_bwd_input(dqkv, wbf16(att.in_proj.weight))
             if li > 0:
                 dx, dx16 = ops.layernorm_bwd(dh1, L.x, ln1.weight, L.m1, L.r1, gbuf(ln1.weight), gbuf(ln1.bias), dres=dx,
-                                             bf16_copy=(st.p_res, below[li - 1]))
+                                             bf16_copy=(st.p_res, below[li - 1], gbuf(mod.layers[li - 1].fc2.bias)))
             else:
                 dx, dx16 = ops.layernorm_bwd(dh1, L.x, ln1.weight, L.m1, L.r1, gbuf(ln1.weight), gbuf(ln1.bias), dres=dx), None
             L.__dict__.clear()       # release this layer's activations (S_l is ~1 GB at the bench shape)
@@ -269,14 +270,14 @@ def _bert_layer_bwd(st, L, dout, seed):
     B, Lq, Lk, D = st.B, st.Lq, st.Lk, st.D
     W, heads, ld = L.W, L.heads, L.ld
     hd = D // heads
-    dz, dzb = ops.layernorm_bwd(dout, L.z, W.ln2_w, L.zm, L.zr, gbuf(W.ln2_w), gbuf(W.ln2_b), bf16_copy=(L.p_hid, L.site_f))
-    _lin_bwd_params(dzb, L.i, W.o2_w, W.o2_b)
+    dz, dzb = ops.layernorm_bwd(dout, L.z, W.ln2_w, L.zm, L.zr, gbuf(W.ln2_w), gbuf(W.ln2_b), bf16_copy=(L.p_hid, L.site_f, gbuf(W.o2_b)))
+    _lin_bwd_params(dzb, L.i, W.o2_w, W.o2_b, bias_done=True)
     du = ops.linear_bwd_input(dzb, wbf16(W.o2_w), act=ops.ACT_GELU_BWD, aux_in=L.u)
     _lin_bwd_params(du, L.a16, W.i_w, W.i_b)
     da = ops.linear_bwd_input(du, wbf16(W.i_w))
     # a32 = LN1(y) feeds the FFN AND the residual add of z: both gradients go through LN1's backward
-    dy, dyb = ops.layernorm_bwd(da, L.y, W.ln1_w, L.am, L.ar, gbuf(W.ln1_w), gbuf(W.ln1_b), dy_add=dz, bf16_copy=(L.p_hid, L.site_o))
-    _lin_bwd_params(dyb, L.ctx, W.o_w, W.o_b)
+    dy, dyb = ops.layernorm_bwd(da, L.y, W.ln1_w, L.am, L.ar, gbuf(W.ln1_w), gbuf(W.ln1_b), dy_add=dz, bf16_copy=(L.p_hid, L.site_o, gbuf(W.o_b)))
+    _lin_bwd_params(dyb, L.ctx, W.o_w, W.o_b, bias_done=True)
     dctx = ops.linear_bwd_input(dyb, wbf16(W.o_w))
     dev = dout.device
     if L.fused:

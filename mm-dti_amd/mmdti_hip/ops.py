@@ -124,16 +124,17 @@ def layernorm_fwd(x, gamma, beta, eps, *, want_f32=False, want_bf16=True, row_ze
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, *, dres=None, dy_add=None, row_zero=None, drop_p=0.0, seed=0, site=0,
                   bf16_copy=None):
-    """-> dx (fp32); with bf16_copy=(p, site) also the bf16 dropout-backward copy of dx for the next GEMM: (dx, dx16)."""
+    """-> dx (fp32); with bf16_copy=(p, site[, colsum_out]) also the bf16 dropout-backward copy of dx for the next GEMM (and
+    its column sums accumulated into colsum_out): (dx, dx16)."""
     D = x.shape[-1]
     rows = x.numel() // D
     dx = torch.empty_like(x)
     rz = _u8(row_zero)
     dx16 = torch.empty(x.shape, device=x.device, dtype=BF16) if bf16_copy is not None else None
-    p2, site2 = bf16_copy if bf16_copy is not None else (0.0, 0)
+    p2, site2, csum = (tuple(bf16_copy) + (None,))[:3] if bf16_copy is not None else (0.0, 0, None)
     lib().mmdti_layernorm_bwd(_stream(), dy.data_ptr(), DT_BF16 if dy.dtype == BF16 else DT_F32, _p(dy_add), x.data_ptr(), gamma.data_ptr(),
                               mean.data_ptr(), rstd.data_ptr(), rows, D, _p(dres), dx.data_ptr(), _p(dgamma), _p(dbeta), _p(rz),
-                              float(drop_p), int(seed), int(site), _p(dx16), float(p2), int(site2))
+                              float(drop_p), int(seed), int(site), _p(dx16), float(p2), int(site2), _p(csum))
     return dx if bf16_copy is None else (dx, dx16)
 
 

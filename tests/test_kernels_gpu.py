@@ -182,6 +182,12 @@ def test_layernorm_bwd_fused_bf16_copy(ops):
         ref = ops.cast_bf16(dx, p, 11, 7)
         assert torch.equal(dx16, ref)
         assert torch.equal(dx, ops.layernorm_bwd(dev(dy), dev(x), dev(g), mean, rstd, dg, db))
+        # and its column sums (the next Linear's bias gradient) == the separate column-sum pass over the same bf16 tensor
+        cs = torch.full((D,), 0.5, device="cuda")
+        _, dx16b = ops.layernorm_bwd(dev(dy), dev(x), dev(g), mean, rstd, dg, db, bf16_copy=(p, 7, cs), seed=11)
+        want = ops.colsum(dx16, torch.full((D,), 0.5, device="cuda"))
+        assert torch.equal(dx16b, dx16)
+        close(cs, want, 1e-5, 1e-4)
 
 
 # ------------------------------------------------------------------------------------------- pair attention
