@@ -112,6 +112,8 @@ def main():
 
     model, rcfg = build_model()
     model = model.to(dev).train()
+    if os.environ.get("MMDTI_NO_OVERLAP") == "1":      # A/B switch: run the two towers back to back on one stream
+        model.overlap_towers = False
     tuner = FineTuner(model, "classification", total_steps=10_000, distributed=(world > 1 or os.environ.get("MMDTI_FORCE_DDP") == "1"))
     _, batch, label = synth(args.batch, args.atoms, args.tokens, seed=1234 + rank, ragged=args.ragged)
     batch = {k: v.to(dev) for k, v in batch.items()}
