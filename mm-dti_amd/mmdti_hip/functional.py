@@ -19,7 +19,7 @@ import torch
 
 from . import ops
 from .ops import BF16, F32
-from .runtime import wbf16, gbuf, dropout_state, notify_grads_ready
+from .runtime import fused_views, wbf16, gbuf, dropout_state, notify_grads_ready
 
 
 # ------------------------------------------------------------------------------------------------- helpers
@@ -236,11 +236,28 @@ def _bert_layer_fwd(st, s1_32, s1_16, s2_16, key_add, W, heads, p_hid, p_att, ep
     hd = D // heads
     ld = (Lk + 7) // 8 * 8
     L = SimpleNamespace(s1_16=s1_16, s2_16=s2_16, ld=ld, heads=heads, self_attn=self_attn, W=W, eps=eps)
-    L.q = ops.linear_fwd(s1_16, wbf16(W.q_w), W.q_b)
-    L.k = ops.linear_fwd(s2_16, wbf16(W.k_w), W.k_b)
-    L.v = ops.linear_fwd(s2_16, wbf16(W.v_w), W.v_b)
     L.site_att = sites.next()
     L.key_add, L.fused = key_add, ops.attn_eligible(Lq, Lk, hd, D)
+    # query/key/value as ONE GEMM when their parameters sit back to back in the arena (trainer._qkv_groups) and the fused
+    # attention kernels (which take row-strided q/k/v) run: [3D, D] for self-attention, [2D, D] (key|value) otherwise
+    L.fw = L.fb = None
+    if L.fused and W.q_b is not None:
+        plist_w, plist_b = ((W.q_w, W.k_w, W.v_w), (W.q_b, W.k_b, W.v_b)) if self_attn else ((W.k_w, W.v_w), (W.k_b, W.v_b))
+        L.fw, L.fb = fused_views(plist_w), fused_views(plist_b)
+        if L.fw is None or L.fb is None:
+            L.fw = L.fb = None
+    if L.fw is not None:
+        if self_attn:
+            L.qkv = ops.linear_fwd(s1_16, L.fw[0], L.fb[1])
+            L.q, L.k, L.v = L.qkv[:, :D], L.qkv[:, D:2 * D], L.qkv[:, 2 * D:]
+        else:
+            L.q = ops.linear_fwd(s1_16, wbf16(W.q_w), W.q_b)
+            L.qkv = ops.linear_fwd(s2_16, L.fw[0], L.fb[1])
+            L.k, L.v = L.qkv[:, :D], L.qkv[:, D:]
+    else:
+        L.q = ops.linear_fwd(s1_16, wbf16(W.q_w), W.q_b)
+        L.k = ops.linear_fwd(s2_16, wbf16(W.k_w), W.k_b)
+        L.v = ops.linear_fwd(s2_16, wbf16(W.v_w), W.v_b)
     if L.fused:
         # scores, softmax, dropout and context in one kernel: the [B,heads,Lq,Lk] tensor never reaches HBM
         L.ctx, L.stats = ops.attn_fwd(L.q, L.k, L.v, key_add, B, heads, Lq, Lk, 1.0 / math.sqrt(hd), p_att, seed, L.site_att)
@@ -280,6 +297,26 @@ def _bert_layer_bwd(st, L, dout, seed):
     _lin_bwd_params(dyb, L.ctx, W.o_w, W.o_b, bias_done=True)
     dctx = ops.linear_bwd_input(dyb, wbf16(W.o_w))
     dev = dout.device
+    if L.fw is not None:
+        # fused q|k|v (or k|v) projection: the attention backward writes straight into one [rows, 3D | 2D] gradient, which
+        # then feeds ONE weight-gradient GEMM, one column sum and ONE input-gradient GEMM
+        dqkv = torch.empty_like(L.qkv)
+        if L.self_attn:
+            outv = (dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:])
+        else:
+            outv = (torch.empty(B * Lq, D, device=dev, dtype=BF16), dqkv[:, :D], dqkv[:, D:])
+        dq, dk, dv = ops.attn_bwd(L.q, L.k, L.v, L.key_add, dctx, L.stats, B, heads, Lq, Lk, 1.0 / math.sqrt(hd), L.p_att, seed, L.site_att,
+                                  out=outv)
+        ops.linear_bwd_weight(dqkv, L.s1_16 if L.self_attn else L.s2_16, L.fw[2])
+        ops.colsum(dqkv, L.fb[2].view(-1), cols=dqkv.shape[1])
+        ds1 = dy
+        if L.self_attn:
+            ops.gemm(dqkv, L.fw[0], M=B * Lq, N=D, K=3 * D, lda=3 * D, ldb=D, transB=True, out=ds1, ldc=D, beta=1.0)
+            return ds1, None
+        _lin_bwd_params(dq, L.s1_16, W.q_w, W.q_b)
+        ops.gemm(dq, wbf16(W.q_w), M=B * Lq, N=D, K=D, lda=D, ldb=D, transB=True, out=ds1, ldc=D, beta=1.0)
+        ds2 = ops.gemm(dqkv, L.fw[0], M=B * Lk, N=D, K=2 * D, lda=2 * D, ldb=D, transB=True, out_dtype=F32)
+        return ds1, ds2
     if L.fused:
         dq, dk, dv = ops.attn_bwd(L.q, L.k, L.v, L.key_add, dctx, L.stats, B, heads, Lq, Lk, 1.0 / math.sqrt(hd), L.p_att, seed, L.site_att)
     else:

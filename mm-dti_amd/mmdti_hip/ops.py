@@ -391,16 +391,22 @@ def attn_fwd(q, k, v, key_add, B, heads, Lq, Lk, scale, drop_p=0.0, seed=0, site
     return ctx, stats
 
 
-def attn_bwd(q, k, v, key_add, dctx, stats, B, heads, Lq, Lk, scale, drop_p=0.0, seed=0, site=0):
+def attn_bwd(q, k, v, key_add, dctx, stats, B, heads, Lq, Lk, scale, drop_p=0.0, seed=0, site=0, out=None):
+    """out: optional (dq, dk, dv) destination views (unit column stride; dk and dv share one row stride)."""
     _chk(dctx, BF16, "attn.dctx")
     D = q.shape[1]
     hd = D // heads
-    dq = torch.empty(B * Lq, D, device=q.device, dtype=BF16)
-    dk = torch.empty(B * Lk, D, device=q.device, dtype=BF16)
-    dv = torch.empty(B * Lk, D, device=q.device, dtype=BF16)
+    if out is not None:
+        dq, dk, dv = out
+        if dk.stride(0) != dv.stride(0) or any(t.stride(1) != 1 or t.dtype != BF16 for t in out):
+            raise MMDTIError("attn_bwd: bad output views")
+    else:
+        dq = torch.empty(B * Lq, D, device=q.device, dtype=BF16)
+        dk = torch.empty(B * Lk, D, device=q.device, dtype=BF16)
+        dv = torch.empty(B * Lk, D, device=q.device, dtype=BF16)
     drow = torch.empty(B, heads, Lq, device=q.device, dtype=F32)
     lib().mmdti_attn_bwd(_stream(), q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(key_add), dctx.data_ptr(), stats.data_ptr(), drow.data_ptr(),
-                         dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, heads, Lq, Lk, hd, q.stride(0), k.stride(0), dctx.stride(0), D, D,
+                         dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, heads, Lq, Lk, hd, q.stride(0), k.stride(0), dctx.stride(0), dq.stride(0), dk.stride(0),
                          float(scale), float(drop_p), int(seed), int(site))
     return dq, dk, dv
 

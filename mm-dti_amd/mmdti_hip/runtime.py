@@ -22,9 +22,24 @@ _ALIGN = 8  # elements: 16 B for the bf16 shadow, 32 B for fp32
 class ParamArena:
     """Flatten a module's trainable parameters into contiguous data / grad / bf16-shadow buffers."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
-        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
-        assert self.params, "no trainable parameters"
+    def __init__(self, params: Iterable[torch.nn.Parameter], adjacent: Iterable[tuple] = ()):
+        """adjacent: tuples of parameters to lay out back to back (e.g. the query/key/value weights of an attention
+        block, so that one GEMM can use them as a single [3D, D] matrix -- see fused_views)."""
+        plist = [p for p in params if p.requires_grad]
+        assert plist, "no trainable parameters"
+        group_of = {}
+        for grp in adjacent:
+            grp = tuple(p for p in grp if p.requires_grad)
+            if len(grp) > 1 and all(id(p) not in group_of for p in grp):
+                for p in grp:
+                    group_of[id(p)] = grp
+        self.params: List[torch.nn.Parameter] = []
+        seen = set()
+        for p in plist:
+            for q in group_of.get(id(p), (p,)):
+                if id(q) not in seen:
+                    seen.add(id(q))
+                    self.params.append(q)
         dev = self.params[0].device
         assert dev.type == "cuda", "ParamArena needs device parameters"
         self.offsets: Dict[int, int] = {}
@@ -60,6 +75,20 @@ class ParamArena:
     def bf16(self, p: torch.nn.Parameter) -> torch.Tensor:
         o, n = self.offsets[id(p)], p.numel()
         return self.shadow[o:o + n].view(p.shape)
+
+    def fused(self, plist):
+        """(bf16 shadow, fp32 data, fp32 grad) views spanning parameters that sit back to back in the arena (rows
+        concatenated), or None."""
+        o0 = self.offsets.get(id(plist[0]))
+        if o0 is None:
+            return None
+        o, cols = o0, plist[0].shape[1:]
+        for p in plist:
+            if self.offsets.get(id(p)) != o or p.shape[1:] != cols:
+                return None
+            o += p.numel()
+        shape = (sum(p.shape[0] for p in plist),) + tuple(cols)
+        return self.shadow[o0:o].view(shape), self.data[o0:o].view(shape), self.grad[o0:o].view(shape)
 
     def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, max_norm: Optional[float] = None):
         """torch.optim.Adam semantics (tasks/trainer.py:160) + optional global-norm clipping (:274), one fused pass."""
@@ -106,6 +135,14 @@ def wbf16(p: torch.Tensor) -> torch.Tensor:
     if arena is not None:
         return arena.bf16(p)
     return _shadow_cache.get(p)
+
+
+def fused_views(plist):
+    """Views over parameters laid out back to back in one ParamArena (see ParamArena(adjacent=...)), else None."""
+    arena = getattr(plist[0], "_mmdti_arena", None)
+    if arena is None or any(getattr(p, "_mmdti_arena", None) is not arena or not p.requires_grad for p in plist):
+        return None
+    return arena.fused(plist)
 
 
 def gbuf(p: torch.Tensor) -> Optional[torch.Tensor]:

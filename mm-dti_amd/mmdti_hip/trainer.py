@@ -39,6 +39,19 @@ def linear_warmup_lr(base_lr: float, step: int, warmup: int, total: int) -> floa
     return base_lr * max(0.0, float(total - step) / float(max(1, total - warmup)))
 
 
+def _qkv_groups(model):
+    """query/key/value Linears of every BERT-style attention block: their weights (and biases) go back to back in the
+    arena so that the layer can run them as ONE [3D, D] GEMM (functional._bert_layer_fwd)."""
+    groups = []
+    for m in model.modules():
+        q, k, v = (getattr(m, n, None) for n in ("query", "key", "value"))
+        if all(isinstance(t, torch.nn.Module) and hasattr(t, "weight") for t in (q, k, v)) and q.weight.shape == k.weight.shape == v.weight.shape:
+            groups.append((q.weight, k.weight, v.weight))
+            if all(getattr(t, "bias", None) is not None for t in (q, k, v)):
+                groups.append((q.bias, k.bias, v.bias))
+    return groups
+
+
 class FineTuner:
     def __init__(self, model, task: str, learning_rate=1e-4, adam_eps=1e-6, warmup_ratio=0.03, total_steps=1000, alpha=1.0, beta=0.1,
                  max_norm: Optional[float] = 5.0, distributed: bool = False, bucket_bytes: int = 64 << 20):
@@ -47,7 +60,7 @@ class FineTuner:
         self.total_steps = total_steps
         self.warmup = int(total_steps * warmup_ratio)
         self.sched_step = 0
-        self.arena = ParamArena(model.parameters())
+        self.arena = ParamArena(model.parameters(), adjacent=_qkv_groups(model))
         self.world = 1
         self.reducer = None
         if distributed:

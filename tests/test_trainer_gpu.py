@@ -11,13 +11,16 @@ pytestmark = pytest.mark.gpu
 from oracle import mmdti_oracle as O
 
 
-def _model(task, odim, **kw):
+def _model(task, odim, wide=False, **kw):
+    """wide: width 128 with head_dim 64 (tower 2) / 32 (fusion) -- the shapes that take the fused attention kernels and,
+    under FineTuner's arena, the fused query|key|value projection."""
     from mmdti_hip.models import mm_model as mm
+    D, H1, H2, HX = (128, 16, 2, 4) if wide else (64, 8, 4, 4)
     mol = mm.molecule_architecture()
-    mol.encoder_layers, mol.encoder_embed_dim, mol.encoder_ffn_embed_dim, mol.encoder_attention_heads = 2, 64, 128, 8
+    mol.encoder_layers, mol.encoder_embed_dim, mol.encoder_ffn_embed_dim, mol.encoder_attention_heads = 2, D, 128, H1
     cross = mm.crossmodal_config()
-    cross.hidden_size, cross.num_attention_heads, cross.intermediate_size = 64, 4, 128
-    rcfg = SimpleNamespace(layers=2, dim=64, heads=4, ffn=128, vocab=40, max_pos=40, type_vocab=1, pad_idx=1, ln_eps=1e-12, hidden_dropout=0.1, attn_dropout=0.1)
+    cross.hidden_size, cross.num_attention_heads, cross.intermediate_size = D, HX, 128
+    rcfg = SimpleNamespace(layers=2, dim=D, heads=H2, ffn=128, vocab=40, max_pos=40, type_vocab=1, pad_idx=1, ln_eps=1e-12, hidden_dropout=0.1, attn_dropout=0.1)
     torch.manual_seed(0)
     return mm.MM_Model.from_configs(odim, task, mol_args=mol, roberta_cfg=rcfg, cross_cfg=cross, gbf_K=16, **kw).cuda()
 
@@ -27,16 +30,24 @@ def _ocfg(task, odim):
                       cross=O.CrossCfg(dim=64, heads=4, ffn=128), task=task, output_dim=odim)
 
 
-def test_step_matches_torch_adam_and_clip():
+@pytest.mark.parametrize("wide", [False, True])
+def test_step_matches_torch_adam_and_clip(wide):
     """One eval-mode (dropout off) step through FineTuner == autograd grads -> clip_grad_norm_(5.0) -> torch Adam(eps 1e-6)
-    with the HF warm-up schedule, on a copy of the same model."""
+    with the HF warm-up schedule, on a copy of the same model.  (wide: the arena side runs query|key|value as one fused
+    GEMM, the reference side as three.)"""
     from mmdti_hip.trainer import FineTuner, linear_warmup_lr
     ocfg = _ocfg("classification", 2)
     batch, label = O.synth_batch(8, 10, 14, ocfg, seed=3, ragged=True)
     dev = {k: v.cuda() for k, v in batch.items()}
-    m1, m2 = _model("classification", 2).eval(), _model("classification", 2).eval()
+    m1, m2 = _model("classification", 2, wide).eval(), _model("classification", 2, wide).eval()
     m2.load_state_dict(m1.state_dict())
     tuner = FineTuner(m1, "classification", learning_rate=1e-3, warmup_ratio=0.5, total_steps=4, max_norm=5.0)
+    if wide:
+        from mmdti_hip.runtime import fused_views
+        att = m1.bert.layers[0].attention.self
+        fw = fused_views((att.query.weight, att.key.weight, att.value.weight))
+        assert fw is not None and fw[0].shape == (3 * 128, 128)                      # laid out back to back by the arena
+        assert fw[1][128:256].data_ptr() == att.key.weight.data_ptr()
     params2 = [p for p in m2.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params2, lr=1e-3, eps=1e-6)
     for step in range(3):
