@@ -111,10 +111,14 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
 }
+// Four uniforms for counter `ctr` from TWO avalanche hashes: each is 16 random bits in the HIGH half of a word, so the
+// callers' `r >= thresh` against the 32-bit threshold p*2^32 keeps working (p effectively quantised to 1/65536).  5 -> 2
+// hashes per 4 elements: this runs in every dropout site of the GEMM epilogues and the LayerNorm / cast kernels.
 __device__ __forceinline__ Rand4 philox4(uint64_t seed, uint32_t site, uint64_t ctr) {
   const uint32_t k = mix32((uint32_t)seed ^ (site * 0x9E3779B9u)) ^ (uint32_t)(seed >> 32);  // wave-uniform: hoisted to SALU
-  const uint32_t c = mix32((uint32_t)ctr ^ k) + (uint32_t)(ctr >> 32) * 0x85EBCA6Bu;
-  return Rand4{mix32(c ^ 0x68E31DA4u), mix32(c ^ 0xB5297A4Du), mix32(c ^ 0x1B56C4E9u), mix32(c + 0x9E3779B9u)};
+  const uint32_t a = mix32(((uint32_t)ctr ^ k) + (uint32_t)(ctr >> 32) * 0x85EBCA6Bu);
+  const uint32_t b = mix32(a ^ 0xB5297A4Du);
+  return Rand4{a << 16, a & 0xffff0000u, b << 16, b & 0xffff0000u};
 }
 // Cheaper variant for the pair-attention probability dropout (277 M elements per layer): TWO avalanche hashes give four
 // 16-bit uniforms, compared against a 16-bit threshold (p quantised to 1/65536: |error| < 8e-6).  ~20 integer ops per 4
