@@ -35,6 +35,21 @@ def _lin_bwd_params(dy_bf16, x_bf16, weight, bias, rows=None, bias_done=False):
             ops.colsum(dy_bf16, gb, cols=bias.numel())
 
 
+def _join_stream_after_backward():
+    """A module backward that writes parameter gradients itself leaves autograd no leaf on its stream, so the engine would
+    not join that stream at the end of backward(): if we are on a side stream, queue the join."""
+    here = torch.cuda.current_stream()
+    if here == torch.cuda.default_stream():
+        return
+
+    def _join(stream=here):
+        cur = torch.cuda.current_stream()
+        if cur != stream:
+            cur.wait_stream(stream)
+
+    torch.autograd.Variable._execution_engine.queue_callback(_join)
+
+
 class _Sites:
     """Dropout site numbering inside one forward call."""
 
@@ -156,6 +171,7 @@ class PairEncoderFn(torch.autograd.Function):
         notify_grads_ready(list(eln.parameters()) + ([] if mod.final_layer_norm is None else list(mod.final_layer_norm.parameters())))
         if G is None:
             G = torch.zeros_like(st.bias0)
+        _join_stream_after_backward()
         return demb.view(B, N, D), G, None, None, None
 
 
@@ -208,6 +224,7 @@ class PairBiasFn(torch.autograd.Function):
                 grads = [gbuf(p) if p.requires_grad else torch.zeros_like(p) for p in ps]
                 ops.gbf_features_bwd(st.dist, st.et, *[p.view(-1) for p in ps], dfeat, *[gr.view(-1) for gr in grads])
         notify_grads_ready(list(gbf.parameters()) + list(proj.parameters()))
+        _join_stream_after_backward()
         return None, None, None, None, None, None
 
 
@@ -225,6 +242,7 @@ class EmbeddingFn(torch.autograd.Function):
         if g is not None:
             ops.embedding_bwd_gemm(ctx.ids, ops.cast_bf16(dout.contiguous()), g, ctx.pad)
         notify_grads_ready([ctx.w])
+        _join_stream_after_backward()
         return None, None, None
 
 
@@ -407,16 +425,7 @@ class RobertaEncoderFn(torch.autograd.Function):
             if g is not None:
                 ops.embedding_bwd_gemm(ids, de16, g, pad)
         notify_grads_ready(mod.embeddings.parameters())
-        # This tower may be running on a side stream (MM_Model overlaps the two towers) and writes its parameter gradients
-        # itself, so autograd sees no leaf on this stream and would not join it at the end of backward(): queue the join.
-        here = torch.cuda.current_stream()
-
-        def _join(stream=here):
-            cur = torch.cuda.current_stream()
-            if cur != stream:
-                cur.wait_stream(stream)
-
-        torch.autograd.Variable._execution_engine.queue_callback(_join)
+        _join_stream_after_backward()   # (MM_Model runs this tower on a side stream)
         return None, None, None, None, None
 
 

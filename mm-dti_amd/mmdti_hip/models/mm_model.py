@@ -234,7 +234,9 @@ class MM_Model(nn.Module):
                            start_smooth=self.fds_cfg.start_smooth, kernel=self.fds_cfg.kernel, ks=self.fds_cfg.ks,
                            sigma=self.fds_cfg.sigma, momentum=self.fds_cfg.momentum)
         self.overlap_towers = bool(params.get('overlap_towers', True))
+        self.split_tower1 = int(params.get('split_tower1', 1))
         self._side = None
+        self._third = None
 
     # ------------------------------------------------------------------ construction helpers
     @classmethod
@@ -256,6 +258,13 @@ class MM_Model(nn.Module):
         if missing:
             raise RuntimeError(f"Uni-Mol checkpoint {path} lacks {len(missing)} tower-1 parameters, e.g. {missing[:5]}")
         self.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
+
+    def _extra_stream(self, i):
+        if self._third is None:
+            self._third = {}
+        if i not in self._third:
+            self._third[i] = torch.cuda.Stream()
+        return self._third[i]
 
     def _side_stream(self):
         if self._side is None:
@@ -287,9 +296,30 @@ class MM_Model(nn.Module):
             with torch.cuda.stream(side):
                 out_bert = self.bert(input_ids, attention_mask, return_dict=True)[0]
 
-        x = EmbeddingFn.apply(self.embed_tokens.weight, src_tokens, self.padding_idx)
-        graph_attn_bias = self.pair_bias(src_distance, src_edge_type)
-        encoder_rep, _, _ = self.encoder.encode(x, graph_attn_bias, padding_mask)
+        def tower1(sl):
+            xs = EmbeddingFn.apply(self.embed_tokens.weight, src_tokens[sl], self.padding_idx)
+            bias_s = self.pair_bias(src_distance[sl], src_edge_type[sl])
+            return self.encoder.encode(xs, bias_s, padding_mask[sl])[0]
+
+        Bm = src_tokens.shape[0]
+        parts = int(self.split_tower1)
+        if side is not None and parts > 1 and Bm % parts == 0 and Bm >= 2 * parts:
+            # Tower 1 in `parts` sub-batches on as many streams: the HBM-bound pair kernels of one overlap the MFMA-bound
+            # GEMMs of another (molecules are independent until InfoNCE, so the arithmetic is unchanged).
+            step = Bm // parts
+            reps = []
+            for i in range(1, parts):
+                st_i = self._extra_stream(i)
+                st_i.wait_stream(main)
+                with torch.cuda.stream(st_i):
+                    reps.append((tower1(slice(i * step, (i + 1) * step)), st_i))
+            rep0 = tower1(slice(0, step))
+            for r, st_i in reps:
+                main.wait_stream(st_i)
+                r.record_stream(main)
+            encoder_rep = torch.cat([rep0] + [r for r, _ in reps], 0)
+        else:
+            encoder_rep = tower1(slice(0, Bm))
 
         if side is not None:
             main.wait_stream(side)
