@@ -15,6 +15,8 @@
 // an operand stored k-major (transposed) keeps its order in LDS ([k][row] image, 16-byte writes) and is
 // transposed for free by ds_read_b64_tr_b16 on the way to the MFMA.
 // XCD-aware block remap keeps tiles that share an A row-panel on one XCD's L2.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mmdti {
@@ -398,6 +400,128 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(GemmArgs a) {
 #undef STG_T
 }
 
+// =====================================================================================================================
+// LDS-DMA variant of the same tile (bare-load shapes only): the (A|B) tile pair is fetched with
+// global_load_lds_dwordx4 -- 16 bytes per lane straight into LDS, no staging registers, no ds_write pass.  The DMA writes
+// lane i of a wave-instruction at base + 16*i, so the LDS image stays the swizzled one the fragment loaders expect by
+// permuting the SOURCE: the lane that owns LDS slot (row, s) fetches global chunk s ^ swizzle(row) (an involution).
+// No load/compute overlap inside a workgroup (fetch, barrier, multiply, barrier); with ~40 fewer registers four
+// workgroups fit a CU and overlap each other instead.
+template <bool TR>
+__device__ __forceinline__ uint32_t glds_offset1(int c, int ld, int row0, int rows) {
+  if (!TR) {
+    const int rl = c >> 3, kc = (c & 7) ^ (rl & 7);
+    const int row = min(row0 + rl, rows - 1);
+    return (uint32_t)(((long long)row * ld + kc * 8) * 2);
+  } else {
+    const int k = c >> 4, rs = (c & 15) ^ (tr_swz(k) >> 3);
+    const int row = min(row0 + rs * 8, rows - 8);
+    return (uint32_t)(((long long)k * ld + row) * 2);
+  }
+}
+template <bool TR>
+__device__ __forceinline__ Off4 glds_offsets(int ld, int row0, int rows, int tid) {
+  return Off4{glds_offset1<TR>(tid, ld, row0, rows), glds_offset1<TR>(tid + 256, ld, row0, rows),
+              glds_offset1<TR>(tid + 512, ld, row0, rows), glds_offset1<TR>(tid + 768, ld, row0, rows)};
+}
+__device__ __forceinline__ void glds_tile(const bf16_t* kbase, const Off4& off, bf16_t* img, int wave) {
+  typedef __attribute__((address_space(1))) const void gptr_t;
+  typedef __attribute__((address_space(3))) void lptr_t;
+  const char* b = reinterpret_cast<const char*>(kbase);
+  bf16_t* d = img + wave * 512;   // 64 lanes x 8 elements per wave-instruction; instruction j covers chunks j*256 ...
+  __builtin_amdgcn_global_load_lds((gptr_t*)(b + off.o0), (lptr_t*)(d), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((gptr_t*)(b + off.o1), (lptr_t*)(d + 2048), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((gptr_t*)(b + off.o2), (lptr_t*)(d + 4096), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((gptr_t*)(b + off.o3), (lptr_t*)(d + 6144), 16, 0, 0);
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 4) void gemm_glds_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+  constexpr int TILE = BM * LDT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
+  const int nwg = tiles_n * tiles_m;
+  const int orig = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.z;
+  const int zb = z / a.splitk, ks = z - zb * a.splitk;
+  const int zo = zb / a.batch_inner, zi = zb - zo * a.batch_inner;
+  const bf16_t* __restrict__ A = a.A + zo * a.sAo + zi * a.sAi;
+  const bf16_t* __restrict__ B = a.B + zo * a.sBo + zi * a.sBi;
+  const int ktiles = a.K / BK;
+  const int per = (ktiles + a.splitk - 1) / a.splitk;
+  const int kt0 = ks * per, kt1 = min(ktiles, kt0 + per);
+  if (kt0 >= kt1) return;
+  f32x4 acc[4][4] = {};
+  const Off4 offA = glds_offsets<TA>(a.lda, m0, a.M, tid), offB = glds_offsets<TB>(a.ldb, n0, a.N, tid);
+  const long long kstepA = TA ? (long long)BK * a.lda : BK, kstepB = TB ? (long long)BK * a.ldb : BK;
+#define MF(I, J) acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb##J, fa##I, acc[I][J], 0, 0, 0)
+#define GEMM_KK(IMGA, IMGB, KK)                                                                    \
+  {                                                                                                \
+    const bf16x8 fa0 = load_frag<TA>(IMGA, wr * 64 + 0, KK, lane), fa1 = load_frag<TA>(IMGA, wr * 64 + 16, KK, lane), \
+                 fa2 = load_frag<TA>(IMGA, wr * 64 + 32, KK, lane), fa3 = load_frag<TA>(IMGA, wr * 64 + 48, KK, lane); \
+    const bf16x8 fb0 = load_frag<TB>(IMGB, wc * 64 + 0, KK, lane), fb1 = load_frag<TB>(IMGB, wc * 64 + 16, KK, lane), \
+                 fb2 = load_frag<TB>(IMGB, wc * 64 + 32, KK, lane), fb3 = load_frag<TB>(IMGB, wc * 64 + 48, KK, lane); \
+    MF(0, 0); MF(0, 1); MF(0, 2); MF(0, 3); MF(1, 0); MF(1, 1); MF(1, 2); MF(1, 3);                \
+    MF(2, 0); MF(2, 1); MF(2, 2); MF(2, 3); MF(3, 0); MF(3, 1); MF(3, 2); MF(3, 3);                \
+  }
+  for (int kt = kt0; kt < kt1; ++kt) {
+    glds_tile(A + kt * kstepA, offA, smem, wave);
+    glds_tile(B + kt * kstepB, offB, smem + TILE, wave);
+    __syncthreads();   // (the compiler drains vmcnt before the barrier: the DMA'd tile is visible to every wave)
+    GEMM_KK(smem, smem + TILE, 0);
+    GEMM_KK(smem, smem + TILE, 1);
+    __syncthreads();   // every wave has read the tile before the next fetch overwrites it
+  }
+#undef GEMM_KK
+#undef MF
+  const long long coff = zo * a.sCo + zi * a.sCi;
+  const bool lead = (ks == 0);
+  const int g4 = (lane >> 4) * 4, l15 = lane & 15;
+  if (a.c_dtype != MMDTI_DT_F32_ATOMIC && a.vec_ok) {
+    float* sC = reinterpret_cast<float*>(smem);
+#define STG_Q(I, J) *reinterpret_cast<f32x4*>(sC + ((I) * 16 + l15) * LDC_S + wc * 64 + (J) * 16 + g4) = acc[I][J]
+#define STG_R(I) STG_Q(I, 0); STG_Q(I, 1); STG_Q(I, 2); STG_Q(I, 3)
+#define EPI_HALF(H)                                                        \
+    if (wr == (H)) { STG_R(0); STG_R(1); STG_R(2); STG_R(3); }             \
+    __syncthreads();                                                       \
+    for (int it = 0; it < 4; ++it) {                                       \
+      const int chunk = tid + it * 256;                                    \
+      const int rr = chunk >> 4, cc = (chunk & 15) * 8;                    \
+      const int row = m0 + (H) * 64 + rr, col = n0 + cc;                   \
+      if (row < a.M && col < a.N) epilogue_oct(a, sC + rr * LDC_S + cc, row, col, lead, coff); \
+    }
+    EPI_HALF(0)
+    __syncthreads();
+    EPI_HALF(1)
+#undef EPI_HALF
+#undef STG_R
+#undef STG_Q
+    return;
+  }
+  float* sW = reinterpret_cast<float*>(smem) + wave * (16 * LDC_W);
+#define STG_T(I, J) *reinterpret_cast<f32x4*>(sW + l15 * LDC_W + (J) * 16 + g4) = acc[I][J]
+#define EPI_PASS(I)                                                                                  \
+  {                                                                                                  \
+    STG_T(I, 0); STG_T(I, 1); STG_T(I, 2); STG_T(I, 3);                                              \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                           \
+    __builtin_amdgcn_wave_barrier();                                                                 \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                           \
+    for (int rr = 0; rr < 16; ++rr)                                                                  \
+      epi_elem(a, sW[rr * LDC_W + lane], m0 + wr * 64 + (I) * 16 + rr, n0 + wc * 64 + lane, lead, coff); \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                           \
+    __builtin_amdgcn_wave_barrier();                                                                 \
+  }
+  EPI_PASS(0) EPI_PASS(1) EPI_PASS(2) EPI_PASS(3)
+#undef EPI_PASS
+#undef STG_T
+}
+
 }  // namespace mmdti
 
 using namespace mmdti;
@@ -468,7 +592,15 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
   // bare-load fast path: no K tail, no ragged 8-row chunk on a k-major operand, offsets fit 32 bits
   const bool fast = (K % BK == 0) && (!transA || M % 8 == 0) && (!transB || N % 8 == 0) && M >= 8 && N >= 8 &&
                     ((long long)(transA ? BK : M) * lda * 2 < 0x7fffffffLL) && ((long long)(transB ? BK : N) * ldb * 2 < 0x7fffffffLL);
-  hipLaunchKernelGGL(kerns[transA ? 1 : 0][transB ? 1 : 0][fast ? 1 : 0], grid, block, smem, s, a);
+  static const kern_t gkerns[2][2] = {{gemm_glds_kernel<false, false>, gemm_glds_kernel<false, true>},
+                                      {gemm_glds_kernel<true, false>, gemm_glds_kernel<true, true>}};
+  // LDS-DMA tile fetch for every bare-load shape except the split-K weight gradients (measured: -15...-20 % on the
+  // N >= 1536 / K >= 1536 shapes, equal at 512x512, +9 % on the atomic split-K ones); MMDTI_GEMM_GLDS=0 turns it off
+  static const int use_glds = getenv("MMDTI_GEMM_GLDS") ? atoi(getenv("MMDTI_GEMM_GLDS")) : 1;
+  if (fast && use_glds && splitk == 1)
+    hipLaunchKernelGGL(gkerns[transA ? 1 : 0][transB ? 1 : 0], grid, block, smem, s, a);
+  else
+    hipLaunchKernelGGL(kerns[transA ? 1 : 0][transB ? 1 : 0][fast ? 1 : 0], grid, block, smem, s, a);
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }
