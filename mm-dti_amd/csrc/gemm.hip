@@ -621,7 +621,7 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
   // N >= 1536 / K >= 1536 shapes, equal at 512x512, +9 % on the atomic split-K ones); MMDTI_GEMM_GLDS=0 turns it off
   static const int use_glds = getenv("MMDTI_GEMM_GLDS") ? atoi(getenv("MMDTI_GEMM_GLDS")) : 1;
   // split-K weight gradients: double-buffered DMA from 48 output tiles up (-5...-13 %), register staging below (+13 %)
-  if (fast && use_glds && splitk > 1 && tiles >= 48)
+  if (fast && use_glds && ((splitk > 1 && tiles >= 48) || use_glds == 3))
     hipLaunchKernelGGL(gkerns2[transA ? 1 : 0][transB ? 1 : 0], grid, block, 4 * (size_t)BM * LDT * sizeof(bf16_t), s, a);
   else if (fast && use_glds && splitk == 1)
     hipLaunchKernelGGL(gkerns[transA ? 1 : 0][transB ? 1 : 0], grid, block, smem, s, a);
