@@ -446,8 +446,8 @@ __global__ __launch_bounds__(256) void pair_attn_fwd_mfma_kernel(const bf16_t* _
 // Each (query block, key tile) contribution to dK/dV is added to an LDS image shared by the block's waves.
 constexpr int TSTR = 20;  // fp32 row stride of the per-wave transpose patch (16-byte aligned rows)
 
-template <int NT, bool TILED, bool FULL>
-__global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ s_in,
+template <int NT, bool TILED, bool FULL, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 3 ? 3 : 2) void pair_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ s_in,
                                                                  const bf16_t* __restrict__ dO, const float* __restrict__ gin, float* __restrict__ gout,
                                                                  bf16_t* __restrict__ dqkv, int N, int H, int ld, float scale,
                                                                  int g_in_zero, uint32_t thresh, float dscale, uint64_t seed,
@@ -455,13 +455,15 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* _
   constexpr int NP = NT * 16;
   __shared__ __attribute__((aligned(16))) float sQ[NP * VSTR + 8];   // Q * scale
   __shared__ __attribute__((aligned(16))) float sK[NP * VSTR + 8];
-  __shared__ __attribute__((aligned(16))) float sV[NP * VSTR + 8];
-  __shared__ __attribute__((aligned(16))) float sD[NP * VSTR + 8];   // dO
+  // V and dO only ever enter the MFMAs as the bf16 values they were loaded as: kept as raw bf16 in LDS (half the bytes;
+  // with the per-wave arrays sized by the real wave count the workgroup stays under 53 KB -> three per CU)
+  __shared__ __attribute__((aligned(16))) bf16_t sV[NP * VSTR + 8];
+  __shared__ __attribute__((aligned(16))) bf16_t sD[NP * VSTR + 8];   // dO
   // per-wave dK / dV accumulators in MFMA accumulator order: [wave][tile][K|V][g][d][r] -- each lane owns one float4 per
   // (tile, K|V), read as the MFMA C input and written back, so the waves never contend (LDS float atomics cost ~57
   // cycles per wave-instruction here and were half of the kernel's time).
-  __shared__ __attribute__((aligned(16))) float redw[4 * NT * 2 * 128];
-  __shared__ __attribute__((aligned(16))) float patch[4][2][16 * TSTR];
+  __shared__ __attribute__((aligned(16))) float redw[NW * NT * 2 * 128];
+  __shared__ __attribute__((aligned(16))) float patch[NW][2][16 * TSTR];
   const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
   const int D = H * HD, D3 = 3 * D;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -479,11 +481,11 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* _
     for (int d = 0; d < 8; ++d) {
       sQ[t * VSTR + d] = q[d] * scale;
       sK[t * VSTR + d] = kk[d];
-      sV[t * VSTR + d] = vv[d];
-      sD[t * VSTR + d] = dd[d];
+      sV[t * VSTR + d] = f2bf(vv[d]);   // (exact: the values were bf16 in memory)
+      sD[t * VSTR + d] = f2bf(dd[d]);
     }
   }
-  for (int t = tid; t < 4 * NT * 2 * 128; t += blockDim.x) redw[t] = 0.f;
+  for (int t = tid; t < NW * NT * 2 * 128; t += blockDim.x) redw[t] = 0.f;
   __syncthreads();
   const int g = lane >> 4, c16 = lane & 15;
   const bool dlane = c16 < 8;
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* _
                            : (qvalid && (FULL ? ((T) < NT - 1 || colok) : ((T) < nlast || ((T) == nlast && colok)))))
 #define PA_FAST(T) (TILED && !EDGE && (FULL ? (T) < NT - 1 : false))
     // B operand of dP^T = V.dO^T : dO[qi][g], dO[qi][g+4]
-    const float dob0 = sD[(qb * 16 + c16) * VSTR + g], dob1 = sD[(qb * 16 + c16) * VSTR + g + 4];
+    const float dob0 = bf2f(sD[(qb * 16 + c16) * VSTR + g]), dob1 = bf2f(sD[(qb * 16 + c16) * VSTR + g + 4]);
     // ---- sweep 1
     f32x4 P[NT], dPm[NT];
     float m = NEG_INF;
@@ -556,7 +558,7 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* _
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       {
-        const float va0 = sV[(t * 16 + c16) * VSTR + g], va1 = sV[(t * 16 + c16) * VSTR + g + 4];
+        const float va0 = bf2f(sV[(t * 16 + c16) * VSTR + g]), va1 = bf2f(sV[(t * 16 + c16) * VSTR + g + 4]);
         f32x4 dp = {0.f, 0.f, 0.f, 0.f};
         dp = __builtin_amdgcn_mfma_f32_16x16x4f32(va0, dob0, dp, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_16x16x4f32(va1, dob1, dp, 0, 0, 0);
@@ -630,7 +632,7 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_mfma_kernel(const bf16_t* _
       for (int st = 0; st < 4; ++st) {   // MFMA step st contracts queries 4*st + g
         aP[st] = pP[(4 * st + g) * TSTR + c16];
         aG[st] = pG[(4 * st + g) * TSTR + c16];
-        bD[st] = sD[(qb * 16 + 4 * st + g) * VSTR + c16];
+        bD[st] = bf2f(sD[(qb * 16 + 4 * st + g) * VSTR + c16]);
         bQ[st] = sQ[(qb * 16 + 4 * st + g) * VSTR + c16];
       }
       // dK / dV of key tile t: accumulator column = d (lanes c16 < 8), rows = keys 16t + 4g + r; the running sums of
@@ -752,17 +754,22 @@ extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, 
   if (ld % 4 == 0 && aligned16(s) && aligned16(g) && N <= 16 * 13) {
     const int nqb = (N + 15) / 16;
     dim3 blk(nqb % 3 == 0 ? 192 : (nqb < 4 ? 64 * nqb : 256));
-#define PA_MB(NT, TL, FL)                                                                                                  \
-  hipLaunchKernelGGL((pair_attn_bwd_mfma_kernel<NT, TL, FL>), grid, blk, 0, st, (const bf16_t*)qkv_bf16, s,                  \
+#define PA_MB(NT, TL, FL, NWV)                                                                                             \
+  hipLaunchKernelGGL((pair_attn_bwd_mfma_kernel<NT, TL, FL, NWV>), grid, blk, 0, st, (const bf16_t*)qkv_bf16, s,             \
                      (const bf16_t*)do_bf16, g, g, (bf16_t*)dqkv_bf16, N, H, ld, scale, g_in_zero, th, sc,                   \
                      (uint64_t)seed, (uint32_t)site)
+#define PA_MBW(NT, TL, FL)                                                                  \
+  do {                                                                                      \
+    if (blk.x == 192) PA_MB(NT, TL, FL, 3); else PA_MB(NT, TL, FL, 4);                      \
+  } while (0)
 #define PA_MBT(NT)                                                                          \
   do {                                                                                      \
-    if (!tiled) PA_MB(NT, false, false);                                                    \
-    else if (nqb == NT) PA_MB(NT, true, true);                                              \
-    else PA_MB(NT, true, false);                                                            \
+    if (!tiled) PA_MBW(NT, false, false);                                                   \
+    else if (nqb == NT) PA_MBW(NT, true, true);                                             \
+    else PA_MBW(NT, true, false);                                                           \
   } while (0)
     if (nqb <= 5) PA_MBT(5); else if (nqb <= 9) PA_MBT(9); else PA_MBT(13);
+#undef PA_MBW
 #undef PA_MBT
 #undef PA_MB
     MMDTI_LAUNCH_CHECK();
