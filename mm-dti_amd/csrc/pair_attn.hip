@@ -292,7 +292,7 @@ constexpr int VSTR = 10;  // fp32 row stride of the V image: (4g+t)*10 + d is ba
 __device__ __forceinline__ int dperm(int d) { return (d & 3) * 2 + (d >> 2); }  // d and d+4 adjacent: one ds_read_b64
 
 template <int NT, bool TILED, bool FULL>
-__global__ __launch_bounds__(256) void pair_attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_in,
+__global__ __launch_bounds__(256, 4) void pair_attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_in,
                                                                  float* __restrict__ s_out, bf16_t* __restrict__ o,
                                                                  const unsigned char* __restrict__ key_pad, int N, int H, int ld,
                                                                  float scale, uint32_t thresh, float dscale, uint64_t seed,
