@@ -54,13 +54,15 @@ int mmdti_abi_version(void);
  * (models/infonce.py:28-29), BertCrossEncoder linears (models/mm_module.py:486-488,527,545,581).
  * A: transA=0 -> [M,K] row-major (lda), transA=1 -> stored [K,M].  B: transB=0 -> [N,K] ("weight" layout),
  * transB=1 -> stored [K,N].  lda/ldb multiples of 8, 16-byte aligned bases.  If K%8 != 0 the k-contiguous
- * operand must hold zeros in its padded tail.  Batch index z = outer*batch_inner + inner.  */
+ * operand must hold zeros in its padded tail.  Batch index z = outer*batch_inner + inner.
+ * colsum_out (nullable, [N] fp32, +=): column sums of the stored C -- the bias gradient of the Linear whose output
+ * gradient C is -- accumulated by the epilogue (aligned, unbatched, unsplit outputs only).  */
 int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void* B, void* C, int M, int N, int K, int lda,
                     int ldb, int ldc, int transA, int transB, int batch_outer, int batch_inner, long long sAo,
                     long long sAi, long long sBo, long long sBi, long long sCo, long long sCi, int splitk,
                     float alpha, float beta, const float* bias, const float* residual, int ldr, int act,
                     const void* aux_in, void* aux_out, int ld_aux, int c_dtype, float drop_p,
-                    unsigned long long seed, unsigned int site);
+                    unsigned long long seed, unsigned int site, float* colsum_out);
 
 /* ---- LayerNorm (unicore LayerNorm eps 1e-5: transformers.py:69,71,114,161; BertLayerNorm eps 1e-12:
  * mm_module.py:320-333; HF nn.LayerNorm) -------------------------------------------------------

@@ -51,6 +51,7 @@ struct GemmArgs {
   uint64_t seed;
   uint32_t site;
   int vec_ok;             // host-checked: every pointer/stride the vector epilogue touches is 16-byte friendly
+  float* colsum;          // [N] fp32 or null: += column sums of the stored C (vector epilogue only) -- a Linear's bias gradient
 };
 
 // Staging registers of one operand tile: 4 x 16-B chunks per thread, as NAMED members (an array here ends up as a
@@ -188,7 +189,7 @@ constexpr int LDC_W = 68;  // fp32 row stride of a wave's 16x64 epilogue patch (
 constexpr int LDC_S = BN + 4;  // fp32 row stride of the epilogue's staging image (528 B)
 
 // Fused epilogue on 8 consecutive columns of one row, read from the LDS staging image.  N % 8 == 0, col % 8 == 0 here.
-__device__ __forceinline__ void epilogue_oct(const GemmArgs& a, const float* src, int row, int col, bool lead, long long coff) {
+__device__ __forceinline__ void epilogue_oct(const GemmArgs& a, const float* src, int row, int col, bool lead, long long coff, float* cs) {
   float v[8];
   {
     const float4 lo = *reinterpret_cast<const float4*>(src);
@@ -239,6 +240,12 @@ __device__ __forceinline__ void epilogue_oct(const GemmArgs& a, const float* src
     u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
     u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
     *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + ci) = u;
+    if (cs) {   // column sums of the ROUNDED values: what a column-sum pass over C would add up
+      cs[0] += __uint_as_float(u.x << 16); cs[1] += __uint_as_float(u.x & 0xffff0000u);
+      cs[2] += __uint_as_float(u.y << 16); cs[3] += __uint_as_float(u.y & 0xffff0000u);
+      cs[4] += __uint_as_float(u.z << 16); cs[5] += __uint_as_float(u.z & 0xffff0000u);
+      cs[6] += __uint_as_float(u.w << 16); cs[7] += __uint_as_float(u.w & 0xffff0000u);
+    }
   } else {
     float* c = reinterpret_cast<float*>(a.C) + ci;
     if (a.beta != 0.f) {
@@ -248,6 +255,25 @@ __device__ __forceinline__ void epilogue_oct(const GemmArgs& a, const float* src
     }
     *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    if (cs) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cs[e] += v[e];
+    }
+  }
+}
+
+// Column sums of one 128x128 output tile: every thread summed 8 columns (tid & 15) over its 8 rows in the epilogue; fold
+// the 16 row groups through LDS, one atomic per column.
+__device__ __forceinline__ void epilogue_colsum(const GemmArgs& a, float* lds, const float* cs, int tid, int n0) {
+  __syncthreads();   // the staging image has been read out
+#pragma unroll
+  for (int e = 0; e < 8; ++e) lds[(tid >> 4) * 128 + (tid & 15) * 8 + e] = cs[e];
+  __syncthreads();
+  if (tid < 128 && n0 + tid < a.N) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += lds[j * 128 + tid];
+    atomicAdd(a.colsum + n0 + tid, t);
   }
 }
 
@@ -372,11 +398,13 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(GemmArgs a) {
       const int chunk = tid + it * 256;                                    \
       const int r = chunk >> 4, cc = (chunk & 15) * 8;                     \
       const int row = m0 + (H) * 64 + r, col = n0 + cc;                    \
-      if (row < a.M && col < a.N) epilogue_oct(a, sC + r * LDC_S + cc, row, col, lead, coff); \
+      if (row < a.M && col < a.N) epilogue_oct(a, sC + r * LDC_S + cc, row, col, lead, coff, a.colsum ? cs : nullptr); \
     }
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     EPI_HALF(0)
     __syncthreads();
     EPI_HALF(1)
+    if (a.colsum) epilogue_colsum(a, sC, cs, tid, n0);
 #undef EPI_HALF
 #undef STG_R
 #undef STG_Q
@@ -515,11 +543,13 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 4) void gemm_glds_kernel(GemmArgs a
       const int chunk = tid + it * 256;                                    \
       const int rr = chunk >> 4, cc = (chunk & 15) * 8;                    \
       const int row = m0 + (H) * 64 + rr, col = n0 + cc;                   \
-      if (row < a.M && col < a.N) epilogue_oct(a, sC + rr * LDC_S + cc, row, col, lead, coff); \
+      if (row < a.M && col < a.N) epilogue_oct(a, sC + rr * LDC_S + cc, row, col, lead, coff, a.colsum ? cs : nullptr); \
     }
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     EPI_HALF(0)
     __syncthreads();
     EPI_HALF(1)
+    if (a.colsum) epilogue_colsum(a, sC, cs, tid, n0);
 #undef EPI_HALF
 #undef STG_R
 #undef STG_Q
@@ -552,7 +582,8 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
                                long long sAo, long long sAi, long long sBo, long long sBi, long long sCo,
                                long long sCi, int splitk, float alpha, float beta, const float* bias,
                                const float* residual, int ldr, int act, const void* aux_in, void* aux_out,
-                               int ld_aux, int c_dtype, float drop_p, unsigned long long seed, unsigned int site) {
+                               int ld_aux, int c_dtype, float drop_p, unsigned long long seed, unsigned int site,
+                               float* colsum_out) {
   MMDTI_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: M,N,K must be positive (got %d,%d,%d)", M, N, K);
   MMDTI_REQUIRE(A && B && C, "gemm: null operand");
   MMDTI_REQUIRE(aligned16(A) && aligned16(B), "gemm: A and B must be 16-byte aligned");
@@ -575,6 +606,7 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
   a.act = act; a.aux_in = (const bf16_t*)aux_in; a.aux_out = (bf16_t*)aux_out; a.ld_aux = ld_aux; a.c_dtype = c_dtype;
   a.drop_thresh = dropout_thresh(drop_p); a.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   a.seed = seed; a.site = site;
+  a.colsum = colsum_out;
   {
     const bool bf = c_dtype == MMDTI_DT_BF16;
     const int cal = bf ? 8 : 4;
@@ -585,6 +617,8 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
     if (aux_out) ok = ok && aligned16(aux_out) && (ld_aux % 8 == 0);
     a.vec_ok = ok ? 1 : 0;
   }
+  MMDTI_REQUIRE(!colsum_out || (a.vec_ok && splitk == 1 && batch_outer * batch_inner == 1 && c_dtype != MMDTI_DT_F32_ATOMIC),
+                "gemm: colsum_out needs the aligned, unbatched, unsplit output path");
   const int tiles = cdiv(M, BM) * cdiv(N, BN);
   dim3 grid(tiles, 1, batch_outer * batch_inner * splitk), block(256);
   MMDTI_REQUIRE(grid.z <= 65535u, "gemm: batch*splitk too large (%u)", grid.z);

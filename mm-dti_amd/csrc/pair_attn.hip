@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256, 4) void pair_attn_fwd_mfma_kernel(const bf16_t
 constexpr int TSTR = 20;  // fp32 row stride of the per-wave transpose patch (16-byte aligned rows)
 
 template <int NT, bool TILED, bool FULL, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 3 ? 3 : 2) void pair_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ s_in,
+__global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ s_in,
                                                                  const bf16_t* __restrict__ dO, const float* __restrict__ gin, float* __restrict__ gout,
                                                                  bf16_t* __restrict__ dqkv, int N, int H, int ld, float scale,
                                                                  int g_in_zero, uint32_t thresh, float dscale, uint64_t seed,

@@ -35,6 +35,13 @@ def _lin_bwd_params(dy_bf16, x_bf16, weight, bias, rows=None, bias_done=False):
             ops.colsum(dy_bf16, gb, cols=bias.numel())
 
 
+def _epilogue_colsum(bias):
+    """Gradient buffer of `bias` if the GEMM epilogue can accumulate column sums into it (vector epilogue: width % 8 == 0)."""
+    if bias is None or bias.numel() % 8 != 0:
+        return None
+    return gbuf(bias)
+
+
 def _join_stream_after_backward():
     """A module backward that writes parameter gradients itself leaves autograd no leaf on its stream, so the engine would
     not join that stream at the end of backward(): if we are on a side stream, queue the join."""
@@ -144,8 +151,9 @@ class PairEncoderFn(torch.autograd.Function):
             # (dx16 = bf16 dropout-backward copy of dx, written by the LayerNorm backward that produced dx)
             dy2 = dx16 if dx16 is not None else ops.cast_bf16(dx, st.p_res, seed, L.site_f)
             _lin_bwd_params(dy2, L.a, layer.fc2.weight, layer.fc2.bias, bias_done=dx16 is not None)
-            du = ops.linear_bwd_input(dy2, wbf16(layer.fc2.weight), act=ops.ACT_GELU_BWD, aux_in=L.u)
-            _lin_bwd_params(du, L.h2, layer.fc1.weight, layer.fc1.bias)
+            cs = _epilogue_colsum(layer.fc1.bias)          # fc1.bias gradient = column sums of du: taken in the GEMM's epilogue
+            du = ops.linear_bwd_input(dy2, wbf16(layer.fc2.weight), act=ops.ACT_GELU_BWD, aux_in=L.u, colsum=cs)
+            _lin_bwd_params(du, L.h2, layer.fc1.weight, layer.fc1.bias, bias_done=cs is not None)
             dh2 = ops.linear_bwd_input(du, wbf16(layer.fc1.weight))
             dx, dy1 = ops.layernorm_bwd(dh2, L.x1, ln2.weight, L.m2, L.r2, gbuf(ln2.weight), gbuf(ln2.bias), dres=dx,
                                         bf16_copy=(st.p_res, L.site_o, gbuf(att.out_proj.bias)))
@@ -307,8 +315,9 @@ def _bert_layer_bwd(st, L, dout, seed):
     hd = D // heads
     dz, dzb = ops.layernorm_bwd(dout, L.z, W.ln2_w, L.zm, L.zr, gbuf(W.ln2_w), gbuf(W.ln2_b), bf16_copy=(L.p_hid, L.site_f, gbuf(W.o2_b)))
     _lin_bwd_params(dzb, L.i, W.o2_w, W.o2_b, bias_done=True)
-    du = ops.linear_bwd_input(dzb, wbf16(W.o2_w), act=ops.ACT_GELU_BWD, aux_in=L.u)
-    _lin_bwd_params(du, L.a16, W.i_w, W.i_b)
+    cs = _epilogue_colsum(W.i_b)
+    du = ops.linear_bwd_input(dzb, wbf16(W.o2_w), act=ops.ACT_GELU_BWD, aux_in=L.u, colsum=cs)
+    _lin_bwd_params(du, L.a16, W.i_w, W.i_b, bias_done=cs is not None)
     da = ops.linear_bwd_input(du, wbf16(W.i_w))
     # a32 = LN1(y) feeds the FFN AND the residual add of z: both gradients go through LN1's backward
     dy, dyb = ops.layernorm_bwd(da, L.y, W.ln1_w, L.am, L.ar, gbuf(W.ln1_w), gbuf(W.ln1_b), dy_add=dz, bf16_copy=(L.p_hid, L.site_o, gbuf(W.o_b)))

@@ -47,7 +47,7 @@ def _u8(mask):
 # --------------------------------------------------------------------------------------------- GEMM
 def gemm(A, B, *, M, N, K, lda, ldb, out=None, ldc=None, transA=False, transB=False, batch=(1, 1),
          sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, alpha=1.0, beta=0.0, bias=None, residual=None, act=ACT_NONE,
-         aux_in=None, aux_out=None, out_dtype=BF16, atomic=False, drop_p=0.0, seed=0, site=0, out_shape=None):
+         aux_in=None, aux_out=None, out_dtype=BF16, atomic=False, drop_p=0.0, seed=0, site=0, out_shape=None, colsum=None):
     """C = epi(alpha * A.B^T); see mmdti_gemm_bf16.  A/B are bf16 tensors (any shape; lda/ldb given explicitly)."""
     _chk(A, BF16, "gemm.A", contiguous=False)
     _chk(B, BF16, "gemm.B", contiguous=False)
@@ -62,7 +62,7 @@ def gemm(A, B, *, M, N, K, lda, ldb, out=None, ldc=None, transA=False, transB=Fa
                           int(transA), int(transB), batch[0], batch[1], sA[0], sA[1], sB[0], sB[1], sC[0], sC[1],
                           splitk, float(alpha), float(beta), _p(bias), _p(residual), ldc if residual is None else residual.stride(-2),
                           act, _p(aux_in), _p(aux_out), N if (aux_in is None and aux_out is None) else (aux_in if aux_in is not None else aux_out).stride(-2),
-                          c_dtype, float(drop_p), int(seed), int(site))
+                          c_dtype, float(drop_p), int(seed), int(site), _p(colsum))
     return out
 
 
@@ -74,12 +74,13 @@ def linear_fwd(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=BF16, 
                 out_dtype=out_dtype, aux_out=aux_out, drop_p=drop_p, seed=seed, site=site)
 
 
-def linear_bwd_input(dy, w, *, act=ACT_NONE, aux_in=None, out_dtype=BF16, K_valid=None):
-    """dx[M,K] = dy[M,N] . w[N,K]  (optionally * gelu'(aux_in))."""
+def linear_bwd_input(dy, w, *, act=ACT_NONE, aux_in=None, out_dtype=BF16, K_valid=None, colsum=None):
+    """dx[M,K] = dy[M,N] . w[N,K]  (optionally * gelu'(aux_in)).  colsum: [K] fp32 buffer that receives += column sums of dx
+    (the bias gradient of the Linear that produced this layer's input, when dx is that Linear's output gradient)."""
     M, N = dy.shape
     K = w.shape[1]
     return gemm(dy, w, M=M, N=K, K=(N if K_valid is None else K_valid), lda=dy.stride(0), ldb=w.stride(0), transB=True, act=act, aux_in=aux_in,
-                out_dtype=out_dtype)
+                out_dtype=out_dtype, colsum=colsum)
 
 
 def _splitk_for(M, N, K):

@@ -672,6 +672,20 @@ def test_gbf_bias_bwd_fused_matches_unfused_chain(ops, B, N, tiled):
         assert r < 2e-2, (name, r)
 
 
+@pytest.mark.parametrize("M,N,K,out_dtype", [(300, 128, 64, torch.bfloat16), (1000, 256, 192, torch.float32), (129, 64, 128, torch.bfloat16)])
+def test_gemm_epilogue_column_sums(ops, M, N, K, out_dtype):
+    """colsum_out: the bias gradient of the producing Linear, accumulated (+=) by the epilogue from the STORED values."""
+    x, w = dev(bf(torch.randn(M, K, generator=G(1)))), dev(bf(torch.randn(N, K, generator=G(2))))
+    cs = torch.full((N,), 0.25, device="cuda")
+    y = ops.gemm(x, w, M=M, N=N, K=K, lda=K, ldb=K, out_dtype=out_dtype, colsum=cs)
+    ref = ops.gemm(x, w, M=M, N=N, K=K, lda=K, ldb=K, out_dtype=out_dtype)
+    assert torch.equal(y, ref)
+    close(cs, 0.25 + y.float().sum(0), 1e-5, 1e-3)
+    from mmdti_hip._abi import MMDTIError
+    with pytest.raises(MMDTIError):                                            # split-K partial sums have no column sums
+        ops.gemm(x, w, M=M, N=N, K=K, lda=K, ldb=K, out=torch.zeros(M, N, device="cuda"), atomic=True, splitk=2, colsum=cs)
+
+
 # ------------------------------------------------------------------------------------------- fused attention
 def _attn_ref(q, k, v, add, heads, scale, keep=None, p_drop=0.0):
     """fp32 torch restatement on bf16-rounded operands (oracle mha, mmdti_oracle.py:320-338, minus the Linears)."""
