@@ -77,7 +77,7 @@ def pmc_traffic(kernel_prefix):
     try:
         import csv
         with open(path) as f:
-            for row in csv.DictReader(f):
+            for row in csv.DictReader(line for line in f if not line.startswith("#")):
                 if kernel_prefix in row["kernel"]:
                     return int(float(row["hbm_bytes_per_launch"]))
     except (OSError, KeyError, ValueError):
@@ -156,7 +156,7 @@ def main():
         roofline = None
         if ms:
             ach = pa_bytes / (ms * 1e-3) / 1e9
-            roofline = {"kernel": "pair_attn_bwd_mfma_kernel<9, true, true>", "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
+            roofline = {"kernel": "pair_attn_bwd_mfma_kernel<9, true, true, 3>", "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
                         "frac": round(ach / 8000.0, 4), "traffic": pmc_traffic("pair_attn_bwd_mfma_kernel"), "algorithmic_bytes_per_launch": pa_bytes,
                         "mean_launch_ms": round(ms, 4), "launches_timed": timers["pair_attn_bwd"]["n"], "other_kernels_ms": {k: round(v["mean_ms"], 4) for k, v in timers.items()}}
         cpu = None
