@@ -128,3 +128,42 @@ def test_step_leaves_no_reference_cycles(task, odim):
         gc.enable()
     assert not leaked, f"{len(leaked)} tensors were only reachable through reference cycles"
     assert grown < (1 << 20), f"device memory grew by {grown} bytes over 3 steps"
+
+
+def test_reference_sized_step_vs_oracle():
+    """The architecture the benchmark runs (Uni-Mol 15 x 512 / 64 heads / 128 Gaussians, RoBERTa 6 x 512 / 8 heads,
+    co-attention 16 heads) at a small batch, through FineTuner's arena: this is the only place where every hot-path
+    specialisation is live at once -- fused pair bias in the tiled layout, the tiled pair-attention kernels, fused
+    attention at head_dim 64 and 32, the fused query|key|value GEMM, LDS-DMA GEMM tiles, bias gradients out of LayerNorm
+    backward and the GELU'-dX epilogue -- against the CPU oracle with the same rounding points."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from mmdti_hip.trainer import FineTuner
+    from mmdti_hip import ops
+    model, _ = bench.build_model()
+    model = model.cuda().eval()                                                       # dropout off: value parity
+    ocfg = O.ModelCfg(task="classification", output_dim=2)
+    ocfg.roberta = O.RobertaCfg(layers=6, dim=512, heads=8, ffn=2048, vocab=600, max_pos=514, pad_idx=1)
+    batch, label = O.synth_batch(6, 40, 48, ocfg, seed=21, ragged=True)
+    P = {k: v.detach().cpu().float().clone().requires_grad_() for k, v in model.state_dict().items() if v.dtype.is_floating_point}
+    tuner = FineTuner(model, "classification", total_steps=10)
+    dev = {k: v.cuda() for k, v in batch.items()}
+    out = tuner.forward_backward(dev, label.cuda())
+    ref = O.mm_forward(batch, P, ocfg, net_target=label, bf16=True)
+    ref_loss, _ = O.step_loss(ref, label, "classification")
+    assert abs(float(out.loss) - float(ref_loss)) <= 1e-3 * abs(float(ref_loss)), (float(out.loss), float(ref_loss))
+    assert abs(float(out.infonce_loss) - float(ref["infonce"])) <= 1e-3 * abs(float(ref["infonce"]))
+    ref_loss.backward()
+    zero_grads = ("pooler", "key.bias", "gbf_proj.linear2.bias")
+    worst = ("", 0.0)
+    cos_min = 1.0
+    for n, p in model.named_parameters():
+        g_ref = P[n].grad if n in P else None
+        if p.grad is None or g_ref is None or any(z in n for z in zero_grads) or float(g_ref.abs().max()) == 0.0:
+            continue
+        a, b = p.grad.detach().float().cpu().reshape(-1), g_ref.reshape(-1)
+        r = float((a - b).norm() / (b.norm() + 1e-20))
+        worst = max(worst, (n, r), key=lambda t: t[1])
+        cos_min = min(cos_min, float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)))
+    assert worst[1] < 0.12 and cos_min > 0.99, (worst, cos_min)
