@@ -573,6 +573,107 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 4) void gemm_glds_kernel(GemmArgs a
 #undef STG_T
 }
 
+// =====================================================================================================================
+// Tall-tile variant of the LDS-DMA kernel: 144 x 128 tiles that ADVANCE by `mstep` rows (129...144), the rows past mstep
+// being computed but not stored.  Why: the resident set is 4 workgroups x 256 CUs = 1024 tiles, and the tower-1 GEMMs
+// have M = 256 molecules x 130 rows = 260 x 128 -- 1040 / 3120 / 4160 tiles, i.e. 2 / 4 / 5 rounds where 1.02 / 3.05 /
+// 4.06 would do (16 tiles past a full round cost a whole extra round: 26.0 -> 36.1 us at N = K = 512).  With mstep =
+// 130 the same GEMMs are exactly 1 / 3 / 4 rounds of 12.5 % taller tiles.  A row-major ([M,K]) operands only; waves
+// split the tile 1 x 4 along N (144 x 32 each, 9 x 2 accumulator tiles).
+constexpr int BMT = 144;
+constexpr int TALL_ROWS_PER_PASS = 48;
+
+template <bool TB>
+__global__ __launch_bounds__(256, 4) void gemm_glds_tall_kernel(GemmArgs a, int mstep) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+  bf16_t* imgA = smem;
+  bf16_t* imgB = smem + BMT * LDT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + mstep - 1) / mstep;
+  const int nwg = tiles_n * tiles_m;
+  const int orig = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+  const int m0 = tm * mstep, n0 = tn * BN;
+  const bf16_t* __restrict__ A = a.A;
+  const bf16_t* __restrict__ B = a.B;
+  const int ktiles = a.K / BK;
+  // A tile: 144 rows x 8 chunks = 1152 chunks of 16 B -> 4.5 per thread (the fifth DMA on waves 0-1 only)
+  uint32_t oA[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int c = j * 256 + tid;
+    const int rl = min(c >> 3, BMT - 1), kc = (c & 7) ^ (rl & 7);
+    const int row = min(m0 + rl, a.M - 1);
+    oA[j] = (uint32_t)(((long long)row * a.lda + kc * 8) * 2);
+  }
+  const Off4 offB = glds_offsets<TB>(a.ldb, n0, a.N, tid);
+  const long long kstepB = TB ? (long long)BK * a.ldb : BK;
+  f32x4 acc[9][2] = {};
+  typedef __attribute__((address_space(1))) const void gptr_t;
+  typedef __attribute__((address_space(3))) void lptr_t;
+#define TMF(I) acc[I][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0, fa##I, acc[I][0], 0, 0, 0); \
+               acc[I][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1, fa##I, acc[I][1], 0, 0, 0)
+#define TALL_KK(KK)                                                                                   \
+  {                                                                                                   \
+    const bf16x8 fb0 = load_frag<TB>(imgB, wave * 32, KK, lane), fb1 = load_frag<TB>(imgB, wave * 32 + 16, KK, lane); \
+    {                                                                                                 \
+      const bf16x8 fa0 = load_frag<false>(imgA, 0, KK, lane), fa1 = load_frag<false>(imgA, 16, KK, lane),   \
+                   fa2 = load_frag<false>(imgA, 32, KK, lane), fa3 = load_frag<false>(imgA, 48, KK, lane),  \
+                   fa4 = load_frag<false>(imgA, 64, KK, lane);                                        \
+      TMF(0); TMF(1); TMF(2); TMF(3); TMF(4);                                                         \
+    }                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);   /* two batches of A fragments: all nine at once would not fit 128 registers */ \
+    {                                                                                                 \
+      const bf16x8 fa5 = load_frag<false>(imgA, 80, KK, lane), fa6 = load_frag<false>(imgA, 96, KK, lane),  \
+                   fa7 = load_frag<false>(imgA, 112, KK, lane), fa8 = load_frag<false>(imgA, 128, KK, lane); \
+      TMF(5); TMF(6); TMF(7); TMF(8);                                                                 \
+    }                                                                                                 \
+  }
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const char* ab = reinterpret_cast<const char*>(A + (long long)kt * BK);
+    bf16_t* d = imgA + wave * 512;
+    __builtin_amdgcn_global_load_lds((gptr_t*)(ab + oA[0]), (lptr_t*)(d), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t*)(ab + oA[1]), (lptr_t*)(d + 2048), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t*)(ab + oA[2]), (lptr_t*)(d + 4096), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t*)(ab + oA[3]), (lptr_t*)(d + 6144), 16, 0, 0);
+    if (wave < 2) __builtin_amdgcn_global_load_lds((gptr_t*)(ab + oA[4]), (lptr_t*)(d + 8192), 16, 0, 0);
+    glds_tile(B + kt * kstepB, offB, imgB, wave);
+    __syncthreads();
+    TALL_KK(0);
+    TALL_KK(1);
+    __syncthreads();
+  }
+#undef TALL_KK
+#undef TMF
+  // epilogue: three passes of 48 rows through a [48][132] fp32 image; every wave parks its 32 columns
+  const long long coff = 0;
+  const int g4 = (lane >> 4) * 4, l15 = lane & 15;
+  float* sC = reinterpret_cast<float*>(smem);
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define TSTG(I, L) *reinterpret_cast<f32x4*>(sC + ((L) * 16 + l15) * LDC_S + wave * 32 + g4) = acc[I][0]; \
+                   *reinterpret_cast<f32x4*>(sC + ((L) * 16 + l15) * LDC_S + wave * 32 + 16 + g4) = acc[I][1]
+#define TPASS(P)                                                                                      \
+  TSTG(3 * (P), 0); TSTG(3 * (P) + 1, 1); TSTG(3 * (P) + 2, 2);                                       \
+  __syncthreads();                                                                                    \
+  for (int it = 0; it < 3; ++it) {                                                                    \
+    const int chunk = tid + it * 256;                                                                 \
+    const int rr = chunk >> 4, cc = (chunk & 15) * 8;                                                 \
+    const int rloc = (P) * TALL_ROWS_PER_PASS + rr, row = m0 + rloc, col = n0 + cc;                   \
+    if (rloc < mstep && row < a.M && col < a.N)                                                       \
+      epilogue_oct(a, sC + rr * LDC_S + cc, row, col, true, coff, a.colsum ? cs : nullptr);           \
+  }
+  TPASS(0)
+  __syncthreads();
+  TPASS(1)
+  __syncthreads();
+  TPASS(2)
+  if (a.colsum) epilogue_colsum(a, sC, cs, tid, n0);
+#undef TPASS
+#undef TSTG
+}
+
 }  // namespace mmdti
 
 using namespace mmdti;
@@ -657,8 +758,29 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
   // split-K weight gradients: double-buffered DMA from 48 output tiles up (-5...-13 %), register staging below (+13 %)
   if (fast && use_glds && ((splitk > 1 && tiles >= 48) || use_glds == 3))
     hipLaunchKernelGGL(gkerns2[transA ? 1 : 0][transB ? 1 : 0], grid, block, 4 * (size_t)BM * LDT * sizeof(bf16_t), s, a);
-  else if (fast && use_glds && splitk == 1)
-    hipLaunchKernelGGL(gkerns[transA ? 1 : 0][transB ? 1 : 0], grid, block, smem, s, a);
+  else if (fast && use_glds && splitk == 1) {
+    // tall tiles when they save a whole round of the 1024 resident workgroups (see gemm_glds_tall_kernel)
+    int mstep = 0;
+    static const int use_tall = getenv("MMDTI_GEMM_TALL") ? atoi(getenv("MMDTI_GEMM_TALL")) : 1;
+    if (use_tall && !transA && a.vec_ok && grid.z == 1 && M >= 1024) {
+      const int slots = 1024, tn = cdiv(N, BN);
+      const int r128 = cdiv(tiles, slots);
+      if (r128 >= 2 && (r128 - 1) * slots >= tn) {
+        const int rows_fit = ((r128 - 1) * slots) / tn;           // row-tiles that fit in one round fewer
+        const int sneed = cdiv(M, rows_fit);
+        // (measured: 2 -> 1 rounds is -12...-16 %; 4 -> 3 and 5 -> 4 rounds lose to the taller tile's own cost)
+        if (sneed > 128 && sneed <= BMT && 1.125 * (r128 - 1) < 0.75 * r128) mstep = sneed;
+      }
+    }
+    if (mstep) {
+      grid.x = cdiv(M, mstep) * cdiv(N, BN);
+      const size_t smem_t = (size_t)(BMT + BN) * LDT * sizeof(bf16_t);
+      if (transB) hipLaunchKernelGGL(gemm_glds_tall_kernel<true>, grid, block, smem_t, s, a, mstep);
+      else hipLaunchKernelGGL(gemm_glds_tall_kernel<false>, grid, block, smem_t, s, a, mstep);
+    } else {
+      hipLaunchKernelGGL(gkerns[transA ? 1 : 0][transB ? 1 : 0], grid, block, smem, s, a);
+    }
+  }
   else
     hipLaunchKernelGGL(kerns[transA ? 1 : 0][transB ? 1 : 0][fast ? 1 : 0], grid, block, smem, s, a);
   MMDTI_LAUNCH_CHECK();

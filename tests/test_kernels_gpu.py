@@ -686,6 +686,30 @@ def test_gemm_epilogue_column_sums(ops, M, N, K, out_dtype):
         ops.gemm(x, w, M=M, N=N, K=K, lda=K, ldb=K, out=torch.zeros(M, N, device="cuda"), atomic=True, splitk=2, colsum=cs)
 
 
+@pytest.mark.parametrize("transB", [False, True])
+def test_gemm_tall_tiles_match_square_tiles(ops, transB, monkeypatch):
+    """M = 256 x 130 rows, N = 512: the shape that switches to 144-row tiles advancing by 130 rows (one round of resident
+    workgroups instead of two).  Same numbers as the 128-row tiling, including the fused epilogue and the column sums."""
+    import os
+    M, N, K = 256 * 130, 512, 192
+    x = dev(bf(torch.randn(M, K, generator=G(1))))
+    w = dev(bf(torch.randn(K, N, generator=G(2)))) if transB else dev(bf(torch.randn(N, K, generator=G(2))))
+    bias, res = dev(torch.randn(N, generator=G(3))), dev(torch.randn(M, N, generator=G(4)))
+    kw = dict(M=M, N=N, K=K, lda=K, ldb=(N if transB else K), transB=transB, bias=bias, residual=res, out_dtype=torch.float32, drop_p=0.1, seed=5, site=2)
+    cs = torch.zeros(N, device="cuda")
+    y = ops.gemm(x, w, colsum=cs, **kw)
+    wf = w.float() if transB else w.float().t()
+    ref_nodrop = x.float() @ wf + bias
+    keep = (y - res) != 0
+    close((y - res)[keep], (ref_nodrop / 0.9)[keep], 2e-3, 2e-2)
+    assert abs(float(keep.float().mean()) - 0.9) < 0.01
+    close(cs, y.sum(0), 1e-4, 2e-2)
+    yb = ops.gemm(x, w, M=M, N=N, K=K, lda=K, ldb=(N if transB else K), transB=transB, bias=bias)   # bf16 output path
+    close(yb, ref_nodrop, 1e-2, 5e-2)
+    # row 129 of every 130-row step is the last row a tall tile stores; row 130 belongs to the next tile
+    assert torch.isfinite(yb.float()).all()
+
+
 # ------------------------------------------------------------------------------------------- fused attention
 def _attn_ref(q, k, v, add, heads, scale, keep=None, p_drop=0.0):
     """fp32 torch restatement on bf16-rounded operands (oracle mha, mmdti_oracle.py:320-338, minus the Linears)."""
