@@ -167,3 +167,55 @@ def test_reference_sized_step_vs_oracle():
         worst = max(worst, (n, r), key=lambda t: t[1])
         cos_min = min(cos_min, float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)))
     assert worst[1] < 0.12 and cos_min > 0.99, (worst, cos_min)
+
+
+def test_full_size_step_properties():
+    """BASELINE.json's full shape (256 molecules x 128 atoms x 256 tokens, reference architecture) -- too large for the
+    oracle, so size-independent properties instead:
+      * eval-mode logits are bit-reproducible (no atomics between the inputs and the logits);
+      * permuting the molecules of the batch permutes the logits and leaves InfoNCE / SupCon unchanged (every kernel's
+        batch indexing, the tiled pair layout and the B x B losses at full size);
+      * a train-mode step has finite losses and gradients, and its global gradient norm repeats across two runs with the
+        same dropout seeds to 1e-3 (fp32 atomic accumulation order is the only non-determinism)."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from mmdti_hip.runtime import dropout_state
+    model, _ = bench.build_model()
+    model = model.cuda().eval()
+    _, batch, label = bench.synth(256, 128, 256, seed=77, ragged=True)
+    dev = {k: v.cuda() for k, v in batch.items()}
+    y = label.cuda()
+    with torch.no_grad():
+        lg1, inf1, ct1 = model(**dev, return_infonce_loss=True, return_ct_loss=True, net_target=y)
+        lg2, inf2, ct2 = model(**dev, return_infonce_loss=True, return_ct_loss=True, net_target=y)
+        assert torch.equal(lg1, lg2)                                   # no atomics between the inputs and the logits
+        # (the two scalar losses are atomic sums over rows: equal up to summation order)
+        assert abs(float(inf1) - float(inf2)) <= 1e-6 * abs(float(inf1)) and abs(float(ct1) - float(ct2)) <= 1e-6 * abs(float(ct1))
+        perm = torch.randperm(256, generator=torch.Generator().manual_seed(3)).cuda()
+        devp = {k: v[perm] for k, v in dev.items()}
+        lgp, infp, ctp = model(**devp, return_infonce_loss=True, return_ct_loss=True, net_target=y[perm])
+    torch.testing.assert_close(lgp, lg1[perm], rtol=1e-4, atol=1e-4)
+    assert abs(float(infp) - float(inf1)) <= 1e-4 * abs(float(inf1)) and abs(float(ctp) - float(ct1)) <= 1e-4 * abs(float(ct1))
+    assert torch.isfinite(lg1).all() and float(inf1) > 0 and float(ct1) > 0
+    # train mode, two runs from the same dropout seed
+    model.train()
+    from mmdti_hip.functional import CELossFn
+    norms = []
+    for _ in range(2):
+        dropout_state.reseed(1234)
+        for p in model.parameters():
+            p.grad = None
+        lg, inf, ct = model(**dev, return_infonce_loss=True, return_ct_loss=True, net_target=y)
+        loss = CELossFn.apply(lg, y) + 0.1 * inf + 0.1 * ct
+        loss.backward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss)
+        sq = 0.0
+        for p in model.parameters():
+            if p.grad is not None:
+                assert torch.isfinite(p.grad).all()
+                sq += float(p.grad.double().pow(2).sum())
+        norms.append(sq ** 0.5)
+    assert abs(norms[0] - norms[1]) <= 1e-3 * norms[0], norms
+    assert norms[0] > 0
