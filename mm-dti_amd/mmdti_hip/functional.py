@@ -91,6 +91,8 @@ class PairEncoderFn(torch.autograd.Function):
         seed = dropout_state.next_seed()
         sites = _Sites()
         st = SimpleNamespace(B=B, N=N, D=D, H=H, ld=ld, M=M, seed=seed, p_emb=p_emb, p_res=p_res, p_att=p_att, layers=[])
+        keep = any(ctx.needs_input_grad)      # inference (torch.no_grad / frozen inputs): nothing is kept for a backward --
+                                              # the 15 per-layer logit tensors are freed as the stack advances
         emb = emb.contiguous()
         st.emb = emb
         st.pad = padding_mask
@@ -118,14 +120,16 @@ class PairEncoderFn(torch.autograd.Function):
             L.a = ops.linear_fwd(L.h2, wbf16(layer.fc1.weight), layer.fc1.bias, act=ops.ACT_GELU, aux_out=L.u)
             L.site_f = sites.next()
             x = ops.linear_fwd(L.a, wbf16(layer.fc2.weight), layer.fc2.bias, residual=L.x1, out_dtype=F32, drop_p=p_res, seed=seed, site=L.site_f)
-            st.layers.append(L)
+            if keep:
+                st.layers.append(L)
         st.x_last = x
         if mod.final_layer_norm is not None:
             fl = mod.final_layer_norm
             out, _, st.f_mean, st.f_rstd = ops.layernorm_fwd(x, fl.weight, fl.bias, fl.eps, want_f32=True, want_bf16=False)
         else:
             out = x
-        ctx.st, ctx.mod = st, mod
+        if keep:
+            ctx.st, ctx.mod = st, mod
         x_last = x.view(B, N, D)
         ctx.mark_non_differentiable(s_prev, x_last)
         return out.view(B, N, D), s_prev, x_last
@@ -198,8 +202,10 @@ class PairBiasFn(torch.autograd.Function):
         if fused:
             # one kernel from distances to the [B,H,N,ld] bias; the three [P,128] intermediates are saved for the backward
             # (tiled pair layout whenever the MFMA pair-attention kernels can take it: their loads become contiguous KiBs)
-            out, (feat, u, h) = ops.gbf_bias_fwd(dist, edge_type, *args, wbf16(proj.linear1.weight), proj.linear1.bias,
-                                                 wbf16(proj.linear2.weight), proj.linear2.bias, ld, save=True, tiled=ops.pair_tiled_ok(N))
+            keep = any(ctx.needs_input_grad)  # inference: the kernel does not even write the [P,128] intermediates
+            out, saved = ops.gbf_bias_fwd(dist, edge_type, *args, wbf16(proj.linear1.weight), proj.linear1.bias,
+                                          wbf16(proj.linear2.weight), proj.linear2.bias, ld, save=keep, tiled=ops.pair_tiled_ok(N))
+            feat, u, h = saved if keep else (None, None, None)
         else:
             feat = ops.gbf_features_fwd(dist, edge_type, *args)
             u = torch.empty(feat.shape[0], proj.linear1.weight.shape[0], device=dist.device, dtype=BF16)
@@ -406,14 +412,17 @@ class RobertaEncoderFn(torch.autograd.Function):
         zeros = torch.zeros_like(ids)
         ops.embedding_fwd(zeros, mod.token_type, out=e, accumulate=True)
         st = SimpleNamespace(B=B, Lq=Lq, Lk=Lq, D=D, seed=seed, ids=ids, pos=pos, zeros=zeros, e=e, layers=[], p_hid=p_hid)
+        keep = any(ctx.needs_input_grad)      # inference: no per-layer activations are kept
         st.site_emb = sites.next()
         x32, x16, st.em, st.er = ops.layernorm_fwd(e.view(B * Lq, D), mod.emb_ln_w, mod.emb_ln_b, cfg.ln_eps, want_f32=True, want_bf16=True,
                                                    drop_p=p_hid, seed=seed, site=st.site_emb)
         key_add = ((1.0 - attention_mask.to(F32)) * torch.finfo(torch.float32).min).contiguous()
         for layer in mod.layers:
             L, x32, x16 = _bert_layer_fwd(st, x32, x16, x16, key_add, bert_weights(layer), cfg.heads, p_hid, p_att, cfg.ln_eps, seed, sites, True)
-            st.layers.append(L)
-        ctx.st, ctx.mod = st, mod
+            if keep:
+                st.layers.append(L)
+        if keep:
+            ctx.st, ctx.mod = st, mod
         return x32.view(B, Lq, D)
 
     @staticmethod
@@ -455,7 +464,8 @@ class CrossLayerFn(torch.autograd.Function):
         s2_16 = ops.cast_bf16(s2.contiguous().view(B * Lk, D))
         L, out32, _ = _bert_layer_fwd(st, s1c, s1_16, s2_16, key_add.contiguous(), bert_weights(layer), cfg.heads, p_hid, p_att, cfg.ln_eps,
                                       seed, sites, False)
-        ctx.st, ctx.L, ctx.layer = st, L, layer
+        if any(ctx.needs_input_grad):
+            ctx.st, ctx.L, ctx.layer = st, L, layer
         return out32.view(B, Lq, D)
 
     @staticmethod

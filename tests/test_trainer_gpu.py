@@ -219,3 +219,30 @@ def test_full_size_step_properties():
         norms.append(sq ** 0.5)
     assert abs(norms[0] - norms[1]) <= 1e-3 * norms[0], norms
     assert norms[0] > 0
+
+
+def test_predict_path_keeps_no_activations():
+    """Inference (model.eval() under torch.no_grad(), the reference's predict path tasks/trainer.py:387-482): same logits as
+    the gradient-enabled forward, bit for bit, while nothing is kept for a backward -- the 15 per-layer pair-logit tensors
+    are freed as the stack advances and the fused pair-bias kernel does not write its three [P,128] intermediates."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    model, _ = bench.build_model()
+    model = model.cuda().eval()
+    _, batch, label = bench.synth(64, 128, 256, seed=5, ragged=False)
+    dev = {k: v.cuda() for k, v in batch.items()}
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    lg_grad = model(**dev)                                            # gradient-enabled forward: activations are kept
+    peak_grad = torch.cuda.max_memory_allocated() - base
+    lg_grad = lg_grad.detach().clone()
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    with torch.no_grad():
+        lg = model(**dev)
+    peak_inf = torch.cuda.max_memory_allocated() - base
+    assert torch.equal(lg, lg_grad)
+    assert peak_inf < 0.35 * peak_grad, (peak_inf, peak_grad)
