@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256, 4) void pair_attn_fwd_mfma_kernel(const bf16_t
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       if (TILED && !EDGE && (FULL ? t < NT - 1 : false)) {
-        S[t] = *reinterpret_cast<const f32x4*>(bin + t * TSTEP + goff);
+        S[t] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(bin + t * TSTEP + goff));
       } else {
         const bool pr = PA_PRED(t);
         const f32x4 ld4 = *reinterpret_cast<const f32x4*>(bin + (pr ? t * TSTEP + goff : 0));
@@ -379,9 +379,9 @@ __global__ __launch_bounds__(256, 4) void pair_attn_fwd_mfma_kernel(const bf16_t
           for (int r = 0; r < 4; ++r) c[r] = (km[r] != 0.f) ? NEG_INF : c[r];
         }
         if (TILED && !EDGE && (FULL ? t < NT - 1 : false)) {
-          *reinterpret_cast<f32x4*>(sout + t * TSTEP + goff) = c;
+          __builtin_nontemporal_store(c, reinterpret_cast<f32x4*>(sout + t * TSTEP + goff));
         } else if (PA_PRED(t)) {
-          *reinterpret_cast<f32x4*>(sout + t * TSTEP + goff) = c;
+          __builtin_nontemporal_store(c, reinterpret_cast<f32x4*>(sout + t * TSTEP + goff));
         }
         S[t] = c;
         m = fmaxf(fmaxf(m, fmaxf(c[0], c[1])), fmaxf(c[2], c[3]));
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
         const int kcol = t * 16 + 4 * g;
         f32x4 c;
         if (PA_FAST(t)) {
-          c = *reinterpret_cast<const f32x4*>(sin_p + t * TSTEP + goff);
+          c = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sin_p + t * TSTEP + goff));
         } else {
           const bool inrow = PA_PRED(t);
           const f32x4 ld4 = *reinterpret_cast<const f32x4*>(sin_p + (inrow ? t * TSTEP + goff : 0));
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       if (PA_FAST(t)) {
-        const f32x4 ld4 = *reinterpret_cast<const f32x4*>(gin_p + (g_in_zero ? 0 : t * TSTEP + goff));
+        const f32x4 ld4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gin_p + (g_in_zero ? 0 : t * TSTEP + goff)));
         Gi[t] = g_in_zero ? f32x4{0.f, 0.f, 0.f, 0.f} : ld4;
       } else {
         const bool inrow = PA_PRED(t) && !g_in_zero;
@@ -609,9 +609,9 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
       }
       if (EDGE && !qvalid) G = f32x4{0.f, 0.f, 0.f, 0.f};
       if (PA_FAST(t)) {
-        *reinterpret_cast<f32x4*>(gout_p + t * TSTEP + goff) = G;
+        __builtin_nontemporal_store(G, reinterpret_cast<f32x4*>(gout_p + t * TSTEP + goff));
       } else if (PA_PRED(t)) {
-        *reinterpret_cast<f32x4*>(gout_p + t * TSTEP + goff) = G;
+        __builtin_nontemporal_store(G, reinterpret_cast<f32x4*>(gout_p + t * TSTEP + goff));
       }
       f32x4 Pd;
 #pragma unroll
