@@ -170,7 +170,9 @@ def main():
             "config": {"workload": f"BBBP-like classification + SupCon + InfoNCE fine-tune step, {args.batch} molecules/GPU x {args.atoms} atoms x "
                                    f"{args.tokens} SMILES tokens (all at max length), fwd+bwd+allreduce+clip+Adam, dropout on",
                        "global_batch": args.batch * world, "atoms": args.atoms, "tokens": args.tokens, "parallelism": f"dp{world}",
-                       "unimol": "15L/512/64h", "chemberta_assumed": "6L/512/8h/ffn2048/vocab600", "infonce_negatives": "global"},
+                       "unimol": "15L/512/64h", "chemberta_assumed": "6L/512/8h/ffn2048/vocab600", "infonce_negatives": "global",
+                       "grad_buckets_reduced_during_backward": None if tuner.reducer is None or not tuner.reducer.active
+                       else f"{tuner.reducer.overlapped}/{len(tuner.reducer.buckets)}"},
             "losses_last_step": losses, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

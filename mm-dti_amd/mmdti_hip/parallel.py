@@ -11,9 +11,9 @@ global batch reproduce the single-process loss and gradients:
     all-reduced with op=AVG, except InfoNCE whose value is already this rank's share of the global loss (hence its
     gradient is pre-multiplied by world_size before the AVG);
   * gradients live in ONE flat fp32 arena (runtime.ParamArena): the all-reduce walks it in large buckets on a side HIP
-    stream, and is launched bucket by bucket while the backward of earlier layers is still running (tower order in the
-    arena is arranged so that buckets complete back-to-front).  xGMI is point-to-point (7 links x ~153 GB/s per GPU): a
-    ring all-reduce is bound by one link, so few large buckets (default 64 MiB) amortise the per-collective latency.
+    stream, and is launched bucket by bucket while the backward of earlier layers is still running (a bucket goes out
+    as soon as every parameter in it has reported its gradients enqueued -- ArenaReducer.on_grads_ready).  xGMI is point-to-point (7 links x ~153 GB/s per GPU): a
+    ring all-reduce is bound by one link, so few large buckets (default 32 MiB) amortise the per-collective latency.
 """
 from __future__ import annotations
 
@@ -81,32 +81,89 @@ class GlobalNegatives:
 
 
 class ArenaReducer:
-    """Bucketed gradient all-reduce (mean) over the flat gradient arena on a side stream."""
+    """Bucketed gradient all-reduce (mean) over the flat gradient arena on a side stream.
 
-    def __init__(self, arena, bucket_bytes: int = 64 << 20, group=None):
+    Overlap with backward: every module backward of functional.py calls runtime.notify_grads_ready(params) once all
+    gradient kernels of `params` are enqueued; on_grads_ready() records a HIP event on that stream (the two towers run
+    their backward on different streams) and, as soon as every parameter overlapping a bucket has reported, launches that
+    bucket's all-reduce on the communication stream behind those events.  Buckets holding a parameter that never reports
+    (no gradient this step) are reduced by finish().  All ranks run the same graph, so the launch order is identical
+    everywhere."""
+
+    def __init__(self, arena, bucket_bytes: int = 32 << 20, group=None):
         self.arena, self.group = arena, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = _collectives_active(self.world)
         n = arena.numel
         per = max(1, bucket_bytes // 4)
+        self.per = per
         self.buckets = [(s, min(n, s + per)) for s in range(0, n, per)]
         self.stream = torch.cuda.Stream() if (self.active and arena.grad.is_cuda) else None
         self._pending = []
+        # parameter -> arena range, bucket -> parameters it needs (only when the arena knows its parameters)
+        self._range = {}
+        self._need = [set() for _ in self.buckets]
+        for p in getattr(arena, "params", ()):
+            lo = arena.offsets[id(p)]
+            hi = lo + p.numel()
+            self._range[id(p)] = (lo, hi)
+            for b in range(lo // per, (hi - 1) // per + 1):
+                self._need[b].add(id(p))
+        self._have = [set() for _ in self.buckets]
+        self._events = [[] for _ in self.buckets]
+        self.overlapped = 0                    # buckets launched from inside backward during the last step (diagnostic)
 
     def reduce_range(self, lo: int, hi: int):
-        """Launch the all-reduce of every not-yet-reduced bucket fully inside [lo, hi) -- called as soon as the backward
-        has finished writing that part of the arena."""
+        """Launch the all-reduce of every not-yet-reduced bucket fully inside [lo, hi) -- for callers that know which
+        part of the arena the backward has finished writing."""
         if not self.active:
             return
         for (s, e) in self.buckets:
             if s >= lo and e <= hi and (s, e) not in self._pending:
                 self._launch(s, e)
 
-    def _launch(self, s, e):
+    def on_grads_ready(self, params):
+        """runtime.notify_grads_ready hook: `params` have all their gradient kernels enqueued on the current stream."""
+        if not self.active:
+            return
+        ev = None
+        if self.stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+        touched = set()
+        for p in params:
+            r = self._range.get(id(p))
+            if r is None:
+                continue
+            for b in range(r[0] // self.per, (r[1] - 1) // self.per + 1):
+                self._have[b].add(id(p))
+                touched.add(b)
+        for b in sorted(touched, reverse=True):
+            if ev is not None:
+                self._events[b].append(ev)
+            if self.buckets[b] not in self._pending and self._have[b] >= self._need[b]:
+                self._launch(*self.buckets[b], events=self._events[b])
+                self.overlapped += 1
+
+    def unreported(self):
+        """ids of parameters that did not report during the last backward, per bucket (diagnostic / tests)."""
+        return [need - have for need, have in zip(self._need, self._have)]
+
+    def begin_step(self):
+        self._have = [set() for _ in self.buckets]
+        self._events = [[] for _ in self.buckets]
+        self._pending = []
+        self.overlapped = 0
+
+    def _launch(self, s, e, events=None):
         view = self.arena.grad[s:e]
         # SUM + scale rather than ReduceOp.AVG: identical result, no dependence on the collective library's AVG support
         if self.stream is not None:
-            self.stream.wait_stream(torch.cuda.current_stream())
+            if events is None:
+                self.stream.wait_stream(torch.cuda.current_stream())
+            else:
+                for ev in events:
+                    self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
                 dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
                 if self.world > 1:

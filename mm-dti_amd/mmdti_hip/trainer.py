@@ -13,6 +13,7 @@ AMP branch :274), same per-epoch FDS statistics pass (:288-306).  What changes i
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -54,7 +55,7 @@ def _qkv_groups(model):
 
 class FineTuner:
     def __init__(self, model, task: str, learning_rate=1e-4, adam_eps=1e-6, warmup_ratio=0.03, total_steps=1000, alpha=1.0, beta=0.1,
-                 max_norm: Optional[float] = 5.0, distributed: bool = False, bucket_bytes: int = 64 << 20):
+                 max_norm: Optional[float] = 5.0, distributed: bool = False, bucket_bytes: int = 32 << 20):
         self.model, self.task = model, task
         self.lr, self.eps, self.alpha, self.beta, self.max_norm = learning_rate, adam_eps, alpha, beta, max_norm
         self.total_steps = total_steps
@@ -63,11 +64,16 @@ class FineTuner:
         self.arena = ParamArena(model.parameters(), adjacent=_qkv_groups(model))
         self.world = 1
         self.reducer = None
+        set_grad_ready_hook(None)
         if distributed:
             self.negs = GlobalNegatives()
             self.world = self.negs.world
             self.reducer = ArenaReducer(self.arena, bucket_bytes)
             self._b_loc = None
+            # gradient buckets leave during backward (MMDTI_NO_REDUCE_OVERLAP=1: all of them after it); sub-batched
+            # tower 1 accumulates into the same gradients several times per step, so it keeps the after-backward form
+            if os.environ.get("MMDTI_NO_REDUCE_OVERLAP") != "1" and getattr(model, "split_tower1", 1) == 1:
+                set_grad_ready_hook(self.reducer.on_grads_ready)
         if task == "regression":
             self.task_loss = lambda lg, y: MSELossFn.apply(lg, y.float())
         elif task in ("classification", "multiclass"):
@@ -87,6 +93,7 @@ class FineTuner:
         self.arena.zero_grad()
         if self.reducer is not None:
             self._bind_global_negatives(net_target.shape[0])
+            self.reducer.begin_step()
         logits, infonce, ct = model(**net_input, return_infonce_loss=True, return_ct_loss=True, net_target=net_target, use_weight=use_weight,
                                     epoch=epoch)
         tl = self.task_loss(logits, net_target)

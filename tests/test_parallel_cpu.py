@@ -101,6 +101,53 @@ def _worker_reducer(rank, world, initfile, out):
     dist.destroy_process_group()
 
 
+class _ParamArena(_FakeArena):
+    """arena stand-in that knows its parameters (sizes 300, 212, 256, 232 -> offsets 0, 300, 512, 768)."""
+
+    def __init__(self):
+        super().__init__(1000)
+        self.params = [torch.nn.Parameter(torch.zeros(k)) for k in (300, 212, 256, 232)]
+        self.offsets, off = {}, 0
+        for p in self.params:
+            self.offsets[id(p)] = off
+            off += p.numel()
+
+
+def _worker_reducer_hook(rank, world, initfile, out):
+    """on_grads_ready: a bucket leaves as soon as every parameter overlapping it has reported, never before."""
+    _init(rank, world, initfile)
+    from mmdti_hip.parallel import ArenaReducer
+    arena = _ParamArena()
+    base = torch.arange(1000, dtype=torch.float32)
+    red = ArenaReducer(arena, bucket_bytes=4 * 256)                      # buckets [0,256) [256,512) [512,768) [768,1000)
+    p0, p1, p2, p3 = arena.params
+    for step in range(2):                                                # second step: begin_step() forgets the first
+        arena.grad.copy_(base * (rank + 1))
+        red.begin_step()
+        red.on_grads_ready([p3])
+        assert red._pending == [(768, 1000)]
+        red.on_grads_ready([p1])                                         # bucket 1 also needs p0 (rows 256..299)
+        assert red._pending == [(768, 1000)]
+        red.on_grads_ready([p2])
+        assert red._pending == [(768, 1000), (512, 768)]
+        torch.testing.assert_close(arena.grad[512:], base[512:] * 1.5)  # reduced (mean of x1, x2) ...
+        torch.testing.assert_close(arena.grad[:512], base[:512] * (rank + 1))   # ... and nothing else touched yet
+        red.on_grads_ready([p0])
+        assert sorted(red._pending) == [(0, 256), (256, 512), (512, 768), (768, 1000)] and red.overlapped == 4
+        red.finish()                                                     # nothing left: no bucket is reduced twice
+        torch.testing.assert_close(arena.grad, base * 1.5)
+    # a parameter that never reports leaves its buckets to finish()
+    arena.grad.copy_(base * (rank + 1))
+    red.begin_step()
+    red.on_grads_ready([p0, p2, p3])
+    assert sorted(red._pending) == [(0, 256), (512, 768), (768, 1000)] and red.unreported() == [set(), {id(p1)}, set(), set()]
+    red.finish()
+    torch.testing.assert_close(arena.grad, base * 1.5)
+    if rank == 0:
+        torch.save({"ok": True}, out)
+    dist.destroy_process_group()
+
+
 def _worker_step_equivalence(rank, world, initfile, out):
     """Full tiny model: rank-local oracle steps with global negatives + averaged gradients == one global step with
     (global InfoNCE, rank-mean of local task/CT losses)."""
@@ -148,7 +195,7 @@ def _worker_step_equivalence(rank, world, initfile, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("worker", [_worker_global_negatives, _worker_reducer, _worker_step_equivalence])
+@pytest.mark.parametrize("worker", [_worker_global_negatives, _worker_reducer, _worker_reducer_hook, _worker_step_equivalence])
 def test_two_ranks_gloo(worker):
     with tempfile.TemporaryDirectory() as td:
         initfile, out = os.path.join(td, "init"), os.path.join(td, "out.pt")

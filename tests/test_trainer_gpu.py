@@ -246,3 +246,44 @@ def test_predict_path_keeps_no_activations():
     peak_inf = torch.cuda.max_memory_allocated() - base
     assert torch.equal(lg, lg_grad)
     assert peak_inf < 0.35 * peak_grad, (peak_inf, peak_grad)
+
+
+def test_gradient_buckets_leave_during_backward_single_rank_group(monkeypatch):
+    """The RCCL path on one GPU (1-rank group): every gradient bucket whose parameters all take part in the step is
+    all-reduced from inside backward (ArenaReducer.on_grads_ready), the rest by finish(); gradients equal those of the
+    plain single-process step.  (Ordering across ranks is covered by tests/test_parallel_cpu.py with 2 gloo ranks.)"""
+    import torch.distributed as dist
+    from mmdti_hip.parallel import init_from_env
+    from mmdti_hip.trainer import FineTuner
+    monkeypatch.setenv("MMDTI_FORCE_DDP", "1")
+    monkeypatch.setenv("MASTER_PORT", "29571")
+    for k in ("RANK", "LOCAL_RANK"):
+        monkeypatch.setenv(k, "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    ocfg = _ocfg("classification", 2)
+    batch, label = O.synth_batch(8, 10, 14, ocfg, seed=5, ragged=True)
+    dev = {k: v.cuda() for k, v in batch.items()}
+    m1, m2 = _model("classification", 2, True).eval(), _model("classification", 2, True).eval()
+    m2.load_state_dict(m1.state_dict())
+    init_from_env(force=True)
+    try:
+        tuner = FineTuner(m1, "classification", distributed=True, bucket_bytes=256 << 10)
+        red = tuner.reducer
+        assert red.active and len(red.buckets) > 4
+        tuner.forward_backward(dev, label.cuda())
+        torch.cuda.synchronize()
+        silent = red.unreported()
+        names = {id(p): n for n, p in m1.named_parameters()}
+        for b, ids in enumerate(silent):
+            for i in ids:                                  # a parameter may stay silent only if it has no gradient at all
+                g = next(p for p in tuner.arena.params if id(p) == i).grad
+                assert float(g.abs().max()) == 0.0, names[i]
+        full = sum(1 for ids in silent if not ids)
+        assert red.overlapped == full and full >= len(red.buckets) - 2, (red.overlapped, full, len(red.buckets))
+        g1 = tuner.arena.grad.clone()
+    finally:
+        dist.destroy_process_group()
+    monkeypatch.delenv("MMDTI_FORCE_DDP")
+    plain = FineTuner(m2, "classification")
+    plain.forward_backward(dev, label.cuda())
+    torch.testing.assert_close(g1, plain.arena.grad, rtol=1e-3, atol=1e-5)
