@@ -56,13 +56,15 @@ int mmdti_abi_version(void);
  * transB=1 -> stored [K,N].  lda/ldb multiples of 8, 16-byte aligned bases.  If K%8 != 0 the k-contiguous
  * operand must hold zeros in its padded tail.  Batch index z = outer*batch_inner + inner.
  * colsum_out (nullable, [N] fp32, +=): column sums of the stored C -- the bias gradient of the Linear whose output
- * gradient C is -- accumulated by the epilogue (aligned, unbatched, unsplit outputs only).  */
+ * gradient C is -- accumulated by the epilogue (aligned, unbatched, unsplit outputs only).
+ * arowsum_out (nullable, [M] fp32, +=, transA only, unbatched): sum over k of op(A)[m][k].  For a weight gradient
+ * dW = dy^T.x (A = dy stored [tokens, out]) that is the Linear's bias gradient, taken inside the same pass over dy.  */
 int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void* B, void* C, int M, int N, int K, int lda,
                     int ldb, int ldc, int transA, int transB, int batch_outer, int batch_inner, long long sAo,
                     long long sAi, long long sBo, long long sBi, long long sCo, long long sCi, int splitk,
                     float alpha, float beta, const float* bias, const float* residual, int ldr, int act,
                     const void* aux_in, void* aux_out, int ld_aux, int c_dtype, float drop_p,
-                    unsigned long long seed, unsigned int site, float* colsum_out);
+                    unsigned long long seed, unsigned int site, float* colsum_out, float* arowsum_out);
 
 /* ---- LayerNorm (unicore LayerNorm eps 1e-5: transformers.py:69,71,114,161; BertLayerNorm eps 1e-12:
  * mm_module.py:320-333; HF nn.LayerNorm) -------------------------------------------------------

@@ -52,7 +52,25 @@ struct GemmArgs {
   uint32_t site;
   int vec_ok;             // host-checked: every pointer/stride the vector epilogue touches is 16-byte friendly
   float* colsum;          // [N] fp32 or null: += column sums of the stored C (vector epilogue only) -- a Linear's bias gradient
+  float* arowsum;         // [M] fp32 or null: += sum_k op(A)[m][k] -- for a weight gradient dW = dy^T.x (A = dy, k-major) that
+                          // is the Linear's bias gradient; taken with one extra MFMA per A fragment against a ones operand
 };
+
+// sum over k of the A rows a wave multiplies: D = ones . fa^T puts rowsum(A[m]) in every register of lane m's column
+__device__ __forceinline__ bf16x8 ones_frag() {
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 o = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  return __builtin_bit_cast(bf16x8, o);
+}
+__device__ __forceinline__ void arowsum_flush(const GemmArgs& a, const f32x4& r0, const f32x4& r1, const f32x4& r2, const f32x4& r3, int row0, int lane) {
+  if (lane < 16) {
+    const int m = row0 + lane;
+    if (m < a.M) atomicAdd(a.arowsum + m, r0[0]);
+    if (m + 16 < a.M) atomicAdd(a.arowsum + m + 16, r1[0]);
+    if (m + 32 < a.M) atomicAdd(a.arowsum + m + 32, r2[0]);
+    if (m + 48 < a.M) atomicAdd(a.arowsum + m + 48, r3[0]);
+  }
+}
 
 // Staging registers of one operand tile: 4 x 16-B chunks per thread, as NAMED members (an array here ends up as a
 // private-memory alloca in some instantiations and the whole pipeline then runs through scratch).
@@ -499,7 +517,16 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 4) void gemm_glds_kernel(GemmArgs a
                  fb2 = load_frag<TB>(IMGB, wc * 64 + 32, KK, lane), fb3 = load_frag<TB>(IMGB, wc * 64 + 48, KK, lane); \
     MF(0, 0); MF(0, 1); MF(0, 2); MF(0, 3); MF(1, 0); MF(1, 1); MF(1, 2); MF(1, 3);                \
     MF(2, 0); MF(2, 1); MF(2, 2); MF(2, 3); MF(3, 0); MF(3, 1); MF(3, 2); MF(3, 3);                \
+    if (TA && DBUF && do_rs) {                                                                     \
+      rs0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa0, rs0, 0, 0, 0);                      \
+      rs1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa1, rs1, 0, 0, 0);                      \
+      rs2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa2, rs2, 0, 0, 0);                      \
+      rs3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa3, rs3, 0, 0, 0);                      \
+    }                                                                                              \
   }
+  const bool do_rs = TA && DBUF && a.arowsum != nullptr && tn == 0 && wc == 0;   // (double-buffered variant only: register room)
+  const bf16x8 ones = ones_frag();
+  f32x4 rs0 = {0.f, 0.f, 0.f, 0.f}, rs1 = rs0, rs2 = rs0, rs3 = rs0;
   if (!DBUF) {
     for (int kt = kt0; kt < kt1; ++kt) {
       glds_tile(A + kt * kstepA, offA, smem, wave);
@@ -529,6 +556,7 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 4) void gemm_glds_kernel(GemmArgs a
   }
 #undef GEMM_KK
 #undef MF
+  if (TA && DBUF && do_rs) arowsum_flush(a, rs0, rs1, rs2, rs3, m0 + wr * 64, lane);
   const long long coff = zo * a.sCo + zi * a.sCi;
   const bool lead = (ks == 0);
   const int g4 = (lane >> 4) * 4, l15 = lane & 15;
@@ -684,7 +712,7 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
                                long long sCi, int splitk, float alpha, float beta, const float* bias,
                                const float* residual, int ldr, int act, const void* aux_in, void* aux_out,
                                int ld_aux, int c_dtype, float drop_p, unsigned long long seed, unsigned int site,
-                               float* colsum_out) {
+                               float* colsum_out, float* arowsum_out) {
   MMDTI_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: M,N,K must be positive (got %d,%d,%d)", M, N, K);
   MMDTI_REQUIRE(A && B && C, "gemm: null operand");
   MMDTI_REQUIRE(aligned16(A) && aligned16(B), "gemm: A and B must be 16-byte aligned");
@@ -708,6 +736,8 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
   a.drop_thresh = dropout_thresh(drop_p); a.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   a.seed = seed; a.site = site;
   a.colsum = colsum_out;
+  a.arowsum = nullptr;
+  MMDTI_REQUIRE(!arowsum_out || (transA && batch_outer * batch_inner == 1), "gemm: arowsum_out needs a k-major A (transA) and no batch");
   {
     const bool bf = c_dtype == MMDTI_DT_BF16;
     const int cal = bf ? 8 : 4;
@@ -756,7 +786,17 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
   // N >= 1536 / K >= 1536 shapes, equal at 512x512, +9 % on the atomic split-K ones); MMDTI_GEMM_GLDS=0 turns it off
   static const int use_glds = getenv("MMDTI_GEMM_GLDS") ? atoi(getenv("MMDTI_GEMM_GLDS")) : 1;
   // split-K weight gradients: double-buffered DMA from 48 output tiles up (-5...-13 %), register staging below (+13 %)
-  if (fast && use_glds && ((splitk > 1 && tiles >= 48) || use_glds == 3))
+  // arowsum rides on the kernel that has register room for it (double-buffered DMA: the large weight gradients); on
+  // the other paths it is the plain column-sum pass over A's memory image ([K][M] row-major)
+  const bool dbuf_path = fast && use_glds && ((splitk > 1 && tiles >= 48) || use_glds == 3);
+  if (arowsum_out) {
+    if (dbuf_path) {
+      a.arowsum = arowsum_out;
+    } else if (int e = mmdti_colsum_bf16(stream, A, K, M, lda, arowsum_out)) {
+      return e;
+    }
+  }
+  if (dbuf_path)
     hipLaunchKernelGGL(gkerns2[transA ? 1 : 0][transB ? 1 : 0], grid, block, 4 * (size_t)BM * LDT * sizeof(bf16_t), s, a);
   else if (fast && use_glds && splitk == 1) {
     // tall tiles when they save a whole round of the 1024 resident workgroups (see gemm_glds_tall_kernel)

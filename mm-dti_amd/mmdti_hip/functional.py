@@ -25,14 +25,16 @@ from .runtime import fused_views, wbf16, gbuf, dropout_state, notify_grads_ready
 # ------------------------------------------------------------------------------------------------- helpers
 def _lin_bwd_params(dy_bf16, x_bf16, weight, bias, rows=None, bias_done=False):
     """dW += dy^T x ; db += colsum(dy)   (atomic accumulation into param.grad).  bias_done: the kernel that produced dy
-    already accumulated its column sums (LayerNorm backward's bf16 copy)."""
+    already accumulated its column sums (LayerNorm backward's bf16 copy).  Otherwise the bias gradient rides on the
+    weight-gradient GEMM, which reads dy anyway (ops.linear_bwd_weight(db=...))."""
     gw = gbuf(weight)
+    gb = gbuf(bias) if (bias is not None and not bias_done) else None
     if gw is not None:
-        ops.linear_bwd_weight(dy_bf16, x_bf16, gw, rows=rows)
-    if bias is not None and not bias_done:
-        gb = gbuf(bias)
-        if gb is not None:
-            ops.colsum(dy_bf16, gb, cols=bias.numel())
+        ops.linear_bwd_weight(dy_bf16, x_bf16, gw, rows=rows, db=gb if (gb is not None and gb.numel() == gw.shape[0]) else None)
+        if gb is not None and gb.numel() == gw.shape[0]:
+            gb = None
+    if gb is not None:
+        ops.colsum(dy_bf16, gb, cols=bias.numel())
 
 
 def _epilogue_colsum(bias):
@@ -340,8 +342,7 @@ def _bert_layer_bwd(st, L, dout, seed):
             outv = (torch.empty(B * Lq, D, device=dev, dtype=BF16), dqkv[:, :D], dqkv[:, D:])
         dq, dk, dv = ops.attn_bwd(L.q, L.k, L.v, L.key_add, dctx, L.stats, B, heads, Lq, Lk, 1.0 / math.sqrt(hd), L.p_att, seed, L.site_att,
                                   out=outv)
-        ops.linear_bwd_weight(dqkv, L.s1_16 if L.self_attn else L.s2_16, L.fw[2])
-        ops.colsum(dqkv, L.fb[2].view(-1), cols=dqkv.shape[1])
+        ops.linear_bwd_weight(dqkv, L.s1_16 if L.self_attn else L.s2_16, L.fw[2], db=L.fb[2].view(-1))
         ds1 = dy
         if L.self_attn:
             ops.gemm(dqkv, L.fw[0], M=B * Lq, N=D, K=3 * D, lda=3 * D, ldb=D, transB=True, out=ds1, ldc=D, beta=1.0)

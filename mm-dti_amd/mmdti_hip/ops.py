@@ -5,6 +5,8 @@ bookkeeping.  Every function launches hand-written gfx950 kernels through ctypes
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ._abi import lib, MMDTIError
@@ -47,7 +49,7 @@ def _u8(mask):
 # --------------------------------------------------------------------------------------------- GEMM
 def gemm(A, B, *, M, N, K, lda, ldb, out=None, ldc=None, transA=False, transB=False, batch=(1, 1),
          sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, alpha=1.0, beta=0.0, bias=None, residual=None, act=ACT_NONE,
-         aux_in=None, aux_out=None, out_dtype=BF16, atomic=False, drop_p=0.0, seed=0, site=0, out_shape=None, colsum=None):
+         aux_in=None, aux_out=None, out_dtype=BF16, atomic=False, drop_p=0.0, seed=0, site=0, out_shape=None, colsum=None, arowsum=None):
     """C = epi(alpha * A.B^T); see mmdti_gemm_bf16.  A/B are bf16 tensors (any shape; lda/ldb given explicitly)."""
     _chk(A, BF16, "gemm.A", contiguous=False)
     _chk(B, BF16, "gemm.B", contiguous=False)
@@ -62,7 +64,7 @@ def gemm(A, B, *, M, N, K, lda, ldb, out=None, ldc=None, transA=False, transB=Fa
                           int(transA), int(transB), batch[0], batch[1], sA[0], sA[1], sB[0], sB[1], sC[0], sC[1],
                           splitk, float(alpha), float(beta), _p(bias), _p(residual), ldc if residual is None else residual.stride(-2),
                           act, _p(aux_in), _p(aux_out), N if (aux_in is None and aux_out is None) else (aux_in if aux_in is not None else aux_out).stride(-2),
-                          c_dtype, float(drop_p), int(seed), int(site), _p(colsum))
+                          c_dtype, float(drop_p), int(seed), int(site), _p(colsum), _p(arowsum))
     return out
 
 
@@ -92,12 +94,21 @@ def _splitk_for(M, N, K):
     return max(1, min(ktiles, sk))
 
 
-def linear_bwd_weight(dy, x, dw, *, rows=None):
-    """dw[N,K] += dy[M,N]^T . x[M,K]   (fp32 atomic accumulate into the gradient arena)."""
+DW_BIAS = os.environ.get("MMDTI_DW_BIAS", "1") != "0"
+
+
+def linear_bwd_weight(dy, x, dw, *, rows=None, db=None):
+    """dw[N,K] += dy[M,N]^T . x[M,K]   (fp32 atomic accumulate into the gradient arena);  db[N] += column sums of dy (the
+    bias gradient, taken inside the same pass over dy)."""
     M = dy.shape[0] if rows is None else rows
     N, K = dw.shape
+    if db is not None:
+        _chk(db, F32, "linear_bwd_weight.db")
+        if not DW_BIAS:                                  # MMDTI_DW_BIAS=0: the separate column-sum pass (A/B switch)
+            colsum(dy, db, cols=N)
+            db = None
     gemm(dy, x, M=N, N=K, K=M, lda=dy.stride(0), ldb=x.stride(0), transA=True, transB=True, out=dw, ldc=dw.stride(0),
-         atomic=True, splitk=_splitk_for(N, K, M))
+         atomic=True, splitk=_splitk_for(N, K, M), arowsum=db)
     return dw
 
 

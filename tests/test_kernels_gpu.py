@@ -686,6 +686,29 @@ def test_gemm_epilogue_column_sums(ops, M, N, K, out_dtype):
         ops.gemm(x, w, M=M, N=N, K=K, lda=K, ldb=K, out=torch.zeros(M, N, device="cuda"), atomic=True, splitk=2, colsum=cs)
 
 
+@pytest.mark.parametrize("rows,N,K", [(33280, 1536, 512), (4096, 1536, 512), (2050, 512, 512), (3000, 104, 64), (4096, 520, 2048)])
+def test_weight_gradient_carries_the_bias_gradient(ops, rows, N, K):
+    """linear_bwd_weight(db=...): dW += dy^T x and db += column sums of dy in ONE pass over dy (an extra MFMA per dy
+    fragment against a ones operand in the double-buffered split-K kernel; the column-sum kernel on the other paths).
+    Both accumulate (+=).  Shapes: the in_proj gradient of the bench, a smaller one, ragged rows, small / unaligned outputs."""
+    dy = dev(bf(torch.randn(rows, N, generator=G(1))))
+    x = dev(bf(torch.randn(rows, K, generator=G(2))))
+    dw, db = torch.full((N, K), 0.5, device="cuda"), torch.full((N,), -0.25, device="cuda")
+    ops.linear_bwd_weight(dy, x, dw, db=db)
+    dw0 = torch.full((N, K), 0.5, device="cuda")
+    ops.linear_bwd_weight(dy, x, dw0)
+    close(dw, dw0, 1e-4, 1e-2)                                    # (atomic accumulation order differs run to run)
+    close(dw, 0.5 + dy.float().t() @ x.float(), 2e-3, 2e-2 * (rows ** 0.5))
+    want = -0.25 + dy.double().sum(0)
+    close(db.double(), want, 1e-4, 1e-3 * (rows ** 0.5))
+    # a row-strided dy (a [rows, 3N] buffer's middle third), as the fused q|k|v layout hands it over
+    big = dev(bf(torch.randn(rows, 3 * N, generator=G(3))))
+    if N % 8 == 0:
+        db2 = torch.zeros(N, device="cuda")
+        ops.linear_bwd_weight(big[:, N:2 * N], x, torch.zeros(N, K, device="cuda"), db=db2)
+        close(db2.double(), big[:, N:2 * N].double().sum(0), 1e-4, 1e-3 * (rows ** 0.5))
+
+
 @pytest.mark.parametrize("transB", [False, True])
 def test_gemm_tall_tiles_match_square_tiles(ops, transB, monkeypatch):
     """M = 256 x 130 rows, N = 512: the shape that switches to 144-row tiles advancing by 130 rows (one round of resident
