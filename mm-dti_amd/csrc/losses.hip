@@ -325,42 +325,75 @@ __global__ __launch_bounds__(256) void fds_smooth_stats_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------- small fp32 linear (classification head)
-__global__ __launch_bounds__(256) void linear_f32_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
-                                                             int rows, int in_f, int out_f, int act, float* __restrict__ y) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (long long)rows * out_f) return;
-  const int r = (int)(t / out_f), o = (int)(t - (long long)r * out_f);
-  float s = b ? b[o] : 0.f;
-  for (int k = 0; k < in_f; ++k) s += x[(long long)r * in_f + k] * W[(long long)o * in_f + k];
-  y[t] = act == 3 ? tanhf(s) : s;
-}
-// dz = dy * act'(y); dx = dz W ; dW += dz^T x ; db += colsum dz.  grid.x over rows*in_f (dx), then dW part.
-__global__ __launch_bounds__(256) void linear_f32_bwd_dx_kernel(const float* __restrict__ W, const float* __restrict__ y, const float* __restrict__ dy,
-                                                                int rows, int in_f, int out_f, int act, float* __restrict__ dx) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (long long)rows * in_f) return;
-  const int r = (int)(t / in_f), k = (int)(t - (long long)r * in_f);
-  float s = 0.f;
-  for (int o = 0; o < out_f; ++o) {
-    float dz = dy[(long long)r * out_f + o];
-    if (act == 3) { float yy = y[(long long)r * out_f + o]; dz *= (1.f - yy * yy); }
-    s += dz * W[(long long)o * in_f + k];
+// One LDS-tiled fp32 kernel for the three products of a small Linear kept in fp32 (mm_model.py:44-84: [B,512] -> 512 ->
+// out): 32 x 32 output tiles, 32-deep k slices, 4 outputs per thread; every global access runs along the operand's
+// contiguous axis.  dz = dy * tanh'(y) is formed while the tile is loaded.
+//   MODE 0: y[r,o]   = act(sum_k x[r,k] W[o,k] + b[o])           M = rows,  N = out_f,    K = in_f
+//   MODE 1: dx[r,k]  =      sum_o dz[r,o] W[o,k]                  M = rows,  N = in_f,     K = out_f
+//   MODE 2: dW[o,k] +=      sum_r dz[r,o] x[r,k] ; db[o] += sum_r dz[r,o]  (column k == in_f)   M = out_f, N = in_f + 1, K = rows
+template <int MODE>
+__global__ __launch_bounds__(256) void linear_f32_tile_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
+                                                              const float* __restrict__ y, const float* __restrict__ dy, int rows, int in_f,
+                                                              int out_f, int act, float* __restrict__ out, float* __restrict__ db) {
+  __shared__ float sA[32][33];   // [m][k]
+  __shared__ float sB[32][33];   // [k][n]
+  const int M = MODE == 2 ? out_f : rows, N = MODE == 0 ? out_f : (MODE == 1 ? in_f : in_f + 1), K = MODE == 0 ? in_f : (MODE == 1 ? out_f : rows);
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  auto dz = [&](int r, int o) {
+    float g = dy[(long long)r * out_f + o];
+    if (act == 3) {
+      const float yy = y[(long long)r * out_f + o];
+      g *= 1.f - yy * yy;
+    }
+    return g;
+  };
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < K; k0 += 32) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = ty + 8 * i;   // the slow index of this thread's element, tx the contiguous one
+      if (MODE == 0) {
+        const int m = m0 + u, n = n0 + u, k = k0 + tx;
+        sA[u][tx] = (m < M && k < K) ? x[(long long)m * in_f + k] : 0.f;
+        sB[tx][u] = (n < N && k < K) ? W[(long long)n * in_f + k] : 0.f;
+      } else if (MODE == 1) {
+        const int m = m0 + u, k = k0 + tx;
+        sA[u][tx] = (m < M && k < K) ? dz(m, k) : 0.f;
+        const int kb = k0 + u, n = n0 + tx;
+        sB[u][tx] = (kb < K && n < N) ? W[(long long)kb * in_f + n] : 0.f;
+      } else {
+        const int k = k0 + u, m = m0 + tx, n = n0 + tx;
+        sA[tx][u] = (k < K && m < M) ? dz(k, m) : 0.f;
+        sB[u][tx] = (k < K && n < N) ? (n < in_f ? x[(long long)k * in_f + n] : 1.f) : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int kk = 0; kk < 32; ++kk) {
+      const float bv = sB[kk][tx];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] += sA[ty * 4 + i][kk] * bv;
+    }
+    __syncthreads();
   }
-  dx[t] = s;
-}
-__global__ __launch_bounds__(256) void linear_f32_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
-                                                                int rows, int in_f, int out_f, int act, float* __restrict__ dW, float* __restrict__ db) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (long long)out_f * (in_f + 1)) return;
-  const int o = (int)(t / (in_f + 1)), k = (int)(t - (long long)o * (in_f + 1));
-  float s = 0.f;
-  for (int r = 0; r < rows; ++r) {
-    float dz = dy[(long long)r * out_f + o];
-    if (act == 3) { float yy = y[(long long)r * out_f + o]; dz *= (1.f - yy * yy); }
-    s += dz * (k < in_f ? x[(long long)r * in_f + k] : 1.f);
+  const int n = n0 + tx;
+  if (n >= N) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty * 4 + i;
+    if (m >= M) continue;
+    if (MODE == 0) {
+      const float v = acc[i] + (b ? b[n] : 0.f);
+      out[(long long)m * out_f + n] = act == 3 ? tanhf(v) : v;
+    } else if (MODE == 1) {
+      out[(long long)m * in_f + n] = acc[i];
+    } else if (n < in_f) {
+      out[(long long)m * in_f + n] += acc[i];     // (one thread per element: the accumulation needs no atomic)
+    } else if (db) {
+      db[m] += acc[i];
+    }
   }
-  if (k < in_f) atomicAdd(dW + (long long)o * in_f + k, s);
-  else if (db) atomicAdd(db + o, s);
 }
 
 // ---------------------------------------------------------------- task losses
@@ -497,8 +530,8 @@ extern "C" int mmdti_fds_smooth_stats(mmdti_stream_t stream, const float* stat, 
 extern "C" int mmdti_linear_f32_fwd(mmdti_stream_t stream, const float* x, const float* W, const float* b, int rows, int in_f, int out_f,
                                     int act, float* y) {
   MMDTI_REQUIRE(x && W && y && rows > 0 && in_f > 0 && out_f > 0 && (act == 0 || act == 3), "linear_f32_fwd: bad arguments");
-  hipLaunchKernelGGL(linear_f32_fwd_kernel, dim3(cdiv((long long)rows * out_f, 256)), dim3(256), 0, (hipStream_t)stream, x, W, b, rows,
-                     in_f, out_f, act, y);
+  hipLaunchKernelGGL(linear_f32_tile_kernel<0>, dim3(cdiv(out_f, 32), cdiv(rows, 32)), dim3(256), 0, (hipStream_t)stream, x, W, b,
+                     (const float*)nullptr, (const float*)nullptr, rows, in_f, out_f, act, y, (float*)nullptr);
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }
@@ -506,8 +539,10 @@ extern "C" int mmdti_linear_f32_bwd(mmdti_stream_t stream, const float* x, const
                                     int in_f, int out_f, int act, float* dx, float* dW, float* db) {
   MMDTI_REQUIRE(x && W && dy && rows > 0 && in_f > 0 && out_f > 0 && (act == 0 || (act == 3 && y)), "linear_f32_bwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  if (dx) hipLaunchKernelGGL(linear_f32_bwd_dx_kernel, dim3(cdiv((long long)rows * in_f, 256)), dim3(256), 0, s, W, y, dy, rows, in_f, out_f, act, dx);
-  if (dW) hipLaunchKernelGGL(linear_f32_bwd_dw_kernel, dim3(cdiv((long long)out_f * (in_f + 1), 256)), dim3(256), 0, s, x, y, dy, rows, in_f, out_f, act, dW, db);
+  if (dx) hipLaunchKernelGGL(linear_f32_tile_kernel<1>, dim3(cdiv(in_f, 32), cdiv(rows, 32)), dim3(256), 0, s, x, W, (const float*)nullptr, y, dy,
+                             rows, in_f, out_f, act, dx, (float*)nullptr);
+  if (dW) hipLaunchKernelGGL(linear_f32_tile_kernel<2>, dim3(cdiv(in_f + 1, 32), cdiv(out_f, 32)), dim3(256), 0, s, x, W, (const float*)nullptr, y, dy,
+                             rows, in_f, out_f, act, dW, db);
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }
