@@ -437,14 +437,36 @@ __global__ __launch_bounds__(256, 4) void pair_attn_fwd_mfma_kernel(const bf16_t
 
 // =====================================================================================================================
 // MFMA-tiled backward, same tiling as the forward: a wave owns 16 queries and sweeps the key tiles twice.
-//   sweep 1: load S^T tiles, row max / sum  ->  P^T ; dP^T = V.dO^T (MFMA) ; dropout mask (kept as 1 bit per element) ;
+//   sweep 1: load S^T tiles, row max / sum  ->  P^T ; dP^T = V.dO^T (MFMA) ; dropout mask (kept in the sign of P) ;
 //            delta = rowsum(dP' * P)
 //   sweep 2: G^T = G_in^T + P^T*(dP'^T - delta)  (16-byte load + store per lane per tile, in place) ;
 //            dQ^T += K^T.G^T (MFMA, G^T is already the B operand) ;
-//            dK += G.Qs and dV += Pd.dO contract over QUERIES (the lane axis of the accumulator layout), so each tile is
-//            transposed through a per-wave 16x16 LDS patch and fed as the A operand.
-// Each (query block, key tile) contribution to dK/dV is added to an LDS image shared by the block's waves.
-constexpr int TSTR = 20;  // fp32 row stride of the per-wave transpose patch (16-byte aligned rows)
+//            dK += G.Q and dV += Pd.dO contract over QUERIES (the lane axis of the accumulator layout), so each tile is
+//            transposed through a per-wave 16x16 LDS patch: written row-major, read back with ds_read_b64_tr_b16.
+// Precision of sweep 2: Q, K, V, dO are bf16 in memory, so they enter the MFMAs exactly; the fp32 factors G and
+// dropout(P) are split into bf16 high + bf16 low parts (x = hi + lo + O(2^-17 |x|)) and every product runs twice on
+// v_mfma_f32_16x16x16_bf16 -- fp32-class products (16 mantissa bits kept of the fp32 factor, fp32 accumulation) at a
+// quarter of the matrix-pipe time and a third of the LDS instructions of the fp32 16x16x4 form this replaces.
+// Each (query block, key tile) contribution to dK/dV is added to an LDS image owned by the wave.
+typedef short pa_s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 pa_bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) pa_s16x4 pa_lds_s16x4;
+
+__device__ __forceinline__ pa_s16x4 pa_pack4(const f32x4& v) {
+  pa_bf16x4 h;
+  h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+  return __builtin_bit_cast(pa_s16x4, h);
+}
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
+__device__ __forceinline__ void pa_split4(const f32x4& v, pa_s16x4& hi, pa_s16x4& lo) {
+  pa_bf16x4 h;
+  h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+  f32x4 r;
+  r[0] = v[0] - (float)h[0]; r[1] = v[1] - (float)h[1]; r[2] = v[2] - (float)h[2]; r[3] = v[3] - (float)h[3];
+  hi = __builtin_bit_cast(pa_s16x4, h);
+  lo = pa_pack4(r);
+}
+#define PA_MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A, B, C, 0, 0, 0)
 
 template <int NT, bool TILED, bool FULL, int NW>
 __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ s_in,
@@ -453,45 +475,54 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
                                                                  int g_in_zero, uint32_t thresh, float dscale, uint64_t seed,
                                                                  uint32_t site) {
   constexpr int NP = NT * 16;
-  __shared__ __attribute__((aligned(16))) float sQ[NP * VSTR + 8];   // Q * scale
-  __shared__ __attribute__((aligned(16))) float sK[NP * VSTR + 8];
-  // V and dO only ever enter the MFMAs as the bf16 values they were loaded as: kept as raw bf16 in LDS (half the bytes;
-  // with the per-wave arrays sized by the real wave count the workgroup stays under 53 KB -> three per CU)
-  __shared__ __attribute__((aligned(16))) bf16_t sV[NP * VSTR + 8];
-  __shared__ __attribute__((aligned(16))) bf16_t sD[NP * VSTR + 8];   // dO
+  constexpr int KSTR = NP + 8;   // row stride (elements) of the d-major K image: 8-byte reads of 8 rows x 2 key groups hit 16 distinct bank pairs
+  // raw bf16 images, exactly as loaded.  sQ / sD / sV: [row][8]; the +16 elements are the tail that tr-reads of the last
+  // rows run into (they only feed output columns d >= 8, which are never used).  sKT: [d][key].
+  __shared__ __attribute__((aligned(16))) bf16_t sQ[NP * 8 + 16];
+  __shared__ __attribute__((aligned(16))) bf16_t sD[NP * 8 + 16];   // dO
+  __shared__ __attribute__((aligned(16))) bf16_t sV[NP * 8];
+  __shared__ __attribute__((aligned(16))) bf16_t sKT[8 * KSTR];
   // per-wave dK / dV accumulators in MFMA accumulator order: [wave][tile][K|V][g][d][r] -- each lane owns one float4 per
   // (tile, K|V), read as the MFMA C input and written back, so the waves never contend (LDS float atomics cost ~57
   // cycles per wave-instruction here and were half of the kernel's time).
   __shared__ __attribute__((aligned(16))) float redw[NW * NT * 2 * 128];
-  __shared__ __attribute__((aligned(16))) float patch[NW][2][16 * TSTR];
+  // per-wave transpose patches [P | G], each [16 queries][16 keys] bf16 (512 B), used twice per tile (high parts, then low
+  // parts: with two patches instead of four the workgroup stays under 40 KB -> four per CU); the 8-byte slot s of row q
+  // sits at slot s ^ (2 * (q >> 3)), which makes both the row writes and the transposing reads conflict-free
+  __shared__ __attribute__((aligned(16))) bf16_t patch[NW][2][256];
   const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
   const int D = H * HD, D3 = 3 * D;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int nKB = (N + 15) >> 4;
   const bf16_t* base = qkv + (long long)b * N * D3 + h * HD;
-  for (int t = tid; t < NP; t += blockDim.x) {
-    float q[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, vv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int t = tid; t < NP + 2; t += blockDim.x) {
+    uint4 q = make_uint4(0u, 0u, 0u, 0u), kk = q, vv = q, dd = q;
     if (t < N) {
-      load8_bf16(base + (long long)t * D3, q);
-      load8_bf16(base + (long long)t * D3 + D, kk);
-      load8_bf16(base + (long long)t * D3 + 2 * D, vv);
-      load8_bf16(dO + ((long long)b * N + t) * D + h * HD, dd);
+      q = *reinterpret_cast<const uint4*>(base + (long long)t * D3);
+      kk = *reinterpret_cast<const uint4*>(base + (long long)t * D3 + D);
+      vv = *reinterpret_cast<const uint4*>(base + (long long)t * D3 + 2 * D);
+      dd = *reinterpret_cast<const uint4*>(dO + ((long long)b * N + t) * D + h * HD);
     }
+    *reinterpret_cast<uint4*>(sQ + t * 8) = q;      // (t = NP, NP + 1: the zeroed tails)
+    *reinterpret_cast<uint4*>(sD + t * 8) = dd;
+    if (t < NP) {
+      *reinterpret_cast<uint4*>(sV + t * 8) = vv;
+      const uint32_t kw[4] = {kk.x, kk.y, kk.z, kk.w};
 #pragma unroll
-    for (int d = 0; d < 8; ++d) {
-      sQ[t * VSTR + d] = q[d] * scale;
-      sK[t * VSTR + d] = kk[d];
-      sV[t * VSTR + d] = f2bf(vv[d]);   // (exact: the values were bf16 in memory)
-      sD[t * VSTR + d] = f2bf(dd[d]);
+      for (int d = 0; d < 8; ++d) sKT[d * KSTR + t] = (bf16_t)((d & 1) ? (kw[d >> 1] >> 16) : (kw[d >> 1] & 0xffffu));
     }
   }
+  for (int t = tid; t < 8 * 8; t += blockDim.x) sKT[(t >> 3) * KSTR + NP + (t & 7)] = 0;
   for (int t = tid; t < NW * NT * 2 * 128; t += blockDim.x) redw[t] = 0.f;
   __syncthreads();
   const int g = lane >> 4, c16 = lane & 15;
   const bool dlane = c16 < 8;
   const float NEG_INF = -INFINITY;
-  float* pP = &patch[wave][0][0];
-  float* pG = &patch[wave][1][0];
+  bf16_t* pw = &patch[wave][0][0];
+  // patch addressing (elements): this lane WRITES row c16, logical slot g ; tr-READS address row 4g + (c16 >> 2), logical slot c16 & 3
+  const int pwr = c16 * 16 + ((g ^ ((c16 >> 3) << 1)) << 2);
+  const int prd = (4 * g + (c16 >> 2)) * 16 + (((c16 & 3) ^ ((g >> 1) << 1)) << 2);
+  const pa_s16x4 zero4 = {0, 0, 0, 0};
   // (layouts, TILED / FULL / EDGE: see the forward kernel.  In a tiled S every pad slot is -inf and in a tiled G every pad
   //  slot is 0 -- both are preserved by the stores below --, so interior tiles run without predicates or pad masking.)
   const int nlast = nKB - 1;
@@ -510,10 +541,16 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
 #define PA_PRED(T) (!TILED ? (qvalid && (T) * 16 + 4 * g < N) \
                            : (qvalid && (FULL ? ((T) < NT - 1 || colok) : ((T) < nlast || ((T) == nlast && colok)))))
 #define PA_FAST(T) (TILED && !EDGE && (FULL ? (T) < NT - 1 : false))
-    // B operand of dP^T = V.dO^T : dO[qi][g], dO[qi][g+4]
-    const float dob0 = bf2f(sD[(qb * 16 + c16) * VSTR + g]), dob1 = bf2f(sD[(qb * 16 + c16) * VSTR + g + 4]);
+    // operands of this query block that do not depend on the key tile:
+    //   dob : B of dP^T = V.dO^T          -> dO[query c16][d = 4g..4g+3]   (k = d: lane groups 2, 3 carry zeros)
+    //   bD  : B of dV  += Pd^T.dO         -> dO[queries 4g..4g+3][d = c16] (transposing read; columns d >= 8 are unused)
+    //   bQ  : B of dK  += G^T.Q           -> Q [queries 4g..4g+3][d = c16]
+    const pa_s16x4 dob = g < 2 ? *reinterpret_cast<const pa_s16x4*>(sD + (qb * 16 + c16) * 8 + 4 * g) : zero4;
+    const int trq = (qb * 16 + 4 * g + (c16 >> 2)) * 8 + 4 * (c16 & 3);
+    const pa_s16x4 bD = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pa_lds_s16x4*)(sD + trq));
+    const pa_s16x4 bQ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pa_lds_s16x4*)(sQ + trq));
     // ---- sweep 1
-    f32x4 P[NT], dPm[NT];
+    f32x4 P[NT];
     float m = NEG_INF;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -558,10 +595,10 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       {
-        const float va0 = bf2f(sV[(t * 16 + c16) * VSTR + g]), va1 = bf2f(sV[(t * 16 + c16) * VSTR + g + 4]);
+        // A of dP^T: V[key 16t + c16][d = 4g..4g+3] (exact bf16 products, fp32 accumulation)
+        const pa_s16x4 va = g < 2 ? *reinterpret_cast<const pa_s16x4*>(sV + (t * 16 + c16) * 8 + 4 * g) : zero4;
         f32x4 dp = {0.f, 0.f, 0.f, 0.f};
-        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(va0, dob0, dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(va1, dob1, dp, 0, 0, 0);
+        dp = PA_MFMA16(va, dob, dp);
         f32x4 pr = P[t] * inv;
         if (thresh) {
           const uint32_t kb = keep4_u16(seed, site, (uint64_t)(rowoff + t * 16 + 4 * g) >> 2, thresh >> 16);
@@ -576,13 +613,12 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
           dl += dp[0] * pr[0] + dp[1] * pr[1] + dp[2] * pr[2] + dp[3] * pr[3];
         }
         P[t] = pr;
-        dPm[t] = dp;
       }
     }
     dl += __shfl_xor(dl, 16, 64);
     dl += __shfl_xor(dl, 32, 64);
-    // ---- sweep 2 (branch-free per tile: G_in tiles are requested together up front, LDS operands are gathered in
-    // batches, so the compiler can keep loads in flight instead of waiting after each one)
+    // ---- sweep 2 (branch-free per tile: G_in tiles are requested together up front, so the loads stay in flight;
+    // dP is formed again per tile -- one 8-byte LDS read and one MFMA are cheaper than 36 more live registers)
     f32x4 Gi[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -600,9 +636,12 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int kcol = t * 16 + 4 * g;
+      const pa_s16x4 va = g < 2 ? *reinterpret_cast<const pa_s16x4*>(sV + (t * 16 + c16) * 8 + 4 * g) : zero4;
+      f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+      dp = PA_MFMA16(va, dob, dp);
       f32x4 G;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) G[r] = fabsf(P[t][r]) * (dPm[t][r] - dl) + Gi[t][r];
+      for (int r = 0; r < 4; ++r) G[r] = fabsf(P[t][r]) * ((P[t][r] > 0.f ? dp[r] * dscale : 0.f) - dl) + Gi[t][r];
       if (!TILED && t * 16 + 16 > N) {   // only the last key tile has columns beyond N (uniform branch): their G must be exactly 0
 #pragma unroll
         for (int r = 0; r < 4; ++r) G[r] = (kcol + r < N) ? G[r] : 0.f;
@@ -617,39 +656,47 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
 #pragma unroll
       for (int r = 0; r < 4; ++r) Pd[r] = P[t][r] > 0.f ? P[t][r] * dscale : 0.f;   // dscale == 1 without dropout
       if (EDGE && !qvalid) Pd = f32x4{0.f, 0.f, 0.f, 0.f};
-      // transpose Pd and G through the wave's LDS patch: written [query][key], read [key][query]
-      *reinterpret_cast<f32x4*>(pP + c16 * TSTR + 4 * g) = Pd;
-      *reinterpret_cast<f32x4*>(pG + c16 * TSTR + 4 * g) = G;
-      // dQ^T += K^T . G^T   (step r: lane-group g carries key 4g + r)
-      // (operand lanes with d >= 8 read past their row: the matching output rows / columns are never stored)
-      float ka[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ka[r] = sK[(t * 16 + 4 * g + r) * VSTR + c16];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dq = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[r], G[r], dq, 0, 0, 0);
-      float aP[4], aG[4], bD[4], bQ[4];
-#pragma unroll
-      for (int st = 0; st < 4; ++st) {   // MFMA step st contracts queries 4*st + g
-        aP[st] = pP[(4 * st + g) * TSTR + c16];
-        aG[st] = pG[(4 * st + g) * TSTR + c16];
-        bD[st] = bf2f(sD[(qb * 16 + 4 * st + g) * VSTR + c16]);
-        bQ[st] = sQ[(qb * 16 + 4 * st + g) * VSTR + c16];
-      }
+      pa_s16x4 Gh, Gl, Ph, Pl;
+      pa_split4(G, Gh, Gl);
+      pa_split4(Pd, Ph, Pl);
+      // transpose Pd and G through the wave's LDS patches: written [query][key], read [key][4 queries]
+      *reinterpret_cast<pa_s16x4*>(pw + pwr) = Ph;
+      *reinterpret_cast<pa_s16x4*>(pw + 256 + pwr) = Gh;
+      // dQ^T += K^T . G^T : A = K[keys 16t + 4g..4g+3][d = c16 & 7] (rows d >= 8 of the result are never stored), B = G^T as it sits
+      const pa_s16x4 ka = *reinterpret_cast<const pa_s16x4*>(sKT + (c16 & 7) * KSTR + t * 16 + 4 * g);
+      dq = PA_MFMA16(ka, Gh, dq);
+      dq = PA_MFMA16(ka, Gl, dq);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const pa_s16x4 aPh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pa_lds_s16x4*)(pw + prd));
+      const pa_s16x4 aGh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pa_lds_s16x4*)(pw + 256 + prd));
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();   // (LDS operations of a wave complete in order: the low parts land after the reads above)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      *reinterpret_cast<pa_s16x4*>(pw + pwr) = Pl;
+      *reinterpret_cast<pa_s16x4*>(pw + 256 + pwr) = Gl;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const pa_s16x4 aPl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pa_lds_s16x4*)(pw + prd));
+      const pa_s16x4 aGl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pa_lds_s16x4*)(pw + 256 + prd));
       // dK / dV of key tile t: accumulator column = d (lanes c16 < 8), rows = keys 16t + 4g + r; the running sums of
       // this wave live in LDS and pass through the MFMA as its C operand.
-      asm volatile("" ::: "memory");   // keep the LDS accumulator loads of later tiles from being hoisted (72 live VGPRs)
       float* accK = redw + ((wave * NT + t) * 2 + 0) * 128 + (g * 8 + dcol) * 4;
       float* accV = accK + 128;
       f32x4 dKt = *reinterpret_cast<const f32x4*>(accK), dVt = *reinterpret_cast<const f32x4*>(accV);
-#pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        dVt = __builtin_amdgcn_mfma_f32_16x16x4f32(aP[st], bD[st], dVt, 0, 0, 0);
-        dKt = __builtin_amdgcn_mfma_f32_16x16x4f32(aG[st], bQ[st], dKt, 0, 0, 0);
-      }
+      dVt = PA_MFMA16(aPh, bD, dVt);
+      dKt = PA_MFMA16(aGh, bQ, dKt);
+      dVt = PA_MFMA16(aPl, bD, dVt);
+      dKt = PA_MFMA16(aGl, bQ, dKt);
       if (dlane) {
         *reinterpret_cast<f32x4*>(accK) = dKt;
         *reinterpret_cast<f32x4*>(accV) = dVt;
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();   // the next tile overwrites the patches
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     // dQ^T accumulator: column = query, rows d = 4g + r (valid for g < 2)
     if (qvalid && g < 2) {
@@ -677,6 +724,8 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
         c2[d] += bk[128 + d * 4];
       }
     }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) a[d] *= scale;     // dK = scale * G^T.Q  (Q sits unscaled in LDS)
     bf16_t* dst = dqkv + ((long long)b * N + key) * D3 + h * HD;
     store8_bf16(dst + D, a);
     store8_bf16(dst + 2 * D, c2);
