@@ -287,9 +287,30 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_kernel(const bf16_t* __rest
 // operand of the P.V product (O^T = V^T.P^T) -- no data movement between the two matrix products.
 // Dropout element index = (bh*N + query)*ld + key (ld % 4 == 0: one RNG call per 4 keys).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int VSTR = 10;  // fp32 row stride of the V image: (4g+t)*10 + d is bank-conflict-free for the 4 lane groups
 
-__device__ __forceinline__ int dperm(int d) { return (d & 3) * 2 + (d >> 2); }  // d and d+4 adjacent: one ds_read_b64
+// Matrix products of both MFMA kernels: Q, K, V, dO are bf16 in memory, so they enter v_mfma_f32_16x16x16_bf16 exactly as
+// loaded; an fp32 factor (the probabilities, G) is split into bf16 high + bf16 low parts (x = hi + lo + O(2^-17 |x|)) and
+// its product runs twice -- fp32-class products with fp32 accumulation at a quarter of the matrix-pipe time and a third
+// of the LDS instructions of the fp32 16x16x4 form.
+typedef short pa_s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 pa_bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) pa_s16x4 pa_lds_s16x4;
+
+__device__ __forceinline__ pa_s16x4 pa_pack4(const f32x4& v) {
+  pa_bf16x4 h;
+  h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+  return __builtin_bit_cast(pa_s16x4, h);
+}
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
+__device__ __forceinline__ void pa_split4(const f32x4& v, pa_s16x4& hi, pa_s16x4& lo) {
+  pa_bf16x4 h;
+  h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+  f32x4 r;
+  r[0] = v[0] - (float)h[0]; r[1] = v[1] - (float)h[1]; r[2] = v[2] - (float)h[2]; r[3] = v[3] - (float)h[3];
+  hi = __builtin_bit_cast(pa_s16x4, h);
+  lo = pa_pack4(r);
+}
+#define PA_MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A, B, C, 0, 0, 0)
 
 template <int NT, bool TILED, bool FULL>
 __global__ __launch_bounds__(256, 4) void pair_attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_in,
@@ -298,9 +319,11 @@ __global__ __launch_bounds__(256, 4) void pair_attn_fwd_mfma_kernel(const bf16_t
                                                                  float scale, uint32_t thresh, float dscale, uint64_t seed,
                                                                  uint32_t site) {
   constexpr int NP = NT * 16;
-  __shared__ __attribute__((aligned(16))) float sQ[NP][8];
-  __shared__ __attribute__((aligned(16))) float sK[NP][8];
-  __shared__ __attribute__((aligned(16))) float sV[NP * VSTR + 8];   // +8: lanes d >= 8 read past the last row (unused rows of O^T)
+  constexpr int KSTR = NP + 8;   // row stride (elements) of the d-major V image (see the backward kernel's sKT)
+  // raw bf16 images, exactly as loaded: sQ / sK [row][8], sVT [d][key]
+  __shared__ __attribute__((aligned(16))) bf16_t sQ[NP * 8];
+  __shared__ __attribute__((aligned(16))) bf16_t sK[NP * 8];
+  __shared__ __attribute__((aligned(16))) bf16_t sVT[8 * KSTR];
   __shared__ __attribute__((aligned(16))) float sM[NP];
   const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
   const int D = H * HD, D3 = 3 * D;
@@ -308,22 +331,22 @@ __global__ __launch_bounds__(256, 4) void pair_attn_fwd_mfma_kernel(const bf16_t
   const int nKB = (N + 15) >> 4;
   const bf16_t* base = qkv + (long long)b * N * D3 + h * HD;
   for (int t = tid; t < NP; t += blockDim.x) {
-    float q[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, vv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint4 q = make_uint4(0u, 0u, 0u, 0u), kk = q, vv = q;
     float msk = 1.f;
     if (t < N) {
-      load8_bf16(base + (long long)t * D3, q);
-      load8_bf16(base + (long long)t * D3 + D, kk);
-      load8_bf16(base + (long long)t * D3 + 2 * D, vv);
+      q = *reinterpret_cast<const uint4*>(base + (long long)t * D3);
+      kk = *reinterpret_cast<const uint4*>(base + (long long)t * D3 + D);
+      vv = *reinterpret_cast<const uint4*>(base + (long long)t * D3 + 2 * D);
       msk = (key_pad && key_pad[b * N + t]) ? 1.f : 0.f;
     }
+    *reinterpret_cast<uint4*>(sQ + t * 8) = q;
+    *reinterpret_cast<uint4*>(sK + t * 8) = kk;
+    const uint32_t vw[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
-    for (int d = 0; d < 8; ++d) {
-      sQ[t][dperm(d)] = q[d] * scale;
-      sK[t][dperm(d)] = kk[d];
-      sV[t * VSTR + d] = vv[d];
-    }
+    for (int d = 0; d < 8; ++d) sVT[d * KSTR + t] = (bf16_t)((d & 1) ? (vw[d >> 1] >> 16) : (vw[d >> 1] & 0xffffu));
     sM[t] = msk;
   }
+  for (int t = tid; t < 8 * 8; t += blockDim.x) sVT[(t >> 3) * KSTR + NP + (t & 7)] = 0;
   __syncthreads();
   const int g = lane >> 4, c16 = lane & 15;
   const float NEG_INF = -INFINITY;
@@ -339,7 +362,9 @@ __global__ __launch_bounds__(256, 4) void pair_attn_fwd_mfma_kernel(const bf16_t
     const int qi = qb * 16 + c16;
     const bool qvalid = EDGE ? qi < N : true;
     const long long rowoff = ((long long)bh * N + (qvalid ? qi : 0)) * ld;   // (also the dropout counter base)
-    const float2 qv = *reinterpret_cast<const float2*>(&sQ[qb * 16 + c16][2 * g]);
+    const pa_s16x4 zero4 = {0, 0, 0, 0};
+    // B of S^T = K.Q^T : Q[query c16][d = 4g..4g+3] (k = d: lane groups 2, 3 carry zeros)
+    const pa_s16x4 qv = g < 2 ? *reinterpret_cast<const pa_s16x4*>(sQ + (qb * 16 + c16) * 8 + 4 * g) : zero4;
     const long long tbase = ((long long)bh * nKB + qb) * nKB * 256 + lane * 4;
     // (row-major: the lane's 4 keys of tile t start at rowoff + 16t + 4g; a lane whose predicate is off reads the row's
     //  first 16 bytes instead -- always inside the tensor, unlike "tile 0 + 4g" when ld < 16)
@@ -370,9 +395,11 @@ __global__ __launch_bounds__(256, 4) void pair_attn_fwd_mfma_kernel(const bf16_t
       {
         const int kcol = t * 16 + 4 * g;
         f32x4 c = S[t];
-        const float2 ka = *reinterpret_cast<const float2*>(&sK[t * 16 + c16][2 * g]);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.x, qv.x, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.y, qv.y, c, 0, 0, 0);
+        const pa_s16x4 ka = g < 2 ? *reinterpret_cast<const pa_s16x4*>(sK + (t * 16 + c16) * 8 + 4 * g) : zero4;
+        f32x4 qk = {0.f, 0.f, 0.f, 0.f};
+        qk = PA_MFMA16(ka, qv, qk);   // exact bf16 products, fp32 accumulation
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] += scale * qk[r];
         if (!TILED || key_pad) {   // (tiled tensors carry -inf in their pad keys already: only a real padding mask is left)
           const f32x4 km = *reinterpret_cast<const f32x4*>(&sM[kcol]);
 #pragma unroll
@@ -414,10 +441,12 @@ __global__ __launch_bounds__(256, 4) void pair_attn_fwd_mfma_kernel(const bf16_t
 #pragma unroll
           for (int r = 0; r < 4; ++r) p[r] = (kb >> r) & 1u ? p[r] * dscale : 0.f;
         }
-        // A operand rows d >= 8 (lanes c16 >= 8) read whatever follows in LDS: those rows of O^T are never used
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          oacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sV[(t * 16 + 4 * g + r) * VSTR + c16], p[r], oacc, 0, 0, 0);
+        // O^T += V^T . P^T : A = V[keys 16t + 4g..4g+3][d = c16 & 7] (rows d >= 8 of the result are never stored), B = P^T as it sits
+        const pa_s16x4 va = *reinterpret_cast<const pa_s16x4*>(sVT + (c16 & 7) * KSTR + t * 16 + 4 * g);
+        pa_s16x4 ph, pl;
+        pa_split4(p, ph, pl);
+        oacc = PA_MFMA16(va, ph, oacc);
+        oacc = PA_MFMA16(va, pl, oacc);
       }
     }
     // O^T accumulator: column = query, rows d = 4g + r (valid for g < 2)
@@ -448,25 +477,6 @@ __global__ __launch_bounds__(256, 4) void pair_attn_fwd_mfma_kernel(const bf16_t
 // v_mfma_f32_16x16x16_bf16 -- fp32-class products (16 mantissa bits kept of the fp32 factor, fp32 accumulation) at a
 // quarter of the matrix-pipe time and a third of the LDS instructions of the fp32 16x16x4 form this replaces.
 // Each (query block, key tile) contribution to dK/dV is added to an LDS image owned by the wave.
-typedef short pa_s16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 pa_bf16x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) pa_s16x4 pa_lds_s16x4;
-
-__device__ __forceinline__ pa_s16x4 pa_pack4(const f32x4& v) {
-  pa_bf16x4 h;
-  h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
-  return __builtin_bit_cast(pa_s16x4, h);
-}
-// x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
-__device__ __forceinline__ void pa_split4(const f32x4& v, pa_s16x4& hi, pa_s16x4& lo) {
-  pa_bf16x4 h;
-  h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
-  f32x4 r;
-  r[0] = v[0] - (float)h[0]; r[1] = v[1] - (float)h[1]; r[2] = v[2] - (float)h[2]; r[3] = v[3] - (float)h[3];
-  hi = __builtin_bit_cast(pa_s16x4, h);
-  lo = pa_pack4(r);
-}
-#define PA_MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A, B, C, 0, 0, 0)
 
 template <int NT, bool TILED, bool FULL, int NW>
 __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ s_in,
