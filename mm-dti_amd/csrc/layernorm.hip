@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 // Backward.  Each block handles ROWS_PER_BLOCK rows (4 waves x 8 rows); dgamma/dbeta partials are kept per lane in
 // registers over the wave's rows, combined across the 4 waves in LDS and added to global with one atomic per column.
-constexpr int LN_BWD_ROWS_PER_WAVE = 8;
+constexpr int LN_BWD_MIN_ROWS_PER_WAVE = 4;
 
 template <int NV, bool DY_BF16>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ dy_add,
@@ -82,20 +82,51 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const unsigned char* __restrict__ row_zero, uint32_t thresh,
                                                      float dscale, uint64_t seed, uint32_t site,
                                                      bf16_t* __restrict__ dx_bf16, uint32_t thresh2, float dscale2,
-                                                     uint32_t site2, float* __restrict__ dx_colsum) {
+                                                     uint32_t site2, float* __restrict__ dx_colsum, int rpw) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [3][4][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = D >> 2;
   float4 ag[NV], ab[NV], ac[NV];   // dgamma, dbeta, column sums of the bf16 copy (the next Linear's bias gradient)
+  float4 gm[NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) ag[i] = ab[i] = ac[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int row_base = (blockIdx.x * 4 + wave) * LN_BWD_ROWS_PER_WAVE;
-  for (int rr = 0; rr < LN_BWD_ROWS_PER_WAVE; ++rr) {
+  for (int i = 0; i < NV; ++i) {
+    ag[i] = ab[i] = ac[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int c = lane + i * 64;
+    gm[i] = c < nvec ? reinterpret_cast<const float4*>(gamma)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int row_base = (blockIdx.x * 4 + wave) * rpw;
+  const int nrow = min(rpw, rows - row_base);
+  // Every byte of a row is requested up front (dy, dy_add, x AND the residual gradient), as raw words, and the next
+  // row's requests go out before this row is reduced: two rows per wave in flight instead of a row's first half.
+  struct RowIn {
+    float4 d32[NV], da[NV], xv[NV], rs[NV];
+    uint2 d16[NV];
+    float mean, rstd;
+    bool zero;
+  };
+  auto fetch = [&](int row, RowIn& R) {
+    R.mean = mean_i[row];
+    R.rstd = rstd_i[row];
+    R.zero = row_zero && row_zero[row];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + i * 64;
+      R.d32[i] = R.da[i] = R.xv[i] = R.rs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      R.d16[i] = make_uint2(0u, 0u);
+      if (c >= nvec) continue;
+      if (DY_BF16) R.d16[i] = reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(dy_) + (long long)row * D)[c];
+      else R.d32[i] = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dy_) + (long long)row * D)[c];
+      if (dy_add) R.da[i] = reinterpret_cast<const float4*>(dy_add + (long long)row * D)[c];
+      R.xv[i] = reinterpret_cast<const float4*>(x + (long long)row * D)[c];
+      if (dres) R.rs[i] = reinterpret_cast<const float4*>(dres + (long long)row * D)[c];
+    }
+  };
+  RowIn cur, nxt;
+  if (nrow > 0) fetch(row_base, cur);
+  for (int rr = 0; rr < nrow; ++rr) {
     const int row = row_base + rr;
-    if (row >= rows) break;
-    const float mean = mean_i[row], rstd = rstd_i[row];
-    const bool zero = row_zero && row_zero[row];
-    const float4* xr = reinterpret_cast<const float4*>(x + (long long)row * D);
+    if (rr + 1 < nrow) fetch(row + 1, nxt);
+    const float mean = cur.mean, rstd = cur.rstd;
     float4 xh[NV], dg[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -105,16 +136,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
       if (c >= nvec) continue;
       float d[4];
       if (DY_BF16) {
-        uint2 pk = reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(dy_) + (long long)row * D)[c];
+        const uint2 pk = cur.d16[i];
         d[0] = bf2f((bf16_t)(pk.x & 0xffff)); d[1] = bf2f((bf16_t)(pk.x >> 16));
         d[2] = bf2f((bf16_t)(pk.y & 0xffff)); d[3] = bf2f((bf16_t)(pk.y >> 16));
       } else {
-        float4 t = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dy_) + (long long)row * D)[c];
-        d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+        d[0] = cur.d32[i].x; d[1] = cur.d32[i].y; d[2] = cur.d32[i].z; d[3] = cur.d32[i].w;
       }
       if (dy_add) {
-        float4 t = reinterpret_cast<const float4*>(dy_add + (long long)row * D)[c];
-        d[0] += t.x; d[1] += t.y; d[2] += t.z; d[3] += t.w;
+        d[0] += cur.da[i].x; d[1] += cur.da[i].y; d[2] += cur.da[i].z; d[3] += cur.da[i].w;
       }
       if (thresh) {
         Rand4 r = philox4(seed, site, ((uint64_t)row * D + (uint64_t)c * 4) >> 2);
@@ -122,8 +151,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
 #pragma unroll
         for (int e = 0; e < 4; ++e) d[e] = rw[e] >= thresh ? d[e] * dscale : 0.f;
       }
-      if (zero) d[0] = d[1] = d[2] = d[3] = 0.f;
-      float4 xv = xr[c], g = reinterpret_cast<const float4*>(gamma)[c];
+      if (cur.zero) d[0] = d[1] = d[2] = d[3] = 0.f;
+      const float4 xv = cur.xv[i], g = gm[i];
       xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
       ag[i].x += d[0] * xh[i].x; ag[i].y += d[1] * xh[i].y; ag[i].z += d[2] * xh[i].z; ag[i].w += d[3] * xh[i].w;
       ab[i].x += d[0]; ab[i].y += d[1]; ab[i].z += d[2]; ab[i].w += d[3];
@@ -139,7 +168,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
       float4 o = make_float4(rstd * (dg[i].x - m1 - xh[i].x * m2), rstd * (dg[i].y - m1 - xh[i].y * m2),
                              rstd * (dg[i].z - m1 - xh[i].z * m2), rstd * (dg[i].w - m1 - xh[i].w * m2));
       if (dres) {
-        float4 r = reinterpret_cast<const float4*>(dres + (long long)row * D)[c];
+        const float4 r = cur.rs[i];
         o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
       }
       reinterpret_cast<float4*>(dx + (long long)row * D)[c] = o;
@@ -159,6 +188,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         }
       }
     }
+    cur = nxt;
   }
   // cross-wave reduction of dgamma/dbeta partials
   float* rg = red + wave * D;
@@ -235,13 +265,16 @@ extern "C" int mmdti_layernorm_bwd(mmdti_stream_t stream, const void* dy, int dy
   const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const uint32_t th2 = dropout_thresh(drop2_p);
   const float sc2 = drop2_p > 0.f ? 1.f / (1.f - drop2_p) : 1.f;
-  dim3 grid(cdiv(rows, 4 * LN_BWD_ROWS_PER_WAVE)), block(256);
+  // rows per wave: enough that the whole grid is resident at once (3 workgroups of 4 waves per CU at this kernel's
+  // register count, 2 for the wide-row variants) -- no second, partly filled round, and fewer dgamma / dbeta atomics
+  const int rpw = max(LN_BWD_MIN_ROWS_PER_WAVE, cdiv(rows, 4 * (ln_nv(D) <= 2 ? 3 : 2) * 256));
+  dim3 grid(cdiv(rows, 4 * rpw)), block(256);
   MMDTI_REQUIRE(!dx_colsum || dx_bf16, "layernorm_bwd: dx_colsum sums the bf16 copy, which was not requested");
   const size_t smem = 12 * (size_t)D * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
 #define LN_B(NV, BF)                                                                                               \
   hipLaunchKernelGGL((ln_bwd_kernel<NV, BF>), grid, block, smem, s, dy, dy_add, x, gamma, mean, rstd, rows, D, dres, dx,  \
-                     dgamma, dbeta, row_zero, th, sc, (uint64_t)seed, (uint32_t)site, (bf16_t*)dx_bf16, th2, sc2, (uint32_t)site2, dx_colsum)
+                     dgamma, dbeta, row_zero, th, sc, (uint64_t)seed, (uint32_t)site, (bf16_t*)dx_bf16, th2, sc2, (uint32_t)site2, dx_colsum, rpw)
   const bool bf = dy_dtype == MMDTI_DT_BF16;
   switch (ln_nv(D)) {
     case 1: if (bf) LN_B(1, true); else LN_B(1, false); break;

@@ -1,0 +1,35 @@
+import sys, torch
+sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/mm-dti_amd')
+from mmdti_hip import ops
+def bench(name, fn, nbytes, iters=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    s=torch.cuda.Event(enable_timing=True); e=torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    ms=s.elapsed_time(e)/iters
+    print(f"{name:44s} {ms*1e3:8.1f} us  {nbytes/ms/1e9:6.2f} TB/s", flush=True)
+D=512
+for M in (33280, 65536):
+    # rotate over several buffer sets so the inputs come from HBM, not the 256 MB infinity cache
+    sets=[]
+    for i in range(6):
+        x=torch.randn(M,D,device='cuda'); dy=torch.randn(M,D,device='cuda').bfloat16(); dres=torch.randn(M,D,device='cuda')
+        sets.append((x,dy,dres))
+    g=torch.randn(D,device='cuda'); b=torch.randn(D,device='cuda')
+    y16,mean,rstd=ops.layernorm_fwd(sets[0][0],g,b,1e-5)[-3:] if False else (None,torch.zeros(M,device='cuda'),torch.ones(M,device='cuda'))
+    dg=torch.zeros(D,device='cuda'); db=torch.zeros(D,device='cuda'); cs=torch.zeros(D,device='cuda')
+    k=[0]
+    def f_bwd():
+        x,dy,dres=sets[k[0]%6]; k[0]+=1
+        ops.layernorm_bwd(dy,x,g,mean,rstd,dg,db,dres=dres,bf16_copy=(0.1,3,cs))
+    bench(f"ln_bwd bf16 dy + dres + bf16 copy M={M}", f_bwd, M*D*(2+4+4+4+2))
+    def f_bwd32():
+        x,dy,dres=sets[k[0]%6]; k[0]+=1
+        ops.layernorm_bwd(dres,x,g,mean,rstd,dg,db)
+    bench(f"ln_bwd f32 dy M={M}", f_bwd32, M*D*(4+4+4))
+    def f_fwd():
+        x,dy,dres=sets[k[0]%6]; k[0]+=1
+        ops.layernorm_fwd(x,g,b,1e-5)
+    bench(f"ln_fwd M={M}", f_fwd, M*D*(4+2))
