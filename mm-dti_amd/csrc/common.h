@@ -165,4 +165,39 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return 0.5f * (1.0f + erfv) + x * kInvSqrt2Pi * e;
 }
 
+// Two elements at a time on <2 x float>: the multiplies / fused multiply-adds of the polynomial compile to the packed
+// v_pk_mul_f32 / v_pk_fma_f32 forms (two fp32 lanes per instruction); only the reciprocal and the exponential stay
+// one-wide.  Same formula, same constants, same results as the scalar functions above.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t erf_poly2(f32x2_t ax, f32x2_t& e) {
+  const f32x2_t d = 1.0f + 0.3275911f * ax;
+  f32x2_t t;
+  t[0] = __builtin_amdgcn_rcpf(d[0]);
+  t[1] = __builtin_amdgcn_rcpf(d[1]);
+  const f32x2_t poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+  const f32x2_t q = -ax * ax;
+  e[0] = __expf(q[0]);
+  e[1] = __expf(q[1]);
+  return 1.0f - poly * e;       // erf(|x|)
+}
+__device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
+  f32x2_t ax, e;
+  ax[0] = fabsf(x[0]); ax[1] = fabsf(x[1]);
+  ax *= 0.70710678118654752440f;
+  const f32x2_t r = erf_poly2(ax, e);
+  f32x2_t er;
+  er[0] = copysignf(r[0], x[0]); er[1] = copysignf(r[1], x[1]);
+  return x * 0.5f * (1.0f + er);
+}
+__device__ __forceinline__ f32x2_t gelu_erf_grad2(f32x2_t x) {
+  const float kInvSqrt2Pi = 0.39894228040143267794f;
+  f32x2_t ax, e;
+  ax[0] = fabsf(x[0]); ax[1] = fabsf(x[1]);
+  ax *= 0.70710678118654752440f;
+  const f32x2_t r = erf_poly2(ax, e);
+  f32x2_t er;
+  er[0] = copysignf(r[0], x[0]); er[1] = copysignf(r[1], x[1]);
+  return 0.5f * (1.0f + er) + x * kInvSqrt2Pi * e;
+}
+
 }  // namespace mmdti

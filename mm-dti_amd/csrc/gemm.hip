@@ -230,13 +230,20 @@ __device__ __forceinline__ void epilogue_oct(const GemmArgs& a, const float* src
       *reinterpret_cast<uint4*>(a.aux_out + (long long)row * a.ld_aux + col) = u;
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+    for (int e = 0; e < 8; e += 2) {
+      const f32x2_t y = gelu_erf2(f32x2_t{v[e], v[e + 1]});
+      v[e] = y[0];
+      v[e + 1] = y[1];
+    }
   } else if (a.act == MMDTI_ACT_GELU_BWD) {
     const uint4 u = *reinterpret_cast<const uint4*>(a.aux_in + (long long)row * a.ld_aux + col);
     const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
-      v[e] *= gelu_erf_grad(__uint_as_float((e & 1) ? (w4[e >> 1] & 0xffff0000u) : (w4[e >> 1] << 16)));
+    for (int e = 0; e < 8; e += 2) {
+      const f32x2_t gr = gelu_erf_grad2(f32x2_t{__uint_as_float(w4[e >> 1] << 16), __uint_as_float(w4[e >> 1] & 0xffff0000u)});
+      v[e] *= gr[0];
+      v[e + 1] *= gr[1];
+    }
   }
   if (a.drop_thresh) {  // N % 8 == 0 on this path, so the 8 elements are Philox counters idx/4 and idx/4+1
     const uint64_t idx = (uint64_t)row * (uint64_t)a.N + col;

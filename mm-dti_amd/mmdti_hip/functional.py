@@ -11,6 +11,8 @@ stream / LayerNorm statistics / softmax / pair-bias chain S fp32, q|k|v and atte
 """
 from __future__ import annotations
 
+import os
+
 import math
 from types import SimpleNamespace
 from typing import List, Optional
@@ -37,9 +39,15 @@ def _lin_bwd_params(dy_bf16, x_bf16, weight, bias, rows=None, bias_done=False):
         ops.colsum(dy_bf16, gb, cols=bias.numel())
 
 
+EPILOGUE_COLSUM = os.environ.get("MMDTI_EPILOGUE_COLSUM", "0") == "1"
+
+
 def _epilogue_colsum(bias):
-    """Gradient buffer of `bias` if the GEMM epilogue can accumulate column sums into it (vector epilogue: width % 8 == 0)."""
-    if bias is None or bias.numel() % 8 != 0:
+    """Gradient buffer of `bias` if the GEMM epilogue should accumulate column sums into it (vector epilogue: width % 8
+    == 0).  Off by default: with 4160 output tiles adding into 2048 addresses the epilogue's atomics cost more (+60 us on
+    the GELU'-dX GEMM of the bench) than letting the bias gradient ride on the weight-gradient GEMM (+5 us), which is what
+    _lin_bwd_params does when this returns None.  MMDTI_EPILOGUE_COLSUM=1 restores the epilogue form."""
+    if not EPILOGUE_COLSUM or bias is None or bias.numel() % 8 != 0:
         return None
     return gbuf(bias)
 

@@ -25,6 +25,10 @@ for M in (33280, 65536):
         x,dy,dres=sets[k[0]%6]; k[0]+=1
         ops.layernorm_bwd(dy,x,g,mean,rstd,dg,db,dres=dres,bf16_copy=(0.1,3,cs))
     bench(f"ln_bwd bf16 dy + dres + bf16 copy M={M}", f_bwd, M*D*(2+4+4+4+2))
+    def f_bwd_nocs():
+        x,dy,dres=sets[k[0]%6]; k[0]+=1
+        ops.layernorm_bwd(dy,x,g,mean,rstd,dg,db,dres=dres,bf16_copy=(0.1,3))
+    bench(f"  same without the column sums M={M}", f_bwd_nocs, M*D*(2+4+4+4+2))
     def f_bwd32():
         x,dy,dres=sets[k[0]%6]; k[0]+=1
         ops.layernorm_bwd(dres,x,g,mean,rstd,dg,db)
