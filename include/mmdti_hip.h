@@ -36,6 +36,9 @@ typedef void* mmdti_stream_t;
 #define MMDTI_ACT_NONE 0
 #define MMDTI_ACT_GELU 1      /* erf GELU; optional aux_out = pre-activation (bf16) */
 #define MMDTI_ACT_GELU_BWD 2  /* multiply by gelu'(aux_in) */
+#define MMDTI_ACT_GELU_G 4    /* erf GELU; aux_out (required) = gelu'(pre-activation) as bf16: the forward has the erf and
+                                 the Gaussian in hand, so the backward (MUL_AUX) is one multiply per element */
+#define MMDTI_ACT_MUL_AUX 5   /* multiply by aux_in (bf16) */
 
 #define MMDTI_DT_F32 0
 #define MMDTI_DT_BF16 1

@@ -189,6 +189,19 @@ __device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
   er[0] = copysignf(r[0], x[0]); er[1] = copysignf(r[1], x[1]);
   return x * 0.5f * (1.0f + er);
 }
+// gelu(x) and gelu'(x) from one erf / one exponential
+__device__ __forceinline__ void gelu_erf_both2(f32x2_t x, f32x2_t& y, f32x2_t& dy) {
+  const float kInvSqrt2Pi = 0.39894228040143267794f;
+  f32x2_t ax, e;
+  ax[0] = fabsf(x[0]); ax[1] = fabsf(x[1]);
+  ax *= 0.70710678118654752440f;
+  const f32x2_t r = erf_poly2(ax, e);
+  f32x2_t er;
+  er[0] = copysignf(r[0], x[0]); er[1] = copysignf(r[1], x[1]);
+  const f32x2_t phi = 0.5f * (1.0f + er);
+  y = x * phi;
+  dy = phi + x * kInvSqrt2Pi * e;
+}
 __device__ __forceinline__ f32x2_t gelu_erf_grad2(f32x2_t x) {
   const float kInvSqrt2Pi = 0.39894228040143267794f;
   f32x2_t ax, e;

@@ -185,6 +185,11 @@ __device__ __forceinline__ void epi_elem(const GemmArgs& a, float accv, int row,
     v = gelu_erf(v);
   } else if (a.act == MMDTI_ACT_GELU_BWD) {
     v *= gelu_erf_grad(bf2f(a.aux_in[(long long)row * a.ld_aux + col]));
+  } else if (a.act == MMDTI_ACT_GELU_G) {
+    a.aux_out[(long long)row * a.ld_aux + col] = f2bf(gelu_erf_grad(v));
+    v = gelu_erf(v);
+  } else if (a.act == MMDTI_ACT_MUL_AUX) {
+    v *= bf2f(a.aux_in[(long long)row * a.ld_aux + col]);
   }
   if (a.drop_thresh) {
     const bool keep = dropout_keep(a.seed, a.site, (uint64_t)row * (uint64_t)a.N + col, a.drop_thresh);
@@ -243,6 +248,29 @@ __device__ __forceinline__ void epilogue_oct(const GemmArgs& a, const float* src
       const f32x2_t gr = gelu_erf_grad2(f32x2_t{__uint_as_float(w4[e >> 1] << 16), __uint_as_float(w4[e >> 1] & 0xffff0000u)});
       v[e] *= gr[0];
       v[e + 1] *= gr[1];
+    }
+  } else if (a.act == MMDTI_ACT_GELU_G) {
+    float gq[8];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      f32x2_t y, dy;
+      gelu_erf_both2(f32x2_t{v[e], v[e + 1]}, y, dy);
+      v[e] = y[0]; v[e + 1] = y[1];
+      gq[e] = dy[0]; gq[e + 1] = dy[1];
+    }
+    uint4 u;
+    u.x = (uint32_t)f2bf(gq[0]) | ((uint32_t)f2bf(gq[1]) << 16);
+    u.y = (uint32_t)f2bf(gq[2]) | ((uint32_t)f2bf(gq[3]) << 16);
+    u.z = (uint32_t)f2bf(gq[4]) | ((uint32_t)f2bf(gq[5]) << 16);
+    u.w = (uint32_t)f2bf(gq[6]) | ((uint32_t)f2bf(gq[7]) << 16);
+    *reinterpret_cast<uint4*>(a.aux_out + (long long)row * a.ld_aux + col) = u;
+  } else if (a.act == MMDTI_ACT_MUL_AUX) {
+    const uint4 u = *reinterpret_cast<const uint4*>(a.aux_in + (long long)row * a.ld_aux + col);
+    const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      v[e] *= __uint_as_float(w4[e >> 1] << 16);
+      v[e + 1] *= __uint_as_float(w4[e >> 1] & 0xffff0000u);
     }
   }
   if (a.drop_thresh) {  // N % 8 == 0 on this path, so the 8 elements are Philox counters idx/4 and idx/4+1
@@ -729,7 +757,10 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
   MMDTI_REQUIRE(c_dtype == MMDTI_DT_F32 || c_dtype == MMDTI_DT_BF16 || c_dtype == MMDTI_DT_F32_ATOMIC, "gemm: bad c_dtype");
   MMDTI_REQUIRE(splitk == 1 || c_dtype == MMDTI_DT_F32_ATOMIC, "gemm: splitk>1 needs the atomic fp32 output mode");
   MMDTI_REQUIRE(splitk == 1 || (act == MMDTI_ACT_NONE && drop_p == 0.f), "gemm: splitk>1 cannot fuse act/dropout");
-  MMDTI_REQUIRE(act != MMDTI_ACT_GELU_BWD || aux_in, "gemm: gelu_bwd needs aux_in");
+  MMDTI_REQUIRE((act != MMDTI_ACT_GELU_BWD && act != MMDTI_ACT_MUL_AUX) || aux_in, "gemm: gelu_bwd / mul_aux need aux_in");
+  MMDTI_REQUIRE(act != MMDTI_ACT_GELU_G || aux_out, "gemm: gelu_g needs aux_out");
+  MMDTI_REQUIRE(act == MMDTI_ACT_NONE || act == MMDTI_ACT_GELU || act == MMDTI_ACT_GELU_BWD || act == MMDTI_ACT_GELU_G || act == MMDTI_ACT_MUL_AUX,
+                "gemm: unknown act %d", act);
   MMDTI_REQUIRE(batch_outer * batch_inner == 1 || (!residual && !aux_in && !aux_out && drop_p == 0.f),
                 "gemm: residual/aux/dropout epilogues are unbatched only");
   MMDTI_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "gemm: dropout p out of range");

@@ -127,7 +127,7 @@ class PairEncoderFn(torch.autograd.Function):
             L.x1 = ops.linear_fwd(L.o, wbf16(att.out_proj.weight), att.out_proj.bias, residual=x, out_dtype=F32, drop_p=p_res, seed=seed, site=L.site_o)
             _, L.h2, L.m2, L.r2 = ops.layernorm_fwd(L.x1, ln2.weight, ln2.bias, ln2.eps)
             L.u = torch.empty(M, layer.fc1.weight.shape[0], device=emb.device, dtype=BF16)
-            L.a = ops.linear_fwd(L.h2, wbf16(layer.fc1.weight), layer.fc1.bias, act=ops.ACT_GELU, aux_out=L.u)
+            L.a = ops.linear_fwd(L.h2, wbf16(layer.fc1.weight), layer.fc1.bias, act=ops.ACT_GELU_FWD, aux_out=L.u)
             L.site_f = sites.next()
             x = ops.linear_fwd(L.a, wbf16(layer.fc2.weight), layer.fc2.bias, residual=L.x1, out_dtype=F32, drop_p=p_res, seed=seed, site=L.site_f)
             if keep:
@@ -166,7 +166,7 @@ class PairEncoderFn(torch.autograd.Function):
             dy2 = dx16 if dx16 is not None else ops.cast_bf16(dx, st.p_res, seed, L.site_f)
             _lin_bwd_params(dy2, L.a, layer.fc2.weight, layer.fc2.bias, bias_done=dx16 is not None)
             cs = _epilogue_colsum(layer.fc1.bias)          # fc1.bias gradient = column sums of du: taken in the GEMM's epilogue
-            du = ops.linear_bwd_input(dy2, wbf16(layer.fc2.weight), act=ops.ACT_GELU_BWD, aux_in=L.u, colsum=cs)
+            du = ops.linear_bwd_input(dy2, wbf16(layer.fc2.weight), act=ops.ACT_GELU_DX, aux_in=L.u, colsum=cs)
             _lin_bwd_params(du, L.h2, layer.fc1.weight, layer.fc1.bias, bias_done=cs is not None)
             dh2 = ops.linear_bwd_input(du, wbf16(layer.fc1.weight))
             dx, dy1 = ops.layernorm_bwd(dh2, L.x1, ln2.weight, L.m2, L.r2, gbuf(ln2.weight), gbuf(ln2.bias), dres=dx,
@@ -316,7 +316,7 @@ def _bert_layer_fwd(st, s1_32, s1_16, s2_16, key_add, W, heads, p_hid, p_att, ep
     L.y = ops.linear_fwd(L.ctx, wbf16(W.o_w), W.o_b, residual=s1_32, out_dtype=F32, drop_p=p_hid, seed=seed, site=L.site_o)
     L.a32, L.a16, L.am, L.ar = ops.layernorm_fwd(L.y, W.ln1_w, W.ln1_b, eps, want_f32=True, want_bf16=True)
     L.u = torch.empty(B * Lq, W.i_w.shape[0], device=s1_32.device, dtype=BF16)
-    L.i = ops.linear_fwd(L.a16, wbf16(W.i_w), W.i_b, act=ops.ACT_GELU, aux_out=L.u)
+    L.i = ops.linear_fwd(L.a16, wbf16(W.i_w), W.i_b, act=ops.ACT_GELU_FWD, aux_out=L.u)
     L.site_f = sites.next()
     L.z = ops.linear_fwd(L.i, wbf16(W.o2_w), W.o2_b, residual=L.a32, out_dtype=F32, drop_p=p_hid, seed=seed, site=L.site_f)
     out32, out16, L.zm, L.zr = ops.layernorm_fwd(L.z, W.ln2_w, W.ln2_b, eps, want_f32=True, want_bf16=True)
@@ -332,7 +332,7 @@ def _bert_layer_bwd(st, L, dout, seed):
     dz, dzb = ops.layernorm_bwd(dout, L.z, W.ln2_w, L.zm, L.zr, gbuf(W.ln2_w), gbuf(W.ln2_b), bf16_copy=(L.p_hid, L.site_f, gbuf(W.o2_b)))
     _lin_bwd_params(dzb, L.i, W.o2_w, W.o2_b, bias_done=True)
     cs = _epilogue_colsum(W.i_b)
-    du = ops.linear_bwd_input(dzb, wbf16(W.o2_w), act=ops.ACT_GELU_BWD, aux_in=L.u, colsum=cs)
+    du = ops.linear_bwd_input(dzb, wbf16(W.o2_w), act=ops.ACT_GELU_DX, aux_in=L.u, colsum=cs)
     _lin_bwd_params(du, L.a16, W.i_w, W.i_b, bias_done=cs is not None)
     da = ops.linear_bwd_input(du, wbf16(W.i_w))
     # a32 = LN1(y) feeds the FFN AND the residual add of z: both gradients go through LN1's backward
@@ -531,7 +531,7 @@ class InfoNCEFn(torch.autograd.Function):
             L = SimpleNamespace()
             L.x16 = ops.cast_bf16(x.contiguous().view(B * n, D), dropout_p, seed, site)
             L.u = torch.empty(B * n, seq[0].weight.shape[0], device=dev, dtype=BF16)
-            L.h = ops.linear_fwd(L.x16, wbf16(seq[0].weight), seq[0].bias, act=ops.ACT_GELU, aux_out=L.u)
+            L.h = ops.linear_fwd(L.x16, wbf16(seq[0].weight), seq[0].bias, act=ops.ACT_GELU_FWD, aux_out=L.u)
             pr = torch.zeros(B * n, ldp, device=dev, dtype=BF16)
             ops.gemm(L.h, wbf16(seq[2].weight), M=B * n, N=d, K=L.h.shape[1], lda=L.h.shape[1], ldb=seq[2].weight.shape[1], out=pr, ldc=ldp,
                      bias=seq[2].bias)
@@ -574,7 +574,7 @@ class InfoNCEFn(torch.autograd.Function):
             if gb is not None:
                 ops.colsum(dpr, gb, cols=d)
             du = ops.gemm(dpr, wbf16(seq[2].weight), M=B * n, N=L.h.shape[1], K=d, lda=ldp, ldb=seq[2].weight.shape[1], transB=True,
-                          act=ops.ACT_GELU_BWD, aux_in=L.u)
+                          act=ops.ACT_GELU_DX, aux_in=L.u)
             _lin_bwd_params(du, L.x16, seq[0].weight, seq[0].bias)
             if not want_dx:
                 return None

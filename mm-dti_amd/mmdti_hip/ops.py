@@ -14,7 +14,11 @@ from ._abi import lib, MMDTIError
 BF16 = torch.bfloat16
 F32 = torch.float32
 
-ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_TANH = 0, 1, 2, 3
+ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_TANH, ACT_GELU_G, ACT_MUL_AUX = 0, 1, 2, 3, 4, 5
+# forward GELU that saves gelu'(u) instead of u, backward = one multiply (MMDTI_GELU_SAVE_GRAD=0: save u, evaluate gelu' in the backward)
+GELU_SAVE_GRAD = os.environ.get("MMDTI_GELU_SAVE_GRAD", "1") != "0"
+ACT_GELU_FWD = ACT_GELU_G if GELU_SAVE_GRAD else ACT_GELU
+ACT_GELU_DX = ACT_MUL_AUX if GELU_SAVE_GRAD else ACT_GELU_BWD
 DT_F32, DT_BF16, DT_F32_ATOMIC = 0, 1, 2
 CT_REGRESS, CT_SINGLE, CT_MULTI = 0, 1, 2
 

@@ -686,6 +686,31 @@ def test_gemm_epilogue_column_sums(ops, M, N, K, out_dtype):
         ops.gemm(x, w, M=M, N=N, K=K, lda=K, ldb=K, out=torch.zeros(M, N, device="cuda"), atomic=True, splitk=2, colsum=cs)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 256, 64), (1000, 2048, 512), (77, 40, 96)])
+def test_gemm_gelu_saving_its_gradient(ops, M, N, K):
+    """ACT_GELU_G: y = gelu(x.w^T + b) and aux = bf16(gelu'(pre-activation)) from the same erf / exponential;
+    ACT_MUL_AUX: dX-GEMM output times that saved factor == the ACT_GELU / ACT_GELU_BWD pair up to the bf16 rounding of the
+    saved tensor (gelu' of the rounded u there, rounded gelu' of the exact u here).  Last shape: scalar epilogue (N % 8 != 0)."""
+    x, w, b = dev(bf(torch.randn(M, K, generator=G(1)))), dev(bf(torch.randn(N, K, generator=G(2)) * 0.2)), dev(torch.randn(N, generator=G(3)))
+    ldx = (N + 7) // 8 * 8
+    u = torch.zeros(M, ldx, device="cuda", dtype=torch.bfloat16)
+    gsv = torch.zeros(M, ldx, device="cuda", dtype=torch.bfloat16)
+    y0 = ops.gemm(x, w, M=M, N=N, K=K, lda=K, ldb=K, bias=b, act=ops.ACT_GELU, aux_out=u)
+    y1 = ops.gemm(x, w, M=M, N=N, K=K, lda=K, ldb=K, bias=b, act=ops.ACT_GELU_G, aux_out=gsv)
+    assert torch.equal(y0, y1)
+    pre = x.float() @ w.float().t() + b
+    t = pre.double()
+    want = 0.5 * (1 + torch.erf(t / 2 ** 0.5)) + t * torch.exp(-0.5 * t * t) / (2 * torch.pi) ** 0.5
+    close(gsv[:, :N].double(), want, 6e-3, 4e-3)                       # bf16 rounding of a value in [-0.13, 1.13]
+    dy = dev(bf(torch.randn(M, ldx, generator=G(4))))[:, :N]
+    wt = dev(bf(torch.randn(K, N, generator=G(5)) * 0.2))              # dX = dy . W  with W [N_out=K? no: weight layout [N, K]]
+    d0 = ops.gemm(x, w, M=M, N=N, K=K, lda=K, ldb=K, act=ops.ACT_GELU_BWD, aux_in=u)
+    d1 = ops.gemm(x, w, M=M, N=N, K=K, lda=K, ldb=K, act=ops.ACT_MUL_AUX, aux_in=gsv)
+    close(d1, d0, 2e-2, 2e-2 * float(d0.float().abs().mean()))
+    raw = ops.gemm(x, w, M=M, N=N, K=K, lda=K, ldb=K, out_dtype=torch.float32)
+    close(d1.float(), raw * gsv[:, :N].float(), 1e-2, 1e-2 * float(raw.abs().mean()))
+
+
 @pytest.mark.parametrize("rows,N,K", [(33280, 1536, 512), (4096, 1536, 512), (2050, 512, 512), (3000, 104, 64), (4096, 520, 2048)])
 def test_weight_gradient_carries_the_bias_gradient(ops, rows, N, K):
     """linear_bwd_weight(db=...): dW += dy^T x and db += column sums of dy in ONE pass over dy (an extra MFMA per dy
