@@ -142,11 +142,28 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
     losses = {"loss": float(out.loss), "task": float(out.task_loss), "infonce": float(out.infonce_loss), "ct": float(out.ct_loss)}
+    # MFMA side of the roofline: every GEMM launch of two EXTRA steps (outside the timed region: ~600 event pairs per
+    # step would perturb `value`) timed with HIP events on its launch stream; algorithmic flops 2*M*N*K per launch.
+    # (every rank runs them: the step holds collectives)
+    # Twice: towers overlapped as in the timed region (a launch's event time then includes sharing the chip with the
+    # other tower's kernels), and towers back to back on one stream (each launch alone on the chip).
+    pa_timers = ops.kernel_timer.summary()
+    gemm_timers = {}
+    was = model.overlap_towers
+    for mode, ov in (("overlapped", was), ("alone", False)):
+        model.overlap_towers = ov
+        ops.kernel_timer.enable(("gemm",))
+        for _ in range(2):
+            tuner.step(batch, label, epoch=0)
+        gemm_timers[mode] = ops.kernel_timer.summary().get("gemm")
+        ops.kernel_timer.disable()
+    model.overlap_towers = was
+    barrier()
 
     if rank == 0:
         N = int(batch["src_tokens"].shape[1])
         H = 64
-        timers = ops.kernel_timer.summary()
+        timers = pa_timers
         # dominant HBM-bound kernel: pair attention backward.  Algorithmic bytes per launch (DESIGN.md "roofline"):
         # per atom pair and head: read S (4 B) + read G (4 B) + write G (4 B) = 12 B  -> 768 B per pair over 64 heads,
         # plus q|k|v|dO|dqkv rows (7 x 16 B per (token, head)).
@@ -159,6 +176,17 @@ def main():
             roofline = {"kernel": "pair_attn_bwd_mfma_kernel<9, true, true, 3>", "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
                         "frac": round(ach / 8000.0, 4), "traffic": pmc_traffic("pair_attn_bwd_mfma_kernel"), "algorithmic_bytes_per_launch": pa_bytes,
                         "mean_launch_ms": round(ms, 4), "launches_timed": timers["pair_attn_bwd"]["n"], "other_kernels_ms": {k: round(v["mean_ms"], 4) for k, v in timers.items()}}
+        roofline_mfma = None
+        if gemm_timers.get("alone"):
+            ga, go = gemm_timers["alone"], gemm_timers["overlapped"]
+            tf = ga["work"] / (ga["total_ms"] * 1e-3) / 1e12
+            roofline_mfma = {"kernel": "gemm_glds_kernel / gemm_glds_tall_kernel / gemm_bf16_kernel (all GEMM launches of a step)", "bound": "mfma",
+                             "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": None,
+                             "launches_per_step": ga["n"] // 2, "gemm_ms_per_step": round(ga["total_ms"] / 2, 3),
+                             "algorithmic_tflop_per_step": round(ga["work"] / 2 / 1e12, 3),
+                             "achieved_with_towers_overlapped": round(go["work"] / (go["total_ms"] * 1e-3) / 1e12, 1),
+                             "note": "HIP events around every GEMM launch of 2 extra steps after the timed region, towers back to back on one stream "
+                                     "(each launch alone on the chip); achieved_with_towers_overlapped: same with the two towers sharing the chip"}
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(args.atoms, args.tokens, args.cpu_sample)
@@ -173,7 +201,7 @@ def main():
                        "unimol": "15L/512/64h", "chemberta_assumed": "6L/512/8h/ffn2048/vocab600", "infonce_negatives": "global",
                        "grad_buckets_reduced_during_backward": None if tuner.reducer is None or not tuner.reducer.active
                        else f"{tuner.reducer.overlapped}/{len(tuner.reducer.buckets)}"},
-            "losses_last_step": losses, "roofline": roofline, "cpu_baseline": cpu,
+            "losses_last_step": losses, "roofline": roofline, "roofline_mfma": roofline_mfma, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if torch.distributed.is_initialized():

@@ -64,11 +64,13 @@ def gemm(A, B, *, M, N, K, lda, ldb, out=None, ldc=None, transA=False, transB=Fa
     c_dtype = DT_F32_ATOMIC if atomic else (DT_BF16 if out.dtype == BF16 else DT_F32)
     if atomic and out.dtype != F32:
         raise MMDTIError("gemm: atomic accumulation needs an fp32 output")
+    t0 = kernel_timer.begin("gemm")
     lib().mmdti_gemm_bf16(_stream(), A.data_ptr(), B.data_ptr(), out.data_ptr(), M, N, K, lda, ldb, ldc,
                           int(transA), int(transB), batch[0], batch[1], sA[0], sA[1], sB[0], sB[1], sC[0], sC[1],
                           splitk, float(alpha), float(beta), _p(bias), _p(residual), ldc if residual is None else residual.stride(-2),
                           act, _p(aux_in), _p(aux_out), N if (aux_in is None and aux_out is None) else (aux_in if aux_in is not None else aux_out).stride(-2),
                           c_dtype, float(drop_p), int(seed), int(site), _p(colsum), _p(arowsum))
+    kernel_timer.end("gemm", t0, 2.0 * M * N * K * batch[0] * batch[1])
     return out
 
 
@@ -585,10 +587,12 @@ class _KernelTimer:
     def __init__(self):
         self.names = ()
         self.events = {}
+        self.work = {}
 
     def enable(self, names):
         self.names = tuple(names)
         self.events = {n: [] for n in self.names}
+        self.work = {n: 0.0 for n in self.names}
 
     def disable(self):
         self.names = ()
@@ -600,12 +604,14 @@ class _KernelTimer:
         e.record()
         return e
 
-    def end(self, name, e0):
+    def end(self, name, e0, work=0.0):
+        """work: algorithmic flops (or bytes) of this launch, summed per name."""
         if e0 is None:
             return
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         self.events[name].append((e0, e1))
+        self.work[name] += work
 
     def summary(self):
         torch.cuda.synchronize()
@@ -613,7 +619,7 @@ class _KernelTimer:
         for n, evs in self.events.items():
             if evs:
                 ts = [a.elapsed_time(b) for a, b in evs]
-                out[n] = {"n": len(ts), "mean_ms": sum(ts) / len(ts), "min_ms": min(ts)}
+                out[n] = {"n": len(ts), "mean_ms": sum(ts) / len(ts), "min_ms": min(ts), "total_ms": sum(ts), "work": self.work.get(n, 0.0)}
         return out
 
 
