@@ -287,3 +287,26 @@ def test_gradient_buckets_leave_during_backward_single_rank_group(monkeypatch):
     plain = FineTuner(m2, "classification")
     plain.forward_backward(dev, label.cuda())
     torch.testing.assert_close(g1, plain.arena.grad, rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("task,odim", [("classification", 2), ("regression", 1)])
+def test_step_has_no_host_synchronisation(task, odim):
+    """The whole step -- forward, three losses, backward, clip, Adam -- enqueues without the host ever waiting for the
+    device (the reference does four float(t.data) reads per step, tasks/trainer.py:195-197,238).  torch's sync debug mode
+    raises on .item(), pageable host<->device copies and the like; the default host tensor([1]) weight of CT_Single
+    (models/contrastive.py:62) used to cost two of them."""
+    from mmdti_hip.trainer import FineTuner
+    ocfg = _ocfg(task, odim)
+    batch, label = O.synth_batch(8, 10, 14, ocfg, seed=7, ragged=True)
+    dev = {k: v.cuda() for k, v in batch.items()}
+    lab = label.cuda()
+    tuner = FineTuner(_model(task, odim).train(), task)
+    for _ in range(2):
+        tuner.step(dev, lab)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        out = tuner.step(dev, lab)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert torch.isfinite(out.loss).item()
