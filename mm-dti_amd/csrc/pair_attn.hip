@@ -627,31 +627,37 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
     }
     dl += __shfl_xor(dl, 16, 64);
     dl += __shfl_xor(dl, 32, 64);
-    // ---- sweep 2 (branch-free per tile: G_in tiles are requested together up front, so the loads stay in flight;
+    // ---- sweep 2 (branch-free per tile;
     // dP is formed again per tile -- one 8-byte LDS read and one MFMA are cheaper than 36 more live registers)
-    f32x4 Gi[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    // G_in tiles are requested PA_LA tiles ahead of their use (a ring of PA_LA quads instead of all NT: 24 registers
+    // fewer at the 168 cap -- no spills), pinned in place by scheduling barriers
+    constexpr int PA_LA = 3;
+    auto load_gin = [&](int t) -> f32x4 {
       if (PA_FAST(t)) {
         const f32x4 ld4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gin_p + (g_in_zero ? 0 : t * TSTEP + goff)));
-        Gi[t] = g_in_zero ? f32x4{0.f, 0.f, 0.f, 0.f} : ld4;
-      } else {
-        const bool inrow = PA_PRED(t) && !g_in_zero;
-        const f32x4 ld4 = *reinterpret_cast<const f32x4*>(gin_p + (inrow ? t * TSTEP + goff : 0));
-        Gi[t] = inrow ? ld4 : f32x4{0.f, 0.f, 0.f, 0.f};
+        return g_in_zero ? f32x4{0.f, 0.f, 0.f, 0.f} : ld4;
       }
-    }
+      const bool inrow = PA_PRED(t) && !g_in_zero;
+      const f32x4 ld4 = *reinterpret_cast<const f32x4*>(gin_p + (inrow ? t * TSTEP + goff : 0));
+      return inrow ? ld4 : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    f32x4 Gq[PA_LA];
+#pragma unroll
+    for (int t = 0; t < PA_LA && t < NT; ++t) Gq[t] = load_gin(t);
     f32x4 dq = {0.f, 0.f, 0.f, 0.f};
     const int dcol = dlane ? c16 : 0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int kcol = t * 16 + 4 * g;
+      const f32x4 Gin = Gq[t % PA_LA];
+      if (t + PA_LA < NT) Gq[t % PA_LA] = load_gin(t + PA_LA);
+      __builtin_amdgcn_sched_barrier(0);
       const pa_s16x4 va = g < 2 ? *reinterpret_cast<const pa_s16x4*>(sV + (t * 16 + c16) * 8 + 4 * g) : zero4;
       f32x4 dp = {0.f, 0.f, 0.f, 0.f};
       dp = PA_MFMA16(va, dob, dp);
       f32x4 G;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) G[r] = fabsf(P[t][r]) * ((P[t][r] > 0.f ? dp[r] * dscale : 0.f) - dl) + Gi[t][r];
+      for (int r = 0; r < 4; ++r) G[r] = fabsf(P[t][r]) * ((P[t][r] > 0.f ? dp[r] * dscale : 0.f) - dl) + Gin[r];
       if (!TILED && t * 16 + 16 > N) {   // only the last key tile has columns beyond N (uniform branch): their G must be exactly 0
 #pragma unroll
         for (int r = 0; r < 4; ++r) G[r] = (kcol + r < N) ? G[r] : 0.f;
