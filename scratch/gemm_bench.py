@@ -10,7 +10,7 @@ def bench(name, fn, flops, iters=20):
     e.record(); torch.cuda.synchronize()
     ms=s.elapsed_time(e)/iters
     print(f"{name:44s} {ms*1e3:9.1f} us  {flops/ms/1e9:8.1f} TF/s")
-M=33280
+M=int(sys.argv[1]) if len(sys.argv)>1 else 33280
 bf=lambda *s: torch.randn(*s,device='cuda').to(torch.bfloat16)
 for (N,K) in [(1536,512),(512,512),(2048,512),(512,2048)]:
     x,w,b=bf(M,K),bf(N,K),torch.randn(N,device='cuda')
