@@ -52,6 +52,7 @@ struct GemmArgs {
   uint32_t site;
   int vec_ok;             // host-checked: every pointer/stride the vector epilogue touches is 16-byte friendly
   float* colsum;          // [N] fp32 or null: += column sums of the stored C (vector epilogue only) -- a Linear's bias gradient
+  int stream_c;           // host-set: C is written with streaming (non-temporal) stores -- outputs too large to be of use in the caches
   float* arowsum;         // [M] fp32 or null: += sum_k op(A)[m][k] -- for a weight gradient dW = dy^T.x (A = dy, k-major) that
                           // is the Linear's bias gradient; taken with one extra MFMA per A fragment against a ones operand
 };
@@ -211,6 +212,14 @@ constexpr int LDC_W = 68;  // fp32 row stride of a wave's 16x64 epilogue patch (
 
 constexpr int LDC_S = BN + 4;  // fp32 row stride of the epilogue's staging image (528 B)
 
+// 16-byte streaming store: the outputs of these GEMMs are 34-270 MB written once and read by a LATER kernel -- kept out of
+// the L2's way (measured: -10...-25 % on the N >= 1536 outputs at 65536 rows, -22 % on the fc1 + GELU epilogue at 33280)
+__device__ __forceinline__ void nt_store16(void* dst, const uint4& u) {
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  const u32x4_t uv = {u.x, u.y, u.z, u.w};
+  __builtin_nontemporal_store(uv, reinterpret_cast<u32x4_t*>(dst));
+}
+
 // Fused epilogue on 8 consecutive columns of one row, read from the LDS staging image.  N % 8 == 0, col % 8 == 0 here.
 __device__ __forceinline__ void epilogue_oct(const GemmArgs& a, const float* src, int row, int col, bool lead, long long coff, float* cs) {
   float v[8];
@@ -232,7 +241,7 @@ __device__ __forceinline__ void epilogue_oct(const GemmArgs& a, const float* src
       u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
       u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
       u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
-      *reinterpret_cast<uint4*>(a.aux_out + (long long)row * a.ld_aux + col) = u;
+      nt_store16(a.aux_out + (long long)row * a.ld_aux + col, u);
     }
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {
@@ -263,7 +272,7 @@ __device__ __forceinline__ void epilogue_oct(const GemmArgs& a, const float* src
     u.y = (uint32_t)f2bf(gq[2]) | ((uint32_t)f2bf(gq[3]) << 16);
     u.z = (uint32_t)f2bf(gq[4]) | ((uint32_t)f2bf(gq[5]) << 16);
     u.w = (uint32_t)f2bf(gq[6]) | ((uint32_t)f2bf(gq[7]) << 16);
-    *reinterpret_cast<uint4*>(a.aux_out + (long long)row * a.ld_aux + col) = u;
+    nt_store16(a.aux_out + (long long)row * a.ld_aux + col, u);
   } else if (a.act == MMDTI_ACT_MUL_AUX) {
     const uint4 u = *reinterpret_cast<const uint4*>(a.aux_in + (long long)row * a.ld_aux + col);
     const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
@@ -292,7 +301,8 @@ __device__ __forceinline__ void epilogue_oct(const GemmArgs& a, const float* src
     u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
     u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
     u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
-    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + ci) = u;
+    if (a.stream_c) nt_store16(reinterpret_cast<bf16_t*>(a.C) + ci, u);
+    else *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + ci) = u;
     if (cs) {   // column sums of the ROUNDED values: what a column-sum pass over C would add up
       cs[0] += __uint_as_float(u.x << 16); cs[1] += __uint_as_float(u.x & 0xffff0000u);
       cs[2] += __uint_as_float(u.y << 16); cs[3] += __uint_as_float(u.y & 0xffff0000u);
@@ -306,8 +316,13 @@ __device__ __forceinline__ void epilogue_oct(const GemmArgs& a, const float* src
       v[0] += a.beta * c0.x; v[1] += a.beta * c0.y; v[2] += a.beta * c0.z; v[3] += a.beta * c0.w;
       v[4] += a.beta * c1.x; v[5] += a.beta * c1.y; v[6] += a.beta * c1.z; v[7] += a.beta * c1.w;
     }
-    *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-    *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    if (a.stream_c) {
+      nt_store16(c, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
+      nt_store16(c + 4, make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])));
+    } else {
+      *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
     if (cs) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) cs[e] += v[e];
@@ -775,6 +790,12 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
   a.seed = seed; a.site = site;
   a.colsum = colsum_out;
   a.arowsum = nullptr;
+  {
+    // streaming stores for outputs of at least MMDTI_GEMM_STREAM_MB (default 96 MB; 0 = always, negative = never)
+    static const long long stream_mb = getenv("MMDTI_GEMM_STREAM_MB") ? atoll(getenv("MMDTI_GEMM_STREAM_MB")) : 96;
+    const long long cbytes = (long long)M * N * (c_dtype == MMDTI_DT_BF16 ? 2 : 4) * batch_outer * batch_inner;
+    a.stream_c = (stream_mb >= 0 && cbytes >= stream_mb * 1000000LL && beta == 0.f) ? 1 : 0;
+  }
   MMDTI_REQUIRE(!arowsum_out || (transA && batch_outer * batch_inner == 1), "gemm: arowsum_out needs a k-major A (transA) and no batch");
   {
     const bool bf = c_dtype == MMDTI_DT_BF16;
