@@ -280,8 +280,9 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_kernel(const bf16_t* __rest
 
 // =====================================================================================================================
 // MFMA-tiled forward.  One wave owns a block of 16 queries and walks the key tiles of 16: the score tile is computed
-// TRANSPOSED, S^T[key][query] = K.Q^T, with v_mfma_f32_16x16x4_f32 (exact fp32; head_dim 8 = two K=4 steps) and the
-// bias tile as the accumulator input, so bias add, S write-out and softmax all happen on the accumulator layout
+// TRANSPOSED, S^T[key][query] = K.Q^T (one v_mfma_f32_16x16x16_bf16 on the raw bf16 q / k rows: head_dim 8 zero-padded
+// to k = 16, exact products, fp32 accumulation), scaled and added to the bias tile in the accumulator layout, so bias
+// add, S write-out and softmax all happen on that layout
 // (lane = query column, 4 consecutive keys per lane-group in registers): pair traffic is one 16-byte load + one 16-byte
 // store per lane per tile, the row softmax needs only two cross-lane steps per query block, and P^T is already the B
 // operand of the P.V product (O^T = V^T.P^T) -- no data movement between the two matrix products.
