@@ -79,3 +79,68 @@ class LengthBucketBatchSampler:
 def epoch_cost(batches, atoms, tokens) -> float:
     atoms, tokens = np.asarray(atoms), np.asarray(tokens)
     return float(sum(padded_cost(atoms[b], tokens[b]) for b in batches))
+
+
+class DevicePrefetcher:
+    """Iterate ``(net_input: dict[str, Tensor], label: Tensor)`` batches with the NEXT batch's host-to-device copies in
+    flight on a side HIP stream while the current step runs (collate / transfer off the critical path).
+
+    The reference moves each batch with synchronous ``.cuda()`` calls inside the step loop (tasks/trainer.py:181-183).
+    Here every host tensor is staged through a pinned buffer (re-used while the shapes repeat), copied with
+    ``non_blocking=True`` on ``self.stream``, and the consumer's stream waits on the copy's event only when it takes the
+    batch -- so a step never waits for PCIe unless the loader itself is the bottleneck.  Values and dtypes are untouched
+    (the kernels take the reference's int64 / fp32 inputs as they are: 2.4 MB per 256-molecule batch).
+    """
+
+    def __init__(self, batches, device):
+        import torch
+        self._torch = torch
+        self.batches = batches
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self._pinned = {}
+
+    def _stage(self, name, t):
+        torch = self._torch
+        if self.stream is None or t.device.type != "cpu":
+            return t.to(self.device)
+        key = (name, tuple(t.shape), t.dtype)
+        buf = self._pinned.get(name)
+        if buf is None or (tuple(buf.shape), buf.dtype) != key[1:]:
+            buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            self._pinned[name] = buf
+        buf.copy_(t)
+        return buf.to(self.device, non_blocking=True)
+
+    def _launch(self, item):
+        torch = self._torch
+        net_input, label = item
+        if self.stream is None:
+            return {k: self._stage(k, v) for k, v in net_input.items()}, self._stage("__label__", label), None
+        with torch.cuda.stream(self.stream):
+            dev_in = {k: self._stage(k, v) for k, v in net_input.items()}
+            dev_lab = self._stage("__label__", label)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return dev_in, dev_lab, ev
+
+    def __iter__(self):
+        torch = self._torch
+        it = iter(self.batches)
+        try:
+            nxt = self._launch(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            dev_in, dev_lab, ev = nxt
+            if ev is not None:
+                torch.cuda.current_stream(self.device).wait_event(ev)
+                for t in list(dev_in.values()) + [dev_lab]:
+                    t.record_stream(torch.cuda.current_stream(self.device))
+                # (the staging buffers are rewritten by the next _launch: its host-side copy_ must not race the DMA)
+                ev.synchronize()
+            try:
+                nxt = self._launch(next(it))
+            except StopIteration:
+                nxt = None
+            yield dev_in, dev_lab

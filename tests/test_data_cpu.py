@@ -40,3 +40,14 @@ def test_bucket_sampler_shards_whole_batches_evenly():
     seen = [i for s in shards for b in s for i in b]
     assert len(seen) == len(set(seen))                                                       # no sample on two ranks
     assert all(len(b) == 32 for s in shards for b in s)
+
+
+def test_device_prefetcher_passes_batches_through_unchanged_on_cpu():
+    import torch
+    from mmdti_hip.data import DevicePrefetcher
+    batches = [({"a": torch.arange(6).view(2, 3) + i, "m": torch.ones(2, 2, dtype=torch.bool)}, torch.tensor([[i], [0]])) for i in range(4)]
+    out = list(DevicePrefetcher(batches, "cpu"))
+    assert len(out) == 4
+    for (bi, li), (bo, lo) in zip(batches, out):
+        assert set(bi) == set(bo) and all(torch.equal(bi[k], bo[k]) and bi[k].dtype == bo[k].dtype for k in bi) and torch.equal(li, lo)
+    assert list(DevicePrefetcher([], "cpu")) == []

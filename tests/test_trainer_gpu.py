@@ -310,3 +310,23 @@ def test_step_has_no_host_synchronisation(task, odim):
     finally:
         torch.cuda.set_sync_debug_mode("default")
     assert torch.isfinite(out.loss).item()
+
+
+def test_device_prefetcher_feeds_the_step():
+    """data.DevicePrefetcher: batches arrive on the device unchanged (pinned staging + side-stream copies, the consumer's
+    stream ordered behind the copy event), and steps driven by it equal steps driven by plain .cuda() batches."""
+    from mmdti_hip.data import DevicePrefetcher
+    from mmdti_hip.trainer import FineTuner
+    ocfg = _ocfg("classification", 2)
+    host = [O.synth_batch(8, 10, 14, ocfg, seed=20 + i, ragged=True) for i in range(3)] + [O.synth_batch(6, 7, 9, ocfg, seed=30, ragged=True)]
+    got = list(DevicePrefetcher(host, "cuda"))
+    assert len(got) == 4
+    for (bi, li), (bo, lo) in zip(host, got):
+        assert all(bo[k].is_cuda and bo[k].dtype == bi[k].dtype and torch.equal(bo[k].cpu(), bi[k]) for k in bi) and torch.equal(lo.cpu(), li)
+    m1, m2 = _model("classification", 2).eval(), _model("classification", 2).eval()
+    m2.load_state_dict(m1.state_dict())
+    t1, t2 = FineTuner(m1, "classification"), FineTuner(m2, "classification")
+    for (b1, l1), (bh, lh) in zip(DevicePrefetcher(host, "cuda"), host):
+        o1 = t1.step(b1, l1)
+        o2 = t2.step({k: v.cuda() for k, v in bh.items()}, lh.cuda())
+        assert abs(float(o1.loss) - float(o2.loss)) <= 1e-5 * abs(float(o2.loss)) + 1e-7
