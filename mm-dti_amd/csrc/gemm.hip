@@ -847,7 +847,9 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
   // split-K weight gradients: double-buffered DMA from 48 output tiles up (-5...-13 %), register staging below (+13 %)
   // arowsum rides on the kernel that has register room for it (double-buffered DMA: the large weight gradients); on
   // the other paths it is the plain column-sum pass over A's memory image ([K][M] row-major)
-  const bool dbuf_path = fast && use_glds && ((splitk > 1 && tiles >= 48) || use_glds == 3);
+  // (a small split-K weight gradient that also carries its bias gradient takes the double-buffered kernel too: +6 us
+  //  there against a 35-50 us column-sum pass over dy)
+  const bool dbuf_path = fast && use_glds && ((splitk > 1 && (tiles >= 48 || (arowsum_out && transA))) || use_glds == 3);
   if (arowsum_out) {
     if (dbuf_path) {
       a.arowsum = arowsum_out;

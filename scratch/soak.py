@@ -7,11 +7,11 @@ tuner=FineTuner(model,"classification",total_steps=400,learning_rate=1e-4)
 _,batch,label=bench.synth(256,128,256,seed=1234)
 batch={k:v.cuda() for k,v in batch.items()}; label=label.cuda()
 ts=[]; losses=[]
-for i in range(300):
+for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 300):
     torch.cuda.synchronize(); t0=time.perf_counter()
     out=tuner.step(batch,label,epoch=0)
     torch.cuda.synchronize(); ts.append((time.perf_counter()-t0)*1e3)
-    if i%25==0 or i==299:
+    if i%50==0:
         losses.append((i,float(out.loss),float(out.task_loss),float(out.infonce_loss),float(out.ct_loss)))
 import statistics
 print('step ms: median %.1f p95 %.1f max(after 5) %.1f'%(statistics.median(ts[5:]), sorted(ts[5:])[int(0.95*len(ts[5:]))], max(ts[5:])))
