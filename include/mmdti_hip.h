@@ -192,7 +192,10 @@ int mmdti_gelu_fwd_bf16(mmdti_stream_t stream, const void* u_bf16, void* y_bf16,
 /* unmasked mean over dim 1 (infonce.py:32-33): x [B,S,ld] bf16 -> out [B,D] fp32 */
 int mmdti_seq_mean_fwd(mmdti_stream_t stream, const void* x_bf16, int B, int S, int D, int ld, float* out);
 /* dx[b,s,:] = dout[b,:]/S  (bf16, [B,S,ld]; pad columns zeroed) */
-int mmdti_seq_mean_bwd(mmdti_stream_t stream, const float* dout, int B, int S, int D, int ld, void* dx_bf16);
+/* dx[b*S+s, d] = bf16(dout[b, d] / S * f(aux[b*S+s, d])): f = 1 (aux_mode 0), aux (1: a saved gelu') or gelu'(aux) (2) -- the
+ * backward of "pool the GELU outputs, then project" (mean_t(W2 h_t + b2) = W2 mean_t(h_t) + b2, infonce.py:28-33) */
+int mmdti_seq_mean_bwd(mmdti_stream_t stream, const float* dout, int B, int S, int D, int ld, void* dx_bf16, const void* aux_bf16,
+                       int ld_aux, int aux_mode);
 /* F.normalize(x, dim=-1) (infonce.py:104-105; contrastive.py:22-23) */
 int mmdti_l2norm_fwd(mmdti_stream_t stream, const float* x, int B, int D, int ldx, float* xhat, float* inv_norm);
 int mmdti_l2norm_bwd(mmdti_stream_t stream, const float* dxhat, const float* xhat, const float* inv_norm, int B,

@@ -40,6 +40,7 @@ def _lin_bwd_params(dy_bf16, x_bf16, weight, bias, rows=None, bias_done=False):
 
 
 EPILOGUE_COLSUM = os.environ.get("MMDTI_EPILOGUE_COLSUM", "0") == "1"
+POOL_THEN_PROJECT = os.environ.get("MMDTI_INFONCE_POOL_FIRST", "1") != "0"      # InfoNCE head: pool the GELU outputs, then project
 
 
 def _epilogue_colsum(bias):
@@ -531,7 +532,17 @@ class InfoNCEFn(torch.autograd.Function):
             L = SimpleNamespace()
             L.x16 = ops.cast_bf16(x.contiguous().view(B * n, D), dropout_p, seed, site)
             L.u = torch.empty(B * n, seq[0].weight.shape[0], device=dev, dtype=BF16)
-            L.h = ops.linear_fwd(L.x16, wbf16(seq[0].weight), seq[0].bias, act=ops.ACT_GELU_FWD, aux_out=L.u)
+            h = ops.linear_fwd(L.x16, wbf16(seq[0].weight), seq[0].bias, act=ops.ACT_GELU_FWD, aux_out=L.u)
+            Hd = h.shape[1]
+            if POOL_THEN_PROJECT and Hd % 8 == 0:
+                # mean_t(W2 h_t + b2) == W2 mean_t(h_t) + b2: pool the GELU outputs (fp32), then ONE [B, Hd] x [d, Hd] fp32 linear
+                # -- instead of a 50-wide bf16 GEMM over every token, its three backward GEMMs and a bf16 round of the
+                # per-token projections.  (The unmasked mean over all positions is the reference's, infonce.py:32-33.)
+                L.hbar = ops.seq_mean_fwd(h, B, n, Hd, Hd)
+                L.mean = ops.linear_f32_fwd(L.hbar, seq[2].weight.detach(), seq[2].bias.detach())
+                L.h = None
+                return L
+            L.h = h
             pr = torch.zeros(B * n, ldp, device=dev, dtype=BF16)
             ops.gemm(L.h, wbf16(seq[2].weight), M=B * n, N=d, K=L.h.shape[1], lda=L.h.shape[1], ldb=seq[2].weight.shape[1], out=pr, ldc=ldp,
                      bias=seq[2].bias)
@@ -566,6 +577,18 @@ class InfoNCEFn(torch.autograd.Function):
         dboth = (dboth * dloss).contiguous()
 
         def proj_bwd(L, dmean, seq, n, dropout_p, site, want_dx):
+            if L.h is None:                                                                  # pooled first (see forward)
+                gw, gb = gbuf(seq[2].weight), gbuf(seq[2].bias)
+                dhbar = ops.linear_f32_bwd(L.hbar, seq[2].weight.detach(), None, dmean.contiguous(), gw, gb)
+                Hd = L.hbar.shape[1]
+                du = ops.seq_mean_bwd(dhbar, B, n, Hd, Hd, aux=L.u, aux_mode=1 if ops.GELU_SAVE_GRAD else 2)
+                _lin_bwd_params(du, L.x16, seq[0].weight, seq[0].bias)
+                if not want_dx:
+                    return None
+                dx = ops.linear_bwd_input(du, wbf16(seq[0].weight), out_dtype=F32)
+                if dropout_p > 0:
+                    dx = ops.dropout_f32(dx, dropout_p, st.seed, site)
+                return dx
             dpr = ops.seq_mean_bwd(dmean.contiguous(), B, n, d, ldp)                       # [B*n, ldp] bf16, pad cols 0
             gw = gbuf(seq[2].weight)
             if gw is not None:

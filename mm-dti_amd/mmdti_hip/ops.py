@@ -436,9 +436,10 @@ def seq_mean_fwd(x, B, S, D, ld):
     return out
 
 
-def seq_mean_bwd(dout, B, S, D, ld):
+def seq_mean_bwd(dout, B, S, D, ld, aux=None, aux_mode=0):
+    """dx[b*S+s] = dout[b] / S (bf16), optionally times aux (aux_mode 1) or gelu'(aux) (2) elementwise."""
     dx = torch.empty(B * S, ld, device=dout.device, dtype=BF16)
-    lib().mmdti_seq_mean_bwd(_stream(), dout.data_ptr(), B, S, D, ld, dx.data_ptr())
+    lib().mmdti_seq_mean_bwd(_stream(), dout.data_ptr(), B, S, D, ld, dx.data_ptr(), _p(aux), 0 if aux is None else aux.stride(0), int(aux_mode))
     return dx
 
 

@@ -435,6 +435,23 @@ def test_seq_mean(ops):
     assert (dx[..., D:] == 0).all()
 
 
+@pytest.mark.parametrize("B,S,D", [(3, 130, 512), (5, 37, 64), (2, 256, 512)])
+def test_seq_mean_wide_rows_and_gelu_factor(ops, B, S, D):
+    """The pooled-first InfoNCE head (mean_t(W2 h_t + b2) = W2 mean_t(h_t) + b2): 16-byte pooling over [B*S, D] bf16 rows and
+    its backward  dx[b*S+s] = dout[b] / S * f(aux[b*S+s])  with f = identity on a saved gelu' (mode 1) or gelu' itself (mode 2)."""
+    x = rt(torch.randn(B, S, D, generator=G(1)))
+    m = ops.seq_mean_fwd(dev(bf(x)).view(B * S, D), B, S, D, D)
+    close(m, x.mean(1), 1e-5, 1e-6)
+    d = torch.randn(B, D, generator=G(2))
+    u = rt(torch.randn(B * S, D, generator=G(3)))
+    want0 = (d / S).unsqueeze(1).expand(B, S, D).reshape(B * S, D)
+    close(ops.seq_mean_bwd(dev(d), B, S, D, D).float().cpu(), rt(want0), 1e-2, 1e-6)
+    close(ops.seq_mean_bwd(dev(d), B, S, D, D, aux=dev(bf(u)), aux_mode=1).float().cpu(), want0 * u, 1e-2, 1e-5)
+    t = u.double()
+    gp = (0.5 * (1 + torch.erf(t / 2 ** 0.5)) + t * torch.exp(-0.5 * t * t) / (2 * torch.pi) ** 0.5).float()
+    close(ops.seq_mean_bwd(dev(d), B, S, D, D, aux=dev(bf(u)), aux_mode=2).float().cpu(), want0 * gp, 1e-2, 1e-5)
+
+
 # ------------------------------------------------------------------------------------------- ConR / SupCon (golden G3)
 def test_ct_losses_golden(ops, golden):
     g = golden("g3_contrastive")
