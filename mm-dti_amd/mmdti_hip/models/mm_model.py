@@ -234,6 +234,7 @@ class MM_Model(nn.Module):
                            start_smooth=self.fds_cfg.start_smooth, kernel=self.fds_cfg.kernel, ks=self.fds_cfg.ks,
                            sigma=self.fds_cfg.sigma, momentum=self.fds_cfg.momentum)
         self.overlap_towers = bool(params.get('overlap_towers', True))
+        self.infonce_on_side_stream = bool(params.get('infonce_on_side_stream', os.environ.get("MMDTI_INFONCE_SIDE", "1") != "0"))
         self.split_tower1 = int(params.get('split_tower1', 1))
         self._side = None
         self._third = None
@@ -327,8 +328,20 @@ class MM_Model(nn.Module):
         else:
             out_bert = self.bert(input_ids, attention_mask, return_dict=True)[0]
 
+        infonce_side = False
         if return_infonce_loss:
-            ct_loss = self.infonce(encoder_rep, out_bert)
+            # The InfoNCE head and the cross-modal block both start from (encoder_rep, out_bert) and meet only in the loss: the
+            # head -- two token-level GEMMs and a dozen latency-bound B x B kernels -- runs on the side stream under the
+            # block's GEMMs (and its backward under the block's backward: autograd replays on the forward's stream).
+            if side is not None and self.infonce_on_side_stream:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    ct_loss = self.infonce(encoder_rep, out_bert)
+                encoder_rep.record_stream(side)
+                out_bert.record_stream(side)
+                infonce_side = True
+            else:
+                ct_loss = self.infonce(encoder_rep, out_bert)
 
         cross_txt_output_layer, cross_output_layer = self.cross_modal_module(encoder_rep, out_bert, img_mask, attention_mask)
         # mm_model.py:572-576 (zero padded rows, concat, masked mean) in one kernel
@@ -347,6 +360,9 @@ class MM_Model(nn.Module):
                 rnc_loss = self.CT(classification_feats_pooled, net_target, logits, weights=weights, w=self.ct_w)
             else:
                 rnc_loss = self.CT(classification_feats_pooled, net_target, logits, w=self.ct_w)
+        if infonce_side:
+            main.wait_stream(side)
+            ct_loss.record_stream(main)
         out = [logits]
         if return_feature:
             out.append(classification_feats_pooled)
