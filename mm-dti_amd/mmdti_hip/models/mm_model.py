@@ -141,13 +141,30 @@ class CrossAttentionModel(nn.Module):
         self.text_attention = BertCrossEncoder(cross_cfg, num_layers)
         self.graph_attention = BertCrossEncoder(cross_cfg, num_layers)
         self.dropout = nn.Dropout(cross_cfg.hidden_dropout_prob)
+        self.two_streams = os.environ.get("MMDTI_CROSS_TWO_STREAMS", "1") != "0"
+        self._stream = None
 
     def forward(self, text_embeddings, graph_embeddings, text_mask, graph_mask):
         text_embeddings = DropoutFn.apply(text_embeddings, self.dropout.p, self.training)
         graph_embeddings = DropoutFn.apply(graph_embeddings, self.dropout.p, self.training)
         extended_txt_mask = (1.0 - text_mask.unsqueeze(1).unsqueeze(2).to(dtype=torch.float32)) * -10000.0
-        graph_to_text = self.graph_attention(graph_embeddings, text_embeddings, extended_txt_mask)[-1]
         extended_img_mask = (1.0 - graph_mask.unsqueeze(1).unsqueeze(2).to(dtype=torch.float32)) * -10000.0
+        if self.two_streams and text_embeddings.is_cuda:
+            # the two directions are independent one-layer blocks: the second runs on its own stream beside the first
+            main = torch.cuda.current_stream()
+            if self._stream is None:
+                self._stream = torch.cuda.Stream()
+            st = self._stream
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                text_to_graph = self.text_attention(text_embeddings, graph_embeddings, extended_img_mask)[-1]
+            for t in (text_embeddings, graph_embeddings, extended_img_mask):
+                t.record_stream(st)
+            graph_to_text = self.graph_attention(graph_embeddings, text_embeddings, extended_txt_mask)[-1]
+            main.wait_stream(st)
+            text_to_graph.record_stream(main)
+            return text_to_graph, graph_to_text
+        graph_to_text = self.graph_attention(graph_embeddings, text_embeddings, extended_txt_mask)[-1]
         text_to_graph = self.text_attention(text_embeddings, graph_embeddings, extended_img_mask)[-1]
         return text_to_graph, graph_to_text
 
