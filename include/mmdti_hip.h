@@ -131,14 +131,15 @@ int mmdti_gbf_features_bwd(mmdti_stream_t stream, const float* dist, const long 
 int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, const long long* edge_type, const float* mul,
                        const float* bias, const float* means, const float* stds, const void* w1_bf16, const float* b1,
                        const void* w2_bf16, const float* b2, int B, int N, int ld, int K, int F, int H, int E, float* out,
-                       void* feat_bf16, void* u_bf16, void* h_bf16, int tiled);
+                       void* feat_bf16, void* u_bf16, void* h_bf16, int flags /* bit 0: tiled pair layout; bit 1: u_bf16 receives
+                       gelu'(pre-activation) instead of the pre-activation (then pass the same bit to mmdti_gbf_bias_bwd) */);
 /* Per-pair half of the backward of mmdti_gbf_bias_fwd, one pass over g = dL/d(out) (same layout flag): writes
  * do_bf16 [B*N*N, 64] = bf16(g re-laid out) and du_bf16 [B*N*N, 128] = bf16((do.W2) * gelu'(u)) -- the A operands of the two
  * weight-gradient GEMMs (dW2 = do^T.h, dW1 = du^T.feat; bias gradients are their column sums) -- and accumulates the
  * Gaussian-layer gradients dmul/dbias [E] and dmeans/dstds [128] (fp32, +=).  E <= 4096. */
 int mmdti_gbf_bias_bwd(mmdti_stream_t stream, const float* g, const float* dist, const long long* edge_type, const float* mul,
                        const float* bias, const float* means, const float* stds, const void* w1_bf16, const void* w2_bf16,
-                       const void* u_bf16, int B, int N, int ld, int K, int F, int H, int E, int tiled, void* do_bf16,
+                       const void* u_bf16, int B, int N, int ld, int K, int F, int H, int E, int flags, void* do_bf16,
                        void* du_bf16, float* dmul, float* dbias, float* dmeans, float* dstds);
 /* [B,N,N,H] fp32 -> [B,H,N,ld] fp32 (mm_model.py:555-556 permute(0,3,1,2).contiguous()) and its gradient
  * [B,H,N,ld] fp32 (or, tiled != 0, the [B,H,nt,nt,256] tile layout of mmdti_gbf_bias_fwd) -> [B,N,N,H] bf16 */

@@ -165,6 +165,18 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return 0.5f * (1.0f + erfv) + x * kInvSqrt2Pi * e;
 }
 
+// gelu(x) and gelu'(x) from one erf / one exponential (scalar form)
+__device__ __forceinline__ void gelu_erf_both(float x, float& y, float& dy) {
+  const float kInvSqrt2Pi = 0.39894228040143267794f;
+  const float ax = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+  const float e = __expf(-ax * ax);
+  const float phi = 0.5f * (1.0f + copysignf(1.0f - poly * e, x));
+  y = x * phi;
+  dy = phi + x * kInvSqrt2Pi * e;
+}
+
 // Two elements at a time on <2 x float>: the multiplies / fused multiply-adds of the polynomial compile to the packed
 // v_pk_mul_f32 / v_pk_fma_f32 forms (two fp32 lanes per instruction); only the reciprocal and the exponential stay
 // one-wide.  Same formula, same constants, same results as the scalar functions above.

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void gbf_bias_fwd_kernel(const float* __restri
                                                            const bf16_t* __restrict__ W2, const float* __restrict__ b2,
                                                            float* __restrict__ out, bf16_t* __restrict__ feat_out,
                                                            bf16_t* __restrict__ u_out, bf16_t* __restrict__ h_out, int B, int N,
-                                                           int ld, int E, int tpm) {
+                                                           int ld, int E, int tpm, int ugrad) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gbf_smem[];
   bf16_t* sW1 = reinterpret_cast<bf16_t*>(gbf_smem);       // [128][136]   W1[f][k]
   bf16_t* sW2 = sW1 + GBF_F * GBF_WS;                       // [64][136]    W2[h][f], f in k-slot order
@@ -312,9 +312,22 @@ __global__ __launch_bounds__(256) void gbf_bias_fwd_kernel(const float* __restri
         }
         const gf32x4 bb = *reinterpret_cast<const gf32x4*>(sB1 + 16 * ft + 4 * g);
         acc += bb;
-        if (SAVE && valid) *reinterpret_cast<uint2*>(u_out + p * GBF_F + 16 * ft + 4 * g) = gbf_pack4(acc);
+        if (SAVE && ugrad) {   // the saved tensor holds gelu'(pre-activation): the erf and the Gaussian are in hand here, and the
+                               // backward kernel -- alone on the chip at the very end of the step -- is left with a multiply
+          gf32x4 gq;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = gelu_erf(acc[r]);
+          for (int r = 0; r < 4; ++r) {
+            float yv, gv;
+            gelu_erf_both(acc[r], yv, gv);
+            acc[r] = yv;
+            gq[r] = gv;
+          }
+          if (valid) *reinterpret_cast<uint2*>(u_out + p * GBF_F + 16 * ft + 4 * g) = gbf_pack4(gq);
+        } else {
+          if (SAVE && valid) *reinterpret_cast<uint2*>(u_out + p * GBF_F + 16 * ft + 4 * g) = gbf_pack4(acc);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = gelu_erf(acc[r]);
+        }
         if (SAVE && valid) *reinterpret_cast<uint2*>(h_out + p * GBF_F + 16 * ft + 4 * g) = gbf_pack4(acc);
         hv[hf] = acc;
         __builtin_amdgcn_sched_barrier(0);  // keep the unrolled tiles in order: hoisted weight fragments would eat the register file
@@ -360,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void gbf_bias_bwd_kernel(const float* __res
                                                            bf16_t* __restrict__ do_out, bf16_t* __restrict__ du_out,
                                                            float* __restrict__ dmul, float* __restrict__ dbias,
                                                            float* __restrict__ dmeans, float* __restrict__ dstds, int B, int N, int ld,
-                                                           int E, int tpm) {
+                                                           int E, int tpm, int ugrad) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gbf_smem[];
   bf16_t* sW1T = reinterpret_cast<bf16_t*>(gbf_smem);   // [128 k][136]  W1^T[k][f], f in k-slot order
   bf16_t* sW2T = sW1T + GBF_K * GBF_WS;                  // [128 f][72]   W2^T[f][h]
@@ -476,10 +489,17 @@ __global__ __launch_bounds__(256, 2) void gbf_bias_bwd_kernel(const float* __res
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, oB[c], acc, 0, 0, 0);
         }
         const uint2 up = upre[ft];
-        acc[0] *= gelu_erf_grad(__uint_as_float(up.x << 16));
-        acc[1] *= gelu_erf_grad(__uint_as_float(up.x & 0xffff0000u));
-        acc[2] *= gelu_erf_grad(__uint_as_float(up.y << 16));
-        acc[3] *= gelu_erf_grad(__uint_as_float(up.y & 0xffff0000u));
+        if (ugrad) {   // (the forward saved gelu' itself)
+          acc[0] *= __uint_as_float(up.x << 16);
+          acc[1] *= __uint_as_float(up.x & 0xffff0000u);
+          acc[2] *= __uint_as_float(up.y << 16);
+          acc[3] *= __uint_as_float(up.y & 0xffff0000u);
+        } else {
+          acc[0] *= gelu_erf_grad(__uint_as_float(up.x << 16));
+          acc[1] *= gelu_erf_grad(__uint_as_float(up.x & 0xffff0000u));
+          acc[2] *= gelu_erf_grad(__uint_as_float(up.y << 16));
+          acc[3] *= gelu_erf_grad(__uint_as_float(up.y & 0xffff0000u));
+        }
         if (valid) *reinterpret_cast<uint2*>(du_out + p * GBF_F + 16 * ft + 4 * g) = gbf_pack4(acc);
         dv[hf] = acc;
         __builtin_amdgcn_sched_barrier(0);
@@ -644,7 +664,8 @@ extern "C" int mmdti_pair_permute_bwd(mmdti_stream_t stream, const float* g, voi
 extern "C" int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, const long long* edge_type, const float* mul,
                                   const float* bias, const float* means, const float* stds, const void* w1_bf16,
                                   const float* b1, const void* w2_bf16, const float* b2, int B, int N, int ld, int K, int F,
-                                  int H, int E, float* out, void* feat_bf16, void* u_bf16, void* h_bf16, int tiled) {
+                                  int H, int E, float* out, void* feat_bf16, void* u_bf16, void* h_bf16, int flags) {
+  const int tiled = flags & 1, ugrad = (flags >> 1) & 1;   // bit 0: tiled pair layout; bit 1: u_bf16 receives gelu'(u) instead of u
   MMDTI_REQUIRE(dist && edge_type && mul && bias && means && stds && w1_bf16 && b1 && w2_bf16 && b2 && out, "gbf_bias_fwd: null argument");
   MMDTI_REQUIRE(K == GBF_K && F == GBF_F && H == GBF_H, "gbf_bias_fwd: built for %d gaussians, %d hidden, %d heads (got %d,%d,%d)",
                 GBF_K, GBF_F, GBF_H, K, F, H);
@@ -661,7 +682,7 @@ extern "C" int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, cons
 #define GBF_L(SAVE, TILED)                                                                                                          \
   hipLaunchKernelGGL((gbf_bias_fwd_kernel<SAVE, TILED>), dim3(grid), dim3(256), smem, (hipStream_t)stream, dist, edge_type, mul, bias, \
                      means, stds, (const bf16_t*)w1_bf16, b1, (const bf16_t*)w2_bf16, b2, out, (bf16_t*)feat_bf16, (bf16_t*)u_bf16, \
-                     (bf16_t*)h_bf16, B, N, ld, E, tpm)
+                     (bf16_t*)h_bf16, B, N, ld, E, tpm, ugrad)
   if (save) { if (tiled) GBF_L(true, true); else GBF_L(true, false); }
   else      { if (tiled) GBF_L(false, true); else GBF_L(false, false); }
 #undef GBF_L
@@ -672,8 +693,9 @@ extern "C" int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, cons
 extern "C" int mmdti_gbf_bias_bwd(mmdti_stream_t stream, const float* g, const float* dist, const long long* edge_type,
                                   const float* mul, const float* bias, const float* means, const float* stds,
                                   const void* w1_bf16, const void* w2_bf16, const void* u_bf16, int B, int N, int ld, int K,
-                                  int F, int H, int E, int tiled, void* do_bf16, void* du_bf16, float* dmul, float* dbias,
+                                  int F, int H, int E, int flags, void* do_bf16, void* du_bf16, float* dmul, float* dbias,
                                   float* dmeans, float* dstds) {
+  const int tiled = flags & 1, ugrad = (flags >> 1) & 1;   // bit 0: tiled pair layout; bit 1: u_bf16 holds gelu'(u)
   MMDTI_REQUIRE(g && dist && edge_type && mul && bias && means && stds && w1_bf16 && w2_bf16 && u_bf16 && do_bf16 && du_bf16 && dmul &&
                     dbias && dmeans && dstds, "gbf_bias_bwd: null argument");
   MMDTI_REQUIRE(K == GBF_K && F == GBF_F && H == GBF_H, "gbf_bias_bwd: built for %d gaussians, %d hidden, %d heads (got %d,%d,%d)",
@@ -698,7 +720,7 @@ extern "C" int mmdti_gbf_bias_bwd(mmdti_stream_t stream, const float* g, const f
 #define GBF_B(TILED)                                                                                                          \
   hipLaunchKernelGGL((gbf_bias_bwd_kernel<TILED>), dim3(grid), dim3(256), smem, (hipStream_t)stream, g, dist, edge_type, mul, bias, \
                      means, stds, (const bf16_t*)w1_bf16, (const bf16_t*)w2_bf16, (const bf16_t*)u_bf16, (bf16_t*)do_bf16,    \
-                     (bf16_t*)du_bf16, dmul, dbias, dmeans, dstds, B, N, ld, E, tpm)
+                     (bf16_t*)du_bf16, dmul, dbias, dmeans, dstds, B, N, ld, E, tpm, ugrad)
   if (tiled) GBF_B(true); else GBF_B(false);
 #undef GBF_B
   MMDTI_LAUNCH_CHECK();

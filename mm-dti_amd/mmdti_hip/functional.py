@@ -215,15 +215,18 @@ class PairBiasFn(torch.autograd.Function):
             # (tiled pair layout whenever the MFMA pair-attention kernels can take it: their loads become contiguous KiBs)
             keep = any(ctx.needs_input_grad)  # inference: the kernel does not even write the [P,128] intermediates
             out, saved = ops.gbf_bias_fwd(dist, edge_type, *args, wbf16(proj.linear1.weight), proj.linear1.bias,
-                                          wbf16(proj.linear2.weight), proj.linear2.bias, ld, save=keep, tiled=ops.pair_tiled_ok(N))
+                                          wbf16(proj.linear2.weight), proj.linear2.bias, ld, save=keep, tiled=ops.pair_tiled_ok(N),
+                                          save_grad=ops.GELU_SAVE_GRAD)
             feat, u, h = saved if keep else (None, None, None)
+            ugrad = ops.GELU_SAVE_GRAD
         else:
             feat = ops.gbf_features_fwd(dist, edge_type, *args)
             u = torch.empty(feat.shape[0], proj.linear1.weight.shape[0], device=dist.device, dtype=BF16)
-            h = ops.linear_fwd(feat, wbf16(proj.linear1.weight), proj.linear1.bias, act=ops.ACT_GELU, aux_out=u)
+            h = ops.linear_fwd(feat, wbf16(proj.linear1.weight), proj.linear1.bias, act=ops.ACT_GELU_FWD, aux_out=u)
+            ugrad = ops.GELU_SAVE_GRAD
             o = ops.linear_fwd(h, wbf16(proj.linear2.weight), proj.linear2.bias, out_dtype=F32)
             out = ops.pair_permute_fwd(o, B, N, H, ld)
-        ctx.st = SimpleNamespace(dist=dist, et=edge_type, feat=feat, u=u, h=h, B=B, N=N, H=H, ld=ld, fused=fused)
+        ctx.st = SimpleNamespace(dist=dist, et=edge_type, feat=feat, u=u, h=h, B=B, N=N, H=H, ld=ld, fused=fused, ugrad=ugrad)
         ctx.gbf, ctx.proj = gbf, proj
         return out
 
@@ -236,13 +239,13 @@ class PairBiasFn(torch.autograd.Function):
             # GEMMs (contraction over all pairs) and their column sums remain
             grads = [gbuf(p) if p.requires_grad else torch.zeros_like(p) for p in ps]
             do, du = ops.gbf_bias_bwd(g.contiguous(), st.dist, st.et, *[p.view(-1) for p in ps], wbf16(proj.linear1.weight),
-                                      wbf16(proj.linear2.weight), st.u, st.ld, *[gr.view(-1) for gr in grads])
+                                      wbf16(proj.linear2.weight), st.u, st.ld, *[gr.view(-1) for gr in grads], u_is_grad=st.ugrad)
             _lin_bwd_params(do, st.h, proj.linear2.weight, proj.linear2.bias)
             _lin_bwd_params(du, st.feat, proj.linear1.weight, proj.linear1.bias)
         else:
             do = ops.pair_permute_bwd(g.contiguous(), st.B, st.N, st.H, st.ld)          # [P,H] bf16
             _lin_bwd_params(do, st.h, proj.linear2.weight, proj.linear2.bias)
-            du = ops.linear_bwd_input(do, wbf16(proj.linear2.weight), act=ops.ACT_GELU_BWD, aux_in=st.u)
+            du = ops.linear_bwd_input(do, wbf16(proj.linear2.weight), act=ops.ACT_MUL_AUX if st.ugrad else ops.ACT_GELU_BWD, aux_in=st.u)
             _lin_bwd_params(du, st.feat, proj.linear1.weight, proj.linear1.bias)
             dfeat = ops.linear_bwd_input(du, wbf16(proj.linear1.weight))
             if any(p.requires_grad for p in ps):

@@ -244,7 +244,7 @@ def gbf_features_bwd(dist, edge_type, mul, bias, means, stds, dfeat, dmul, dbias
                                  dstds.data_ptr())
 
 
-def gbf_bias_fwd(dist, edge_type, mul, bias, means, stds, w1, b1, w2, b2, ld, save=True, tiled=False):
+def gbf_bias_fwd(dist, edge_type, mul, bias, means, stds, w1, b1, w2, b2, ld, save=True, tiled=False, save_grad=False):
     """Fused gbf + gbf_proj + permute -> (out [B,H,N,ld] fp32 -- or the tiled pair layout --, (feat, u, h) [P,128] bf16 or None)."""
     _chk(dist, F32, "gbf.dist"); _chk(edge_type, torch.int64, "gbf.edge_type"); _chk(w1, BF16, "gbf.w1"); _chk(w2, BF16, "gbf.w2")
     B, N, _ = dist.shape
@@ -255,12 +255,12 @@ def gbf_bias_fwd(dist, edge_type, mul, bias, means, stds, w1, b1, w2, b2, ld, sa
     t0 = kernel_timer.begin("gbf_features_fwd")
     lib().mmdti_gbf_bias_fwd(_stream(), dist.data_ptr(), edge_type.data_ptr(), mul.data_ptr(), bias.data_ptr(), means.data_ptr(), stds.data_ptr(),
                              w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), B, N, ld, K, Fh, Hh, mul.numel(), out.data_ptr(),
-                             *([t.data_ptr() for t in saved] if save else [0, 0, 0]), int(tiled))
+                             *([t.data_ptr() for t in saved] if save else [0, 0, 0]), int(tiled) | (2 if save_grad else 0))
     kernel_timer.end("gbf_features_fwd", t0)
     return out, saved
 
 
-def gbf_bias_bwd(g, dist, edge_type, mul, bias, means, stds, w1, w2, u, ld, dmul, dbias, dmeans, dstds):
+def gbf_bias_bwd(g, dist, edge_type, mul, bias, means, stds, w1, w2, u, ld, dmul, dbias, dmeans, dstds, u_is_grad=False):
     """Per-pair half of the fused pair-bias backward -> (do [P,64] bf16, du [P,128] bf16); Gaussian grads accumulated."""
     B, N, _ = dist.shape
     Hh, Fh = w2.shape
@@ -269,7 +269,7 @@ def gbf_bias_bwd(g, dist, edge_type, mul, bias, means, stds, w1, w2, u, ld, dmul
     du = torch.empty(P, Fh, device=g.device, dtype=BF16)
     lib().mmdti_gbf_bias_bwd(_stream(), g.data_ptr(), dist.data_ptr(), edge_type.data_ptr(), mul.data_ptr(), bias.data_ptr(), means.data_ptr(),
                              stds.data_ptr(), w1.data_ptr(), w2.data_ptr(), u.data_ptr(), B, N, ld, w1.shape[1], Fh, Hh, mul.numel(),
-                             int(pair_is_tiled(g)), do.data_ptr(), du.data_ptr(), dmul.data_ptr(), dbias.data_ptr(), dmeans.data_ptr(),
+                             int(pair_is_tiled(g)) | (2 if u_is_grad else 0), do.data_ptr(), du.data_ptr(), dmul.data_ptr(), dbias.data_ptr(), dmeans.data_ptr(),
                              dstds.data_ptr())
     return do, du
 

@@ -687,6 +687,18 @@ def test_gbf_bias_bwd_fused_matches_unfused_chain(ops, B, N, tiled):
     for a, b_, name in zip(gr, gr_r, ("dmul", "dbias", "dmeans", "dstds")):
         r = float((a - b_).norm() / (b_.norm() + 1e-12))
         assert r < 2e-2, (name, r)
+    # flag bit 1: the forward saves gelu'(u) (same erf / exponential as its GELU), the backward multiplies
+    _, (feat2, ug, h2) = ops.gbf_bias_fwd(*d, w1, b1, w2, b2, ld, save=True, tiled=tiled, save_grad=True)
+    assert torch.equal(feat2, feat) and torch.equal(h2, h)
+    t = u.double()
+    close(ug.double(), 0.5 * (1 + torch.erf(t / 2 ** 0.5)) + t * torch.exp(-0.5 * t * t) / (2 * torch.pi) ** 0.5, 2e-2, 8e-3)   # (u itself is bf16-rounded)
+    gr2 = [torch.zeros_like(t_) for t_ in d[2:]]
+    do2, du2 = ops.gbf_bias_bwd(g, *d, w1, w2, ug, ld, *gr2, u_is_grad=True)
+    assert torch.equal(do2, do)
+    assert float((du2.float() - du_r.float()).abs().mean()) < 6e-3 * float(du_r.float().abs().mean()) + 1e-6
+    for a, b_, name in zip(gr2, gr_r, ("dmul", "dbias", "dmeans", "dstds")):
+        r = float((a - b_).norm() / (b_.norm() + 1e-12))
+        assert r < 2e-2, (name, r)
 
 
 @pytest.mark.parametrize("M,N,K,out_dtype", [(300, 128, 64, torch.bfloat16), (1000, 256, 192, torch.float32), (129, 64, 128, torch.bfloat16)])
