@@ -68,6 +68,38 @@ def _join_stream_after_backward():
     torch.autograd.Variable._execution_engine.queue_callback(_join)
 
 
+# Weight gradients held back to the end of the pair encoder's backward: the fused pair-bias backward that follows it runs
+# alone on the chip and is latency-bound (waves parked 80 % of their cycles), so the weight-gradient GEMMs of the last few
+# layers -- leaves of the backward graph -- are launched on their own stream right before it and run underneath it.
+DEFER_WGRAD_LAYERS = int(os.environ.get("MMDTI_DEFER_WGRAD", "4"))
+_wgrad_stream_obj = None
+_wgrad_keep = []
+
+
+def _launch_deferred_wgrads(deferred, layers):
+    """deferred: argument tuples of _lin_bwd_params whose operands must stay alive until the stream is joined."""
+    global _wgrad_stream_obj
+    if not deferred:
+        return
+    main = torch.cuda.current_stream()
+    if _wgrad_stream_obj is None:
+        _wgrad_stream_obj = torch.cuda.Stream()
+    ws = _wgrad_stream_obj
+    ws.wait_stream(main)
+    with torch.cuda.stream(ws):
+        for args, kw in deferred:
+            _lin_bwd_params(*args, **kw)
+        for layer in layers:
+            notify_grads_ready(layer.parameters())     # (recorded on this stream: the reducer's event sits behind the GEMMs)
+    _wgrad_keep.append(deferred)
+
+    def _join(stream=ws):
+        torch.cuda.current_stream().wait_stream(stream)
+        _wgrad_keep.clear()                             # operands may be recycled now: later work is ordered behind the join
+
+    torch.autograd.Variable._execution_engine.queue_callback(_join)
+
+
 class _Sites:
     """Dropout site numbering inside one forward call."""
 
@@ -160,26 +192,35 @@ class PairEncoderFn(torch.autograd.Function):
             dx, dx16 = dout, None
         G = None
         below = [Lb.site_f for Lb in st.layers[:-1]]      # site of the FFN dropout of the layer UNDER each layer
+        deferred, deferred_layers = [], []
+        n_defer = DEFER_WGRAD_LAYERS if dout.is_cuda else 0
         for li, layer, L in zip(range(len(st.layers) - 1, -1, -1), reversed(mod.layers), reversed(st.layers)):
             att, ln1, ln2 = layer.self_attn, layer.self_attn_layer_norm, layer.final_layer_norm
+            hold = li < n_defer                          # this layer's weight gradients wait for the end (see _launch_deferred_wgrads)
+
+            def _wgrad(*args, **kw):
+                if hold:
+                    deferred.append((args, kw))
+                else:
+                    _lin_bwd_params(*args, **kw)
             # ---- FFN:  x2 = x1 + drop(fc2(gelu(fc1(LN2(x1)))))
             # (dx16 = bf16 dropout-backward copy of dx, written by the LayerNorm backward that produced dx)
             dy2 = dx16 if dx16 is not None else ops.cast_bf16(dx, st.p_res, seed, L.site_f)
-            _lin_bwd_params(dy2, L.a, layer.fc2.weight, layer.fc2.bias, bias_done=dx16 is not None)
+            _wgrad(dy2, L.a, layer.fc2.weight, layer.fc2.bias, bias_done=dx16 is not None)
             cs = _epilogue_colsum(layer.fc1.bias)          # fc1.bias gradient = column sums of du: taken in the GEMM's epilogue
             du = ops.linear_bwd_input(dy2, wbf16(layer.fc2.weight), act=ops.ACT_GELU_DX, aux_in=L.u, colsum=cs)
-            _lin_bwd_params(du, L.h2, layer.fc1.weight, layer.fc1.bias, bias_done=cs is not None)
+            _wgrad(du, L.h2, layer.fc1.weight, layer.fc1.bias, bias_done=cs is not None)
             dh2 = ops.linear_bwd_input(du, wbf16(layer.fc1.weight))
             dx, dy1 = ops.layernorm_bwd(dh2, L.x1, ln2.weight, L.m2, L.r2, gbuf(ln2.weight), gbuf(ln2.bias), dres=dx,
                                         bf16_copy=(st.p_res, L.site_o, gbuf(att.out_proj.bias)))
             # ---- attention:  x1 = x + drop(out_proj(attn(LN1(x))))
-            _lin_bwd_params(dy1, L.o, att.out_proj.weight, att.out_proj.bias, bias_done=True)
+            _wgrad(dy1, L.o, att.out_proj.weight, att.out_proj.bias, bias_done=True)
             do = ops.linear_bwd_input(dy1, wbf16(att.out_proj.weight))
             g_zero = G is None
             if g_zero:
                 G = torch.empty_like(L.s)
             dqkv = ops.pair_attn_bwd(L.qkv, L.s, do, G, B, N, H, ld, scale, g_zero, st.p_att, seed, L.site_att)
-            _lin_bwd_params(dqkv, L.h1, att.in_proj.weight, att.in_proj.bias)
+            _wgrad(dqkv, L.h1, att.in_proj.weight, att.in_proj.bias)
             dh1 = ops.linear_bwd_input(dqkv, wbf16(att.in_proj.weight))
             if li > 0:
                 dx, dx16 = ops.layernorm_bwd(dh1, L.x, ln1.weight, L.m1, L.r1, gbuf(ln1.weight), gbuf(ln1.bias), dres=dx,
@@ -187,13 +228,17 @@ class PairEncoderFn(torch.autograd.Function):
             else:
                 dx, dx16 = ops.layernorm_bwd(dh1, L.x, ln1.weight, L.m1, L.r1, gbuf(ln1.weight), gbuf(ln1.bias), dres=dx), None
             L.__dict__.clear()       # release this layer's activations (S_l is ~1 GB at the bench shape)
-            notify_grads_ready(layer.parameters())
+            if hold:
+                deferred_layers.append(layer)
+            else:
+                notify_grads_ready(layer.parameters())
         eln = mod.emb_layer_norm
         demb = ops.layernorm_bwd(dx, st.emb.view(M, D), eln.weight, st.emb_mean, st.emb_rstd, gbuf(eln.weight), gbuf(eln.bias),
                                  row_zero=None if st.pad is None else st.pad.reshape(-1), drop_p=st.p_emb, seed=seed, site=st.site_emb)
         notify_grads_ready(list(eln.parameters()) + ([] if mod.final_layer_norm is None else list(mod.final_layer_norm.parameters())))
         if G is None:
             G = torch.zeros_like(st.bias0)
+        _launch_deferred_wgrads(deferred, deferred_layers)
         _join_stream_after_backward()
         return demb.view(B, N, D), G, None, None, None
 
