@@ -149,15 +149,17 @@ def main():
     # other tower's kernels), and towers back to back on one stream (each launch alone on the chip).
     pa_timers = ops.kernel_timer.summary()
     gemm_timers = {}
-    was = model.overlap_towers
-    for mode, ov in (("overlapped", was), ("alone", False)):
-        model.overlap_towers = ov
+    from mmdti_hip import functional as Fn
+    was = (model.overlap_towers, model.infonce_on_side_stream, model.cross_modal_module.two_streams, Fn.DEFER_WGRAD_LAYERS)
+    for mode, ov in (("overlapped", True), ("alone", False)):
+        if not ov:      # every stream-level overlap off: each launch has the chip to itself
+            model.overlap_towers, model.infonce_on_side_stream, model.cross_modal_module.two_streams, Fn.DEFER_WGRAD_LAYERS = False, False, False, 0
         ops.kernel_timer.enable(("gemm",))
         for _ in range(2):
             tuner.step(batch, label, epoch=0)
         gemm_timers[mode] = ops.kernel_timer.summary().get("gemm")
         ops.kernel_timer.disable()
-    model.overlap_towers = was
+    model.overlap_towers, model.infonce_on_side_stream, model.cross_modal_module.two_streams, Fn.DEFER_WGRAD_LAYERS = was
     barrier()
 
     if rank == 0:
