@@ -314,7 +314,7 @@ __device__ __forceinline__ void pa_split4(const f32x4& v, pa_s16x4& hi, pa_s16x4
 #define PA_MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A, B, C, 0, 0, 0)
 
 template <int NT, bool TILED, bool FULL>
-__global__ __launch_bounds__(256, 4) void pair_attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_in,
+__global__ __launch_bounds__(256, NT > 13 ? 2 : 4) void pair_attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_in,
                                                                  float* __restrict__ s_out, bf16_t* __restrict__ o,
                                                                  const unsigned char* __restrict__ key_pad, int N, int H, int ld,
                                                                  float scale, uint32_t thresh, float dscale, uint64_t seed,
@@ -752,6 +752,9 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
 }  // namespace mmdti
 using namespace mmdti;
 
+// key tiles of 16 the MFMA kernels are instantiated for: 17 covers the reference's crop (max_atoms = 256 -> N <= 258, data/conformer.py:53,199-204)
+#define PA_MAX_NT 17
+
 static int check_common(const char* fn, int B, int N, int H, int ld) {
   MMDTI_REQUIRE(B > 0 && N > 0 && H > 0, "%s: B,N,H must be positive", fn);
   MMDTI_REQUIRE(N <= 320, "%s: N=%d exceeds the supported 320 atoms (+BOS/EOS)", fn, N);
@@ -764,7 +767,7 @@ extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, 
                                    void* o_bf16, const unsigned char* key_pad, int B, int N, int H, int ld,
                                    float scale, float drop_p, unsigned long long seed, unsigned int site, int tiled) {
   if (int e = check_common("pair_attn_fwd", B, N, H, ld)) return e;
-  MMDTI_REQUIRE(!tiled || (ld % 4 == 0 && N <= 16 * 13), "pair_attn_fwd: the tiled pair layout needs ld %% 4 == 0 and N <= 208");
+  MMDTI_REQUIRE(!tiled || (ld % 4 == 0 && N <= 16 * PA_MAX_NT), "pair_attn_fwd: the tiled pair layout needs ld %% 4 == 0 and N <= 272");
   MMDTI_REQUIRE(qkv_bf16 && bias_in && s_out && o_bf16, "pair_attn_fwd: null pointer");
   MMDTI_REQUIRE(aligned16(qkv_bf16), "pair_attn_fwd: qkv must be 16-byte aligned");
   MMDTI_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "pair_attn_fwd: dropout p out of range");
@@ -773,7 +776,7 @@ extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, 
   dim3 grid(B * H), block(256);
   hipStream_t s = (hipStream_t)stream;
   // (same eligibility rule as the backward: the two MFMA kernels share one dropout-mask generator)
-  if (ld % 4 == 0 && aligned16(bias_in) && aligned16(s_out) && N <= 16 * 13) {
+  if (ld % 4 == 0 && aligned16(bias_in) && aligned16(s_out) && N <= 16 * PA_MAX_NT) {
     const int nqb = (N + 15) / 16;
     dim3 blk(nqb % 3 == 0 ? 192 : (nqb < 4 ? 64 * nqb : 256));
 #define PA_M(NT, TL, FL)                                                                                                    \
@@ -785,7 +788,7 @@ extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, 
     else if (nqb == NT) PA_M(NT, true, true);                                               \
     else PA_M(NT, true, false);                                                             \
   } while (0)
-    if (nqb <= 5) PA_MT(5); else if (nqb <= 9) PA_MT(9); else PA_MT(13);
+    if (nqb <= 5) PA_MT(5); else if (nqb <= 9) PA_MT(9); else if (nqb <= 13) PA_MT(13); else PA_MT(17);
 #undef PA_MT
 #undef PA_M
     MMDTI_LAUNCH_CHECK();
@@ -810,14 +813,14 @@ extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, 
                                    float* g, void* dqkv_bf16, int B, int N, int H, int ld, float scale,
                                    int g_in_zero, float drop_p, unsigned long long seed, unsigned int site, int tiled) {
   if (int e = check_common("pair_attn_bwd", B, N, H, ld)) return e;
-  MMDTI_REQUIRE(!tiled || (ld % 4 == 0 && N <= 16 * 13), "pair_attn_bwd: the tiled pair layout needs ld %% 4 == 0 and N <= 208");
+  MMDTI_REQUIRE(!tiled || (ld % 4 == 0 && N <= 16 * PA_MAX_NT), "pair_attn_bwd: the tiled pair layout needs ld %% 4 == 0 and N <= 272");
   MMDTI_REQUIRE(qkv_bf16 && s && do_bf16 && g && dqkv_bf16, "pair_attn_bwd: null pointer");
   MMDTI_REQUIRE(aligned16(qkv_bf16) && aligned16(do_bf16) && aligned16(dqkv_bf16), "pair_attn_bwd: alignment");
   const uint32_t th = dropout_thresh(drop_p);
   const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   dim3 grid(B * H), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (ld % 4 == 0 && aligned16(s) && aligned16(g) && N <= 16 * 13) {
+  if (ld % 4 == 0 && aligned16(s) && aligned16(g) && N <= 16 * PA_MAX_NT) {
     const int nqb = (N + 15) / 16;
     dim3 blk(nqb % 3 == 0 ? 192 : (nqb < 4 ? 64 * nqb : 256));
 #define PA_MB(NT, TL, FL, NWV)                                                                                             \
@@ -834,7 +837,7 @@ extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, 
     else if (nqb == NT) PA_MBW(NT, true, true);                                             \
     else PA_MBW(NT, true, false);                                                           \
   } while (0)
-    if (nqb <= 5) PA_MBT(5); else if (nqb <= 9) PA_MBT(9); else PA_MBT(13);
+    if (nqb <= 5) PA_MBT(5); else if (nqb <= 9) PA_MBT(9); else if (nqb <= 13) PA_MBT(13); else PA_MBT(17);
 #undef PA_MBW
 #undef PA_MBT
 #undef PA_MB

@@ -23,12 +23,16 @@ def padded_cost(atoms: Sequence[int], tokens: Sequence[int]) -> float:
 class LengthBucketBatchSampler:
     """Batch sampler (yields lists of dataset indices) that groups molecules of similar (atom count, SMILES token count).
 
-    * every index appears exactly once per epoch (``drop_last=False``) or is dropped only from a final short batch;
+    * every index appears exactly once per epoch (``drop_last=False``, single process); with ``drop_last=True`` the
+      ``n % batch_size`` molecules left out are drawn AT RANDOM each epoch (as the reference's shuffled ``drop_last``
+      DataLoader does, tasks/trainer.py:143-150) -- never systematically the largest ones;
     * ``shuffle``: the ORDER of batches and the membership within a size neighbourhood are reshuffled every epoch from
       ``seed + epoch`` (call ``set_epoch``) -- samples still meet different partners from epoch to epoch, which the
       in-batch contrastive losses need;
     * data parallel: ``rank`` / ``world`` deal whole batches round-robin and trim to a common count, so that every rank
-      runs the same number of steps (the gradient all-reduce is collective).
+      runs the same number of steps (the gradient all-reduce is collective).  Every dealt batch is FULL: the InfoNCE
+      all-gather (parallel.GlobalNegatives) needs the same B_loc on all ranks at a step, so with ``world > 1`` a random
+      remainder is left out each epoch even when ``drop_last=False``.
     """
 
     def __init__(self, atom_counts: Sequence[int], token_counts: Sequence[int], batch_size: int, shuffle: bool = True, seed: int = 0,
@@ -48,17 +52,20 @@ class LengthBucketBatchSampler:
         n = len(self.atoms)
         # sort by the dominant cost term (atoms, then tokens); jitter within a neighbourhood of batches so that membership
         # changes between epochs while sizes stay close
-        key = self.atoms * 4096 + self.tokens
-        order = np.argsort(key, kind="stable")
+        keep = np.arange(n)
+        if (self.drop_last or self.world > 1) and n % self.batch_size:
+            # leave out a random remainder BEFORE sorting (dropping the tail of the size-sorted order would always drop the
+            # largest molecules)
+            keep = np.sort(rng.permutation(n)[: n - n % self.batch_size]) if self.shuffle else keep[: n - n % self.batch_size]
+        key = self.atoms[keep] * 4096 + self.tokens[keep]
+        order = keep[np.argsort(key, kind="stable")]
         if self.shuffle:
             span = self.batch_size * self.neighbourhood
-            for s in range(0, n, span):
+            for s in range(0, len(order), span):
                 seg = order[s:s + span]
                 rng.shuffle(seg)
                 order[s:s + span] = seg
-        batches = [order[s:s + self.batch_size].tolist() for s in range(0, n, self.batch_size)]
-        if self.drop_last and batches and len(batches[-1]) < self.batch_size:
-            batches.pop()
+        batches = [order[s:s + self.batch_size].tolist() for s in range(0, len(order), self.batch_size)]
         if self.shuffle:
             perm = rng.permutation(len(batches))
             batches = [batches[i] for i in perm]
@@ -72,7 +79,7 @@ class LengthBucketBatchSampler:
 
     def __len__(self) -> int:
         n = len(self.atoms)
-        nb = n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+        nb = n // self.batch_size if (self.drop_last or self.world > 1) else (n + self.batch_size - 1) // self.batch_size
         return nb // self.world if self.world > 1 else nb
 
 

@@ -21,8 +21,8 @@ from ..functional import PairBiasFn, EmbeddingFn
 from .. import ops
 from .transformers import TransformerEncoderWithPair
 from .bert_layers import RobertaTower
-from .mm_model import (GaussianLayer, NonLinearHead, molecule_architecture, fds_config, crossmodal_config, pad_1d_tokens, pad_2d,
-                       pad_coords)
+from ..collate import FIELD_RULES, collate_field, stack_labels, tokenize
+from .mm_model import GaussianLayer, NonLinearHead, molecule_architecture, fds_config, crossmodal_config
 
 
 class UnimolEncoder(nn.Module):
@@ -77,24 +77,13 @@ class UnimolEncoder(nn.Module):
         return encoder_rep
 
     def batch_collate_fn(self, samples):
+        """The 3D-conformer fields of MM_Model.batch_collate_fn (layout rules: mmdti_hip.collate); other keys are skipped."""
+        feats = [s[0] for s in samples]
         batch = {}
-        for k in samples[0][0].keys():
-            if k == 'src_coord':
-                v = pad_coords([torch.tensor(s[0][k]).float() for s in samples], pad_idx=0.0)
-            elif k == 'src_edge_type':
-                v = pad_2d([torch.tensor(s[0][k]).long() for s in samples], pad_idx=self.padding_idx)
-            elif k == 'src_distance':
-                v = pad_2d([torch.tensor(s[0][k]).float() for s in samples], pad_idx=0.0)
-            elif k == 'src_tokens':
-                v = pad_1d_tokens([torch.tensor(s[0][k]).long() for s in samples], pad_idx=self.padding_idx)
-            else:
-                continue
-            batch[k] = v
-        try:
-            label = torch.tensor([s[1] for s in samples])
-        except Exception:
-            label = None
-        return batch, label
+        for key in feats[0]:
+            if key in FIELD_RULES:
+                batch[key] = collate_field(key, (f[key] for f in feats), self.padding_idx)
+        return batch, stack_labels(samples)
 
 
 class ChembertaEncoder(nn.Module):
@@ -116,13 +105,9 @@ class ChembertaEncoder(nn.Module):
         return self.bert(input_ids=input_ids, attention_mask=attention_mask, return_dict=True)[0]
 
     def batch_collate_fn(self, samples):
+        """The SMILES half of the collate (no truncation here: encoder.py:563 passes padding=True only)."""
+        feats = [s[0] for s in samples]
         batch = {}
-        if 'smile' in samples[0][0].keys():
-            batch_text = self.tokenizer([i[0]['smile'] for i in samples], padding=True, return_tensors="pt")
-            batch['input_ids'] = batch_text['input_ids']
-            batch['attention_mask'] = batch_text['attention_mask']
-        try:
-            label = torch.tensor([s[1] for s in samples])
-        except Exception:
-            label = None
-        return batch, label
+        if 'smile' in feats[0]:
+            batch['input_ids'], batch['attention_mask'] = tokenize(self.tokenizer, (f['smile'] for f in feats), truncation=False)
+        return batch, stack_labels(samples)

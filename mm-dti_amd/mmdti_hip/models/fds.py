@@ -29,20 +29,26 @@ def anomaly_clean_regression(data):
 
 
 def _kernel_window(kernel, ks, sigma):
-    """FDS._get_kernel_window (fds.py:69-84): tiny host-side table built once at construction."""
+    """The ks-tap smoothing window over label buckets (values of FDS._get_kernel_window, fds.py:69-84; the four windows
+    the reference can produce are pinned by tests/golden/g4_fds_*.npz).  All three shapes are unit-sum:
+      gaussian : scipy's truncated-at-4-sigma, reflect-extended Gaussian filter applied to a centred unit impulse of length
+                 ks (for ks < 8*sigma the reflected tails fold back into the window -- that folding is part of the values);
+      triang   : scipy's triangular window;
+      laplace  : exp(-|k|/sigma) on k = -half..half."""
     from scipy.ndimage import gaussian_filter1d
     from scipy.signal.windows import triang
-    assert kernel in ['gaussian', 'triang', 'laplace']
-    half_ks = (ks - 1) // 2
+    half = (ks - 1) // 2
     if kernel == 'gaussian':
-        base_kernel = np.array([0.] * half_ks + [1.] + [0.] * half_ks, dtype=np.float32)
-        kernel_window = gaussian_filter1d(base_kernel, sigma=sigma) / sum(gaussian_filter1d(base_kernel, sigma=sigma))
+        impulse = np.zeros(2 * half + 1, dtype=np.float32)
+        impulse[half] = 1.0
+        taps = gaussian_filter1d(impulse, sigma=sigma)
     elif kernel == 'triang':
-        kernel_window = triang(ks) / sum(triang(ks))
+        taps = triang(ks)
+    elif kernel == 'laplace':
+        taps = np.exp(-np.abs(np.arange(-half, half + 1)) / sigma) / (2.0 * sigma)
     else:
-        laplace = lambda x: np.exp(-abs(x) / sigma) / (2. * sigma)
-        kernel_window = np.array(list(map(laplace, np.arange(-half_ks, half_ks + 1)))) / sum(map(laplace, np.arange(-half_ks, half_ks + 1)))
-    return torch.tensor(np.asarray(kernel_window), dtype=torch.float32)
+        raise AssertionError(f"FDS kernel must be gaussian, triang or laplace, got {kernel!r}")
+    return torch.tensor(np.asarray(taps / sum(taps)), dtype=torch.float32)
 
 
 class FDS(nn.Module):

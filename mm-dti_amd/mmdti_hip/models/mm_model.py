@@ -29,6 +29,7 @@ import torch.nn as nn
 from ..unicore_compat import Dictionary, init_bert_params, get_activation_fn
 from ..functional import PairBiasFn, EmbeddingFn, DropoutFn, MaskedPoolFn, LinearF32Fn
 from .. import ops
+from ..collate import right_pad, collate_field, stack_labels, tokenize
 from .transformers import TransformerEncoderWithPair
 from .bert_layers import BertCrossEncoder, RobertaTower
 from .infonce import InfoNCE
@@ -38,30 +39,18 @@ BACKBONE = {'transformer': TransformerEncoderWithPair}
 
 
 def pad_1d_tokens(values, pad_idx):
-    """utils/util.py:7-38 (right pad)."""
-    size = max(v.size(0) for v in values)
-    res = values[0].new(len(values), size).fill_(pad_idx)
-    for i, v in enumerate(values):
-        res[i][: len(v)].copy_(v)
-    return res
+    """utils/util.py:7-38."""
+    return right_pad(values, pad_idx)
 
 
 def pad_2d(values, pad_idx):
     """utils/util.py:41-72."""
-    size = max(v.size(0) for v in values)
-    res = values[0].new(len(values), size, size).fill_(pad_idx)
-    for i, v in enumerate(values):
-        res[i][: len(v), : len(v)].copy_(v)
-    return res
+    return right_pad(values, pad_idx, square=True)
 
 
 def pad_coords(values, pad_idx):
     """utils/util.py:75-105."""
-    size = max(v.size(0) for v in values)
-    res = values[0].new(len(values), size, 3).fill_(pad_idx)
-    for i, v in enumerate(values):
-        res[i][: len(v), :].copy_(v)
-    return res
+    return right_pad(values, pad_idx, tail=(3,))
 
 
 class ClassificationHead(nn.Module):
@@ -389,28 +378,22 @@ class MM_Model(nn.Module):
             out.append(rnc_loss)
         return out[0] if len(out) == 1 else tuple(out)
 
-    # ------------------------------------------------------------------ collate (unchanged semantics, :645-682)
+    # ------------------------------------------------------------------ collate (semantics of :645-682, pinned by G9)
     def batch_collate_fn(self, samples):
-        batch = {}
-        for k in samples[0][0].keys():
-            if k == 'src_coord':
-                v = pad_coords([torch.tensor(s[0][k]).float() for s in samples], pad_idx=0.0)
-            elif k == 'src_edge_type':
-                v = pad_2d([torch.tensor(s[0][k]).long() for s in samples], pad_idx=self.padding_idx)
-            elif k == 'src_distance':
-                v = pad_2d([torch.tensor(s[0][k]).float() for s in samples], pad_idx=0.0)
-            elif k == 'src_tokens':
-                v = pad_1d_tokens([torch.tensor(s[0][k]).long() for s in samples], pad_idx=self.padding_idx)
-            elif k == 'weights':
-                v = torch.tensor([s[0][k] for s in samples])
-            if k != 'smile':
-                batch[k] = v
-        if 'smile' in samples[0][0].keys():
-            batch_text = self.tokenizer([i[0]['smile'] for i in samples], padding=True, truncation=True, return_tensors="pt")
-            batch['input_ids'] = batch_text['input_ids']
-            batch['attention_mask'] = batch_text['attention_mask']
-        try:
-            label = torch.tensor([s[1] for s in samples])
-        except Exception:
-            label = None
-        return batch, label
+        """samples: list of (feature dict, label) as DataHub / TorchDataset yield them -> (batch dict, label tensor|None).
+        Layout rules: ``mmdti_hip.collate``.  A key without a layout rule re-uses the previous field's value, as the
+        reference's loop variable does (and raises if it comes first)."""
+        feats = [s[0] for s in samples]
+        batch, last = {}, None
+        for key in feats[0]:
+            if key == 'smile':
+                continue
+            v = collate_field(key, (f[key] for f in feats), self.padding_idx)
+            if v is None:
+                if last is None:
+                    raise UnboundLocalError(f"batch_collate_fn: no layout rule for the first feature key {key!r}")
+                v = last
+            batch[key] = last = v
+        if 'smile' in feats[0]:
+            batch['input_ids'], batch['attention_mask'] = tokenize(self.tokenizer, (f['smile'] for f in feats))
+        return batch, stack_labels(samples)

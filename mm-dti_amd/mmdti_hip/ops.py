@@ -302,7 +302,7 @@ def pair_permute_bwd(g, B, N, H, ld):
 #   standard  [B, H, N, ld]            row-major planes (ld = pair_ld(N))
 #   tiled     [B, H, nt, nt, 256]      nt = ceil(N/16): every 16x16 (query, key) tile stored in MFMA accumulator order, element
 #             (q, k) of a tile at ((k%16)//4 * 16 + q%16) * 4 + k%4 -- a wave's access to a tile is ONE contiguous KiB.
-# The tiled form is what the hot path uses (N <= 208); pair_tile / pair_untile convert at the boundary (tests, aux outputs).
+# The tiled form is what the hot path uses (N <= 272: the reference crops at 256 atoms, N <= 258); pair_tile / pair_untile convert at the boundary (tests, aux outputs).
 def pair_is_tiled(t):
     return t.dim() == 5
 
@@ -312,7 +312,7 @@ def pair_tiles(N):
 
 
 def pair_tiled_ok(N):
-    return N <= 208
+    return N <= 272
 
 
 def pair_empty(B, H, N, device, tiled, zero=False):

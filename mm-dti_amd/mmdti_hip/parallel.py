@@ -57,12 +57,27 @@ class GlobalNegatives:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.active = _collectives_active(self.world)
+        self._checked = False
+
+    def _check_equal_rows(self, x: torch.Tensor):
+        """all_gather_into_tensor / the adjoint's row slicing assume the same B_loc on every rank; a mismatch would hang
+        or slice the wrong rows inside RCCL.  Checked on the first call (every rank makes it at the same point) and on
+        every call with MMDTI_DDP_CHECK=1: one 2-element MIN/MAX message."""
+        n = torch.tensor([x.shape[0], -x.shape[0]], device=x.device, dtype=torch.int64)
+        dist.all_reduce(n, op=dist.ReduceOp.MAX, group=self.group)
+        hi, lo = int(n[0]), -int(n[1])
+        if hi != lo:
+            raise RuntimeError(f"GlobalNegatives: ranks hold different local batch sizes at this step ({lo}..{hi}); use a "
+                               "sampler that deals equal batches (data.LengthBucketBatchSampler(world>1), drop_last)")
 
     def gather(self, x: torch.Tensor) -> torch.Tensor:
         """[B_loc, C] -> [world*B_loc, C] in rank order (equal B_loc on every rank)."""
         if not self.active:
             return x
         x = x.contiguous()
+        if not self._checked or os.environ.get("MMDTI_DDP_CHECK") == "1":
+            self._check_equal_rows(x)
+            self._checked = True
         out = torch.empty(self.world * x.shape[0], x.shape[1], device=x.device, dtype=x.dtype)
         dist.all_gather_into_tensor(out, x, group=self.group)
         return out

@@ -57,13 +57,27 @@ class ParamArena:
             p.data = self.data[o:o + n].view(p.shape)
             p.grad = self.grad[o:o + n].view(p.shape)
             p._mmdti_arena = self
+        self._version: Dict[int, int] = {}
         self.refresh_shadow()
         self.adam_m: Optional[torch.Tensor] = None
         self.adam_v: Optional[torch.Tensor] = None
         self.step_count = 0
 
     def refresh_shadow(self):
+        """Re-cast the whole fp32 arena into the bf16 shadow the GEMMs read."""
         ops.lib().mmdti_cast_f32_bf16(ops._stream(), self.data.data_ptr(), self.shadow.data_ptr(), self.numel, 0.0, 0, 0)
+        for p in self.params:
+            self._version[id(p)] = p._version
+
+    def _fresh(self, p):
+        """The shadow is refreshed by the constructor and by adam_step (which writes both through raw pointers).  Any
+        OTHER in-place write to a parameter -- ``load_state_dict`` on a model already bound to the arena (the reference
+        trains, then loads the best checkpoint into the same model, tasks/trainer.py:406-410), ``p.copy_()`` -- bumps the
+        tensor's version counter: re-cast that parameter's slice before a GEMM reads it."""
+        if p._version != self._version[id(p)]:
+            o, n = self.offsets[id(p)], p.numel()
+            ops.lib().mmdti_cast_f32_bf16(ops._stream(), self.data[o:o + n].data_ptr(), self.shadow[o:o + n].data_ptr(), n, 0.0, 0, 0)
+            self._version[id(p)] = p._version
 
     def zero_grad(self):
         self.grad.zero_()
@@ -73,6 +87,7 @@ class ParamArena:
                 p.grad = self.grad[o:o + n].view(p.shape)
 
     def bf16(self, p: torch.nn.Parameter) -> torch.Tensor:
+        self._fresh(p)
         o, n = self.offsets[id(p)], p.numel()
         return self.shadow[o:o + n].view(p.shape)
 
@@ -87,6 +102,8 @@ class ParamArena:
             if self.offsets.get(id(p)) != o or p.shape[1:] != cols:
                 return None
             o += p.numel()
+        for p in plist:
+            self._fresh(p)
         shape = (sum(p.shape[0] for p in plist),) + tuple(cols)
         return self.shadow[o0:o].view(shape), self.data[o0:o].view(shape), self.grad[o0:o].view(shape)
 
@@ -174,15 +191,28 @@ dropout_state = DropoutState()
 
 
 # ---- gradient-ready notifications (consumed by parallel.ArenaReducer to overlap the all-reduce with backward) ----
-_grad_ready_hook = None
+_grad_ready_hooks: Dict[int, object] = {}
 
 
-def set_grad_ready_hook(fn):
-    global _grad_ready_hook
-    _grad_ready_hook = fn
+def add_grad_ready_hook(owner, fn):
+    """Register `fn(params)`; one hook per owner (a FineTuner).  Each reducer ignores parameters outside its own arena,
+    so several engines in one process do not disturb each other.  Held weakly: a dead owner's hook disappears."""
+    ref = weakref.WeakMethod(fn) if hasattr(fn, "__self__") else (lambda f=fn: f)
+    _grad_ready_hooks[id(owner)] = ref
+
+
+def remove_grad_ready_hook(owner):
+    _grad_ready_hooks.pop(id(owner), None)
 
 
 def notify_grads_ready(params):
     """Called by the backward of a module once every gradient of `params` has been enqueued on the stream."""
-    if _grad_ready_hook is not None:
-        _grad_ready_hook(params)
+    if not _grad_ready_hooks:
+        return
+    params = list(params)
+    for key, ref in list(_grad_ready_hooks.items()):
+        fn = ref()
+        if fn is None:
+            del _grad_ready_hooks[key]
+        else:
+            fn(params)

@@ -21,14 +21,14 @@ import torch
 
 from .functional import CELossFn, MSELossFn
 from .parallel import ArenaReducer, GlobalNegatives
-from .runtime import ParamArena, set_grad_ready_hook
+from .runtime import ParamArena, add_grad_ready_hook, remove_grad_ready_hook, dropout_state
 
 
 @dataclass
 class StepOutput:
-    loss: torch.Tensor
+    loss: torch.Tensor                      # this rank's step loss (alpha*task + beta*infonce_global + beta*ct)
     task_loss: torch.Tensor
-    infonce_loss: Optional[torch.Tensor]
+    infonce_loss: Optional[torch.Tensor]    # the GLOBAL InfoNCE value (under DDP: sum of the ranks' shares)
     ct_loss: Optional[torch.Tensor]
     logits: torch.Tensor
 
@@ -64,16 +64,23 @@ class FineTuner:
         self.arena = ParamArena(model.parameters(), adjacent=_qkv_groups(model))
         self.world = 1
         self.reducer = None
-        set_grad_ready_hook(None)
+        remove_grad_ready_hook(self)
         if distributed:
             self.negs = GlobalNegatives()
             self.world = self.negs.world
+            if self.negs.active:
+                # replicas must start identical: the cross-modal block, InfoNCE head and classification head are random-
+                # initialised, so rank 0's arena is broadcast (no reliance on every rank seeding alike) ...
+                torch.distributed.broadcast(self.arena.data, src=0)
+                self.arena.refresh_shadow()
+                # ... while dropout masks must DIFFER across ranks (each rank holds different molecules)
+                dropout_state.reseed(dropout_state.base + 0x9E37 * (self.negs.rank + 1))
             self.reducer = ArenaReducer(self.arena, bucket_bytes)
             self._b_loc = None
             # gradient buckets leave during backward (MMDTI_NO_REDUCE_OVERLAP=1: all of them after it); sub-batched
             # tower 1 accumulates into the same gradients several times per step, so it keeps the after-backward form
             if os.environ.get("MMDTI_NO_REDUCE_OVERLAP") != "1" and getattr(model, "split_tower1", 1) == 1:
-                set_grad_ready_hook(self.reducer.on_grads_ready)
+                add_grad_ready_hook(self, self.reducer.on_grads_ready)
         if task == "regression":
             self.task_loss = lambda lg, y: MSELossFn.apply(lg, y.float())
         elif task in ("classification", "multiclass"):
@@ -87,30 +94,51 @@ class FineTuner:
             self.model.infonce.set_global_negatives(self.negs.gather, self.negs.reduce_scatter, self.negs.row0(b_loc))
             self._b_loc = b_loc
 
-    def forward_backward(self, net_input: dict, net_target: torch.Tensor, epoch: int = 0, use_weight: bool = False) -> StepOutput:
-        """optimizer.zero_grad(); model(...); loss; loss.backward()  (+ gradient all-reduce under DDP)."""
+    def forward_backward(self, net_input: dict, net_target: torch.Tensor, epoch: int = 0, use_weight: bool = False,
+                         return_infonce_loss: bool = True, return_ct_loss: bool = True, loss_func=None) -> StepOutput:
+        """optimizer.zero_grad(); model(...); loss; loss.backward()  (+ gradient all-reduce under DDP).  The two flags
+        select the reference's four call forms (tasks/trainer.py:184-212); ``loss_func`` replaces the built-in task-loss
+        kernel with any callable on (logits, target)."""
         model = self.model
         self.arena.zero_grad()
         if self.reducer is not None:
             self._bind_global_negatives(net_target.shape[0])
             self.reducer.begin_step()
-        logits, infonce, ct = model(**net_input, return_infonce_loss=True, return_ct_loss=True, net_target=net_target, use_weight=use_weight,
-                                    epoch=epoch)
-        tl = self.task_loss(logits, net_target)
-        # under DDP `infonce` is this rank's share of the GLOBAL loss: x world so that the rank-mean of gradients is exact
-        loss = self.alpha * tl + self.beta * (infonce * self.world if self.world > 1 else infonce) + self.beta * ct
+        kw = dict(epoch=epoch)
+        if return_infonce_loss:
+            kw["return_infonce_loss"] = True
+        if return_ct_loss:
+            kw.update(return_ct_loss=True, use_weight=use_weight)
+        if return_ct_loss or return_infonce_loss:
+            kw["net_target"] = net_target
+        out = model(**net_input, **kw)
+        out = out if isinstance(out, tuple) else (out,)
+        logits = out[0]
+        infonce = out[1] if return_infonce_loss else None
+        ct = out[-1] if (return_ct_loss and len(out) > (2 if return_infonce_loss else 1)) else None
+        tl = (loss_func or self.task_loss)(logits, net_target)
+        loss = self.alpha * tl
+        if infonce is not None:
+            # under DDP `infonce` is this rank's share of the GLOBAL loss: x world so that the rank-mean of gradients is exact
+            loss = loss + self.beta * (infonce * self.world if self.world > 1 else infonce)
+        if ct is not None:
+            loss = loss + self.beta * ct
         loss.backward()
+        infonce_global = None if infonce is None else infonce.detach()
         if self.reducer is not None:
+            if infonce is not None and self.negs.active and self.world > 1:
+                infonce_global = infonce_global.clone()
+                torch.distributed.all_reduce(infonce_global, op=torch.distributed.ReduceOp.SUM)      # 4 bytes, for logging
             self.reducer.finish()
-        return StepOutput(loss.detach(), tl.detach(), infonce.detach(), ct.detach(), logits.detach())
+        return StepOutput(loss.detach(), tl.detach(), infonce_global, None if ct is None else ct.detach(), logits.detach())
 
     def optimizer_step(self):
         lr = linear_warmup_lr(self.lr, self.sched_step, self.warmup, self.total_steps)
         self.arena.adam_step(lr, eps=self.eps, max_norm=self.max_norm)
         self.sched_step += 1
 
-    def step(self, net_input: dict, net_target: torch.Tensor, epoch: int = 0, use_weight: bool = False) -> StepOutput:
-        out = self.forward_backward(net_input, net_target, epoch, use_weight)
+    def step(self, net_input: dict, net_target: torch.Tensor, epoch: int = 0, use_weight: bool = False, **kw) -> StepOutput:
+        out = self.forward_backward(net_input, net_target, epoch, use_weight, **kw)
         self.optimizer_step()
         return out
 

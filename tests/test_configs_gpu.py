@@ -1,0 +1,197 @@
+"""GPU tests of the BASELINE.json configurations and shape limits that round 1 left uncovered (VERDICT r01 "missing" 4-5,
+"next" 2): N up to the reference's crop (258), C3 (regression + ConR + FDS) at the reference architecture, the benchmark's
+exact all-max-length workload at full size, and C1's workload (ESOL-like: 1 128 molecules, batch 16, one epoch) through
+the Trainer drop-in and ``batch_collate_fn``."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import mmdti_oracle as O
+from g9util import tiny_cfg, refarch_cfg, product_model, load_fixture_weights, rel_l2, cosine, tokenizer_from
+
+ZERO_GRADS = ("pooler", "key.bias", "gbf_proj.linear2.bias")
+
+
+def _grad_report(model, P):
+    worst, cos_min = ("", 0.0), 1.0
+    for n, p in model.named_parameters():
+        ref = P[n].grad if n in P else None
+        if p.grad is None or ref is None or any(z in n for z in ZERO_GRADS) or float(ref.abs().max()) == 0.0:
+            continue
+        worst = max(worst, (n, rel_l2(p.grad, ref)), key=lambda t: t[1])
+        cos_min = min(cos_min, cosine(p.grad, ref))
+    return worst, cos_min
+
+
+# ------------------------------------------------------------------------------------------------ N up to 258
+@pytest.mark.parametrize("N", [209, 240, 258])
+def test_unimol_tower_at_reference_crop_sizes(N):
+    """Tower 1 (embedding -> fused pair bias -> 2-layer pair encoder, H = 64 so the fused/tiled hot path is the one running)
+    at the atom counts the reference's crop allows (N = atoms + 2 <= 258) against the oracle with the same rounding points."""
+    ocfg = tiny_cfg("classification", 40)
+    ocfg.unimol = O.UniMolCfg(layers=2, dim=512, ffn=256, heads=64, K=128, vocab=31, emb_dropout=0.0, dropout=0.0, attn_dropout=0.0, pooler_dropout=0.0)
+    ocfg.cross, ocfg.roberta = O.CrossCfg(dim=512, heads=16, ffn=128, hidden_dropout=0.0, attn_dropout=0.0), O.RobertaCfg(layers=1, dim=512, heads=8, ffn=128, vocab=40, max_pos=40, hidden_dropout=0.0, attn_dropout=0.0)
+    P = {k: v.requires_grad_() for k, v in O.init_params(ocfg, seed=11, std=0.05).items()}
+    model = product_model(ocfg).cuda().eval()
+    load_fixture_weights(model, P)
+    batch, _ = O.synth_batch(2, N - 2, 12, ocfg, seed=N, ragged=False)
+    batch["src_tokens"][1, N - 40:] = 0                                   # second molecule shorter: real key padding at this size
+    batch["src_edge_type"][1, N - 40:, :] = 0; batch["src_edge_type"][1, :, N - 40:] = 0
+    batch["src_distance"][1, N - 40:, :] = 0; batch["src_distance"][1, :, N - 40:] = 0
+    from mmdti_hip import ops
+    from mmdti_hip.functional import EmbeddingFn
+    assert ops.pair_tiled_ok(N)
+    dev = {k: v.cuda() for k, v in batch.items()}
+    pad = dev["src_tokens"].eq(0)
+    x = EmbeddingFn.apply(model.embed_tokens.weight, dev["src_tokens"], 0)
+    bias = model.pair_bias(dev["src_distance"], dev["src_edge_type"])
+    assert ops.pair_is_tiled(bias)
+    enc, s_last, _ = model.encoder.encode(x, bias, pad)
+    g = torch.randn(enc.shape, generator=torch.Generator().manual_seed(1))
+    (enc * g.cuda()).sum().backward()
+    xo = torch.nn.functional.embedding(batch["src_tokens"], P["embed_tokens.weight"], padding_idx=0)
+    bo = O.pair_bias(batch["src_distance"], batch["src_edge_type"], P, bf16=True)
+    eo, so = O.unimol_encoder(xo, bo, batch["src_tokens"].eq(0), P, ocfg.unimol, bf16=True, with_aux=False)
+    (eo * g).sum().backward()
+    assert rel_l2(enc, eo) < 3e-3, rel_l2(enc, eo)
+    s_hip = ops.pair_untile(s_last, N).cpu()
+    so = so.view(2, 64, N, N)
+    fin = torch.isfinite(so)
+    assert torch.equal(torch.isfinite(s_hip), fin) and rel_l2(s_hip[fin], so[fin]) < 3e-3
+    worst, cos_min = _grad_report(model, P)
+    assert worst[1] < 6e-2 and cos_min > 0.995, (worst, cos_min)
+
+
+# ------------------------------------------------------------------------------------------------ C3 at the reference architecture
+def test_c3_regression_conr_fds_at_reference_architecture():
+    """BASELINE config 3 (docking-score-like regression + ConR + FDS, bf16, 1 GPU) at 15L/512/64h through FineTuner: an FDS
+    statistics pass, then a training step at epoch 1 with smoothing live, against the oracle (same rounding points for the
+    logic; pure fp32 for the north star's 1e-3 on the losses)."""
+    from mmdti_hip.trainer import FineTuner
+    ocfg = refarch_cfg("regression", 600)
+    P = {k: v.requires_grad_() for k, v in O.init_params(ocfg, seed=31, std=0.02).items()}
+    raw = np.random.default_rng(5).normal(0, 1, 400)
+    model = product_model(ocfg, fds=True, fds_num=30, _fds_raw_values=raw, use_scaler=False).cuda().train()
+    load_fixture_weights(model, P)
+    batch, label = O.synth_batch(6, 40, 48, ocfg, seed=33, ragged=True)
+    dev = {k: v.cuda() for k, v in batch.items()}
+    y = label.cuda()
+    tuner = FineTuner(model, "regression", total_steps=10)
+    tuner.fds_epoch_pass([(dev, y)], 0)                                   # tasks/trainer.py:288-306 at the end of epoch 0
+    model.FDS.update_last_epoch_stats(1)
+    fo = O.FDSOracle(512, float(model.FDS.min_value), float(model.FDS.bin_width), bucket_num=30, start_smooth=1, kernel="gaussian", ks=5, sigma=1)
+    with torch.no_grad():
+        f0 = O.mm_forward(batch, P, ocfg, net_target=label, training=True, bf16=True)["pooled"]
+    fo.update_last_epoch_stats(0); fo.update_running_stats(f0, label, 0); fo.update_last_epoch_stats(1)
+    assert torch.equal(model.FDS.num_samples_tracked.cpu(), fo.num_samples_tracked)
+    assert rel_l2(model.FDS.running_mean, fo.running_mean) < 5e-3
+    out = tuner.forward_backward(dev, y, epoch=1)
+    ref = O.mm_forward(batch, P, ocfg, net_target=label, fds=fo, epoch=1, training=True, bf16=True)
+    ref_loss, ref_tl = O.step_loss(ref, label, "regression")
+    with torch.no_grad():
+        ref32 = O.mm_forward(batch, {k: v.detach() for k, v in P.items()}, ocfg, net_target=label, fds=fo, epoch=1, training=True, bf16=False)
+        loss32, tl32 = O.step_loss(ref32, label, "regression")
+    assert abs(float(out.loss) - float(ref_loss)) <= 1e-3 * abs(float(ref_loss)), (float(out.loss), float(ref_loss))
+    assert abs(float(out.infonce_loss) - float(ref32["infonce"])) <= 1e-3 * abs(float(ref32["infonce"]))
+    assert abs(float(out.task_loss) - float(tl32)) <= 3e-3 * abs(float(tl32)) + 1e-5
+    assert abs(float(out.loss) - float(loss32)) <= 2e-3 * abs(float(loss32))
+    ref_loss.backward()
+    worst, cos_min = _grad_report(model, P)
+    assert worst[1] < 0.12 and cos_min > 0.99, (worst, cos_min)
+
+
+# ------------------------------------------------------------------------------------------------ the bench's exact workload
+def test_full_size_all_max_length_step_properties():
+    """bench.py's workload -- 256 molecules, every one at 128 atoms / 256 tokens, so the FULL tile variants
+    (pair_attn_*<9, true, true, ...>) and unpadded fused attention run at full size.  Size-independent properties:
+    bit-reproducible eval logits, permutation equivariance over the batch, finite train step whose gradient norm repeats."""
+    import bench
+    from mmdti_hip.runtime import dropout_state
+    from mmdti_hip.functional import CELossFn
+    model, _ = bench.build_model()
+    model = model.cuda().eval()
+    _, batch, label = bench.synth(256, 128, 256, seed=79, ragged=False)
+    assert not batch["src_tokens"].eq(0).any() and not batch["input_ids"].eq(1).any()
+    dev = {k: v.cuda() for k, v in batch.items()}
+    y = label.cuda()
+    with torch.no_grad():
+        lg1, inf1, ct1 = model(**dev, return_infonce_loss=True, return_ct_loss=True, net_target=y)
+        lg2, _, _ = model(**dev, return_infonce_loss=True, return_ct_loss=True, net_target=y)
+        assert torch.equal(lg1, lg2)
+        perm = torch.randperm(256, generator=torch.Generator().manual_seed(4)).cuda()
+        lgp, infp, ctp = model(**{k: v[perm] for k, v in dev.items()}, return_infonce_loss=True, return_ct_loss=True, net_target=y[perm])
+    torch.testing.assert_close(lgp, lg1[perm], rtol=1e-4, atol=1e-4)
+    assert abs(float(infp) - float(inf1)) <= 1e-4 * abs(float(inf1)) and abs(float(ctp) - float(ct1)) <= 1e-4 * abs(float(ct1))
+    model.train()
+    norms = []
+    for _ in range(2):
+        dropout_state.reseed(4321)
+        for p in model.parameters():
+            p.grad = None
+        lg, inf, ct = model(**dev, return_infonce_loss=True, return_ct_loss=True, net_target=y)
+        loss = CELossFn.apply(lg, y) + 0.1 * inf + 0.1 * ct
+        loss.backward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss)
+        norms.append(sum(float(p.grad.double().pow(2).sum()) for p in model.parameters() if p.grad is not None) ** 0.5)
+    assert norms[0] > 0 and abs(norms[0] - norms[1]) <= 1e-3 * norms[0], norms
+
+
+# ------------------------------------------------------------------------------------------------ C1's workload
+def test_c1_esol_like_epoch_through_trainer(tmp_path):
+    """BASELINE config 1's WORKLOAD on the GPU path (the config itself is the reference's CPU plumbing run, which cannot
+    start here: RDKit / Uni-Core / addict are absent): 1 128 synthetic molecules (ESOL's size), batch 16, regression, one
+    epoch through ``mmdti_hip.tasks.Trainer`` + ``MM_Model.batch_collate_fn`` with a local tokenizer, at the reference
+    architecture.  The first step is checked against the oracle; the epoch must reduce the training loss."""
+    from mmdti_hip.tasks import Trainer
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "g9_collate.npz"), allow_pickle=False))
+    tok_json = str(g["tok_json"])
+    tok = tokenizer_from(tok_json, 254)
+    ocfg = refarch_cfg("regression", len(tok))
+    P = O.init_params(ocfg, seed=41, std=0.02)
+    model = product_model(ocfg, tok, dropout=False)
+    load_fixture_weights(model, P)
+    rng = np.random.default_rng(42)
+    alphabet = [c for c in __import__("json").loads(tok_json)["model"]["vocab"] if len(c) == 1]
+    samples = []
+    for _ in range(1128 + 64):
+        na = int(np.clip(round(rng.normal(26, 9)), 4, 60))                # ESOL molecules are small (with H: ~26 atoms on average)
+        atoms = rng.choice(np.arange(4, 30), size=na)
+        d = O.coords2unimol(atoms, rng.normal(0, 3.0, size=(na, 3)), 31)
+        d["smile"] = "".join(rng.choice(alphabet, size=int(np.clip(round(0.6 * na), 3, 60))))
+        # a learnable target: a function of the composition
+        samples.append((d, np.array([0.05 * float((atoms == 4).sum()) - 0.08 * float((atoms == 6).sum()) + 0.1 * rng.normal()], dtype=np.float32)))
+    train, valid = samples[:1128], samples[1128:]
+    first = {}
+    real = model.batch_collate_fn
+
+    def collate(s):
+        out = real(s)
+        if "batch" not in first and model.training and torch.is_grad_enabled():
+            first["batch"] = out
+        return out
+
+    model.batch_collate_fn = collate
+    trainer = Trainer(save_path=str(tmp_path), task="regression", metrics="mse", learning_rate=1e-4, batch_size=16, epochs=1, warmup_ratio=0.03,
+                      patience=20, max_norm=5.0, use_cuda=True, use_amp=True, alpha=1, beta=0.1, seed=42)
+    y_pred = trainer.fit_predict(model, train, valid, torch.nn.MSELoss(), lambda x: x, str(tmp_path), 0, None, return_infonce_loss=True,
+                                 return_ct_loss=True, use_weight=False)
+    steps = trainer.history[0]["steps"]
+    assert steps.shape == (1128 // 16, 4) and np.isfinite(steps).all() and y_pred.shape == (64, 1)
+    b, y = first["batch"]
+    assert b["src_tokens"].shape[0] == 16 and b["src_edge_type"].dtype == torch.int64 and "src_coord" in b
+    ref = O.mm_forward(b, P, ocfg, net_target=y.float(), training=True, bf16=False)
+    ref_loss, ref_tl = O.step_loss(ref, y.float(), "regression")
+    assert abs(steps[0, 0] - float(ref_loss)) <= 2e-3 * abs(float(ref_loss)), (steps[0], float(ref_loss))
+    assert abs(steps[0, 2] - float(ref["infonce"])) <= 1e-3 * abs(float(ref["infonce"]))
+    assert steps[-10:, 0].mean() < steps[:10, 0].mean(), (steps[:10, 0].mean(), steps[-10:, 0].mean())
+    assert os.path.exists(os.path.join(str(tmp_path), "model_0.pth"))

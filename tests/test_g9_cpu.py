@@ -17,8 +17,7 @@ from oracle import mmdti_oracle as O
 from oracle import trainer_oracle as TO
 
 
-def T(a):
-    return torch.from_numpy(np.asarray(a))
+from g9util import T, samples_from, zero_dropout_cfg, tiny_cfg, refarch_cfg, tokenizer_from, product_model
 
 
 def close(a, b, rtol=2e-5, atol=2e-6, msg=""):
@@ -30,34 +29,6 @@ def close(a, b, rtol=2e-5, atol=2e-6, msg=""):
 def rel_l2(a, b):
     a, b = a.detach().double().flatten(), T(b).double().flatten() if not isinstance(b, torch.Tensor) else b.detach().double().flatten()
     return float((a - b).norm() / (b.norm() + 1e-30))
-
-
-def samples_from(g, prefix=""):
-    n = int(g[prefix + "n_samples"])
-    smiles = [str(s) for s in g[prefix + "smiles"]]
-    out = []
-    for i in range(n):
-        d = {k: g[f"{prefix}s{i}_{k}"] for k in ("src_tokens", "src_distance", "src_coord", "src_edge_type")}
-        d["smile"] = smiles[i]
-        if f"{prefix}s{i}_weights" in g:
-            d["weights"] = float(g[f"{prefix}s{i}_weights"])
-        out.append((d, g[f"{prefix}s{i}_label"]))
-    return out
-
-
-def zero_dropout_cfg(u: dict, r: dict, c: dict, task, out_dim):
-    return O.ModelCfg(unimol=O.UniMolCfg(emb_dropout=0.0, dropout=0.0, attn_dropout=0.0, pooler_dropout=0.0, **u),
-                      roberta=O.RobertaCfg(hidden_dropout=0.0, attn_dropout=0.0, **r),
-                      cross=O.CrossCfg(hidden_dropout=0.0, attn_dropout=0.0, **c), task=task, output_dim=out_dim, infonce_dropout=0.0)
-
-
-TINY_U = dict(layers=2, dim=64, ffn=128, heads=8, K=128, vocab=31)
-TINY_C = dict(dim=64, heads=4, ffn=128)
-
-
-def tiny_cfg(task, vocab_rob):
-    return zero_dropout_cfg(TINY_U, dict(layers=2, dim=64, heads=4, ffn=128, vocab=vocab_rob, max_pos=40), TINY_C, task,
-                            1 if task == "regression" else 2)
 
 
 # ------------------------------------------------------------------------------------------------ G9a: encoder wiring
@@ -154,11 +125,9 @@ def test_g9_model_refarch_oracle(golden, tag):
     seed stored in the fixture."""
     g = golden("g9_model_refarch_" + tag)
     task = str(g["task"])
-    cfg = zero_dropout_cfg(dict(layers=15, dim=512, ffn=2048, heads=64, K=128, vocab=31),
-                           dict(layers=6, dim=512, heads=8, ffn=2048, vocab=int(g["vocab_rob"]), max_pos=514),
-                           dict(dim=512, heads=16, ffn=2048), task, 1 if task == "regression" else 2)
+    cfg = refarch_cfg(task, int(g["vocab_rob"]))
     P = {k: v.requires_grad_() for k, v in O.init_params(cfg, seed=int(g["seed"]), std=float(g["std"])).items()}
-    assert float(P["encoder.layers.7.fc1.weight"][5, 7]) == float(g["w_check"][0])      # same generator stream as the fixture
+    assert float(P["encoder.layers.7.fc1.weight"].detach()[5, 7]) == float(g["w_check"][0])      # same generator stream as the fixture
     batch = {k[2:]: T(v) for k, v in g.items() if k.startswith("b_") and k != "b_label"}
     label = T(g["b_label"])
     tgt = label.float() if task == "regression" else label.long()
@@ -177,32 +146,13 @@ def test_g9_model_refarch_oracle(golden, tag):
 
 
 # ------------------------------------------------------------------------------------------------ G9c: collate (a0)
-def _tokenizer(tok_json, max_len):
-    from tokenizers import Tokenizer
-    from transformers import PreTrainedTokenizerFast
-    return PreTrainedTokenizerFast(tokenizer_object=Tokenizer.from_str(tok_json), bos_token="<s>", eos_token="</s>",
-                                   pad_token="<pad>", unk_token="<unk>", model_max_length=max_len)
-
-
-def _product_model(tokenizer, task="classification"):
-    from types import SimpleNamespace
-    from mmdti_hip.models import mm_model as mm
-    mol = mm.molecule_architecture()
-    mol.encoder_layers, mol.encoder_embed_dim, mol.encoder_ffn_embed_dim, mol.encoder_attention_heads = 2, 64, 128, 8
-    cross = mm.crossmodal_config()
-    cross.hidden_size, cross.num_attention_heads, cross.intermediate_size = 64, 4, 128
-    rcfg = SimpleNamespace(layers=2, dim=64, heads=4, ffn=128, vocab=len(tokenizer), max_pos=40, type_vocab=1, pad_idx=1, ln_eps=1e-12,
-                           hidden_dropout=0.0, attn_dropout=0.0)
-    return mm.MM_Model.from_configs(2, task, mol_args=mol, roberta_cfg=rcfg, cross_cfg=cross, _tokenizer=tokenizer)
-
-
 def test_g9_collate_oracle_and_product(golden):
     """batch_collate_fn (mm_model.py:645-682): the oracle's restatement AND the product's host-side collate against the
     reference's own output -- bit-exact for every tensor, same key order, truncation and the label=None fallback."""
     g = golden("g9_collate")
-    tok = _tokenizer(str(g["tok_json"]), int(g["max_len"]))
+    tok = tokenizer_from(str(g["tok_json"]), int(g["max_len"]))
     samples = samples_from(g)
-    model = _product_model(tok)
+    model = product_model(tiny_cfg("classification", len(tok)), tok)
     for name, fn in (("oracle", lambda s: TO.collate(s, 0, tok)), ("product", model.batch_collate_fn)):
         b, y = fn(samples)
         assert list(b.keys()) == [str(k) for k in g["key_order"]], name
@@ -226,7 +176,7 @@ def test_g10_trainer_oracle(golden, tag):
     P = {k[3:]: T(v) for k, v in g.items() if k.startswith("w0_") and T(v).is_floating_point()}
     vocab_rob = P["bert.embeddings.word_embeddings.weight"].shape[0]
     cfg = tiny_cfg(task, vocab_rob)
-    tok = _tokenizer(str(g["tok_json"]), 38)
+    tok = tokenizer_from(str(g["tok_json"]), 38)
     train, valid = samples_from(g, "train_"), samples_from(g, "valid_")
     fds = None
     if task == "regression":

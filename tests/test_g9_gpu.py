@@ -1,0 +1,312 @@
+"""GPU parity of the HIP path against the reference's OWN execution (fixtures G9/G10; tests/golden/make_golden_g9.py).
+
+The fixtures hold fp32 outputs of the reference's ``models/transformers.py``, ``models/mm_model.py`` and
+``tasks/trainer.py`` on CPU (Uni-Core's layer inside them is the oracle's restatement: wiring is pinned, Uni-Core numerics
+are not).  The HIP path computes with bf16 GEMM operands, so tolerances here are the cost of bf16 and are written next to
+each assert: losses 1e-3 relative (north star), embeddings / logits by relative L2, gradients by relative L2 + cosine.
+Integer / mask / layout facts (in-place -inf fill, tuple arities, batch orders, collate) are exact.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mmdti_oracle as O
+from g9util import (T, samples_from, tiny_cfg, refarch_cfg, tokenizer_from, product_model, load_fixture_weights, rel_l2, cosine)
+
+ZERO_GRADS = ("pooler", "key.bias", "gbf_proj.linear2.bias")     # analytically zero (softmax shift invariance): rounding noise on both sides
+REPORT = {}
+
+
+def _report(name, **vals):
+    REPORT[name] = {k: (float(v) if not isinstance(v, (str, list, dict)) else v) for k, v in vals.items()}
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_report.json"), "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+# ------------------------------------------------------------------------------------------------ encoder (a5)
+@pytest.mark.parametrize("tag", ["pad_nohead", "nopad_head", "pad_head"])
+def test_g9_encoder_hip(golden, tag):
+    """TransformerEncoderWithPair.forward through the reference's signature vs the reference file's own output."""
+    from mmdti_hip.models.transformers import TransformerEncoderWithPair
+    g = golden("g9_encoder_" + tag)
+    H = int(g["heads"])
+    B, N, D = g["emb"].shape
+    has_head_ln = "w_final_head_layer_norm.weight" in g
+    enc = TransformerEncoderWithPair(encoder_layers=2, embed_dim=D, ffn_embed_dim=128, attention_heads=H,
+                                     no_final_head_layer_norm=not has_head_ln).cuda().eval()
+    enc.load_state_dict({k[2:]: T(v) for k, v in g.items() if k.startswith("w_")}, strict=True)
+    emb = T(g["emb"]).cuda().requires_grad_()
+    leaf = T(g["bias0"]).cuda().requires_grad_()
+    attn_mask = leaf * 1.0
+    pm = T(g["padding_mask"]).cuda() if bool(g["has_padding"]) else None
+    x, attn, delta, x_norm, delta_norm = enc(emb, attn_mask=attn_mask, padding_mask=pm)
+    # exact facts: the caller's tensor after the in-place key-padding merge; where the logits are -inf
+    assert torch.equal(attn_mask.detach().cpu(), T(g["attn_mask_after"]))
+    fin = torch.isfinite(T(g["attn"]))
+    assert torch.equal(torch.isfinite(attn.cpu()), fin)
+    r = dict(x=rel_l2(x, g["x"]), attn=rel_l2(attn.cpu()[fin], T(g["attn"])[fin]), delta=rel_l2(delta, g["delta"]))
+    _report("g9_encoder_" + tag, **r)
+    assert r["x"] < 1e-2 and r["attn"] < 1e-2 and r["delta"] < 2e-2, r           # bf16 operands, 2 layers, weights N(0, 0.08)
+    assert abs(float(x_norm) - float(g["x_norm"])) < 2e-3 * max(1.0, abs(float(g["x_norm"])))
+    assert abs(float(delta_norm) - float(g["delta_norm"])) < 2e-3 * max(1.0, abs(float(g["delta_norm"])))
+    (x * T(g["gx"]).cuda()).sum().backward()
+    assert rel_l2(emb.grad, g["d_emb"]) < 4e-2 and cosine(emb.grad, g["d_emb"]) > 0.999
+    keep = ~T(g["padding_mask"]).view(B, 1, 1, N).expand(B, H, N, N) if pm is not None else torch.ones(B, H, N, N, dtype=torch.bool)
+    gb, rb = leaf.grad.cpu().view(B, H, N, N), T(g["d_bias"]).view(B, H, N, N)
+    assert rel_l2(gb[keep], rb[keep]) < 4e-2
+    worst = 0.0
+    for n, p in enc.named_parameters():
+        if bool(g["hasgrad_" + n]):
+            assert p.grad is not None, n
+            worst = max(worst, rel_l2(p.grad, g["g_" + n]))
+        else:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+    assert worst < 5e-2, worst
+
+
+# ------------------------------------------------------------------------------------------------ MM_Model wiring (a1-a19)
+def _capture_towers(model):
+    """encoder_rep / out_bert of the next forward (mm_model.py:559,562)."""
+    store = {}
+    real = model.encoder.encode
+
+    def encode(*a, **k):
+        out = real(*a, **k)
+        store["enc"] = out[0].detach()
+        return out
+
+    model.encoder.encode = encode
+    model.bert.register_forward_hook(lambda m, i, o: store.__setitem__("bert", o[0].detach()))
+    return store
+
+
+def _task_loss(task, logits, tgt):
+    from mmdti_hip.functional import CELossFn, MSELossFn
+    return MSELossFn.apply(logits, tgt) if task == "regression" else CELossFn.apply(logits, tgt)
+
+
+@pytest.mark.parametrize("tag", ["cls", "reg_fds"])
+def test_g9_model_tiny_hip(golden, tag):
+    g = golden("g9_model_tiny_" + tag)
+    task = str(g["task"])
+    sd = {k[2:]: T(v) for k, v in g.items() if k.startswith("w_")}
+    ocfg = tiny_cfg(task, sd["bert.embeddings.word_embeddings.weight"].shape[0])
+    kw = dict(fds=True, fds_num=10, _fds_raw_values=g["fds_raw"], use_scaler=False) if task == "regression" else {}
+    model = product_model(ocfg, **kw).cuda()
+    load_fixture_weights(model, sd)
+    store = _capture_towers(model)
+    batch = {k[2:]: T(v).cuda() for k, v in g.items() if k.startswith("b_") and k != "b_label"}
+    label = T(g["b_label"]).cuda()
+    tgt = label.float() if task == "regression" else label.long()
+    model.train()                                          # every dropout probability is 0: value parity in train mode
+    epoch = 0
+    if task == "regression":
+        assert abs(float(model.FDS.min_value) - float(g["fds_min_value"])) < 1e-12 and abs(float(model.FDS.bin_width) - float(g["fds_bin_width"])) < 1e-12
+        samples = samples_from(g)
+        batches = [model.batch_collate_fn(samples[i:i + 6]) for i in (0, 6)]
+        for ep in (0, 1):                                  # tasks/trainer.py:288-306, twice
+            feats, labs = [], []
+            with torch.no_grad():
+                for b, y in batches:
+                    _, f = model(**{k: v.cuda() for k, v in b.items()}, epoch=ep, return_feature=True, net_target=y.cuda().float())
+                    feats.append(f); labs.append(y.cuda().float())
+            assert rel_l2(torch.cat(feats), g[f"fds_feats_ep{ep}"]) < 1e-2
+            model.FDS.update_last_epoch_stats(ep)
+            model.FDS.update_running_stats(torch.cat(feats), torch.cat(labs), ep)
+            for k, v in model.FDS.state_dict().items():
+                ref = T(g[f"fds_ep{ep}_{k}"])
+                if k in ("epoch", "num_samples_tracked"):
+                    assert torch.equal(v.cpu(), ref), (k, ep)                    # bucket membership is integer work: exact
+                else:
+                    assert rel_l2(v, ref) < 3e-2, (k, ep, rel_l2(v, ref))        # statistics of bf16-computed features
+        model.FDS.update_last_epoch_stats(2)
+        # from here on use the reference's buffers so that the step below isolates the forward wiring
+        model.FDS.load_state_dict({k[len("fds_ep2_"):]: T(v) for k, v in g.items() if k.startswith("fds_ep2_")}, strict=False)
+        epoch = 2
+    logits, infonce, ct = model(**batch, return_infonce_loss=True, return_ct_loss=True, net_target=tgt, use_weight=False, epoch=epoch)
+    r = dict(enc=rel_l2(store["enc"], g["o_enc"]), bert=rel_l2(store["bert"], g["o_bert"]), logits=rel_l2(logits, g["o_logits"]),
+             infonce=abs(float(infonce) - float(g["o_infonce"])) / abs(float(g["o_infonce"])),
+             ct=abs(float(ct) - float(g["o_ct"])) / max(abs(float(g["o_ct"])), 1e-6))
+    tl = _task_loss(task, logits, tgt)
+    loss = 1.0 * tl + 0.1 * infonce + 0.1 * ct
+    r["loss"] = abs(float(loss) - float(g["o_loss"])) / abs(float(g["o_loss"]))
+    _report("g9_model_tiny_" + tag, **r)
+    assert r["enc"] < 1e-2 and r["bert"] < 1e-2 and r["logits"] < 2e-2, r
+    assert r["infonce"] < 1e-3 and r["loss"] < 1e-3, r                              # north star: losses within 1e-3 relative
+    assert r["ct"] < 5e-3 or abs(float(ct) - float(g["o_ct"])) < 2e-4, r            # B=6 ConR/SupCon over exp(x/0.07): amplifies feature rounding
+    loss.backward()
+    worst, cos_min = ("", 0.0), 1.0
+    for n, p in model.named_parameters():
+        key = "hasgrad_" + n
+        if key not in g:
+            continue
+        if not bool(g[key]):
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        assert p.grad is not None, n
+        ref = T(g["g_" + n])
+        if any(z in n for z in ZERO_GRADS) or float(ref.abs().max()) < 1e-7:
+            continue
+        rr = rel_l2(p.grad, ref)
+        worst = max(worst, (n, rr), key=lambda t: t[1])
+        cos_min = min(cos_min, cosine(p.grad, ref))
+    assert worst[1] < 8e-2 and cos_min > 0.99, (worst, cos_min)
+    # return protocol (mm_model.py:585-618): arity exact, values to bf16 tolerance
+    nt = dict(net_target=tgt) if task == "regression" else {}
+    with torch.no_grad():
+        r1 = model(**batch, epoch=epoch, **nt)
+        r2 = model(**batch, return_infonce_loss=True, epoch=epoch, **nt)
+        r3 = model(**batch, return_ct_loss=True, net_target=tgt, epoch=epoch)
+        r4 = model(**batch, return_feature=True, net_target=tgt, epoch=epoch)
+        r5 = model(**batch, return_feature=True, return_infonce_loss=True, return_ct_loss=True, net_target=tgt, epoch=epoch)
+        model.eval()
+        r6 = model(**batch, return_ct_loss=True, epoch=epoch)
+        r7 = model(**batch, epoch=epoch)
+    assert [1 if torch.is_tensor(r1) else len(r1), len(r2), len(r3), len(r4), len(r5)] == list(g["arity"]) and torch.is_tensor(r6)
+    assert rel_l2(r1, g["r1_logits"]) < 2e-2 and rel_l2(r7, g["r7_eval_logits"]) < 2e-2
+    assert rel_l2(r5[1], g["r5_feats"]) < 1e-2 and rel_l2(r4[1], g["r4_feats"]) < 1e-2   # smoothed features are what is returned (aliasing)
+    assert abs(float(r2[1]) - float(g["r2_infonce"])) < 1e-3 * abs(float(g["r2_infonce"]))
+    assert abs(float(r5[3]) - float(g["r5_ct"])) < 5e-3 * abs(float(g["r5_ct"])) + 2e-4
+
+
+@pytest.mark.parametrize("tag", ["cls", "reg"])
+def test_g9_model_refarch_hip(golden, tag):
+    """The reference architecture -- 15 x 512 / 64 heads / 128 Gaussians, 6-layer RoBERTa, 16-head fusion -- against the
+    reference's own fp32 run of models/mm_model.py: embeddings, logits, losses and gradients at full depth."""
+    g = golden("g9_model_refarch_" + tag)
+    task = str(g["task"])
+    ocfg = refarch_cfg(task, int(g["vocab_rob"]))
+    P = O.init_params(ocfg, seed=int(g["seed"]), std=float(g["std"]))
+    assert float(P["encoder.layers.7.fc1.weight"][5, 7]) == float(g["w_check"][0])
+    model = product_model(ocfg).cuda()
+    load_fixture_weights(model, P)
+    store = _capture_towers(model)
+    model.train()
+    batch = {k[2:]: T(v).cuda() for k, v in g.items() if k.startswith("b_") and k != "b_label"}
+    label = T(g["b_label"]).cuda()
+    tgt = label.float() if task == "regression" else label.long()
+    logits, infonce, ct = model(**batch, return_infonce_loss=True, return_ct_loss=True, net_target=tgt, use_weight=False, epoch=0)
+    tl = _task_loss(task, logits, tgt)
+    loss = 1.0 * tl + 0.1 * infonce + 0.1 * ct
+    r = dict(enc=rel_l2(store["enc"], g["o_enc"]), bert=rel_l2(store["bert"], g["o_bert"]), logits=rel_l2(logits, g["o_logits"]),
+             infonce=abs(float(infonce) - float(g["o_infonce"])) / abs(float(g["o_infonce"])),
+             ct=abs(float(ct) - float(g["o_ct"])) / max(abs(float(g["o_ct"])), 1e-6),
+             task_loss=abs(float(tl) - float(g["o_task_loss"])) / abs(float(g["o_task_loss"])),
+             loss=abs(float(loss) - float(g["o_loss"])) / abs(float(g["o_loss"])))
+    loss.backward()
+    names = [str(n) for n in g["gn_names"]]
+    grads = dict(model.named_parameters())
+    gn_err = {}
+    for n, ref in zip(names, g["gn"]):
+        if any(z in n for z in ZERO_GRADS) or float(ref) < 1e-9:
+            continue
+        assert grads[n].grad is not None, n
+        gn_err[n] = abs(float(grads[n].grad.norm()) - float(ref)) / float(ref)
+    worst_gn = max(gn_err.items(), key=lambda t: t[1])
+    full = {k[2:]: (rel_l2(grads[k[2:]].grad, g[k]), cosine(grads[k[2:]].grad, g[k])) for k in g if k.startswith("g_")}
+    worst_full = max(full.items(), key=lambda t: t[1][0])
+    r.update(worst_grad_norm_err=worst_gn[1], worst_grad_rel_l2=worst_full[1][0], min_grad_cos=min(v[1] for v in full.values()))
+    _report("g9_model_refarch_" + tag, **r, worst_grad_norm_param=worst_gn[0], worst_grad_param=worst_full[0])
+    # embeddings after 15 pre-LN layers / 6 post-LN layers with bf16 GEMM operands (bound measured)
+    assert r["enc"] < 2e-2 and r["bert"] < 1e-2 and r["logits"] < 3e-2, r
+    assert r["infonce"] < 1e-3 and r["task_loss"] < 2e-3 and r["loss"] < 1e-3, r
+    assert r["ct"] < 1e-2 or abs(float(ct) - float(g["o_ct"])) < 5e-4, r           # B=4 contrastive term (exp(x/0.07) of bf16-computed features)
+    assert worst_gn[1] < 0.1 and worst_full[1][0] < 0.12 and r["min_grad_cos"] > 0.99, (worst_gn, worst_full, r["min_grad_cos"])
+
+
+# ------------------------------------------------------------------------------------------------ trainer (a18)
+@pytest.mark.parametrize("tag", ["reg_fds", "cls"])
+def test_g10_trainer_hip(golden, tag, tmp_path):
+    """The Trainer drop-in (mmdti_hip.tasks.Trainer) against the reference's own ``Trainer.fit_predict`` run: 4 epochs x 5
+    steps of batch 4 (+ FDS passes, validation, best-checkpoint reload) on the same samples with the same torch seed."""
+    from mmdti_hip.tasks import Trainer
+    g = golden("g10_trainer_" + tag)
+    task = str(g["task"])
+    hp = json.loads(str(g["hp_json"]))
+    sd = {k[3:]: T(v) for k, v in g.items() if k.startswith("w0_")}
+    tok = tokenizer_from(str(g["tok_json"]), 38)
+    ocfg = tiny_cfg(task, sd["bert.embeddings.word_embeddings.weight"].shape[0])
+    kw = dict(fds=True, fds_num=6, _fds_raw_values=g["fds_raw"], use_scaler=False) if task == "regression" else {}
+    model = product_model(ocfg, tok, **kw)
+    load_fixture_weights(model, sd)
+    train, valid = samples_from(g, "train_"), samples_from(g, "valid_")
+    ids = {id(s[0]): i for i, s in enumerate(train)}
+    ids.update({id(s[0]): 100 + i for i, s in enumerate(valid)})
+    orders = []
+    real_collate = model.batch_collate_fn
+
+    def collate(samples):
+        phase = 2 if not model.training else (0 if torch.is_grad_enabled() else 1)
+        orders.append([phase] + [ids[id(s[0])] for s in samples] + [-1] * (4 - len(samples)))
+        return real_collate(samples)
+
+    model.batch_collate_fn = collate
+    hp = dict(hp, use_cuda=True)
+    trainer = Trainer(save_path=str(tmp_path), **hp)
+    loss_func = torch.nn.MSELoss() if task == "regression" else None
+    act = (lambda x: x) if task == "regression" else (lambda x: torch.softmax(x, dim=-1)[:, 1:])
+    torch.manual_seed(1234)
+    y_pred = trainer.fit_predict(model, train, valid, loss_func, act, str(tmp_path), 0, None, return_infonce_loss=True, return_ct_loss=True,
+                                 use_weight=False)
+    # exact: every loader pass (training shuffles, FDS passes, validation) saw the reference's batches in its order
+    assert np.array_equal(np.array(orders), g["batch_order"])
+    steps = np.concatenate([h["steps"] for h in trainer.history])            # [20, 4] = loss, task, infonce, ct
+    err = dict(task=float(np.max(np.abs(steps[:, 1] - g["step_task_loss"]) / (np.abs(g["step_task_loss"]) + 1e-2))),
+               infonce=float(np.max(np.abs(steps[:, 2] - g["step_infonce"]) / np.abs(g["step_infonce"]))),
+               ct=float(np.max(np.abs(steps[:, 3] - g["step_ct"]))),
+               y_pred=float(np.max(np.abs(y_pred - g["y_pred"]))), first_step_task=abs(float(steps[0, 1] - g["step_task_loss"][0])))
+    ck = torch.load(os.path.join(str(tmp_path), "model_0.pth"), map_location="cpu", weights_only=True)["model_state_dict"]
+    ref_keys = {k[3:] for k in g if k.startswith("ck_")}
+    assert set(ck) == ref_keys, (sorted(set(ck) ^ ref_keys)[:8])              # checkpoint key set is the reference's
+    err["ckpt"] = max(rel_l2(ck[k], g["ck_" + k]) for k in ck if ck[k].is_floating_point() and float(np.abs(g["ck_" + k]).max()) > 0
+                      and not k.startswith("FDS."))
+    _report("g10_trainer_" + tag, **err)
+    # 20 optimizer steps at lr 5e-4 with bf16 GEMMs vs the reference's fp32 CPU run: drift accumulates with training
+    assert err["first_step_task"] < 2e-3 and err["task"] < 5e-2 and err["infonce"] < 1e-2 and err["ct"] < 5e-2, err
+    assert err["y_pred"] < 3e-2 and err["ckpt"] < 2e-2, err
+    if task == "regression":
+        assert torch.equal(ck["FDS.epoch"], T(g["ck_FDS.epoch"])) and torch.equal(ck["FDS.num_samples_tracked"], T(g["ck_FDS.num_samples_tracked"]))
+        assert rel_l2(ck["FDS.running_mean"], g["ck_FDS.running_mean"]) < 5e-2
+
+
+def test_reference_amp_protocol_loop_around_hip_model():
+    """INTEGRATION.md section 4's other route: the reference's OWN step body (tasks/trainer.py:181-193,270-282 -- fp16
+    autocast + GradScaler + clip_grad_norm_ + torch.optim.Adam + HF warm-up) wrapped around the HIP MM_Model, against
+    FineTuner on a copy of the model.  The HIP autograd nodes take no part in autocast (they compute bf16/fp32 inside) and
+    write parameter gradients linear in the incoming (scaled) gradient, so unscale_ recovers them exactly (scale is 2^16)."""
+    from transformers.optimization import get_linear_schedule_with_warmup
+    from mmdti_hip.trainer import FineTuner
+    ocfg = tiny_cfg("classification", 40)
+    m1, m2 = product_model(ocfg).cuda().train(), product_model(ocfg).cuda().train()
+    m2.load_state_dict(m1.state_dict())
+    batch, label = O.synth_batch(8, 10, 14, ocfg, seed=3, ragged=True)
+    dev = {k: v.cuda() for k, v in batch.items()}
+    y = label.cuda()
+    tuner = FineTuner(m1, "classification", learning_rate=1e-3, warmup_ratio=0.25, total_steps=8, max_norm=5.0)
+    params = [p for p in m2.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-3, eps=1e-6)
+    sched = get_linear_schedule_with_warmup(opt, num_warmup_steps=2, num_training_steps=8)
+    scaler = torch.amp.GradScaler("cuda")
+    for step in range(4):
+        out = tuner.step(dev, y)
+        opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.float16):
+            lg, infonce, ct = m2(**dev, return_infonce_loss=True, return_ct_loss=True, net_target=y, use_weight=False, epoch=0)
+            rg = torch.nn.functional.cross_entropy(lg, y.flatten())          # the reference's task loss as a stock op under autocast
+            loss = 1 * rg + 0.1 * infonce + 0.1 * ct
+        scaler.scale(loss).backward()
+        scaler.unscale_(opt)
+        torch.nn.utils.clip_grad_norm_(m2.parameters(), 5.0)
+        scaler.step(opt)
+        scaler.update()
+        sched.step()
+        assert abs(float(loss) - float(out.loss)) <= 1e-3 * abs(float(loss)), (step, float(loss), float(out.loss))
+    worst = max(rel_l2(p1, p2) for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()) if p1.requires_grad)
+    assert worst < 2e-3, worst

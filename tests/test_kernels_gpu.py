@@ -217,9 +217,11 @@ def _pair_ref(qkv, bias, key_pad, H, scale, dO=None, g_in=None):
 
 
 @pytest.mark.parametrize("tiled", [False, True])
-@pytest.mark.parametrize("B,N,H", [(2, 7, 8), (3, 70, 4), (2, 130, 64), (1, 200, 2)])
+@pytest.mark.parametrize("B,N,H", [(2, 7, 8), (3, 70, 4), (2, 130, 64), (1, 200, 2), (1, 210, 64), (2, 240, 8), (1, 258, 64), (1, 272, 4)])
 def test_pair_attn(ops, B, N, H, tiled):
-    """Both pair layouts: row-major [B,H,N,ld] planes and the tiled [B,H,nt,nt,256] form the hot path streams."""
+    """Both pair layouts: row-major [B,H,N,ld] planes and the tiled [B,H,nt,nt,256] form the hot path streams.
+    N in 209..258 is what the reference's crop at max_atoms=256 can produce (data/conformer.py:53,199-204): the NT=17
+    instantiation of the MFMA kernels; 272 is its last supported size."""
     D = H * 8
     ld = ops.pair_ld(N)
     scale = 8 ** -0.5
