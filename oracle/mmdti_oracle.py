@@ -109,15 +109,23 @@ class ModelCfg:
     infonce_dropout: float = 0.1
 
 
-def _r(x: Tensor, on: bool) -> Tensor:
+# Rounding sites of the bf16 contract (tests/test_rounding_budget_cpu.py switches them one at a time to attribute the
+# distance between the bf16 path and the fp32 reference): "w" GEMM weights, "x" GEMM inputs (LayerNorm / attention /
+# GELU outputs), "qkv" the stored q|k|v of tower 1, "qkv2" q,k,v of towers 2 / fusion, "p" their attention probabilities,
+# "proj" per-token InfoNCE projections (only when the head projects before pooling).
+ALL_SITES = frozenset({"w", "x", "qkv", "qkv2", "p", "proj"})
+BF16_SITES = set(ALL_SITES)
+
+
+def _r(x: Tensor, on: bool, site: str = "x") -> Tensor:
     """bf16 round-trip used by the ``emulate_bf16`` contract."""
-    return x.to(torch.bfloat16).to(torch.float32) if on else x
+    return x.to(torch.bfloat16).to(torch.float32) if (on and site in BF16_SITES) else x
 
 
 def linear(x: Tensor, w: Tensor, b: Optional[Tensor], bf16: bool = False) -> Tensor:
     """nn.Linear.  Under the bf16 contract both operands are rounded, the
     accumulation and bias add stay fp32."""
-    return F.linear(_r(x, bf16), _r(w, bf16), b)
+    return F.linear(_r(x, bf16, "x"), _r(w, bf16, "w"), b)
 
 
 def gelu(x: Tensor) -> Tensor:
@@ -234,7 +242,7 @@ def unimol_layer(x: Tensor, bias: Tensor, P: Params, pre: str, cfg: UniMolCfg,
     r = x
     h = layer_norm(x, P[pre + "self_attn_layer_norm.weight"], P[pre + "self_attn_layer_norm.bias"], cfg.ln_eps)
     qkv = linear(h, P[pre + "self_attn.in_proj.weight"], P[pre + "self_attn.in_proj.bias"], bf16)
-    qkv = _r(qkv, bf16)                       # HIP path stores q,k,v as bf16
+    qkv = _r(qkv, bf16, "qkv")                # HIP path stores q,k,v as bf16
     q, k, v = qkv.chunk(3, dim=-1)
     scaling = hd ** -0.5
 
@@ -324,16 +332,16 @@ def mha(q_in: Tensor, kv_in: Tensor, key_add_mask: Tensor, P: Params, pre: str, 
     B, Lq, D = q_in.shape
     Lk = kv_in.shape[1]
     hd = D // heads
-    q = _r(linear(q_in, P[pre + "query.weight"], P[pre + "query.bias"], bf16), bf16)
-    k = _r(linear(kv_in, P[pre + "key.weight"], P[pre + "key.bias"], bf16), bf16)
-    v = _r(linear(kv_in, P[pre + "value.weight"], P[pre + "value.bias"], bf16), bf16)
+    q = _r(linear(q_in, P[pre + "query.weight"], P[pre + "query.bias"], bf16), bf16, "qkv2")
+    k = _r(linear(kv_in, P[pre + "key.weight"], P[pre + "key.bias"], bf16), bf16, "qkv2")
+    v = _r(linear(kv_in, P[pre + "value.weight"], P[pre + "value.bias"], bf16), bf16, "qkv2")
     q = q.view(B, Lq, heads, hd).transpose(1, 2)
     k = k.view(B, Lk, heads, hd).transpose(1, 2)
     v = v.view(B, Lk, heads, hd).transpose(1, 2)
     s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(hd)
     s = s + key_add_mask.view(B, 1, 1, Lk)
     p = dropout(torch.softmax(s, dim=-1), attn_p, training)
-    p = _r(p, bf16)
+    p = _r(p, bf16, "p")
     ctx = torch.matmul(p, v).transpose(1, 2).contiguous().view(B, Lq, D)
     return ctx
 
@@ -423,7 +431,7 @@ def infonce_embed(query: Tensor, positive: Tensor, P: Params, pre: str = "infonc
 
     def proj(x, name):
         h = F.gelu(linear(x, P[pre + name + ".0.weight"], P[pre + name + ".0.bias"], bf16))
-        return _r(linear(h, P[pre + name + ".2.weight"], P[pre + name + ".2.bias"], bf16), bf16)   # HIP path stores the projections bf16
+        return _r(linear(h, P[pre + name + ".2.weight"], P[pre + name + ".2.bias"], bf16), bf16, "proj")   # per-token projections stored bf16 (project-then-pool order)
 
     return proj(xq, "info_proj_query").mean(dim=1), proj(positive, "info_proj_positive").mean(dim=1)
 
