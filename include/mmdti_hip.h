@@ -50,6 +50,10 @@ typedef void* mmdti_stream_t;
 
 const char* mmdti_last_error(void);
 int mmdti_abi_version(void);
+/* Run-time tuning switches (A/B measurements inside one process; defaults come from the environment variable of the same
+ * upper-cased name, e.g. MMDTI_GEMM_BIG).  Known names: "gemm_big" (0 off, 1 where the shape fills the chip, 2 every
+ * eligible shape); "gemm_dbg" (measurement only: 1 = the large-tile GEMM skips its epilogue).  Returns MMDTI_ERR_INVALID for an unknown name.  Not part of any reference interface. */
+int mmdti_set_option(const char* name, int value);
 
 /* ---- GEMM: C = epi(alpha * A.B^T) ----------------------------------------------------------
  * Replaces nn.Linear / torch.bmm fwd+bwd: unicore in_proj/out_proj/fc1/fc2 (models/transformers.py:137-139),
@@ -61,13 +65,18 @@ int mmdti_abi_version(void);
  * colsum_out (nullable, [N] fp32, +=): column sums of the stored C -- the bias gradient of the Linear whose output
  * gradient C is -- accumulated by the epilogue (aligned, unbatched, unsplit outputs only).
  * arowsum_out (nullable, [M] fp32, +=, transA only, unbatched): sum over k of op(A)[m][k].  For a weight gradient
- * dW = dy^T.x (A = dy stored [tokens, out]) that is the Linear's bias gradient, taken inside the same pass over dy.  */
+ * dW = dy^T.x (A = dy stored [tokens, out]) that is the Linear's bias gradient, taken inside the same pass over dy.
+ * workspace (nullable, workspace_bytes): device scratch for split-K.  With it, a split-K product of a large-tile shape
+ * writes one fp32 partial per split with plain stores and a second pass adds their sum into C -- global float atomics
+ * run at a fifth of the store rate on this chip -- instead of atomicAdd-ing every partial into C.  Without it (or when
+ * it is too small: splits * M * N * 4 bytes) the atomic form runs.  Contents on return are unspecified. */
 int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void* B, void* C, int M, int N, int K, int lda,
                     int ldb, int ldc, int transA, int transB, int batch_outer, int batch_inner, long long sAo,
                     long long sAi, long long sBo, long long sBi, long long sCo, long long sCi, int splitk,
                     float alpha, float beta, const float* bias, const float* residual, int ldr, int act,
                     const void* aux_in, void* aux_out, int ld_aux, int c_dtype, float drop_p,
-                    unsigned long long seed, unsigned int site, float* colsum_out, float* arowsum_out);
+                    unsigned long long seed, unsigned int site, float* colsum_out, float* arowsum_out, void* workspace,
+                    long long workspace_bytes);
 
 /* ---- LayerNorm (unicore LayerNorm eps 1e-5: transformers.py:69,71,114,161; BertLayerNorm eps 1e-12:
  * mm_module.py:320-333; HF nn.LayerNorm) -------------------------------------------------------

@@ -16,6 +16,7 @@
 // transposed for free by ds_read_b64_tr_b16 on the way to the MFMA.
 // XCD-aware block remap keeps tiles that share an A row-panel on one XCD's L2.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -53,6 +54,8 @@ struct GemmArgs {
   int vec_ok;             // host-checked: every pointer/stride the vector epilogue touches is 16-byte friendly
   float* colsum;          // [N] fp32 or null: += column sums of the stored C (vector epilogue only) -- a Linear's bias gradient
   int stream_c;           // host-set: C is written with streaming (non-temporal) stores -- outputs too large to be of use in the caches
+  int dbg;                // measurement switch (see g_gemm_dbg)
+  long long slab;         // split-K partials: split ks writes C + ks * slab (elements) instead of accumulating into C; 0 = off
   float* arowsum;         // [M] fp32 or null: += sum_k op(A)[m][k] -- for a weight gradient dW = dy^T.x (A = dy, k-major) that
                           // is the Linear's bias gradient; taken with one extra MFMA per A fragment against a ones operand
 };
@@ -752,9 +755,293 @@ __global__ __launch_bounds__(256, 4) void gemm_glds_tall_kernel(GemmArgs a, int 
 #undef TSTG
 }
 
+
+// =====================================================================================================================
+// 256 x 256 tile, 8 waves, LDS-DMA prefetch in flight ACROSS barriers (cdna guide 5, "the 256^2 8-phase template").
+//
+// The 128 x 128 kernels above run fetch -> barrier -> 16 MFMAs -> barrier with every DMA drained at each barrier and
+// lean on four co-resident workgroups to overlap each other: that structure tops out near 900 TF/s, and the long-K
+// weight gradients (K = 33 280 / 65 536 tokens: 35 % of the step's GEMM time) sat at 470-640 TF/s on it.  Here ONE
+// workgroup owns the CU (128 KB of LDS: two K-tiles of (A | B), each 256 rows x 64 k), a K-tile is multiplied in four
+// phases of 16 MFMAs per wave -- the four (A half, B half) quadrants of the wave's 128 x 64 output -- and every phase
+// issues the DMA of one 16 KB piece of a LATER K-tile; the pieces are waited for with a counted s_waitcnt vmcnt(6) once
+// per K-tile, so three pieces (six loads per thread) stay in flight across the raw s_barriers.
+//
+// Pieces.  Operand X of a K-tile is staged as two pieces X0, X1 = rows [0,128) and [128,256) of the tile, each stored as
+// an ordinary 128-row tile image ([row][k] swizzled, or [k][row] for a k-major operand -- 256 contiguous bytes of global
+// memory per k), so the fragment loaders of the 128 x 128 kernels read it unchanged.  Every wave works in BOTH pieces of
+// each operand: wave (wr, wc) owns rows h*128 + wr*64 + [0,64) (h = 0, 1) and columns g*128 + wc*32 + [0,32) (g = 0, 1) of
+// the output tile, so each phase needs only one piece of A.
+// Fragments are double-buffered in registers: a phase multiplies what the PREVIOUS phase read while its own LDS reads (for
+// the next phase) and its DMA piece run under the MFMAs.  A phase is (A half, one 32-deep k half) x all four column tiles
+// of the wave: 4 + 4 fragments, 16 MFMAs -- 24 fragment reads per K-tile, none repeated.  K-tile t in buffer t & 1 (the
+// reads of a phase are retired before its closing barrier, so a region may be restaged in the NEXT phase):
+//     phase 1: MFMA A0.k0 x B.k0 | read A1.k0             | DMA A0(t+1) -> other buffer  (A0(t-1) was last read in phase 3 of t-1)
+//     phase 2: MFMA A1.k0 x B.k0 | read A1.k1, B.k1       | DMA A1(t+1) -> other buffer  (A1(t-1): phase 2 of t-1)
+//     phase 3: MFMA A1.k1 x B.k1 | read A0.k1             | DMA B0(t+2) -> this buffer   (B(t): phase 2); s_waitcnt vmcnt(4)
+//     phase 4: MFMA A0.k1 x B.k1 | read A0.k0, B.k0 (t+1) | DMA B1(t+2) -> this buffer;                   s_waitcnt vmcnt(4)
+// Phase 3's wait leaves only the two pieces issued last (A1(t+1), B0(t+2)) in flight: A0(t+1) and both B pieces of tile t+1
+// have landed and the closing barrier publishes them before phase 4 reads them; phase 4's wait does the same for A1(t+1),
+// read in phase 1 of tile t+1 (a staged buffer is read one phase after the wait that retires it).  Tiles past the end of
+// the K range re-fetch the last tile (harmless: those regions are never read again).
+constexpr int BBM = 256, BBN = 256;
+constexpr int BIG_PIECE = 128 * BK;          // elements of one 16 KB piece
+constexpr int BIG_BUF = 4 * BIG_PIECE;       // A0 | A1 | B0 | B1
+constexpr int LDC_B = BBN + 4;               // fp32 row stride of the epilogue's [64][260] staging image
+
+// byte offset (relative to the operand's K-tile origin) of chunk c (0..1023) of piece 0; same source-side swizzles as glds_offset1
+template <bool TR>
+__device__ __forceinline__ uint32_t big_offset1(int c, int ld, int row0) {
+  // piece-local row r (0..127) is matrix row row0 + r (piece 1 starts 128 rows further: a wave-uniform constant)
+  if (!TR) {
+    const int rl = c >> 3, kc = (c & 7) ^ (rl & 7);
+    return (uint32_t)(((long long)(row0 + rl) * ld + kc * 8) * 2);
+  } else {
+    const int k = c >> 4, rs = (c & 15) ^ (tr_swz(k) >> 3);
+    return (uint32_t)(((long long)k * ld + row0 + rs * 8) * 2);
+  }
+}
+// kbase: wave-uniform origin of the piece (K-tile origin + piece offset); d2: element distance of the thread's second chunk
+__device__ __forceinline__ void big_issue(const bf16_t* kbase, long long d2, uint32_t off, bf16_t* piece, int wave) {
+  typedef __attribute__((address_space(1))) const void gptr_t;
+  typedef __attribute__((address_space(3))) void lptr_t;
+  const char* b = reinterpret_cast<const char*>(kbase);
+  bf16_t* d = piece + wave * 512;          // wave-instruction j covers chunks j*512 + wave*64 + lane
+  __builtin_amdgcn_global_load_lds((gptr_t*)(b + off), (lptr_t*)(d), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((gptr_t*)(reinterpret_cast<const char*>(kbase + d2) + off), (lptr_t*)(d + 4096), 16, 0, 0);
+}
+
+// C[m][n] += sum over splits of slab[s][m][n]   (the second pass of the slab form of split-K)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C, int M, int N, int ldc, int splits) {
+  const long long n4 = (long long)M * N / 4, stride = (long long)gridDim.x * 256;
+  const int n4row = N / 4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 s = *reinterpret_cast<const float4*>(slabs + i * 4);
+    for (int k = 1; k < splits; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(slabs + (long long)k * M * N + i * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const long long row = i / n4row, col = (i - row * n4row) * 4;
+    float4* dst = reinterpret_cast<float4*>(C + row * ldc + col);
+    float4 c = *dst;
+    c.x += s.x; c.y += s.y; c.z += s.z; c.w += s.w;
+    *dst = c;
+  }
+}
+
+struct Frag4 {
+  bf16x8 f0, f1, f2, f3;
+};
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512, 1) void gemm_big_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = (a.N + BBN - 1) / BBN, tiles_m = (a.M + BBM - 1) / BBM;
+  const int nwg = tiles_n * tiles_m;
+  const int orig = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+  const int m0 = tm * BBM, n0 = tn * BBN;
+  const int ks = blockIdx.z;
+  const int ktiles = a.K / BK;
+  const int per = (ktiles + a.splitk - 1) / a.splitk;
+  const int kt0 = ks * per, kt1 = min(ktiles, kt0 + per);
+  if (kt0 >= kt1) return;
+  const int nt = kt1 - kt0;
+  const bf16_t* __restrict__ A = a.A + (long long)kt0 * (TA ? (long long)BK * a.lda : BK);
+  const bf16_t* __restrict__ B = a.B + (long long)kt0 * (TB ? (long long)BK * a.ldb : BK);
+  const long long kstepA = TA ? (long long)BK * a.lda : BK, kstepB = TB ? (long long)BK * a.ldb : BK;
+  // (M and N are multiples of 256 here -- host-checked -- so no source row is clamped and the eight per-thread source
+  //  offsets reduce to ONE per operand plus wave-uniform constants that fold into the scalar tile base)
+  const uint32_t oA = big_offset1<TA>(tid, a.lda, m0), oB = big_offset1<TB>(tid, a.ldb, n0);
+  const long long dA2 = TA ? (long long)32 * a.lda : (long long)64 * a.lda;    // second chunk of a thread (tid + 512), elements
+  const long long dB2 = TB ? (long long)32 * a.ldb : (long long)64 * a.ldb;
+  const long long hA = TA ? 128 : (long long)128 * a.lda;                       // piece 1 vs piece 0: 128 rows further
+  const long long hB = TB ? 128 : (long long)128 * a.ldb;
+  f32x4 acc[8][4] = {};
+  const bool do_rs = TA && a.arowsum != nullptr && tn == 0;   // bias gradient: row sums of op(A), one row tile of each half per wave column
+  const bf16x8 ones = ones_frag();
+  f32x4 rs0 = {0.f, 0.f, 0.f, 0.f}, rs1 = rs0;
+
+#define BIG_TILE(T) min((T), nt - 1)
+#define BIG_A(T) (A + BIG_TILE(T) * kstepA)
+#define BIG_B(T) (B + BIG_TILE(T) * kstepB)
+#define BIG_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+  // prologue: every piece of tile 0; of tile 1 the two B pieces (the steady state enters a tile with them in flight)
+  big_issue(BIG_A(0), dA2, oA, smem, wave);
+  big_issue(BIG_B(0), dB2, oB, smem + 2 * BIG_PIECE, wave);
+  big_issue(BIG_B(0) + hB, dB2, oB, smem + 3 * BIG_PIECE, wave);
+  big_issue(BIG_A(0) + hA, dA2, oA, smem + BIG_PIECE, wave);
+  big_issue(BIG_B(1), dB2, oB, smem + BIG_BUF + 2 * BIG_PIECE, wave);
+  big_issue(BIG_B(1) + hB, dB2, oB, smem + BIG_BUF + 3 * BIG_PIECE, wave);
+  BIG_WAIT(4);
+  __builtin_amdgcn_s_barrier();
+
+  Frag4 FAx, FAy, FBx, FBy;
+  // fragments of one k half (KK): A = the four 16-row tiles of the wave's rows in piece IMG; B = the wave's four 16-column
+  // tiles, two from each B piece
+#define BIG_LDA(F, IMG, KK)                                                                                          \
+  F.f0 = load_frag<TA>(IMG, wr * 64 + 0, KK, lane);  F.f1 = load_frag<TA>(IMG, wr * 64 + 16, KK, lane);               \
+  F.f2 = load_frag<TA>(IMG, wr * 64 + 32, KK, lane); F.f3 = load_frag<TA>(IMG, wr * 64 + 48, KK, lane)
+#define BIG_LDB(F, BUF, KK)                                                                                          \
+  F.f0 = load_frag<TB>(BUF + 2 * BIG_PIECE, wc * 32 + 0, KK, lane); F.f1 = load_frag<TB>(BUF + 2 * BIG_PIECE, wc * 32 + 16, KK, lane); \
+  F.f2 = load_frag<TB>(BUF + 3 * BIG_PIECE, wc * 32 + 0, KK, lane); F.f3 = load_frag<TB>(BUF + 3 * BIG_PIECE, wc * 32 + 16, KK, lane)
+#define BMF(R, C, FA, FB) acc[R][C] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB.f##C, FA.f##R, acc[(R) + RB][C], 0, 0, 0)
+  // 16 MFMAs: the wave's four row tiles of A half H (acc rows H*4 + 0..3) x its four column tiles, one k half
+#define BIG_MF8(H, FA, FB, R0, R1)                                                                                   \
+  acc[H * 4 + R0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB.f0, FA.f##R0, acc[H * 4 + R0][0], 0, 0, 0);         \
+  acc[H * 4 + R0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB.f1, FA.f##R0, acc[H * 4 + R0][1], 0, 0, 0);         \
+  acc[H * 4 + R0][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB.f2, FA.f##R0, acc[H * 4 + R0][2], 0, 0, 0);         \
+  acc[H * 4 + R0][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB.f3, FA.f##R0, acc[H * 4 + R0][3], 0, 0, 0);         \
+  acc[H * 4 + R1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB.f0, FA.f##R1, acc[H * 4 + R1][0], 0, 0, 0);         \
+  acc[H * 4 + R1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB.f1, FA.f##R1, acc[H * 4 + R1][1], 0, 0, 0);         \
+  acc[H * 4 + R1][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB.f2, FA.f##R1, acc[H * 4 + R1][2], 0, 0, 0);         \
+  acc[H * 4 + R1][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB.f3, FA.f##R1, acc[H * 4 + R1][3], 0, 0, 0)
+#define BIG_RS(ACC, FA)                                                                                              \
+  if (do_rs) {                                                                                                       \
+    const bf16x8 s0 = wc == 0 ? FA.f0 : wc == 1 ? FA.f1 : wc == 2 ? FA.f2 : FA.f3;                                    \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, s0, ACC, 0, 0, 0);                                            \
+  }
+  // one phase: the LDS reads of the NEXT phase's fragments and the DMA of a later tile's piece are issued first / in
+  // the middle and run under this phase's 16 MFMAs (which use fragments read one phase earlier); every read is retired
+  // before the closing barrier, so the region it came from may be restaged in the next phase
+#define BIG_PHASE(H, FA, FB, RSACC, LOADS, ISSUE, WAITS)                                                              \
+  LOADS;                                                                                                             \
+  __builtin_amdgcn_sched_barrier(0);                                                                                 \
+  __builtin_amdgcn_s_setprio(1);                                                                                     \
+  BIG_MF8(H, FA, FB, 0, 1);                                                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                                                                 \
+  ISSUE;                                                                                                             \
+  __builtin_amdgcn_sched_barrier(0);                                                                                 \
+  BIG_MF8(H, FA, FB, 2, 3);                                                                                          \
+  BIG_RS(RSACC, FA);                                                                                                 \
+  __builtin_amdgcn_s_setprio(0);                                                                                     \
+  WAITS;                                                                                                             \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                                                                 \
+  __builtin_amdgcn_s_barrier();                                                                                      \
+  __builtin_amdgcn_sched_barrier(0)
+
+  BIG_LDA(FAx, smem, 0);
+  BIG_LDB(FBx, smem, 0);
+  for (int t = 0; t < nt; ++t) {
+    bf16_t* cur = smem + (t & 1) * BIG_BUF;
+    bf16_t* oth = smem + ((t & 1) ^ 1) * BIG_BUF;
+    // c1: (A0, k 0..31)   | read A1 k-half 0            | DMA A0(t+1) -> other buffer (free since phase 4 of tile t-1)
+    BIG_PHASE(0, FAx, FBx, rs0, BIG_LDA(FAy, cur + BIG_PIECE, 0), big_issue(BIG_A(t + 1), dA2, oA, oth, wave), (void)0);
+    // c2: (A1, k 0..31)   | read A1 and B k-half 1      | DMA A1(t+1) -> other buffer (free since phase 3 of tile t-1)
+    BIG_PHASE(1, FAy, FBx, rs1, BIG_LDA(FAx, cur + BIG_PIECE, 1); BIG_LDB(FBy, cur, 1),
+              big_issue(BIG_A(t + 1) + hA, dA2, oA, oth + BIG_PIECE, wave), (void)0);
+    // c3: (A1, k 32..63)  | read A0 k-half 1            | DMA B0(t+2) -> this buffer (B was last read in phase 2); wait: A0(t+1), B(t+1) landed
+    BIG_PHASE(1, FAx, FBy, rs1, BIG_LDA(FAy, cur, 1), big_issue(BIG_B(t + 2), dB2, oB, cur + 2 * BIG_PIECE, wave), BIG_WAIT(4));
+    // c4: (A0, k 32..63)  | read A0, B of tile t+1      | DMA B1(t+2) -> this buffer; wait: A1(t+1) landed
+    BIG_PHASE(0, FAy, FBy, rs0, BIG_LDA(FAx, oth, 0); BIG_LDB(FBx, oth, 0),
+              big_issue(BIG_B(t + 2) + hB, dB2, oB, cur + 3 * BIG_PIECE, wave), BIG_WAIT(4));
+  }
+  BIG_WAIT(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();   // no DMA in flight, no read outstanding: LDS is free for the epilogue
+#undef BIG_PHASE
+#undef BIG_MF8
+#undef BMF
+#undef BIG_LDA
+#undef BIG_LDB
+#undef BIG_WAIT
+#undef BIG_A
+#undef BIG_B
+#undef BIG_TILE
+  const int l15 = lane & 15, g4 = (lane >> 4) * 4;
+  if (a.dbg & 1) {   // loop-only timing: keep the accumulators live, store nothing in practice
+    float keep = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) keep += acc[i][0][0] + acc[i][1][1] + acc[i][2][2] + acc[i][3][3];
+    if (keep == 1.2345e-30f) reinterpret_cast<float*>(a.C)[0] = keep;
+    return;
+  }
+  if (do_rs && lane < 16) {
+    // D = ones . fa^T: every register of lane m's column holds the row sum of local row m (wave column wc took row tile wc of each half)
+    const int m = m0 + wr * 64 + wc * 16 + lane;
+    if (m < a.M) atomicAdd(a.arowsum + m, rs0[0]);
+    if (m + 128 < a.M) atomicAdd(a.arowsum + m + 128, rs1[0]);
+  }
+#undef BIG_RS
+  const bool lead = (ks == 0);
+  const long long coff = a.slab * ks;      // (slab mode: every split owns a private fp32 copy of the output)
+  // accumulator (R = H*4 + i, C = G*2 + j): row m0 + H*128 + wr*64 + i*16 + (lane & 15), columns n0 + G*128 + wc*32 + j*16 + 4*(lane >> 4) + {0..3}
+  if (a.c_dtype != MMDTI_DT_F32_ATOMIC && a.vec_ok) {
+    // four passes of 64 rows through a [64][260] fp32 image; 512 threads then run the fused epilogue on 8 contiguous columns each
+    float* sC = reinterpret_cast<float*>(smem);
+#define BSTG(R, L, C) *reinterpret_cast<f32x4*>(sC + ((L) * 16 + l15) * LDC_B + ((C) >> 1) * 128 + wc * 32 + ((C) & 1) * 16 + g4) = acc[R][C]
+#define BSTG_ROW(R, L) BSTG(R, L, 0); BSTG(R, L, 1); BSTG(R, L, 2); BSTG(R, L, 3)
+#define BIG_PASS(P)                                                                                                   \
+    if (wr == ((P) & 1)) { BSTG_ROW(((P) >> 1) * 4 + 0, 0); BSTG_ROW(((P) >> 1) * 4 + 1, 1); BSTG_ROW(((P) >> 1) * 4 + 2, 2); BSTG_ROW(((P) >> 1) * 4 + 3, 3); } \
+    __syncthreads();                                                                                                  \
+    for (int it = 0; it < 4; ++it) {                                                                                  \
+      const int chunk = tid + it * 512;                                                                               \
+      const int rr = chunk >> 5, cc = (chunk & 31) * 8;                                                               \
+      const int row = m0 + (P) * 64 + rr, col = n0 + cc;                                                              \
+      if (row < a.M && col < a.N) epilogue_oct(a, sC + rr * LDC_B + cc, row, col, lead, coff, nullptr);               \
+    }
+    BIG_PASS(0)
+    __syncthreads();
+    BIG_PASS(1)
+    __syncthreads();
+    BIG_PASS(2)
+    __syncthreads();
+    BIG_PASS(3)
+#undef BIG_PASS
+#undef BSTG_ROW
+#undef BSTG
+    return;
+  }
+  // atomic (split-K) / unaligned outputs: a private 16 x 68 fp32 patch per wave, one row tile at a time
+  float* sW = reinterpret_cast<float*>(smem) + wave * (16 * LDC_W);
+#define BSTG_T(R, C) *reinterpret_cast<f32x4*>(sW + l15 * LDC_W + (C) * 16 + g4) = acc[R][C]
+#define BIG_EPI(R)                                                                                   \
+  {                                                                                                  \
+    BSTG_T(R, 0); BSTG_T(R, 1); BSTG_T(R, 2); BSTG_T(R, 3);                                          \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                           \
+    __builtin_amdgcn_wave_barrier();                                                                 \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                           \
+    for (int rr = 0; rr < 16; ++rr)                                                                  \
+      epi_elem(a, sW[rr * LDC_W + lane], m0 + ((R) >> 2) * 128 + wr * 64 + ((R) & 3) * 16 + rr, n0 + (lane >> 5) * 128 + wc * 32 + (lane & 31), lead, 0); \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                           \
+    __builtin_amdgcn_wave_barrier();                                                                 \
+  }
+  BIG_EPI(0) BIG_EPI(1) BIG_EPI(2) BIG_EPI(3) BIG_EPI(4) BIG_EPI(5) BIG_EPI(6) BIG_EPI(7)
+#undef BIG_EPI
+#undef BSTG_T
+}
+
 }  // namespace mmdti
 
 using namespace mmdti;
+
+static int g_gemm_big = getenv("MMDTI_GEMM_BIG") ? atoi(getenv("MMDTI_GEMM_BIG")) : 1;
+static int g_gemm_dbg = 0;     // measurement only: 1 = gemm_big_kernel returns after its K loop (no epilogue, no slab pass)
+
+extern "C" int mmdti_set_option(const char* name, int value) {
+  MMDTI_REQUIRE(name != nullptr, "set_option: null name");
+  if (strcmp(name, "gemm_big") == 0) { g_gemm_big = value; return MMDTI_OK; }
+  if (strcmp(name, "gemm_dbg") == 0) { g_gemm_dbg = value; return MMDTI_OK; }
+  set_error("set_option: unknown option '%s'", name);
+  return MMDTI_ERR_INVALID;
+}
+
+// Shapes on which the 256 x 256 kernel (one workgroup per CU) beats the 128 x 128 ones (four per CU): enough tiles to fill
+// the 256 CUs with little waste in the last round (measured table: DESIGN.md section 4 "GEMM").
+static bool big_shape_pays(int M, int N, int K, int splitk, int transA, int transB) {
+  // Measured on MI355X against the 128 x 128 kernels (scratch/gemm_big_test.py, profiles/r02_gemm_big_ab.json).  The K loop
+  // of this kernel runs at 900-1300 TF/s, but with ONE workgroup per CU nothing overlaps a tile's epilogue (an HBM / VALU
+  // burst of 15-20 us for a 256 x 256 fp32 / GELU tile) with another tile's loop, and 33 280-row outputs quantise badly on
+  // 256 CUs (130 row tiles).  It pays where the loop dominates and the tile count divides the chip:
+  const long long tiles = (long long)cdiv(M, 256) * cdiv(N, 256);
+  if (splitk > 1) return K >= 16384 && 256 % tiles == 0 && tiles >= 4;     // long-K weight gradients: 4 or 16 output tiles (x1.02...1.25)
+  return tiles % 256 == 0 && !transB && K >= 512 && N <= 2048 && M >= 65536;   // tower-2 forward shapes in whole rounds (x1.03...1.10)
+}
 
 extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void* B, void* C, int M, int N, int K,
                                int lda, int ldb, int ldc, int transA, int transB, int batch_outer, int batch_inner,
@@ -762,7 +1049,7 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
                                long long sCi, int splitk, float alpha, float beta, const float* bias,
                                const float* residual, int ldr, int act, const void* aux_in, void* aux_out,
                                int ld_aux, int c_dtype, float drop_p, unsigned long long seed, unsigned int site,
-                               float* colsum_out, float* arowsum_out) {
+                               float* colsum_out, float* arowsum_out, void* workspace, long long workspace_bytes) {
   MMDTI_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: M,N,K must be positive (got %d,%d,%d)", M, N, K);
   MMDTI_REQUIRE(A && B && C, "gemm: null operand");
   MMDTI_REQUIRE(aligned16(A) && aligned16(B), "gemm: A and B must be 16-byte aligned");
@@ -790,6 +1077,8 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
   a.seed = seed; a.site = site;
   a.colsum = colsum_out;
   a.arowsum = nullptr;
+  a.slab = 0;
+  a.dbg = g_gemm_dbg;
   {
     // streaming stores for outputs of at least MMDTI_GEMM_STREAM_MB (default 96 MB; 0 = always, negative = never)
     static const long long stream_mb = getenv("MMDTI_GEMM_STREAM_MB") ? atoll(getenv("MMDTI_GEMM_STREAM_MB")) : 96;
@@ -850,6 +1139,52 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
   // (a small split-K weight gradient that also carries its bias gradient takes the double-buffered kernel too: +6 us
   //  there against a 35-50 us column-sum pass over dy)
   const bool dbuf_path = fast && use_glds && ((splitk > 1 && (tiles >= 48 || (arowsum_out && transA))) || use_glds == 3);
+  // 256 x 256 tiles with the DMA in flight across barriers (gemm_big_kernel): MMDTI_GEMM_BIG=0 off, 1 (default) where
+  // the shape fills the chip, 2 every eligible shape
+  const int use_big = g_gemm_big;
+  const bool big_ok = fast && use_big && batch_outer * batch_inner == 1 && !colsum_out && M >= 256 && N >= 256 &&
+                      (c_dtype == MMDTI_DT_F32_ATOMIC || a.vec_ok) && M % 256 == 0 && N % 256 == 0;
+  if (big_ok && (use_big == 2 || big_shape_pays(M, N, K, splitk, transA, transB))) {
+    typedef void (*bkern_t)(GemmArgs);
+    static const bkern_t bkerns[2][2] = {{gemm_big_kernel<false, false>, gemm_big_kernel<false, true>},
+                                         {gemm_big_kernel<true, false>, gemm_big_kernel<true, true>}};
+    const size_t smem_b = (size_t)2 * BIG_BUF * sizeof(bf16_t);
+    static bool big_attr = false;
+    if (!big_attr) {
+      for (int i = 0; i < 4; ++i)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(bkerns[i >> 1][i & 1]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b) != hipSuccess) {
+          set_error("gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", smem_b);
+          return MMDTI_ERR_LAUNCH;
+        }
+      big_attr = true;
+    }
+    const int btiles = cdiv(M, BBM) * cdiv(N, BBN);
+    int sk = splitk;
+    if (splitk > 1) {   // weight gradients: about one workgroup per CU, at least 4 K-tiles per split
+      sk = max(1, min(K / BK / 4, cdiv(256, btiles)));
+      const int kts = K / BK, per = cdiv(kts, sk);
+      sk = cdiv(kts, per);          // no empty split (the slab form sums EVERY slab)
+    }
+    a.splitk = sk;
+    a.arowsum = arowsum_out;
+    dim3 bgrid(btiles, 1, sk);
+    const long long slab = (long long)M * N;
+    const bool slabs = sk > 1 && workspace && aligned16(workspace) && workspace_bytes >= (long long)sk * slab * 4 && N % 8 == 0 &&
+                       alpha == 1.f && !bias && !residual && act == MMDTI_ACT_NONE && slab % 4 == 0 && aligned16(C) && ldc % 4 == 0;
+    if (slabs && !(g_gemm_dbg & 1)) {
+      // split ks stores its partial tile into slab ks (vector epilogue, plain stores); splitk_reduce_kernel adds the sum into C
+      GemmArgs p = a;
+      p.C = workspace; p.ldc = N; p.c_dtype = MMDTI_DT_F32; p.beta = 0.f; p.vec_ok = 1; p.stream_c = 0; p.slab = slab;
+      hipLaunchKernelGGL(bkerns[transA ? 1 : 0][transB ? 1 : 0], bgrid, dim3(512), smem_b, s, p);
+      const long long n4 = slab / 4;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)min((n4 + 255) / 256, 4096LL)), dim3(256), 0, s, (const float*)workspace,
+                         reinterpret_cast<float*>(C), M, N, ldc, sk);
+    } else {
+      hipLaunchKernelGGL(bkerns[transA ? 1 : 0][transB ? 1 : 0], bgrid, dim3(512), smem_b, s, a);
+    }
+    MMDTI_LAUNCH_CHECK();
+    return MMDTI_OK;
+  }
   if (arowsum_out) {
     if (dbuf_path) {
       a.arowsum = arowsum_out;

@@ -53,7 +53,8 @@ def _u8(mask):
 # --------------------------------------------------------------------------------------------- GEMM
 def gemm(A, B, *, M, N, K, lda, ldb, out=None, ldc=None, transA=False, transB=False, batch=(1, 1),
          sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, alpha=1.0, beta=0.0, bias=None, residual=None, act=ACT_NONE,
-         aux_in=None, aux_out=None, out_dtype=BF16, atomic=False, drop_p=0.0, seed=0, site=0, out_shape=None, colsum=None, arowsum=None):
+         aux_in=None, aux_out=None, out_dtype=BF16, atomic=False, drop_p=0.0, seed=0, site=0, out_shape=None, colsum=None, arowsum=None,
+         workspace=None):
     """C = epi(alpha * A.B^T); see mmdti_gemm_bf16.  A/B are bf16 tensors (any shape; lda/ldb given explicitly)."""
     _chk(A, BF16, "gemm.A", contiguous=False)
     _chk(B, BF16, "gemm.B", contiguous=False)
@@ -69,8 +70,11 @@ def gemm(A, B, *, M, N, K, lda, ldb, out=None, ldc=None, transA=False, transB=Fa
                           int(transA), int(transB), batch[0], batch[1], sA[0], sA[1], sB[0], sB[1], sC[0], sC[1],
                           splitk, float(alpha), float(beta), _p(bias), _p(residual), ldc if residual is None else residual.stride(-2),
                           act, _p(aux_in), _p(aux_out), N if (aux_in is None and aux_out is None) else (aux_in if aux_in is not None else aux_out).stride(-2),
-                          c_dtype, float(drop_p), int(seed), int(site), _p(colsum), _p(arowsum))
-    kernel_timer.end("gemm", t0, 2.0 * M * N * K * batch[0] * batch[1])
+                          c_dtype, float(drop_p), int(seed), int(site), _p(colsum), _p(arowsum), _p(workspace),
+                          0 if workspace is None else workspace.numel() * workspace.element_size())
+    kernel_timer.end("gemm", t0, 2.0 * M * N * K * batch[0] * batch[1],
+                     tag=(M, N, K, int(transA), int(transB), batch[0] * batch[1], splitk, act, out.dtype == BF16, aux_in is not None or aux_out is not None,
+                          residual is not None))
     return out
 
 
@@ -101,6 +105,7 @@ def _splitk_for(M, N, K):
 
 
 DW_BIAS = os.environ.get("MMDTI_DW_BIAS", "1") != "0"
+SPLITK_SLABS = os.environ.get("MMDTI_SPLITK_SLABS", "1") != "0"
 
 
 def linear_bwd_weight(dy, x, dw, *, rows=None, db=None):
@@ -113,8 +118,14 @@ def linear_bwd_weight(dy, x, dw, *, rows=None, db=None):
         if not DW_BIAS:                                  # MMDTI_DW_BIAS=0: the separate column-sum pass (A/B switch)
             colsum(dy, db, cols=N)
             db = None
+    # split-K scratch for the large-tile kernel (one fp32 partial per split, summed by a second pass: no atomics); from the
+    # caching allocator, so it is tied to the launch stream like any other temporary
+    ws = None
+    if SPLITK_SLABS and N % 256 == 0 and K % 256 == 0 and M >= 4096:
+        tiles = (N // 256) * (K // 256)
+        ws = torch.empty(min(-(-256 // tiles), M // 256) * N * K, device=dy.device, dtype=F32)
     gemm(dy, x, M=N, N=K, K=M, lda=dy.stride(0), ldb=x.stride(0), transA=True, transB=True, out=dw, ldc=dw.stride(0),
-         atomic=True, splitk=_splitk_for(N, K, M), arowsum=db)
+         atomic=True, splitk=_splitk_for(N, K, M), arowsum=db, workspace=ws)
     return dw
 
 
@@ -589,11 +600,13 @@ class _KernelTimer:
         self.names = ()
         self.events = {}
         self.work = {}
+        self.tags = {}
 
     def enable(self, names):
         self.names = tuple(names)
         self.events = {n: [] for n in self.names}
         self.work = {n: 0.0 for n in self.names}
+        self.tags = {n: [] for n in self.names}
 
     def disable(self):
         self.names = ()
@@ -605,14 +618,29 @@ class _KernelTimer:
         e.record()
         return e
 
-    def end(self, name, e0, work=0.0):
-        """work: algorithmic flops (or bytes) of this launch, summed per name."""
+    def end(self, name, e0, work=0.0, tag=None):
+        """work: algorithmic flops (or bytes) of this launch, summed per name; tag: anything that identifies the launch's
+        shape (by_tag() groups on it)."""
         if e0 is None:
             return
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         self.events[name].append((e0, e1))
         self.work[name] += work
+        self.tags[name].append((tag, work))
+
+    def by_tag(self, name):
+        """{tag: {"n", "mean_ms", "total_ms", "work"}} of the launches recorded under `name`."""
+        torch.cuda.synchronize()
+        out = {}
+        for (a, b), (tag, work) in zip(self.events.get(name, ()), self.tags.get(name, ())):
+            d = out.setdefault(tag, {"n": 0, "total_ms": 0.0, "work": 0.0})
+            d["n"] += 1
+            d["total_ms"] += a.elapsed_time(b)
+            d["work"] += work
+        for d in out.values():
+            d["mean_ms"] = d["total_ms"] / d["n"]
+        return out
 
     def summary(self):
         torch.cuda.synchronize()

@@ -1,0 +1,93 @@
+"""Correctness + A/B timing of gemm_big_kernel (256x256, DMA in flight across barriers) against the 128x128 kernels and torch."""
+import os, sys, json, itertools
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "mm-dti_amd"))
+import torch
+from mmdti_hip import ops
+lib = ops.lib()
+def setbig(v): lib.mmdti_set_option(b"gemm_big", v)
+dev = "cuda"
+g = torch.Generator(device="cpu").manual_seed(0)
+def rnd(*shape, scale=1.0): return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).to(dev)
+
+def run(M, N, K, tA, tB, mode):
+    """mode: 'bf16' plain, 'gelu' (bias + GELU_G + aux_out), 'mulaux', 'res' (fp32 out + residual + bias), 'atomic' (split-K fp32 += with arowsum)"""
+    A = rnd(K, M) if tA else rnd(M, K)
+    B = rnd(K, N) if tB else rnd(N, K)
+    Af = (A.float().t() if tA else A.float()); Bf = (B.float().t() if tB else B.float())
+    ref = Af @ Bf.t()
+    kw = dict(M=M, N=N, K=K, lda=A.stride(0), ldb=B.stride(0), transA=bool(tA), transB=bool(tB))
+    outs = {}
+    for big in (0, 2):
+        setbig(big)
+        if mode == "bf16":
+            o = ops.gemm(A, B, **kw); got = (o.float(),)
+            want = (ref,)
+        elif mode == "gelu":
+            bias = torch.randn(N, generator=g).to(dev) * 0.1
+            aux = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            o = ops.gemm(A, B, bias=bias, act=ops.ACT_GELU_G, aux_out=aux, **kw)
+            u = (ref * 0.05 + 0) if False else ref
+            z = ref + bias
+            want = (torch.nn.functional.gelu(z), 0.5 * (1 + torch.erf(z / 2 ** 0.5)) + z * torch.exp(-0.5 * z * z) / (2 * 3.141592653589793) ** 0.5)
+            got = (o.float(), aux.float())
+        elif mode == "mulaux":
+            aux = rnd(M, N)
+            o = ops.gemm(A, B, act=ops.ACT_MUL_AUX, aux_in=aux, **kw); got = (o.float(),); want = (ref * aux.float(),)
+        elif mode == "res":
+            bias = torch.randn(N, generator=g).to(dev) * 0.1
+            res = torch.randn(M, N, generator=g).to(dev)
+            o = ops.gemm(A, B, bias=bias, residual=res, out_dtype=torch.float32, **kw); got = (o,); want = (ref + bias + res,)
+        elif mode == "atomic":
+            out = torch.ones(M, N, device=dev, dtype=torch.float32)
+            rs = torch.zeros(M, device=dev, dtype=torch.float32)
+            ops.gemm(A, B, out=out, ldc=N, atomic=True, splitk=ops._splitk_for(M, N, K), arowsum=rs if tA else None, workspace=WS if big else None, **kw)
+            got = (out, rs) if tA else (out,); want = (ref + 1.0, Af.sum(1)) if tA else (ref + 1.0,)
+        outs[big] = got
+        for gt, wt in zip(got, want):
+            err = (gt - wt).abs().max().item() / (wt.abs().max().item() + 1e-9)
+            tol = 2e-2 if mode in ("bf16", "gelu", "mulaux") else 2e-3
+            assert err < tol, (M, N, K, tA, tB, mode, big, err)
+    # timing
+    def bench(big, reps=20):
+        setbig(big)
+        fn = {"bf16": lambda: ops.gemm(A, B, **kw),
+              "gelu": lambda: ops.gemm(A, B, bias=bias, act=ops.ACT_GELU_G, aux_out=aux, **kw),
+              "mulaux": lambda: ops.gemm(A, B, act=ops.ACT_MUL_AUX, aux_in=aux, **kw),
+              "res": lambda: ops.gemm(A, B, bias=bias, residual=res, out_dtype=torch.float32, **kw),
+              "atomic": lambda: ops.gemm(A, B, out=out, ldc=N, atomic=True, splitk=ops._splitk_for(M, N, K), arowsum=rs if tA else None, workspace=WS if big else None, **kw)}[mode]
+        for _ in range(3): fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps): fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
+    t0, t2 = bench(0), bench(2)
+    lib.mmdti_set_option(b"gemm_dbg", 1)
+    tl = bench(2)
+    lib.mmdti_set_option(b"gemm_dbg", 0)
+    tf = 2.0 * M * N * K / 1e6
+    print(f"{M:6d} {N:5d} {K:6d} tA={tA} tB={tB} {mode:7s} old {t0:8.1f} us ({tf / t0:5.0f} TF)   big {t2:8.1f} us ({tf / t2:5.0f} TF)   x{t0 / t2:.2f}   big loop only {tl:7.1f} us ({tf / tl:5.0f} TF)", flush=True)
+    return dict(M=M, N=N, K=K, tA=tA, tB=tB, mode=mode, old_us=t0, big_us=t2)
+
+WS = torch.empty(64 * 1024 * 1024, device=dev, dtype=torch.float32)
+rows = []
+quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+# correctness on awkward shapes first
+for (M, N, K, tA, tB, mode) in [(256, 256, 64, 0, 0, "bf16"), (256, 256, 128, 0, 0, "bf16"), (512, 768, 192, 0, 1, "bf16"), (520, 264, 256, 0, 0, "bf16"),
+                                (1000, 1000, 320, 1, 1, "atomic"), (768, 512, 4096, 1, 1, "atomic"), (300, 520, 512, 0, 0, "res"), (512, 512, 512, 1, 0, "bf16"),
+                                (2048, 512, 1024, 0, 1, "mulaux"), (1024, 2048, 512, 0, 0, "gelu")]:
+    rows.append(run(M, N, K, tA, tB, mode))
+if not quick:
+    for (M, N, K, tA, tB, mode) in [
+        (33280, 2048, 512, 0, 0, "gelu"), (33280, 2048, 512, 0, 1, "mulaux"), (65536, 2048, 512, 0, 0, "gelu"), (65536, 2048, 512, 0, 1, "mulaux"),
+        (33280, 512, 2048, 0, 0, "res"), (65536, 512, 2048, 0, 0, "res"), (33280, 512, 2048, 0, 1, "bf16"), (65536, 512, 2048, 0, 1, "bf16"),
+        (33280, 1536, 512, 0, 0, "bf16"), (65536, 1536, 512, 0, 0, "bf16"), (33280, 512, 1536, 0, 1, "bf16"), (65536, 512, 1536, 0, 1, "bf16"),
+        (33280, 512, 512, 0, 0, "res"), (65536, 512, 512, 0, 0, "res"), (33280, 512, 512, 0, 1, "bf16"), (65536, 512, 512, 0, 1, "bf16"),
+        (512, 2048, 33280, 1, 1, "atomic"), (2048, 512, 33280, 1, 1, "atomic"), (1536, 512, 33280, 1, 1, "atomic"), (512, 512, 33280, 1, 1, "atomic"),
+        (512, 2048, 65536, 1, 1, "atomic"), (2048, 512, 65536, 1, 1, "atomic"), (1536, 512, 65536, 1, 1, "atomic"), (512, 512, 65536, 1, 1, "atomic"),
+        (8192, 8192, 8192, 0, 0, "bf16"), (4096, 4096, 4096, 0, 0, "bf16")]:
+        rows.append(run(M, N, K, tA, tB, mode))
+json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "gemm_big_ab.json"), "w"), indent=1)
+setbig(1)

@@ -1,0 +1,37 @@
+"""Per-shape GEMM time inside the bench step (every stream overlap off: each launch alone on the chip), with the
+roofline bound of each shape: max(2MNK / 2.5 PF, bytes / 6.3 TB/s)."""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "mm-dti_amd"))
+import torch, bench
+from mmdti_hip import ops
+from mmdti_hip import functional as Fn
+from mmdti_hip.trainer import FineTuner
+model, _ = bench.build_model()
+model = model.cuda().train()
+model.overlap_towers = False; model.infonce_on_side_stream = False; model.cross_modal_module.two_streams = False; Fn.DEFER_WGRAD_LAYERS = 0
+tuner = FineTuner(model, "classification", total_steps=1000)
+_, batch, label = bench.synth(256, 128, 256, seed=1234)
+batch = {k: v.cuda() for k, v in batch.items()}; label = label.cuda()
+for _ in range(3): tuner.step(batch, label)
+torch.cuda.synchronize()
+ops.kernel_timer.enable(("gemm",))
+for _ in range(3): tuner.step(batch, label)
+rows = ops.kernel_timer.by_tag("gemm")
+ops.kernel_timer.disable()
+tot = 0.0
+out = []
+for tag, d in rows.items():
+    M, N, K, tA, tB, nb, sk, act, obf, aux, res = tag
+    flops = 2.0 * M * N * K * nb
+    byts = 2.0 * nb * (M * K + N * K) + (2 if obf else 4) * nb * M * N * (2 if (res or sk > 1) else 1) + (2 * M * N if aux else 0)
+    t_mfma, t_hbm = flops / 2.5e15 * 1e6, byts / 6.3e12 * 1e6
+    us = d["mean_ms"] * 1e3
+    out.append(dict(M=M, N=N, K=K, tA=tA, tB=tB, batch=nb, splitk=sk, act=act, n_per_step=d["n"] / 3, us=us, tflops=flops / us / 1e6, bound_us=max(t_mfma, t_hbm),
+                    bound="mfma" if t_mfma > t_hbm else "hbm", ms_per_step=d["total_ms"] / 3, frac_of_bound=max(t_mfma, t_hbm) / us))
+out.sort(key=lambda r: -r["ms_per_step"])
+print(f"{'M':>6} {'N':>5} {'K':>6} tA tB  sk act  n/step     us   TF/s  bound_us bound  frac  ms/step")
+for r in out:
+    print(f"{r['M']:6d} {r['N']:5d} {r['K']:6d}  {r['tA']}  {r['tB']} {r['splitk']:3d} {r['act']:3d} {r['n_per_step']:7.1f} {r['us']:7.1f} {r['tflops']:6.0f} {r['bound_us']:9.1f} {r['bound']:>5} {r['frac_of_bound']:5.2f} {r['ms_per_step']:8.3f}")
+print("total GEMM ms/step", sum(r["ms_per_step"] for r in out), " at-bound ms/step", sum(r["bound_us"] * r["n_per_step"] for r in out) / 1e3)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "gemm_shapes.json"), "w"), indent=1)

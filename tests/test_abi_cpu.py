@@ -33,7 +33,7 @@ def test_argument_validation_happens_before_any_launch():
     lib = _abi.lib()
     assert lib._dll.mmdti_abi_version() == 1
     with pytest.raises(_abi.MMDTIError, match="multiples of 8"):
-        lib.mmdti_gemm_bf16(0, 16, 16, 16, 8, 8, 12, 12, 12, 8, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0, 0)
+        lib.mmdti_gemm_bf16(0, 16, 16, 16, 8, 8, 12, 12, 12, 8, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0, 0, 0, 0)
     with pytest.raises(_abi.MMDTIError, match="exceeds"):
         lib.mmdti_pair_attn_fwd(0, 16, 16, 16, 16, 0, 1, 400, 8, 400, 0.35, 0.0, 0, 0, 0)
     with pytest.raises(_abi.MMDTIError, match="temperature"):
