@@ -11,12 +11,19 @@ the reference's probabilities.  Weak scaling: 256 molecules per rank; InfoNCE ne
   python bench.py --gpus 1 --steps 10 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, timed live with HIP
-events on the launch stream) and `cpu_baseline` (the CPU oracle on a bounded sample of the same workload).
+Prints ONE JSON line on rank 0 (contract in the task statement):
+  roofline      the kernel family that takes the most GPU time of the step (the GEMMs: bound "mfma"), timed live with HIP
+                events on the launch streams;
+  rooflines     the same for every hot kernel family (pair attention fwd/bwd, the fused pair-distance kernel fwd/bwd that
+                the north star names for the HBM figure, fused attention fwd/bwd, LayerNorm fwd/bwd, GEMMs), each with its
+                algorithmic bytes or flops per launch, mean launch time and fraction of the 8 TB/s / 2.5 PF peak;
+  cpu_baseline  the fp32 CPU oracle (kind "port") on a bounded sample of the same workload, median of 3 steps.
 """
 import argparse
+import glob
 import json
 import os
+import statistics
 import sys
 import time
 from types import SimpleNamespace
@@ -26,6 +33,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "mm-dti_amd"))
 
 import torch
+
+HBM_PEAK_GBS, MFMA_PEAK_TFS = 8000.0, 2500.0          # /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def build_model(task="classification", output_dim=2):
@@ -38,51 +47,96 @@ def build_model(task="classification", output_dim=2):
 
 
 def synth(B, atoms, tokens, seed, task="classification", ragged=False):
-    from oracle import mmdti_oracle as O          # synthetic-batch generator only (seeded numpy); no oracle compute here
-    cfg = O.ModelCfg(task=task, output_dim=2 if task == "classification" else 1)
-    batch, label = O.synth_batch(B, atoms, tokens, cfg, seed=seed, ragged=ragged)
-    return cfg, batch, label
+    """Seeded synthetic collated batch (mmdti_hip.synth: the reference's layout, host-side numpy)."""
+    from mmdti_hip.synth import synth_batch
+    batch, label = synth_batch(B, atoms, tokens, task=task, seed=seed, ragged=ragged)
+    return None, batch, label
 
 
-def cpu_baseline(atoms, tokens, sample_B=8, iters=2):
-    """The CPU oracle (fp32 PyTorch restatement, kind='port') fwd+bwd on a bounded sample of the same workload."""
+def cpu_baseline(atoms, tokens, sample_B=32, iters=3, scaling_B=8):
+    """The CPU oracle (fp32 PyTorch restatement, kind='port') fwd+bwd on a bounded sample of the same workload: median of
+    `iters` timed steps after one warm-up at sample_B molecules, plus one timed step at scaling_B to show how the rate
+    depends on the sample size (small GEMMs under-use many cores)."""
     from oracle import mmdti_oracle as O
     torch.set_num_threads(max(1, min(os.cpu_count() or 1, 64)))
     cfg = O.ModelCfg(task="classification", output_dim=2)
     P = {k: v.requires_grad_() for k, v in O.init_params(cfg, seed=1).items()}
-    batch, label = O.synth_batch(sample_B, atoms, tokens, cfg, seed=99, ragged=False)
 
-    def one():
-        for p in P.values():
-            p.grad = None
-        out = O.mm_forward(batch, P, cfg, net_target=label, training=True)
-        loss, _ = O.step_loss(out, label, cfg.task)
-        loss.backward()
+    def timed(B, n):
+        batch, label = O.synth_batch(B, atoms, tokens, cfg, seed=99, ragged=False)
 
-    one()
-    t0 = time.perf_counter()
-    for _ in range(iters):
+        def one():
+            for p in P.values():
+                p.grad = None
+            out = O.mm_forward(batch, P, cfg, net_target=label, training=True)
+            loss, _ = O.step_loss(out, label, cfg.task)
+            loss.backward()
+
         one()
-    dt = (time.perf_counter() - t0) / iters
-    return {"value": sample_B / dt, "unit": "molecules/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{iters} timed fwd+bwd steps (after 1 warm-up) of the fp32 PyTorch-CPU oracle on {sample_B} molecules x {atoms} atoms x {tokens} "
-                      f"tokens, same architecture, dropout on; {dt:.2f} s/step"}
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            one()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts)
+
+    small = timed(scaling_B, 1) if scaling_B and scaling_B < sample_B else None
+    dt = timed(sample_B, iters)
+    out = {"value": sample_B / dt, "unit": "molecules/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"median of {iters} fwd+bwd steps (after 1 warm-up) of the fp32 PyTorch-CPU oracle on {sample_B} molecules x {atoms} atoms x "
+                     f"{tokens} tokens, same architecture, dropout on; {dt:.2f} s/step"}
+    if small:
+        out["scaling"] = {f"B{scaling_B}_molecules_per_s": round(scaling_B / small, 3), f"B{sample_B}_molecules_per_s": round(sample_B / dt, 3)}
+    return out
 
 
 def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of `kernel_prefix` from the committed PMC summary (profiles/r01_bench_pmc_hbm_traffic.csv:
-    separate FETCH_SIZE / WRITE_SIZE rocprofv3 passes of this same command, gfx950 units already applied there).  PMC
-    counters cannot be collected from inside the timed run, so this is the recorded value or null."""
-    path = os.path.join(ROOT, "profiles", "r01_bench_pmc_hbm_traffic.csv")
-    try:
-        import csv
-        with open(path) as f:
-            for row in csv.DictReader(line for line in f if not line.startswith("#")):
-                if kernel_prefix in row["kernel"]:
-                    return int(float(row["hbm_bytes_per_launch"]))
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+    """HBM bytes per launch of `kernel_prefix` from the NEWEST committed PMC summary (profiles/r*_bench_pmc_hbm_traffic.csv:
+    separate FETCH_SIZE / WRITE_SIZE rocprofv3 passes of this command, gfx950 corrections applied by profiles/summarize.py).
+    PMC counters cannot be collected from inside the timed run, so this is the recorded value, or null."""
+    import csv
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_hbm_traffic.csv")), reverse=True):
+        try:
+            with open(path) as f:
+                for row in csv.DictReader(line for line in f if not line.startswith("#")):
+                    if row["kernel"].replace("mmdti::", "").startswith(kernel_prefix):
+                        return int(float(row["hbm_bytes_per_launch"])), os.path.basename(path)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+# kernel families timed live: name -> (device kernel-name prefix for the PMC lookup, bound)
+FAMILIES = {
+    "pair_attn_fwd": ("pair_attn_fwd_mfma_kernel", "hbm"),
+    "pair_attn_bwd": ("pair_attn_bwd_mfma_kernel", "hbm"),
+    "gbf_bias_fwd": ("gbf_bias_fwd_kernel", "hbm"),        # "the pair-distance kernel" of the north star
+    "gbf_bias_bwd": ("gbf_bias_bwd_kernel", "hbm"),
+    "ln_fwd": ("ln_fwd_kernel", "hbm"),
+    "ln_bwd": ("ln_bwd_kernel", "hbm"),
+    "attn_fwd": ("attn_fwd_kernel", "mfma"),
+    "attn_bwd": ("attn_bwd_q_kernel", "mfma"),
+    "gemm": ("gemm_", "mfma"),
+}
+
+
+def family_rooflines(summary, steps):
+    rows = []
+    for name, (prefix, bound) in FAMILIES.items():
+        d = summary.get(name)
+        if not d or not d["total_ms"]:
+            continue
+        per_launch = d["work"] / d["n"]
+        rate = d["work"] / (d["total_ms"] * 1e-3)
+        peak = HBM_PEAK_GBS if bound == "hbm" else MFMA_PEAK_TFS
+        ach = rate / 1e9 if bound == "hbm" else rate / 1e12
+        traffic, src = pmc_traffic(prefix) if bound == "hbm" else (None, None)
+        rows.append({"kernel": name, "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+                     "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": src,
+                     ("algorithmic_bytes_per_launch" if bound == "hbm" else "algorithmic_flop_per_launch"): int(per_launch),
+                     "mean_launch_ms": round(d["mean_ms"], 4), "launches_per_step": round(d["n"] / steps, 1), "ms_per_step": round(d["total_ms"] / steps, 3)})
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    return rows
 
 
 def main():
@@ -94,7 +148,8 @@ def main():
     ap.add_argument("--atoms", type=int, default=128)
     ap.add_argument("--tokens", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=8)
+    ap.add_argument("--cpu-sample", type=int, default=32)
+    ap.add_argument("--no-rooflines", action="store_true", help="skip the extra (untimed) steps that time every kernel family")
     ap.add_argument("--ragged", action="store_true", help="molecules of mixed length padded to the batch maximum (not the headline workload)")
     args = ap.parse_args()
 
@@ -130,80 +185,79 @@ def main():
     for _ in range(args.warmup):
         out = tuner.step(batch, label, epoch=0)
     barrier()
-    ops.kernel_timer.enable(("pair_attn_bwd", "pair_attn_fwd", "gbf_features_fwd"))
+    # inside the timed region only the two pair-attention kernels are event-timed (30 launches per step); everything else is
+    # timed in extra steps afterwards so that ~1 000 event pairs per step do not perturb `value`
+    ops.kernel_timer.enable(("pair_attn_bwd", "pair_attn_fwd"))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = tuner.step(batch, label, epoch=0)
     barrier()
     dt = time.perf_counter() - t0
+    in_step = ops.kernel_timer.summary()
     ops.kernel_timer.disable()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
     losses = {"loss": float(out.loss), "task": float(out.task_loss), "infonce": float(out.infonce_loss), "ct": float(out.ct_loss)}
-    # MFMA side of the roofline: every GEMM launch of two EXTRA steps (outside the timed region: ~600 event pairs per
-    # step would perturb `value`) timed with HIP events on its launch stream; algorithmic flops 2*M*N*K per launch.
-    # (every rank runs them: the step holds collectives)
-    # Twice: towers overlapped as in the timed region (a launch's event time then includes sharing the chip with the
-    # other tower's kernels), and towers back to back on one stream (each launch alone on the chip).
-    pa_timers = ops.kernel_timer.summary()
-    gemm_timers = {}
-    from mmdti_hip import functional as Fn
-    was = (model.overlap_towers, model.infonce_on_side_stream, model.cross_modal_module.two_streams, Fn.DEFER_WGRAD_LAYERS)
-    for mode, ov in (("overlapped", True), ("alone", False)):
-        if not ov:      # every stream-level overlap off: each launch has the chip to itself
-            model.overlap_towers, model.infonce_on_side_stream, model.cross_modal_module.two_streams, Fn.DEFER_WGRAD_LAYERS = False, False, False, 0
-        ops.kernel_timer.enable(("gemm",))
-        for _ in range(2):
-            tuner.step(batch, label, epoch=0)
-        gemm_timers[mode] = ops.kernel_timer.summary().get("gemm")
-        ops.kernel_timer.disable()
-    model.overlap_towers, model.infonce_on_side_stream, model.cross_modal_module.two_streams, Fn.DEFER_WGRAD_LAYERS = was
+
+    # every kernel family in two extra modes (every rank runs them: the step holds collectives):
+    #   "overlapped": streams as in the timed region (a launch's event time includes sharing the chip with the other tower);
+    #   "alone"     : towers back to back on one stream, every stream-level overlap off -- each launch has the chip to itself.
+    fam = {}
+    extra = 0 if args.no_rooflines else 2
+    if extra:
+        from mmdti_hip import functional as Fn
+        was = (model.overlap_towers, model.infonce_on_side_stream, model.cross_modal_module.two_streams, Fn.DEFER_WGRAD_LAYERS)
+        for mode, ov in (("overlapped", True), ("alone", False)):
+            if not ov:
+                model.overlap_towers, model.infonce_on_side_stream, model.cross_modal_module.two_streams, Fn.DEFER_WGRAD_LAYERS = False, False, False, 0
+            ops.kernel_timer.enable(tuple(FAMILIES))
+            for _ in range(extra):
+                tuner.step(batch, label, epoch=0)
+            fam[mode] = ops.kernel_timer.summary()
+            ops.kernel_timer.disable()
+        model.overlap_towers, model.infonce_on_side_stream, model.cross_modal_module.two_streams, Fn.DEFER_WGRAD_LAYERS = was
     barrier()
 
     if rank == 0:
         N = int(batch["src_tokens"].shape[1])
-        H = 64
-        timers = pa_timers
-        # dominant HBM-bound kernel: pair attention backward.  Algorithmic bytes per launch (DESIGN.md "roofline"):
-        # per atom pair and head: read S (4 B) + read G (4 B) + write G (4 B) = 12 B  -> 768 B per pair over 64 heads,
-        # plus q|k|v|dO|dqkv rows (7 x 16 B per (token, head)).
-        pairs = args.batch * N * N
-        pa_bytes = pairs * H * 12 + args.batch * N * H * 7 * 16
-        ms = timers.get("pair_attn_bwd", {}).get("mean_ms")
-        roofline = None
-        if ms:
-            ach = pa_bytes / (ms * 1e-3) / 1e9
-            roofline = {"kernel": "pair_attn_bwd_mfma_kernel<9, true, true, 3>", "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
-                        "frac": round(ach / 8000.0, 4), "traffic": pmc_traffic("pair_attn_bwd_mfma_kernel"), "algorithmic_bytes_per_launch": pa_bytes,
-                        "mean_launch_ms": round(ms, 4), "launches_timed": timers["pair_attn_bwd"]["n"], "other_kernels_ms": {k: round(v["mean_ms"], 4) for k, v in timers.items()}}
-        roofline_mfma = None
-        if gemm_timers.get("alone"):
-            ga, go = gemm_timers["alone"], gemm_timers["overlapped"]
-            tf = ga["work"] / (ga["total_ms"] * 1e-3) / 1e12
-            roofline_mfma = {"kernel": "gemm_glds_kernel / gemm_glds_tall_kernel / gemm_bf16_kernel (all GEMM launches of a step)", "bound": "mfma",
-                             "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": None,
-                             "launches_per_step": ga["n"] // 2, "gemm_ms_per_step": round(ga["total_ms"] / 2, 3),
-                             "algorithmic_tflop_per_step": round(ga["work"] / 2 / 1e12, 3),
-                             "achieved_with_towers_overlapped": round(go["work"] / (go["total_ms"] * 1e-3) / 1e12, 1),
-                             "note": "HIP events around every GEMM launch of 2 extra steps after the timed region, towers back to back on one stream "
-                                     "(each launch alone on the chip); achieved_with_towers_overlapped: same with the two towers sharing the chip"}
+        rooflines, roofline = [], None
+        if fam:
+            rooflines = family_rooflines(fam["alone"], extra)
+            over = {r["kernel"]: r for r in family_rooflines(fam["overlapped"], extra)}
+            for r in rooflines:
+                o = over.get(r["kernel"])
+                if o:
+                    r["achieved_in_overlapped_step"] = o["achieved"]
+                    r["ms_per_step_overlapped"] = o["ms_per_step"]
+            # the two pair-attention kernels were also timed INSIDE the timed region: report those launch times too
+            for r in rooflines:
+                d = in_step.get(r["kernel"])
+                if d:
+                    r["mean_launch_ms_in_timed_region"] = round(d["mean_ms"], 4)
+                    r["launches_timed_in_region"] = d["n"]
+            roofline = dict(rooflines[0])               # the family with the most GPU time per step
+            roofline["kernel"] = {"gemm": "gemm_glds_kernel / gemm_glds_tall_kernel / gemm_big_kernel / gemm_bf16_kernel (all GEMM launches of a step)"}.get(
+                roofline["kernel"], roofline["kernel"])
+            roofline["note"] = ("dominant kernel family by GPU time; HIP events on the launch stream around every launch of 2 extra steps after the timed "
+                                "region with every stream-level overlap off (each launch alone on the chip); achieved = algorithmic work / summed launch time")
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(args.atoms, args.tokens, args.cpu_sample)
         mols = args.batch * world * args.steps
+        shape = "mixed lengths padded to the batch maximum" if args.ragged else "all at max length"
         line = {
             "metric": "molecules/sec fwd+bwd (InfoNCE fine-tune)", "value": round(mols / dt, 2), "unit": "molecules/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"BBBP-like classification + SupCon + InfoNCE fine-tune step, {args.batch} molecules/GPU x {args.atoms} atoms x "
-                                   f"{args.tokens} SMILES tokens (all at max length), fwd+bwd+allreduce+clip+Adam, dropout on",
-                       "global_batch": args.batch * world, "atoms": args.atoms, "tokens": args.tokens, "parallelism": f"dp{world}",
+                                   f"{args.tokens} SMILES tokens ({shape}), fwd+bwd+allreduce+clip+Adam, dropout on",
+                       "global_batch": args.batch * world, "atoms": args.atoms, "tokens": args.tokens, "padded_N": N, "parallelism": f"dp{world}",
                        "unimol": "15L/512/64h", "chemberta_assumed": "6L/512/8h/ffn2048/vocab600", "infonce_negatives": "global",
                        "grad_buckets_reduced_during_backward": None if tuner.reducer is None or not tuner.reducer.active
                        else f"{tuner.reducer.overlapped}/{len(tuner.reducer.buckets)}"},
-            "losses_last_step": losses, "roofline": roofline, "roofline_mfma": roofline_mfma, "cpu_baseline": cpu,
+            "losses_last_step": losses, "roofline": roofline, "rooflines": rooflines, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if torch.distributed.is_initialized():

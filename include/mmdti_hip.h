@@ -78,6 +78,20 @@ int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void* B, void* C
                     unsigned long long seed, unsigned int site, float* colsum_out, float* arowsum_out, void* workspace,
                     long long workspace_bytes);
 
+/* ---- Grouped weight gradients of one transformer layer -----------------------------------------
+ * The weight half of nn.Linear's backward for up to 8 Linears that saw the SAME token rows (unicore in_proj / out_proj /
+ * fc1 / fc2 of one encoder layer, models/transformers.py:137-139; query|key|value / dense / intermediate / output of one
+ * RoBERTa or BertCrossAttention layer, mm_model.py:562, mm_module.py:470-587):
+ *   dw[i] [n_out[i], lddw[i]] fp32 += dy[i]^T . x[i],   db[i] [n_out[i]] fp32 += column sums of dy[i]   (db or db[i] may be null)
+ * dy[i]: [rows, ldy[i]] bf16, x[i]: [rows, ldx[i]] bf16; n_out, n_in multiples of 256; rows a multiple of 64.
+ * One launch over all output tiles with a K split chosen to fill the chip; partial sums go through `workspace`
+ * (mmdti_linear_dw_grouped_splits(total 256x256 tiles, rows) * sum_i n_out[i]*n_in[i] * 4 bytes) and a second pass adds
+ * them into dw.  The argument tables are HOST arrays of nprob entries. */
+int mmdti_linear_dw_grouped(mmdti_stream_t stream, int nprob, const void* const* dy_bf16, const void* const* x_bf16,
+                            float* const* dw, float* const* db, const int* n_out, const int* n_in, const int* ldy,
+                            const int* ldx, const int* lddw, int rows, void* workspace, long long workspace_bytes);
+int mmdti_linear_dw_grouped_splits(int tiles, int rows);
+
 /* ---- LayerNorm (unicore LayerNorm eps 1e-5: transformers.py:69,71,114,161; BertLayerNorm eps 1e-12:
  * mm_module.py:320-333; HF nn.LayerNorm) -------------------------------------------------------
  * y = LN(x)*gamma+beta, then optional dropout, then rows with row_zero[r]!=0 forced to 0

@@ -817,6 +817,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   const int n4row = N / 4;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     float4 s = *reinterpret_cast<const float4*>(slabs + i * 4);
+#pragma unroll 8
     for (int k = 1; k < splits; ++k) {
       const float4 v = *reinterpret_cast<const float4*>(slabs + (long long)k * M * N + i * 4);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
@@ -833,19 +834,12 @@ struct Frag4 {
   bf16x8 f0, f1, f2, f3;
 };
 
+// one 256 x 256 output tile (tm, tn), K-split ks of a.splitk
 template <bool TA, bool TB>
-__global__ __launch_bounds__(512, 1) void gemm_big_kernel(GemmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+__device__ __forceinline__ void big_tile(const GemmArgs& a, int tm, int tn, int ks, bf16_t* smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
-  const int tiles_n = (a.N + BBN - 1) / BBN, tiles_m = (a.M + BBM - 1) / BBM;
-  const int nwg = tiles_n * tiles_m;
-  const int orig = blockIdx.x;
-  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
   const int m0 = tm * BBM, n0 = tn * BBN;
-  const int ks = blockIdx.z;
   const int ktiles = a.K / BK;
   const int per = (ktiles + a.splitk - 1) / a.splitk;
   const int kt0 = ks * per, kt1 = min(ktiles, kt0 + per);
@@ -1014,6 +1008,80 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(GemmArgs a) {
   BIG_EPI(0) BIG_EPI(1) BIG_EPI(2) BIG_EPI(3) BIG_EPI(4) BIG_EPI(5) BIG_EPI(6) BIG_EPI(7)
 #undef BIG_EPI
 #undef BSTG_T
+}
+
+// XCD-aware bijective remap of a linear workgroup id (cdna guide T1): consecutive hardware ids go round-robin over the
+// 8 XCDs, so each XCD gets a contiguous chunk of the tile list
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512, 1) void gemm_big_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+  const int tiles_n = (a.N + BBN - 1) / BBN, tiles_m = (a.M + BBM - 1) / BBM;
+  const int wg = xcd_remap(blockIdx.x, tiles_n * tiles_m);
+  const int tm = wg / tiles_n;
+  big_tile<TA, TB>(a, tm, wg - tm * tiles_n, blockIdx.z, smem);
+}
+
+// ---- grouped weight gradients ------------------------------------------------------------------------------------------
+// The Linears of one transformer layer produce their weight gradients dW_i[N_i, K_i] = dy_i^T . x_i over the SAME token
+// range (33 280 / 65 536 rows).  One at a time, each is 4-16 output tiles of 256 x 256 and needs a 16- to 64-way K split
+// to fill 256 CUs -- and every split costs a 4 MB pass over dW (fp32 partials).  Launched together the layer's GEMMs are
+// 48 tiles, a 5-way split fills the chip, and the partial-sum traffic falls four-fold (255 -> 60 MB per tower-1 layer).
+constexpr int GROUP_MAX = 8;
+struct GroupProb {
+  const bf16_t* A;      // dy  [rows, N_out] (k-major: rows = tokens)
+  const bf16_t* B;      // x   [rows, N_in]
+  float* C;             // dW  [N_out, ldc] fp32 (+=)
+  float* arowsum;       // db  [N_out] (+=) or null
+  float* slab;          // this problem's partials: [splitk][N_out][N_in] fp32
+  int M, N, lda, ldb, ldc;
+  int tile0, tiles_n;   // first global tile id, tiles along N
+};
+struct GroupArgs {
+  GroupProb p[GROUP_MAX];
+  int nprob, ntiles, K, splitk;
+};
+
+__global__ __launch_bounds__(512, 1) void gemm_big_grouped_kernel(GroupArgs g) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+  const int wg = xcd_remap(blockIdx.x, g.ntiles);
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < GROUP_MAX; ++i) pi += (i < g.nprob && wg >= g.p[i].tile0) ? 1 : 0;
+  const GroupProb& pr = g.p[pi];
+  GemmArgs a;
+  a.A = pr.A; a.B = pr.B; a.C = pr.slab; a.M = pr.M; a.N = pr.N; a.K = g.K; a.lda = pr.lda; a.ldb = pr.ldb; a.ldc = pr.N;
+  a.batch_inner = 1; a.sAo = a.sAi = a.sBo = a.sBi = a.sCo = a.sCi = 0;
+  a.splitk = g.splitk; a.alpha = 1.f; a.beta = 0.f; a.bias = nullptr; a.residual = nullptr; a.ldr = 0; a.act = MMDTI_ACT_NONE;
+  a.aux_in = nullptr; a.aux_out = nullptr; a.ld_aux = 0; a.c_dtype = MMDTI_DT_F32; a.drop_thresh = 0; a.drop_scale = 1.f; a.seed = 0; a.site = 0;
+  a.vec_ok = 1; a.colsum = nullptr; a.stream_c = 0; a.dbg = 0; a.slab = (long long)pr.M * pr.N; a.arowsum = pr.arowsum;
+  const int t = wg - pr.tile0, tm = t / pr.tiles_n;
+  big_tile<true, true>(a, tm, t - tm * pr.tiles_n, blockIdx.z, smem);
+}
+
+// dW_i += sum over splits of slab_i[s]   (all problems of a group in one launch; blockIdx.y = problem)
+__global__ __launch_bounds__(256) void grouped_reduce_kernel(GroupArgs g) {
+  const GroupProb& pr = g.p[blockIdx.y];
+  const long long n4 = (long long)pr.M * pr.N / 4, stride = (long long)gridDim.x * 256;
+  const long long slab = (long long)pr.M * pr.N;
+  const int n4row = pr.N / 4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int k = 0; k < g.splitk; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(pr.slab + k * slab + i * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const long long row = i / n4row, col = (i - row * n4row) * 4;
+    float4* dst = reinterpret_cast<float4*>(pr.C + row * pr.ldc + col);
+    float4 c = *dst;
+    c.x += s.x; c.y += s.y; c.z += s.z; c.w += s.w;
+    *dst = c;
+  }
 }
 
 }  // namespace mmdti
@@ -1221,4 +1289,67 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
     hipLaunchKernelGGL(kerns[transA ? 1 : 0][transB ? 1 : 0][fast ? 1 : 0], grid, block, smem, s, a);
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
+}
+
+extern "C" int mmdti_linear_dw_grouped(mmdti_stream_t stream, int nprob, const void* const* dy_bf16, const void* const* x_bf16,
+                                       float* const* dw, float* const* db, const int* n_out, const int* n_in, const int* ldy,
+                                       const int* ldx, const int* lddw, int rows, void* workspace, long long workspace_bytes) {
+  MMDTI_REQUIRE(nprob >= 1 && nprob <= GROUP_MAX, "linear_dw_grouped: 1..%d problems (got %d)", GROUP_MAX, nprob);
+  MMDTI_REQUIRE(dy_bf16 && x_bf16 && dw && n_out && n_in && ldy && ldx && lddw, "linear_dw_grouped: null argument table");
+  MMDTI_REQUIRE(rows >= 1024 && rows % BK == 0, "linear_dw_grouped: rows must be a multiple of %d and >= 1024 (got %d)", BK, rows);
+  MMDTI_REQUIRE(workspace && aligned16(workspace), "linear_dw_grouped: a 16-byte aligned workspace is required");
+  GroupArgs g;
+  g.nprob = nprob; g.K = rows;
+  int tiles = 0;
+  long long elems = 0;
+  for (int i = 0; i < nprob; ++i) {
+    MMDTI_REQUIRE(dy_bf16[i] && x_bf16[i] && dw[i], "linear_dw_grouped: null operand in problem %d", i);
+    MMDTI_REQUIRE(n_out[i] > 0 && n_in[i] > 0 && n_out[i] % BBM == 0 && n_in[i] % BBN == 0, "linear_dw_grouped: dimensions must be multiples of 256 (problem %d: %d x %d)", i, n_out[i], n_in[i]);
+    MMDTI_REQUIRE(ldy[i] % 8 == 0 && ldx[i] % 8 == 0 && lddw[i] % 4 == 0 && aligned16(dy_bf16[i]) && aligned16(x_bf16[i]) && aligned16(dw[i]),
+                  "linear_dw_grouped: alignment (problem %d)", i);
+    MMDTI_REQUIRE((long long)BK * ldy[i] * 2 < 0x7fffffffLL && (long long)BK * ldx[i] * 2 < 0x7fffffffLL, "linear_dw_grouped: row stride too large");
+    GroupProb& p = g.p[i];
+    p.A = (const bf16_t*)dy_bf16[i]; p.B = (const bf16_t*)x_bf16[i]; p.C = dw[i]; p.arowsum = db ? db[i] : nullptr;
+    p.M = n_out[i]; p.N = n_in[i]; p.lda = ldy[i]; p.ldb = ldx[i]; p.ldc = lddw[i];
+    p.tile0 = tiles; p.tiles_n = n_in[i] / BBN;
+    tiles += (n_out[i] / BBM) * p.tiles_n;
+    elems += (long long)n_out[i] * n_in[i];
+  }
+  for (int i = nprob; i < GROUP_MAX; ++i) { g.p[i] = g.p[0]; g.p[i].tile0 = 0x7fffffff; }
+  g.ntiles = tiles;
+  const int kts = rows / BK;
+  int sk = max(1, min(kts / 4, cdiv(256, tiles)));
+  sk = cdiv(kts, cdiv(kts, sk));                     // no empty split: every slab is summed
+  g.splitk = sk;
+  MMDTI_REQUIRE(workspace_bytes >= (long long)sk * elems * 4, "linear_dw_grouped: workspace too small (%lld bytes needed for %d splits)",
+                (long long)sk * elems * 4, sk);
+  float* ws = reinterpret_cast<float*>(workspace);
+  for (int i = 0; i < nprob; ++i) {
+    g.p[i].slab = ws;
+    ws += (long long)sk * g.p[i].M * g.p[i].N;
+  }
+  const size_t smem_b = (size_t)2 * BIG_BUF * sizeof(bf16_t);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b) != hipSuccess) {
+      set_error("linear_dw_grouped: hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", smem_b);
+      return MMDTI_ERR_LAUNCH;
+    }
+    attr = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gemm_big_grouped_kernel, dim3(tiles, 1, sk), dim3(512), smem_b, s, g);
+  long long max_n4 = 0;
+  for (int i = 0; i < nprob; ++i) max_n4 = max(max_n4, (long long)g.p[i].M * g.p[i].N / 4);
+  hipLaunchKernelGGL(grouped_reduce_kernel, dim3((unsigned)min((max_n4 + 255) / 256, 2048LL), nprob), dim3(256), 0, s, g);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+/* splits the grouped weight-gradient launch will use for `tiles` output tiles over `rows` tokens (workspace sizing) */
+extern "C" int mmdti_linear_dw_grouped_splits(int tiles, int rows) {
+  if (tiles <= 0 || rows < BK) return 1;
+  const int kts = rows / BK;
+  const int sk = max(1, min(kts / 4, cdiv(256, tiles)));
+  return cdiv(kts, cdiv(kts, sk));
 }

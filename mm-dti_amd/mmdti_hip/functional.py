@@ -39,6 +39,30 @@ def _lin_bwd_params(dy_bf16, x_bf16, weight, bias, rows=None, bias_done=False):
         ops.colsum(dy_bf16, gb, cols=bias.numel())
 
 
+def _lin_bwd_params_many(calls, raw_items=()):
+    """calls: [(args, kwargs)] of _lin_bwd_params for Linears of ONE layer (same token rows): their weight gradients go out as a
+    single grouped launch (ops.linear_bwd_weight_grouped); bias gradients ride on it, leftovers take the column-sum pass.
+    raw_items: ready-made (dy, x, dw_buffer, db_buffer | None, rows | None) entries (fused query|key|value views)."""
+    items, late = list(raw_items), []
+    for args, kw in calls:
+        dy, x, weight, bias = args[:4]
+        rows, bias_done = kw.get("rows"), kw.get("bias_done", False)
+        gw = gbuf(weight)
+        gb = gbuf(bias) if (bias is not None and not bias_done) else None
+        if gw is None:
+            if gb is not None:
+                late.append((dy, gb, bias.numel()))
+            continue
+        rides = gb is not None and gb.numel() == gw.shape[0]
+        items.append((dy, x, gw, gb if rides else None, rows))
+        if gb is not None and not rides:
+            late.append((dy, gb, bias.numel()))
+    if items:
+        ops.linear_bwd_weight_grouped(items)
+    for dy, gb, cols in late:
+        ops.colsum(dy, gb, cols=cols)
+
+
 EPILOGUE_COLSUM = os.environ.get("MMDTI_EPILOGUE_COLSUM", "0") == "1"
 POOL_THEN_PROJECT = os.environ.get("MMDTI_INFONCE_POOL_FIRST", "1") != "0"      # InfoNCE head: pool the GELU outputs, then project
 
@@ -87,8 +111,8 @@ def _launch_deferred_wgrads(deferred, layers):
     ws = _wgrad_stream_obj
     ws.wait_stream(main)
     with torch.cuda.stream(ws):
-        for args, kw in deferred:
-            _lin_bwd_params(*args, **kw)
+        for group in deferred:                      # one list of _lin_bwd_params calls per layer
+            _lin_bwd_params_many(group)
         for layer in layers:
             notify_grads_ready(layer.parameters())     # (recorded on this stream: the reducer's event sits behind the GEMMs)
     _wgrad_keep.append(deferred)
@@ -197,12 +221,10 @@ class PairEncoderFn(torch.autograd.Function):
         for li, layer, L in zip(range(len(st.layers) - 1, -1, -1), reversed(mod.layers), reversed(st.layers)):
             att, ln1, ln2 = layer.self_attn, layer.self_attn_layer_norm, layer.final_layer_norm
             hold = li < n_defer                          # this layer's weight gradients wait for the end (see _launch_deferred_wgrads)
+            pending = []                                 # the layer's four weight gradients leave as ONE grouped launch
 
             def _wgrad(*args, **kw):
-                if hold:
-                    deferred.append((args, kw))
-                else:
-                    _lin_bwd_params(*args, **kw)
+                pending.append((args, kw))
             # ---- FFN:  x2 = x1 + drop(fc2(gelu(fc1(LN2(x1)))))
             # (dx16 = bf16 dropout-backward copy of dx, written by the LayerNorm backward that produced dx)
             dy2 = dx16 if dx16 is not None else ops.cast_bf16(dx, st.p_res, seed, L.site_f)
@@ -227,10 +249,13 @@ class PairEncoderFn(torch.autograd.Function):
                                              bf16_copy=(st.p_res, below[li - 1], gbuf(mod.layers[li - 1].fc2.bias)))
             else:
                 dx, dx16 = ops.layernorm_bwd(dh1, L.x, ln1.weight, L.m1, L.r1, gbuf(ln1.weight), gbuf(ln1.bias), dres=dx), None
-            L.__dict__.clear()       # release this layer's activations (S_l is ~1 GB at the bench shape)
             if hold:
+                deferred.append(pending)
                 deferred_layers.append(layer)
             else:
+                _lin_bwd_params_many(pending)
+            L.__dict__.clear()       # release this layer's activations (S_l is ~1 GB at the bench shape)
+            if not hold:
                 notify_grads_ready(layer.parameters())
         eln = mod.emb_layer_norm
         demb = ops.layernorm_bwd(dx, st.emb.view(M, D), eln.weight, st.emb_mean, st.emb_rstd, gbuf(eln.weight), gbuf(eln.bias),
@@ -378,15 +403,16 @@ def _bert_layer_bwd(st, L, dout, seed):
     B, Lq, Lk, D = st.B, st.Lq, st.Lk, st.D
     W, heads, ld = L.W, L.heads, L.ld
     hd = D // heads
+    pend, raw = [], []                     # the layer's weight gradients leave as one grouped launch (see _lin_bwd_params_many)
     dz, dzb = ops.layernorm_bwd(dout, L.z, W.ln2_w, L.zm, L.zr, gbuf(W.ln2_w), gbuf(W.ln2_b), bf16_copy=(L.p_hid, L.site_f, gbuf(W.o2_b)))
-    _lin_bwd_params(dzb, L.i, W.o2_w, W.o2_b, bias_done=True)
+    pend.append(((dzb, L.i, W.o2_w, W.o2_b), dict(bias_done=True)))
     cs = _epilogue_colsum(W.i_b)
     du = ops.linear_bwd_input(dzb, wbf16(W.o2_w), act=ops.ACT_GELU_DX, aux_in=L.u, colsum=cs)
-    _lin_bwd_params(du, L.a16, W.i_w, W.i_b, bias_done=cs is not None)
+    pend.append(((du, L.a16, W.i_w, W.i_b), dict(bias_done=cs is not None)))
     da = ops.linear_bwd_input(du, wbf16(W.i_w))
     # a32 = LN1(y) feeds the FFN AND the residual add of z: both gradients go through LN1's backward
     dy, dyb = ops.layernorm_bwd(da, L.y, W.ln1_w, L.am, L.ar, gbuf(W.ln1_w), gbuf(W.ln1_b), dy_add=dz, bf16_copy=(L.p_hid, L.site_o, gbuf(W.o_b)))
-    _lin_bwd_params(dyb, L.ctx, W.o_w, W.o_b, bias_done=True)
+    pend.append(((dyb, L.ctx, W.o_w, W.o_b), dict(bias_done=True)))
     dctx = ops.linear_bwd_input(dyb, wbf16(W.o_w))
     dev = dout.device
     if L.fw is not None:
@@ -399,14 +425,16 @@ def _bert_layer_bwd(st, L, dout, seed):
             outv = (torch.empty(B * Lq, D, device=dev, dtype=BF16), dqkv[:, :D], dqkv[:, D:])
         dq, dk, dv = ops.attn_bwd(L.q, L.k, L.v, L.key_add, dctx, L.stats, B, heads, Lq, Lk, 1.0 / math.sqrt(hd), L.p_att, seed, L.site_att,
                                   out=outv)
-        ops.linear_bwd_weight(dqkv, L.s1_16 if L.self_attn else L.s2_16, L.fw[2], db=L.fb[2].view(-1))
+        raw.append((dqkv, L.s1_16 if L.self_attn else L.s2_16, L.fw[2], L.fb[2].view(-1), None))
         ds1 = dy
         if L.self_attn:
             ops.gemm(dqkv, L.fw[0], M=B * Lq, N=D, K=3 * D, lda=3 * D, ldb=D, transB=True, out=ds1, ldc=D, beta=1.0)
+            _lin_bwd_params_many(pend, raw)
             return ds1, None
-        _lin_bwd_params(dq, L.s1_16, W.q_w, W.q_b)
+        pend.append(((dq, L.s1_16, W.q_w, W.q_b), {}))
         ops.gemm(dq, wbf16(W.q_w), M=B * Lq, N=D, K=D, lda=D, ldb=D, transB=True, out=ds1, ldc=D, beta=1.0)
         ds2 = ops.gemm(dqkv, L.fw[0], M=B * Lk, N=D, K=2 * D, lda=2 * D, ldb=D, transB=True, out_dtype=F32)
+        _lin_bwd_params_many(pend, raw)
         return ds1, ds2
     if L.fused:
         dq, dk, dv = ops.attn_bwd(L.q, L.k, L.v, L.key_add, dctx, L.stats, B, heads, Lq, Lk, 1.0 / math.sqrt(hd), L.p_att, seed, L.site_att)
@@ -425,9 +453,10 @@ def _bert_layer_bwd(st, L, dout, seed):
         dk = torch.empty(B * Lk, D, device=dev, dtype=BF16)
         ops.gemm(dS, L.q, M=Lk, N=hd, K=Lq, lda=ld, ldb=D, transA=True, transB=True, out=dk, ldc=D, batch=(B, heads),
                  sA=(heads * Lq * ld, Lq * ld), sB=(Lq * D, hd), sC=(Lk * D, hd))
-    _lin_bwd_params(dq, L.s1_16, W.q_w, W.q_b)
-    _lin_bwd_params(dk, L.s2_16, W.k_w, W.k_b)
-    _lin_bwd_params(dv, L.s2_16, W.v_w, W.v_b)
+    pend.append(((dq, L.s1_16, W.q_w, W.q_b), {}))
+    pend.append(((dk, L.s2_16, W.k_w, W.k_b), {}))
+    pend.append(((dv, L.s2_16, W.v_w, W.v_b), {}))
+    _lin_bwd_params_many(pend, raw)
     # ds1 = dy (residual) + dq.Wq ; ds2 = dk.Wk + dv.Wv     (fp32, accumulated by the GEMM's beta=1 epilogue)
     ds1 = dy
     ops.gemm(dq, wbf16(W.q_w), M=B * Lq, N=D, K=D, lda=D, ldb=D, transB=True, out=ds1, ldc=D, beta=1.0)

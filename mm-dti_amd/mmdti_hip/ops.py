@@ -129,6 +129,50 @@ def linear_bwd_weight(dy, x, dw, *, rows=None, db=None):
     return dw
 
 
+GROUPED_DW = os.environ.get("MMDTI_GROUPED_DW", "1") != "0"
+
+
+def _dw_groupable(dy, x, dw, rows):
+    return (dy.dtype == BF16 and x.dtype == BF16 and dw.dtype == F32 and dy.stride(-1) == 1 and x.stride(-1) == 1 and dw.stride(-1) == 1 and
+            dw.shape[0] % 256 == 0 and dw.shape[1] % 256 == 0 and rows % 64 == 0 and rows >= 4096 and dy.stride(0) % 8 == 0 and
+            x.stride(0) % 8 == 0 and dw.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and dw.data_ptr() % 16 == 0)
+
+
+def linear_bwd_weight_grouped(items):
+    """items: [(dy [rows, N_out] bf16, x [rows, N_in] bf16, dw [N_out, N_in] fp32, db [N_out] fp32 | None, rows | None)] -- the
+    weight (and bias) gradients of several Linears over the same token rows in ONE launch (mmdti_linear_dw_grouped: the K
+    split that fills the chip is shared by all of them, so the fp32 partial-sum traffic is a quarter of what the GEMMs need
+    one at a time).  Items that do not fit the grouped kernel's shape rules run through linear_bwd_weight."""
+    import ctypes
+    norm = [(dy, x, dw, db, dy.shape[0] if rows is None else rows) for dy, x, dw, db, rows in items]
+    groups = {}
+    for it in norm:
+        if GROUPED_DW and _dw_groupable(it[0], it[1], it[2], it[4]):
+            groups.setdefault(it[4], []).append(it)
+        else:
+            linear_bwd_weight(it[0], it[1], it[2], rows=it[4], db=it[3])
+    for rows, grp in groups.items():
+        while grp:
+            chunk, grp = grp[:8], grp[8:]
+            if len(chunk) == 1:
+                it = chunk[0]
+                linear_bwd_weight(it[0], it[1], it[2], rows=rows, db=it[3])
+                continue
+            n = len(chunk)
+            tiles = sum((it[2].shape[0] // 256) * (it[2].shape[1] // 256) for it in chunk)
+            sk = lib()._dll.mmdti_linear_dw_grouped_splits(tiles, rows)
+            ws = torch.empty(sk * sum(it[2].shape[0] * it[2].shape[1] for it in chunk), device=chunk[0][0].device, dtype=F32)
+            vp, ip = ctypes.c_void_p * n, ctypes.c_int * n
+            t0 = kernel_timer.begin("gemm")
+            lib().mmdti_linear_dw_grouped(_stream(), n, vp(*[it[0].data_ptr() for it in chunk]), vp(*[it[1].data_ptr() for it in chunk]),
+                                          vp(*[it[2].data_ptr() for it in chunk]), vp(*[_p(it[3]) for it in chunk]),
+                                          ip(*[it[2].shape[0] for it in chunk]), ip(*[it[2].shape[1] for it in chunk]),
+                                          ip(*[it[0].stride(0) for it in chunk]), ip(*[it[1].stride(0) for it in chunk]),
+                                          ip(*[it[2].stride(0) for it in chunk]), rows, ws.data_ptr(), ws.numel() * 4)
+            work = sum(2.0 * it[2].shape[0] * it[2].shape[1] * rows for it in chunk)
+            kernel_timer.end("gemm", t0, work, tag=("grouped_dw", tuple((it[2].shape[0], it[2].shape[1]) for it in chunk), rows))
+
+
 def colsum(x, out, cols=None):
     _chk(x, BF16, "colsum.x", contiguous=False)
     _chk(out, F32, "colsum.out")
@@ -146,8 +190,10 @@ def layernorm_fwd(x, gamma, beta, eps, *, want_f32=False, want_bf16=True, row_ze
     mean = torch.empty(rows, device=x.device, dtype=F32)
     rstd = torch.empty(rows, device=x.device, dtype=F32)
     rz = _u8(row_zero)
+    t0 = kernel_timer.begin("ln_fwd")
     lib().mmdti_layernorm_fwd(_stream(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), rows, D, _p(y32), _p(y16),
                               mean.data_ptr(), rstd.data_ptr(), _p(rz), float(drop_p), int(seed), int(site))
+    kernel_timer.end("ln_fwd", t0, float(rows) * D * (4 + (4 if want_f32 else 0) + (2 if want_bf16 else 0)))
     return y32, y16, mean, rstd
 
 
@@ -161,9 +207,12 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, *, dres=None, dy_add=
     rz = _u8(row_zero)
     dx16 = torch.empty(x.shape, device=x.device, dtype=BF16) if bf16_copy is not None else None
     p2, site2, csum = (tuple(bf16_copy) + (None,))[:3] if bf16_copy is not None else (0.0, 0, None)
+    t0 = kernel_timer.begin("ln_bwd")
     lib().mmdti_layernorm_bwd(_stream(), dy.data_ptr(), DT_BF16 if dy.dtype == BF16 else DT_F32, _p(dy_add), x.data_ptr(), gamma.data_ptr(),
                               mean.data_ptr(), rstd.data_ptr(), rows, D, _p(dres), dx.data_ptr(), _p(dgamma), _p(dbeta), _p(rz),
                               float(drop_p), int(seed), int(site), _p(dx16), float(p2), int(site2), _p(csum))
+    kernel_timer.end("ln_bwd", t0, float(rows) * D * (dy.element_size() + 4 + 4 + (4 if dres is not None else 0) + (4 if dy_add is not None else 0) +
+                                                     (2 if bf16_copy is not None else 0)))
     return dx if bf16_copy is None else (dx, dx16)
 
 
@@ -263,11 +312,12 @@ def gbf_bias_fwd(dist, edge_type, mul, bias, means, stds, w1, b1, w2, b2, ld, sa
     K = w1.shape[1]
     out = pair_empty(B, Hh, N, dist.device, tiled) if tiled else torch.empty(B, Hh, N, ld, device=dist.device, dtype=F32)
     saved = tuple(torch.empty(B * N * N, 128, device=dist.device, dtype=BF16) for _ in range(3)) if save else None
-    t0 = kernel_timer.begin("gbf_features_fwd")
+    t0 = kernel_timer.begin("gbf_bias_fwd")
     lib().mmdti_gbf_bias_fwd(_stream(), dist.data_ptr(), edge_type.data_ptr(), mul.data_ptr(), bias.data_ptr(), means.data_ptr(), stds.data_ptr(),
                              w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), B, N, ld, K, Fh, Hh, mul.numel(), out.data_ptr(),
                              *([t.data_ptr() for t in saved] if save else [0, 0, 0]), int(tiled) | (2 if save_grad else 0))
-    kernel_timer.end("gbf_features_fwd", t0)
+    # algorithmic bytes per atom pair: 4 (distance) + edge type in, 64 heads x 4 B of bias out (+ 3 x 256 B kept for the backward)
+    kernel_timer.end("gbf_bias_fwd", t0, float(B * N * N) * (4 + edge_type.element_size() + Hh * 4 + (3 * 256 if save else 0)))
     return out, saved
 
 
@@ -278,10 +328,13 @@ def gbf_bias_bwd(g, dist, edge_type, mul, bias, means, stds, w1, w2, u, ld, dmul
     P = B * N * N
     do = torch.empty(P, Hh, device=g.device, dtype=BF16)
     du = torch.empty(P, Fh, device=g.device, dtype=BF16)
+    t0 = kernel_timer.begin("gbf_bias_bwd")
     lib().mmdti_gbf_bias_bwd(_stream(), g.data_ptr(), dist.data_ptr(), edge_type.data_ptr(), mul.data_ptr(), bias.data_ptr(), means.data_ptr(),
                              stds.data_ptr(), w1.data_ptr(), w2.data_ptr(), u.data_ptr(), B, N, ld, w1.shape[1], Fh, Hh, mul.numel(),
                              int(pair_is_tiled(g)) | (2 if u_is_grad else 0), do.data_ptr(), du.data_ptr(), dmul.data_ptr(), dbias.data_ptr(), dmeans.data_ptr(),
                              dstds.data_ptr())
+    # per pair: G 64 x 4 B + saved gelu' 256 B + distance / edge type in, do 128 B + du 256 B out
+    kernel_timer.end("gbf_bias_bwd", t0, float(P) * (Hh * g.element_size() + 256 + 4 + edge_type.element_size() + 2 * Hh + 2 * Fh))
     return do, du
 
 
@@ -364,7 +417,8 @@ def pair_attn_fwd(qkv, bias_in, key_pad, B, N, H, ld, scale, drop_p=0.0, seed=0,
     t0 = kernel_timer.begin("pair_attn_fwd")
     lib().mmdti_pair_attn_fwd(_stream(), qkv.data_ptr(), bias_in.data_ptr(), s_out.data_ptr(), o.data_ptr(), _p(kp), B, N, H, ld,
                               float(scale), float(drop_p), int(seed), int(site), int(tiled))
-    kernel_timer.end("pair_attn_fwd", t0)
+    # per (pair, head): read the bias / previous logits 4 B, write S 4 B; per (token, head): q|k|v in (48 B), o out (16 B)
+    kernel_timer.end("pair_attn_fwd", t0, float(B) * H * (N * N * 8.0 + N * 64.0))
     return s_out, o
 
 
@@ -376,7 +430,8 @@ def pair_attn_bwd(qkv, s, do, g, B, N, H, ld, scale, g_in_zero, drop_p=0.0, seed
     t0 = kernel_timer.begin("pair_attn_bwd")
     lib().mmdti_pair_attn_bwd(_stream(), qkv.data_ptr(), s.data_ptr(), do.data_ptr(), g.data_ptr(), dqkv.data_ptr(), B, N, H, ld,
                               float(scale), int(g_in_zero), float(drop_p), int(seed), int(site), int(tiled))
-    kernel_timer.end("pair_attn_bwd", t0)
+    # per (pair, head): read S 4 B, read + write G (4 B each; the first layer reads none); per (token, head): 7 x 16 B rows
+    kernel_timer.end("pair_attn_bwd", t0, float(B) * H * (N * N * (4.0 + g.element_size() * (1 if g_in_zero else 2)) + N * 112.0))
     return dqkv
 
 
@@ -415,8 +470,10 @@ def attn_fwd(q, k, v, key_add, B, heads, Lq, Lk, scale, drop_p=0.0, seed=0, site
     hd = D // heads
     ctx = torch.empty(B * Lq, D, device=q.device, dtype=BF16)
     stats = torch.empty(B, heads, Lq, 2, device=q.device, dtype=F32)
+    t0 = kernel_timer.begin("attn_fwd")
     lib().mmdti_attn_fwd(_stream(), q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(key_add), ctx.data_ptr(), stats.data_ptr(), B, heads, Lq, Lk,
                          hd, q.stride(0), k.stride(0), D, float(scale), float(drop_p), int(seed), int(site))
+    kernel_timer.end("attn_fwd", t0, 4.0 * B * heads * Lq * Lk * hd)          # flops: q.k^T and p.v
     return ctx, stats
 
 
@@ -434,9 +491,11 @@ def attn_bwd(q, k, v, key_add, dctx, stats, B, heads, Lq, Lk, scale, drop_p=0.0,
         dk = torch.empty(B * Lk, D, device=q.device, dtype=BF16)
         dv = torch.empty(B * Lk, D, device=q.device, dtype=BF16)
     drow = torch.empty(B, heads, Lq, device=q.device, dtype=F32)
+    t0 = kernel_timer.begin("attn_bwd")
     lib().mmdti_attn_bwd(_stream(), q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(key_add), dctx.data_ptr(), stats.data_ptr(), drow.data_ptr(),
                          dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, heads, Lq, Lk, hd, q.stride(0), k.stride(0), dctx.stride(0), dq.stride(0), dk.stride(0),
                          float(scale), float(drop_p), int(seed), int(site))
+    kernel_timer.end("attn_bwd", t0, 10.0 * B * heads * Lq * Lk * hd)         # flops of the five products an attention backward needs (scores once)
     return dq, dk, dv
 
 

@@ -33,7 +33,7 @@ def stats(src, dst):
     rows = list(csv.DictReader(open(find(src, "*kernel_stats.csv"))))
     rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
     with open(dst, "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline (11 steps in the trace: 2 warm-up + 5 timed + 4 extra steps of the roofline_mfma GEMM timing)\n")
+        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline (11 steps in the trace: 2 warm-up + 5 timed + 4 extra steps of the per-family roofline timing)\n")
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_ms", "avg_us", "percent", "min_us", "max_us"])
         for r in rows[:40]:
@@ -75,8 +75,29 @@ def pmc(fetch_dir, write_dir, dst):
             w.writerow([r[0], r[1], f"{r[2]:.1f}", f"{r[3]:.1f}", f"{r[4]:.0f}"])
 
 
+def rdreq(src, dst):
+    """Second view of the read traffic (is FETCH_SIZE x 2 right for the tiled pair reads?): the L2's memory-side
+    read REQUEST counters.  TCC_EA0_RDREQ counts every request, TCC_EA0_RDREQ_32B the 32-byte ones; FETCH_SIZE is
+    RDREQ x 64 B (MI355X_MICROARCH.md, HBM): if the remaining requests are 128 B wide the bytes read are
+    32 * n32 + 128 * (n - n32), if 64 B wide 32 * n32 + 64 * (n - n32) -- both are listed."""
+    n_all, n32 = counter_means(src, "TCC_EA0_RDREQ_sum"), counter_means(src, "TCC_EA0_RDREQ_32B_sum")
+    rows = []
+    for k, (v, n) in n_all.items():
+        v32 = n32.get(k, (0.0, 0))[0]
+        rows.append((k, n, v, v32, 32 * v32 + 64 * (v - v32), 32 * v32 + 128 * (v - v32)))
+    rows.sort(key=lambda r: -r[5] * r[1])
+    with open(dst, "w") as f:
+        f.write("# rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-rooflines\n")
+        w = csv.writer(f)
+        w.writerow(["kernel", "launches", "RDREQ_mean", "RDREQ_32B_mean", "read_bytes_if_64B_requests", "read_bytes_if_128B_requests"])
+        for r in rows[:30]:
+            w.writerow([r[0], r[1], f"{r[2]:.0f}", f"{r[3]:.0f}", f"{r[4]:.0f}", f"{r[5]:.0f}"])
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "rdreq":
+        rdreq(sys.argv[2], sys.argv[3])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])

@@ -882,3 +882,30 @@ def test_attn_fused_rejects_unsupported_shapes(ops):
     q2 = torch.zeros(16, 96, device="cuda", dtype=torch.bfloat16)
     with pytest.raises(MMDTIError):
         ops.attn_fwd(q2, q2, q2, None, 1, 2, 16, 16, 0.1)                  # head_dim 48
+
+
+def test_grouped_weight_gradients(ops):
+    """mmdti_linear_dw_grouped: the weight + bias gradients of several Linears over the same token rows in one launch (slab
+    split-K, no atomics) == dy^T.x / column sums of dy in fp32, accumulated INTO the buffers; ineligible items fall back."""
+    rows = 4096 + 64 * 3
+    g = G(11)
+    shapes = [(512, 2048), (2048, 512), (1536, 512), (512, 512), (256, 768)]
+    items, refs = [], []
+    for i, (no, ni) in enumerate(shapes):
+        big = torch.randn(rows, no + 64, generator=g)          # dy as a column slice of a wider buffer (row stride != N_out)
+        dy = bf(big).cuda()[:, :no] if i == 2 else bf(torch.randn(rows, no, generator=g)).cuda()
+        x = bf(torch.randn(rows, ni, generator=g)).cuda()
+        dw = torch.randn(no, ni, generator=g).cuda()
+        db = torch.randn(no, generator=g).cuda() if i != 1 else None
+        refs.append((dw.clone() + dy.float().t() @ x.float(), None if db is None else db.clone() + dy.float().sum(0)))
+        items.append((dy, x, dw, db, None))
+    # one item that the grouped kernel cannot take (N_in not a multiple of 256): must still be computed
+    dy_s, x_s = bf(torch.randn(rows, 512, generator=g)).cuda(), bf(torch.randn(rows, 136, generator=g)).cuda()
+    dw_s, db_s = torch.zeros(512, 136).cuda(), torch.zeros(512).cuda()
+    items.append((dy_s, x_s, dw_s, db_s, None))
+    refs.append((dy_s.float().t() @ x_s.float(), dy_s.float().sum(0)))
+    ops.linear_bwd_weight_grouped(items)
+    for (dy, x, dw, db, _), (rw, rb) in zip(items, refs):
+        close(dw, rw, 2e-3, 2e-2)
+        if db is not None:
+            close(db, rb, 2e-3, 2e-2)
