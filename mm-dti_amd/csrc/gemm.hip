@@ -1229,7 +1229,7 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
     const int btiles = cdiv(M, BBM) * cdiv(N, BBN);
     int sk = splitk;
     if (splitk > 1) {   // weight gradients: about one workgroup per CU, at least 4 K-tiles per split
-      sk = max(1, min(K / BK / 4, cdiv(256, btiles)));
+      sk = max(1, min(K / BK / 4, 256 / btiles));      // floor: one round of workgroups (a 257th would cost a whole second round)
       const int kts = K / BK, per = cdiv(kts, sk);
       sk = cdiv(kts, per);          // no empty split (the slab form sums EVERY slab)
     }
@@ -1318,7 +1318,7 @@ extern "C" int mmdti_linear_dw_grouped(mmdti_stream_t stream, int nprob, const v
   for (int i = nprob; i < GROUP_MAX; ++i) { g.p[i] = g.p[0]; g.p[i].tile0 = 0x7fffffff; }
   g.ntiles = tiles;
   const int kts = rows / BK;
-  int sk = max(1, min(kts / 4, cdiv(256, tiles)));
+  int sk = max(1, min(kts / 4, 256 / max(1, tiles)));   // floor: all workgroups resident in ONE round
   sk = cdiv(kts, cdiv(kts, sk));                     // no empty split: every slab is summed
   g.splitk = sk;
   MMDTI_REQUIRE(workspace_bytes >= (long long)sk * elems * 4, "linear_dw_grouped: workspace too small (%lld bytes needed for %d splits)",
@@ -1350,6 +1350,6 @@ extern "C" int mmdti_linear_dw_grouped(mmdti_stream_t stream, int nprob, const v
 extern "C" int mmdti_linear_dw_grouped_splits(int tiles, int rows) {
   if (tiles <= 0 || rows < BK) return 1;
   const int kts = rows / BK;
-  const int sk = max(1, min(kts / 4, cdiv(256, tiles)));
+  const int sk = max(1, min(kts / 4, 256 / max(1, tiles)));
   return cdiv(kts, cdiv(kts, sk));
 }

@@ -123,7 +123,7 @@ def linear_bwd_weight(dy, x, dw, *, rows=None, db=None):
     ws = None
     if SPLITK_SLABS and N % 256 == 0 and K % 256 == 0 and M >= 4096:
         tiles = (N // 256) * (K // 256)
-        ws = torch.empty(min(-(-256 // tiles), M // 256) * N * K, device=dy.device, dtype=F32)
+        ws = torch.empty(max(1, min(256 // tiles, M // 256)) * N * K, device=dy.device, dtype=F32)
     gemm(dy, x, M=N, N=K, K=M, lda=dy.stride(0), ldb=x.stride(0), transA=True, transB=True, out=dw, ldc=dw.stride(0),
          atomic=True, splitk=_splitk_for(N, K, M), arowsum=db, workspace=ws)
     return dw

@@ -22,6 +22,15 @@ ops.kernel_timer.disable()
 tot = 0.0
 out = []
 for tag, d in rows.items():
+    if tag[0] == "grouped_dw":
+        flops = d["work"] / d["n"]
+        us = d["mean_ms"] * 1e3
+        byts = sum(2.0 * tag[2] * (a + b) + 8.0 * a * b for a, b in tag[1])
+        t_mfma, t_hbm = flops / 2.5e15 * 1e6, byts / 6.3e12 * 1e6
+        print("grouped dW", tag[1], "rows", tag[2], f"n/step {d['n'] / 3:.1f}  {us:.1f} us  {flops / us / 1e6:.0f} TF/s  bound {max(t_mfma, t_hbm):.1f} us  ms/step {d['total_ms'] / 3:.3f}")
+        out.append(dict(M=0, N=0, K=tag[2], tA=1, tB=1, batch=1, splitk=0, act=0, n_per_step=d["n"] / 3, us=us, tflops=flops / us / 1e6, bound_us=max(t_mfma, t_hbm),
+                        bound="mfma", ms_per_step=d["total_ms"] / 3, frac_of_bound=max(t_mfma, t_hbm) / us, grouped=str(tag[1])))
+        continue
     M, N, K, tA, tB, nb, sk, act, obf, aux, res = tag
     flops = 2.0 * M * N * K * nb
     byts = 2.0 * nb * (M * K + N * K) + (2 if obf else 4) * nb * M * N * (2 if (res or sk > 1) else 1) + (2 * M * N if aux else 0)
