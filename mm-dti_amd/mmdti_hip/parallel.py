@@ -201,6 +201,49 @@ class ArenaReducer:
         self._pending = []
 
 
+PAD_VALUES = {"src_tokens": 0, "src_edge_type": 0, "src_distance": 0.0, "src_coord": 0.0, "input_ids": 1, "attention_mask": 0}
+
+
+def pad_to_global_lengths(batch: dict, group=None, pad_values: Optional[dict] = None) -> dict:
+    """Right-pad a rank's collated batch to the LARGEST atom / token length any rank holds at this step (one 2-int MAX
+    all-reduce).  The reference's InfoNCE head averages its per-token projections over ALL positions including padding
+    (infonce.py:32-33), so the loss depends on the padded length: with rank-local collation every rank must use the global
+    lengths for N ranks to reproduce the single-process value on the union batch.  pad_values: per-key fill (defaults to the
+    reference's: dictionary pad 0 for tokens / edge types, 0.0 for distances, RoBERTa pad 1 for input_ids, 0 for the mask)."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return batch
+    pv = dict(PAD_VALUES, **(pad_values or {}))
+    n_loc = batch["src_tokens"].shape[1]
+    l_loc = batch["input_ids"].shape[1] if "input_ids" in batch else 0
+    lens = torch.tensor([n_loc, l_loc], device=batch["src_tokens"].device, dtype=torch.int64)
+    dist.all_reduce(lens, op=dist.ReduceOp.MAX, group=group)
+    n_glob, l_glob = int(lens[0]), int(lens[1])
+    out = {}
+    for k, v in batch.items():
+        if k in ("src_tokens",):
+            grow = (0, n_glob - n_loc)
+        elif k in ("src_distance", "src_edge_type"):
+            grow = (0, n_glob - n_loc, 0, n_glob - n_loc)
+        elif k == "src_coord":
+            grow = (0, 0, 0, n_glob - n_loc)
+        elif k in ("input_ids", "attention_mask"):
+            grow = (0, l_glob - l_loc)
+        else:
+            out[k] = v
+            continue
+        out[k] = torch.nn.functional.pad(v, grow, value=pv[k]) if any(grow) else v
+    return out
+
+
+def gather_features(negs: "GlobalNegatives", feats: torch.Tensor, labels: torch.Tensor):
+    """FDS statistics under data parallelism (tasks/trainer.py:288-306 has one process): every rank contributes the pooled
+    features and labels of its shard; all ranks end with the same (features, labels) of the whole epoch, so the FDS buffers
+    -- which are part of the checkpoint -- stay identical across ranks."""
+    if negs is None or negs.world <= 1:
+        return feats, labels
+    return negs.gather(feats.contiguous()), negs.gather(labels.float().view(labels.shape[0], -1).contiguous())
+
+
 def shard_batch(batch: dict, label, rank: int, world: int):
     """Contiguous split of an already-collated GLOBAL batch.  Every shard keeps the global padded lengths, which keeps
     the reference's unmasked InfoNCE mean (infonce.py:32-33) identical to the single-process value."""

@@ -135,6 +135,9 @@ class Trainer(object):
         net_input, net_target = batch
         if isinstance(net_input, dict):
             net_input = {k: v.to(self.device, non_blocking=True) for k, v in net_input.items()}
+            if self.distributed:
+                from ..parallel import pad_to_global_lengths
+                net_input = pad_to_global_lengths(net_input)        # the unmasked InfoNCE mean needs one padded length on all ranks
         else:
             net_input = {'net_input': net_input.to(self.device)}
         net_target = net_target.to(self.device, non_blocking=True)

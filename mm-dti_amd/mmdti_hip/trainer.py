@@ -20,7 +20,7 @@ from typing import Optional
 import torch
 
 from .functional import CELossFn, MSELossFn
-from .parallel import ArenaReducer, GlobalNegatives
+from .parallel import ArenaReducer, GlobalNegatives, gather_features
 from .runtime import ParamArena, add_grad_ready_hook, remove_grad_ready_hook, dropout_state
 
 
@@ -156,6 +156,6 @@ class FineTuner:
             labels.append(net_target)
         f, y = torch.cat(feats), torch.cat(labels)
         if self.world > 1:
-            f, y = self.negs.gather(f), self.negs.gather(y.float().view(y.shape[0], -1))
+            f, y = gather_features(self.negs, f, y)
         model.FDS.update_last_epoch_stats(epoch)
         model.FDS.update_running_stats(f, y, epoch)

@@ -51,3 +51,37 @@ def test_device_prefetcher_passes_batches_through_unchanged_on_cpu():
     for (bi, li), (bo, lo) in zip(batches, out):
         assert set(bi) == set(bo) and all(torch.equal(bi[k], bo[k]) and bi[k].dtype == bo[k].dtype for k in bi) and torch.equal(li, lo)
     assert list(DevicePrefetcher([], "cpu")) == []
+
+
+def test_bucket_sampler_equal_batches_on_every_rank_without_drop_last():
+    """with world > 1 and drop_last=False a short last batch used to be dealt to ONE rank, so ranks met a step with
+    different B_loc (the InfoNCE all-gather then hangs or mis-slices).  Every dealt batch is full now, at every step."""
+    from mmdti_hip.data import LengthBucketBatchSampler
+    atoms, tokens = _lengths(100, seed=4)
+    for epoch in range(20):
+        shards = []
+        for r in range(2):
+            s = LengthBucketBatchSampler(atoms, tokens, 8, shuffle=True, seed=1, drop_last=False, rank=r, world=2)
+            s.set_epoch(epoch)
+            shards.append(list(s))
+            assert len(shards[-1]) == len(s)
+        assert len(shards[0]) == len(shards[1])
+        assert all(len(a) == len(b) == 8 for a, b in zip(*shards))
+        seen = [i for sh in shards for b in sh for i in b]
+        assert len(seen) == len(set(seen))
+
+
+def test_bucket_sampler_drop_last_is_not_size_biased():
+    """drop_last used to drop the tail of the size-sorted order -- always the largest molecules.  The remainder is
+    drawn at random each epoch (as the reference's shuffled drop_last DataLoader does, tasks/trainer.py:143-150)."""
+    from mmdti_hip.data import LengthBucketBatchSampler
+    atoms, tokens = _lengths(203, seed=6)
+    dropped = []
+    for epoch in range(40):
+        s = LengthBucketBatchSampler(atoms, tokens, 8, shuffle=True, seed=2, drop_last=True)
+        s.set_epoch(epoch)
+        kept = {i for b in s for i in b}
+        assert len(kept) == 200
+        dropped += [atoms[i] for i in range(203) if i not in kept]
+    # dropped molecules look like the population, not like its largest members
+    assert np.mean(dropped) < np.mean(atoms) + 1.0 * np.std(atoms) and min(dropped) <= np.median(atoms)

@@ -195,7 +195,101 @@ def _worker_step_equivalence(rank, world, initfile, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("worker", [_worker_global_negatives, _worker_reducer, _worker_reducer_hook, _worker_step_equivalence])
+def _worker_fds_stats_identical(rank, world, initfile, out):
+    """FDS epoch pass under DDP: each rank holds the pooled features of ITS shard; after parallel.gather_features every rank
+    updates its FDS buffers from the whole epoch -> buffers identical on all ranks and equal to the single-process run."""
+    _init(rank, world, initfile)
+    from mmdti_hip.parallel import GlobalNegatives, gather_features
+    from oracle import mmdti_oracle as O
+    g = torch.Generator().manual_seed(5)
+    feats_all, labels_all = torch.randn(24, 16, generator=g), torch.randn(24, 1, generator=g)
+    b = 24 // world
+    negs = GlobalNegatives()
+    f, y = gather_features(negs, feats_all[rank * b:(rank + 1) * b].clone(), labels_all[rank * b:(rank + 1) * b].clone())
+    assert f.shape == (24, 16) and torch.equal(f, feats_all) and torch.equal(y, labels_all)
+    def run(ff, yy):
+        fo = O.FDSOracle(16, -2.5, 0.5, bucket_num=10, kernel="gaussian", ks=5, sigma=1)
+        fo.update_last_epoch_stats(0); fo.update_running_stats(ff, yy, 0); fo.update_last_epoch_stats(1)
+        return fo.state()
+    mine, ref = run(f, y), run(feats_all, labels_all)
+    for k in mine:
+        assert torch.equal(mine[k], ref[k]), k
+        other = mine[k].clone()
+        dist.broadcast(other, src=0)
+        assert torch.equal(other, mine[k]), k                                   # identical across ranks, bit for bit
+    if rank == 0:
+        torch.save({"ok": True}, out)
+    dist.destroy_process_group()
+
+
+def _worker_bucket_sampler_global_infonce(rank, world, initfile, out):
+    """LengthBucketBatchSampler(rank, world) deals equal-size batches; every rank collates its own molecules, pads to the
+    GLOBAL lengths (parallel.pad_to_global_lengths) and joins the global InfoNCE: the sum of the ranks' shares equals the
+    single-process InfoNCE on the union of the two batches collated together."""
+    _init(rank, world, initfile)
+    from mmdti_hip.parallel import GlobalNegatives, pad_to_global_lengths
+    from mmdti_hip.data import LengthBucketBatchSampler
+    from mmdti_hip.collate import right_pad
+    from oracle import mmdti_oracle as O
+    import numpy as np
+    cfg = O.ModelCfg(unimol=O.UniMolCfg(layers=1, dim=32, ffn=64, heads=4, K=8, vocab=31),
+                     roberta=O.RobertaCfg(layers=1, dim=32, heads=2, ffn=64, vocab=40, max_pos=40),
+                     cross=O.CrossCfg(dim=32, heads=2, ffn=64), task="classification", output_dim=2)
+    P = O.init_params(cfg, seed=3, std=0.1)
+    rng = np.random.default_rng(2)
+    mols = []
+    for _ in range(37):                                                    # 37 molecules, batch 4, 2 ranks: a ragged remainder
+        na, nl = int(rng.integers(2, 9)), int(rng.integers(4, 12))
+        d = O.coords2unimol(rng.integers(4, 30, size=na), rng.normal(0, 3, size=(na, 3)), 31)
+        ids = np.concatenate([[0], rng.integers(4, 40, size=nl - 2), [2]]).astype(np.int64)
+        mols.append((d, ids))
+    atoms, toks = [len(m[0]["src_tokens"]) - 2 for m in mols], [len(m[1]) for m in mols]
+    def collate(idx):
+        ids = right_pad([torch.from_numpy(mols[i][1]) for i in idx], 1)
+        return {"src_tokens": right_pad([torch.from_numpy(mols[i][0]["src_tokens"]) for i in idx], 0),
+                "src_distance": right_pad([torch.from_numpy(mols[i][0]["src_distance"]) for i in idx], 0.0, square=True),
+                "src_edge_type": right_pad([torch.from_numpy(mols[i][0]["src_edge_type"]) for i in idx], 0, square=True),
+                "input_ids": ids, "attention_mask": ids.ne(1).long()}
+    mine = list(LengthBucketBatchSampler(atoms, toks, 4, shuffle=True, seed=7, rank=rank, world=world))
+    both = [list(LengthBucketBatchSampler(atoms, toks, 4, shuffle=True, seed=7, rank=r, world=world)) for r in range(world)]
+    assert len(mine) == len(both[1 - rank]) and all(len(b) == 4 for b in mine)          # same step count, same B_loc at every step
+    negs = GlobalNegatives()
+    for step in range(2):
+        batch = pad_to_global_lengths(collate(mine[step]))
+        enc, bert, _ = O.mm_features(batch, P, cfg)
+        a, b = O.infonce_embed(enc, bert, P, p=0.0)
+        allv = negs.gather(torch.cat((a, b), 1))
+        d = a.shape[1]
+        qh, kh = torch.nn.functional.normalize(allv[:, :d], dim=-1), torch.nn.functional.normalize(allv[:, d:], dim=-1)
+        logits = qh @ kh.T / 0.1
+        r0 = negs.row0(4)
+        rows = slice(r0, r0 + 4)
+        share = ((torch.logsumexp(logits[rows], 1) - logits[rows].diagonal(offset=r0)).sum()
+                 + (torch.logsumexp(logits.T[rows], 1) - logits.T[rows].diagonal(offset=r0)).sum()) / (2 * allv.shape[0])
+        dist.all_reduce(share)
+        union = collate(both[0][step] + both[1][step])                     # single process: the union batch collated together
+        enc, bert, _ = O.mm_features(union, P, cfg)
+        ref = O.infonce_forward(enc, bert, P, p=0.0)
+        torch.testing.assert_close(share, ref, rtol=1e-5, atol=1e-6)
+    if rank == 0:
+        torch.save({"ok": True}, out)
+    dist.destroy_process_group()
+
+
+def _worker_unequal_local_batches_raise(rank, world, initfile, out):
+    """GlobalNegatives.gather refuses ranks that hold different B_loc at a step (it would otherwise hang or mis-slice in RCCL)."""
+    _init(rank, world, initfile)
+    from mmdti_hip.parallel import GlobalNegatives
+    negs = GlobalNegatives()
+    with pytest.raises(RuntimeError, match="different local batch sizes"):
+        negs.gather(torch.zeros(4 + rank, 6))
+    if rank == 0:
+        torch.save({"ok": True}, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("worker", [_worker_global_negatives, _worker_reducer, _worker_reducer_hook, _worker_step_equivalence,
+                                    _worker_fds_stats_identical, _worker_bucket_sampler_global_infonce, _worker_unequal_local_batches_raise])
 def test_two_ranks_gloo(worker):
     with tempfile.TemporaryDirectory() as td:
         initfile, out = os.path.join(td, "init"), os.path.join(td, "out.pt")

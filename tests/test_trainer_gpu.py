@@ -267,9 +267,15 @@ def test_gradient_buckets_leave_during_backward_single_rank_group(monkeypatch):
     m2.load_state_dict(m1.state_dict())
     init_from_env(force=True)
     try:
+        from mmdti_hip.runtime import dropout_state
+        base0 = dropout_state.base
         tuner = FineTuner(m1, "classification", distributed=True, bucket_bytes=256 << 10)
         red = tuner.reducer
         assert red.active and len(red.buckets) > 4
+        # replicas start from rank 0's arena (broadcast) and every rank draws its own dropout masks (reseeded by rank)
+        assert dropout_state.base != base0
+        assert torch.equal(tuner.arena.shadow.float(), tuner.arena.data.to(torch.bfloat16).float())
+        dropout_state.reseed(base0)
         tuner.forward_backward(dev, label.cuda())
         torch.cuda.synchronize()
         silent = red.unreported()
@@ -330,3 +336,32 @@ def test_device_prefetcher_feeds_the_step():
         o1 = t1.step(b1, l1)
         o2 = t2.step({k: v.cuda() for k, v in bh.items()}, lh.cuda())
         assert abs(float(o1.loss) - float(o2.loss)) <= 1e-5 * abs(float(o2.loss)) + 1e-7
+
+
+def test_arena_shadow_follows_load_state_dict():
+    """weights written AFTER the arena is bound -- the reference trains, then loads the best checkpoint
+    into the same model for prediction (tasks/trainer.py:406-410) -- must reach the bf16 shadow the GEMMs read.  Bind the
+    arena, load different weights, compare eval logits with a freshly built model holding the same weights."""
+    from mmdti_hip.trainer import FineTuner
+    ocfg = _ocfg("classification", 2)
+    batch, label = O.synth_batch(6, 10, 14, ocfg, seed=9, ragged=True)
+    dev = {k: v.cuda() for k, v in batch.items()}
+    m1, m2 = _model("classification", 2, True), _model("classification", 2, True)
+    with torch.no_grad():
+        for p in m2.parameters():
+            p.add_(0.05 * torch.randn_like(p))           # "the best checkpoint": different weights everywhere
+    tuner = FineTuner(m1, "classification", total_steps=10)
+    tuner.step(dev, label.cuda())                            # arena bound, shadow refreshed by adam_step
+    m1.load_state_dict(m2.state_dict())                      # in-place copy_ into the arena views
+    m1.eval(); m2.eval()
+    with torch.no_grad():
+        a = m1(**dev)
+        b = m2(**dev)
+    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
+    # and a direct in-place edit of one weight is picked up too
+    with torch.no_grad():
+        m1.classification_head.dense.weight.mul_(0.5)
+        m2.classification_head.dense.weight.mul_(0.5)
+        m1.encoder.layers[0].fc1.weight.copy_(m2.encoder.layers[0].fc1.weight * 1.5)
+        m2.encoder.layers[0].fc1.weight.mul_(1.5)
+        torch.testing.assert_close(m1(**dev), m2(**dev), rtol=1e-4, atol=1e-5)
