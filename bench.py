@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--no-rooflines", action="store_true", help="skip the extra (untimed) steps that time every kernel family")
+    ap.add_argument("--graph", action="store_true", help="replay the step from one captured HIP graph (FineTuner.graphed_step; single GPU)")
     ap.add_argument("--ragged", action="store_true", help="molecules of mixed length padded to the batch maximum (not the headline workload)")
     args = ap.parse_args()
 
@@ -182,15 +183,16 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    step = tuner.graphed_step if (args.graph and world == 1) else tuner.step
     for _ in range(args.warmup):
-        out = tuner.step(batch, label, epoch=0)
+        out = step(batch, label, epoch=0)
     barrier()
     # inside the timed region only the two pair-attention kernels are event-timed (30 launches per step); everything else is
     # timed in extra steps afterwards so that ~1 000 event pairs per step do not perturb `value`
     ops.kernel_timer.enable(("pair_attn_bwd", "pair_attn_fwd"))
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = tuner.step(batch, label, epoch=0)
+        out = step(batch, label, epoch=0)
     barrier()
     dt = time.perf_counter() - t0
     in_step = ops.kernel_timer.summary()
@@ -254,7 +256,7 @@ def main():
             "config": {"workload": f"BBBP-like classification + SupCon + InfoNCE fine-tune step, {args.batch} molecules/GPU x {args.atoms} atoms x "
                                    f"{args.tokens} SMILES tokens ({shape}), fwd+bwd+allreduce+clip+Adam, dropout on",
                        "global_batch": args.batch * world, "atoms": args.atoms, "tokens": args.tokens, "padded_N": N, "parallelism": f"dp{world}",
-                       "unimol": "15L/512/64h", "chemberta_assumed": "6L/512/8h/ffn2048/vocab600", "infonce_negatives": "global",
+                       "launch": "one HIP graph per step" if (args.graph and world == 1) else "eager (one launch per kernel)", "unimol": "15L/512/64h", "chemberta_assumed": "6L/512/8h/ffn2048/vocab600", "infonce_negatives": "global",
                        "grad_buckets_reduced_during_backward": None if tuner.reducer is None or not tuner.reducer.active
                        else f"{tuner.reducer.overlapped}/{len(tuner.reducer.buckets)}"},
             "losses_last_step": losses, "roofline": roofline, "rooflines": rooflines, "cpu_baseline": cpu,

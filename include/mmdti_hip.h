@@ -284,10 +284,22 @@ int mmdti_ce_loss(mmdti_stream_t stream, const float* logits, const long long* t
 /* sum of squares of g into out[0] (atomic; zero first) */
 int mmdti_sumsq_f32(mmdti_stream_t stream, const float* g, long long n, float* out);
 /* Adam (torch.optim.Adam semantics, eps outside sqrt of bias-corrected v): p,m,v updated in place; also refreshes the
- * bf16 shadow copy of p.  grad is multiplied by *grad_scale_dev (device scalar, e.g. clip coefficient) if non-null. */
+ * bf16 shadow copy of p.  grad is multiplied by *grad_scale_dev (device scalar, e.g. clip coefficient) if non-null.
+ * step_state_dev (nullable): the device-resident schedule of mmdti_step_state_advance -- when given, lr and the bias
+ * corrections are read from it and the by-value lr / step are ignored (a captured HIP graph replays with fresh values). */
 int mmdti_adam_step(mmdti_stream_t stream, float* p, const float* g, float* m, float* v, void* p_bf16, long long n,
                     float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                    const float* grad_scale_dev);
+                    const float* grad_scale_dev, const float* step_state_dev);
+/* Device-resident step state, so that a whole fine-tune step (tasks/trainer.py:177-283) can be captured in ONE HIP graph
+ * and replayed: state[4] fp32 = {optimizer steps taken, this step's learning rate (HF linear warm-up / decay,
+ * tasks/trainer.py:161-162), 1-beta1^t, sqrt(1-beta2^t)}; salt[2] u64 = {counter, mixed word}.  Call once at the top of
+ * every step (inside the captured region): advances both. */
+int mmdti_step_state_advance(mmdti_stream_t stream, float* state, unsigned long long* salt, float base_lr, int warmup_steps,
+                             int total_steps, float beta1, float beta2);
+/* Copies *salt into the dropout generators of every kernel library: all dropout sites launched after it on the stream XOR
+ * their (seed, site) streams with it -- masks change from replay to replay although seed and site are frozen in the graph.
+ * 0 (the initial value) leaves the generators exactly as the by-value seeds define them. */
+int mmdti_seed_salt_pull(mmdti_stream_t stream, const unsigned long long* salt);
 
 /* ---- hardware probes used by the test-suite ------------------------------------------------- */
 /* out[64*4] <- what ds_read_b64_tr_b16 returns to each lane for an LDS image holding element index == value */

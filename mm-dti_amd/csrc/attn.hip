@@ -42,6 +42,7 @@ struct AttnShape {
 };
 
 __device__ __forceinline__ uint32_t attn_rng_key(uint64_t seed, uint32_t site, uint32_t bh) {
+  seed = salted(seed);
   return mix32((mix32((uint32_t)seed ^ (site * 0x9E3779B9u)) ^ (uint32_t)(seed >> 32)) + bh * 0x85EBCA6Bu);
 }
 // keep iff a 16-bit uniform >= thresh16 (p quantised to 1/65536).  idx = query * key_stride + key.
@@ -403,6 +404,7 @@ static int attn_check(const char* name, const void* q, const void* k, const void
 }
 
 }  // namespace mmdti
+MMDTI_DEFINE_SALT_PULL(attn)
 using namespace mmdti;
 
 extern "C" int mmdti_attn_fwd(mmdti_stream_t stream, const void* q_bf16, const void* k_bf16, const void* v_bf16,

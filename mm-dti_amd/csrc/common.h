@@ -107,6 +107,25 @@ __device__ __forceinline__ float wave_sum8_scatter(const float (&v)[8], int lane
 struct Rand4 {
   uint32_t x, y, z, w;
 };
+// Per-step salt of every dropout stream.  A launch receives (seed, site) by VALUE; when the step is replayed from a captured
+// HIP graph those values are frozen into the graph, so the part that must change from step to step lives in device memory:
+// one 64-bit word per translation unit (a plain `static __device__` -- no relocatable device code), refreshed from the
+// trainer's step-state buffer by mmdti_seed_salt_pull at the top of every step (a graph node like any other).  It stays 0
+// unless a caller opts in, and then forward and backward of a step still see the same value.
+static __device__ unsigned long long g_seed_salt = 0ull;
+__device__ __forceinline__ uint64_t salted(uint64_t seed) { return seed ^ g_seed_salt; }
+#define MMDTI_DEFINE_SALT_PULL(TU)                                                                                   \
+  namespace mmdti {                                                                                                  \
+  __global__ void seed_salt_pull_kernel_##TU(const unsigned long long* __restrict__ src) { g_seed_salt = *src; }     \
+  void salt_pull_##TU(hipStream_t s, const unsigned long long* src) {                                                \
+    hipLaunchKernelGGL(seed_salt_pull_kernel_##TU, dim3(1), dim3(1), 0, s, src);                                     \
+  }                                                                                                                  \
+  }
+void salt_pull_gemm(hipStream_t s, const unsigned long long* src);
+void salt_pull_layernorm(hipStream_t s, const unsigned long long* src);
+void salt_pull_pair_attn(hipStream_t s, const unsigned long long* src);
+void salt_pull_attn(hipStream_t s, const unsigned long long* src);
+void salt_pull_elementwise(hipStream_t s, const unsigned long long* src);
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
@@ -115,6 +134,7 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 // callers' `r >= thresh` against the 32-bit threshold p*2^32 keeps working (p effectively quantised to 1/65536).  5 -> 2
 // hashes per 4 elements: this runs in every dropout site of the GEMM epilogues and the LayerNorm / cast kernels.
 __device__ __forceinline__ Rand4 philox4(uint64_t seed, uint32_t site, uint64_t ctr) {
+  seed = salted(seed);
   const uint32_t k = mix32((uint32_t)seed ^ (site * 0x9E3779B9u)) ^ (uint32_t)(seed >> 32);  // wave-uniform: hoisted to SALU
   const uint32_t a = mix32(((uint32_t)ctr ^ k) + (uint32_t)(ctr >> 32) * 0x85EBCA6Bu);
   const uint32_t b = mix32(a ^ 0xB5297A4Du);
@@ -124,6 +144,7 @@ __device__ __forceinline__ Rand4 philox4(uint64_t seed, uint32_t site, uint64_t 
 // 16-bit uniforms, compared against a 16-bit threshold (p quantised to 1/65536: |error| < 8e-6).  ~20 integer ops per 4
 // elements.  Returns a 4-bit keep mask (bit r = element r kept).
 __device__ __forceinline__ uint32_t keep4_u16(uint64_t seed, uint32_t site, uint64_t ctr, uint32_t thresh16) {
+  seed = salted(seed);
   const uint32_t k = mix32((uint32_t)seed ^ (site * 0x9E3779B9u)) ^ (uint32_t)(seed >> 32);
   const uint32_t a = mix32(((uint32_t)ctr ^ k) + (uint32_t)(ctr >> 32) * 0x85EBCA6Bu);
   const uint32_t b = mix32(a ^ 0xB5297A4Du);

@@ -377,11 +377,37 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
+// Step state kept on the device so that a whole training step can be replayed from a captured HIP graph (host-side
+// counters would be frozen into the graph): st[0] = optimizer steps taken, st[1] = learning rate of THIS step (HF linear
+// warm-up / decay, transformers.get_linear_schedule_with_warmup as tasks/trainer.py:161-162 uses it), st[2] = 1 - beta1^t,
+// st[3] = sqrt(1 - beta2^t); salt = the per-step dropout salt (mmdti_seed_salt_pull copies it into every kernel library).
+__global__ void step_state_advance_kernel(float* __restrict__ st, unsigned long long* __restrict__ salt, float base_lr, int warmup, int total,
+                                          float b1, float b2) {
+  const int k = (int)st[0];                      // scheduler steps already taken: the schedule's lambda(k) is this step's rate
+  const float lam = k < warmup ? (float)k / (float)max(1, warmup) : fmaxf(0.f, (float)(total - k) / (float)max(1, total - warmup));
+  const float t = (float)(k + 1);
+  st[0] = t;
+  st[1] = base_lr * lam;
+  st[2] = 1.f - powf(b1, t);
+  st[3] = sqrtf(1.f - powf(b2, t));
+  unsigned long long x = *salt + 0x9E3779B97F4A7C15ull;       // splitmix64: a fresh, well-mixed word per step
+  unsigned long long z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  *salt = x;
+  salt[1] = z ^ (z >> 31);
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, bf16_t* __restrict__ pb, long long n, float lr, float b1,
                                                    float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                                   const float* __restrict__ gscale) {
+                                                   const float* __restrict__ gscale, const float* __restrict__ state) {
   const float gs = gscale ? *gscale : 1.0f;
+  if (state) {               // device-resident schedule (graph replay): this step's rate and bias corrections
+    lr = state[1];
+    bc1 = state[2];
+    bc2_sqrt = state[3];
+  }
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     float gi = g[i] * gs;
     float pi = p[i];
@@ -412,6 +438,7 @@ __global__ __launch_bounds__(64) void probe_tr_kernel(int stride, unsigned short
 }
 
 }  // namespace mmdti
+MMDTI_DEFINE_SALT_PULL(elementwise)
 using namespace mmdti;
 
 extern "C" const char* mmdti_last_error(void) { return g_err; }
@@ -583,12 +610,33 @@ extern "C" int mmdti_sumsq_f32(mmdti_stream_t stream, const float* g, long long 
 
 extern "C" int mmdti_adam_step(mmdti_stream_t stream, float* p, const float* g, float* m, float* v, void* p_bf16,
                                long long n, float lr, float beta1, float beta2, float eps, float weight_decay,
-                               int step, const float* grad_scale_dev) {
-  MMDTI_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
+                               int step, const float* grad_scale_dev, const float* step_state_dev) {
+  MMDTI_REQUIRE(p && g && m && v && n > 0 && (step >= 1 || step_state_dev), "adam_step: bad arguments");
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                     (bf16_t*)p_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale_dev);
+                     (bf16_t*)p_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale_dev, step_state_dev);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_step_state_advance(mmdti_stream_t stream, float* state, unsigned long long* salt, float base_lr, int warmup_steps,
+                                        int total_steps, float beta1, float beta2) {
+  MMDTI_REQUIRE(state && salt, "step_state_advance: null pointer");
+  MMDTI_REQUIRE(total_steps > 0 && warmup_steps >= 0, "step_state_advance: bad schedule");
+  hipLaunchKernelGGL(step_state_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, salt, base_lr, warmup_steps, total_steps, beta1, beta2);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_seed_salt_pull(mmdti_stream_t stream, const unsigned long long* salt) {
+  MMDTI_REQUIRE(salt != nullptr, "seed_salt_pull: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  salt_pull_gemm(s, salt);
+  salt_pull_layernorm(s, salt);
+  salt_pull_pair_attn(s, salt);
+  salt_pull_attn(s, salt);
+  salt_pull_elementwise(s, salt);
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }

@@ -1086,6 +1086,7 @@ __global__ __launch_bounds__(256) void grouped_reduce_kernel(GroupArgs g) {
 
 }  // namespace mmdti
 
+MMDTI_DEFINE_SALT_PULL(gemm)
 using namespace mmdti;
 
 static int g_gemm_big = getenv("MMDTI_GEMM_BIG") ? atoi(getenv("MMDTI_GEMM_BIG")) : 1;

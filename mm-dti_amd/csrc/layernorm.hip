@@ -220,6 +220,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
 }
 
 }  // namespace mmdti
+MMDTI_DEFINE_SALT_PULL(layernorm)
 using namespace mmdti;
 
 static int ln_nv(int D) { return (D / 4 + 63) / 64; }

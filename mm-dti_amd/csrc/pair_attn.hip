@@ -750,6 +750,7 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
 }
 
 }  // namespace mmdti
+MMDTI_DEFINE_SALT_PULL(pair_attn)
 using namespace mmdti;
 
 // key tiles of 16 the MFMA kernels are instantiated for: 17 covers the reference's crop (max_atoms = 256 -> N <= 258, data/conformer.py:53,199-204)

@@ -640,9 +640,25 @@ def sumsq(g, out):
     return out
 
 
-def adam_step(p, g, m, v, p_bf16, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None):
+def adam_step(p, g, m, v, p_bf16, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None, step_state=None):
+    """step_state: the device-resident schedule (step_state_advance) -- lr / step are then read on the device."""
     lib().mmdti_adam_step(_stream(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(p_bf16), p.numel(), float(lr), float(beta1),
-                          float(beta2), float(eps), float(weight_decay), int(step), _p(grad_scale))
+                          float(beta2), float(eps), float(weight_decay), int(step), _p(grad_scale), _p(step_state))
+
+
+def step_state_advance(state, salt, base_lr, warmup, total, beta1=0.9, beta2=0.999):
+    """state [4] fp32, salt [2] int64 (device): advance the optimizer-step counter, this step's learning rate / bias
+    corrections and the dropout salt, then publish the salt to every kernel library."""
+    _chk(state, F32, "step_state.state"); _chk(salt, torch.int64, "step_state.salt")
+    lib().mmdti_step_state_advance(_stream(), state.data_ptr(), salt.data_ptr(), float(base_lr), int(warmup), int(total), float(beta1), float(beta2))
+    lib().mmdti_seed_salt_pull(_stream(), salt.data_ptr() + 8)
+
+
+def seed_salt_reset():
+    """Back to salt 0: dropout streams are exactly what the by-value (seed, site) pairs define (the eager path's contract)."""
+    z = torch.zeros(1, device="cuda", dtype=torch.int64)
+    lib().mmdti_seed_salt_pull(_stream(), z.data_ptr())
+    torch.cuda.current_stream().synchronize()
 
 
 def probe_tr_read(stride):

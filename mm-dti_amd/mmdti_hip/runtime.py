@@ -107,8 +107,9 @@ class ParamArena:
         shape = (sum(p.shape[0] for p in plist),) + tuple(cols)
         return self.shadow[o0:o].view(shape), self.data[o0:o].view(shape), self.grad[o0:o].view(shape)
 
-    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, max_norm: Optional[float] = None):
-        """torch.optim.Adam semantics (tasks/trainer.py:160) + optional global-norm clipping (:274), one fused pass."""
+    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, max_norm: Optional[float] = None, step_state=None):
+        """torch.optim.Adam semantics (tasks/trainer.py:160) + optional global-norm clipping (:274), one fused pass.
+        step_state: device-resident schedule (ops.step_state_advance) -- lr and the step count then live on the device."""
         if self.adam_m is None:
             self.adam_m = torch.zeros_like(self.data)
             self.adam_v = torch.zeros_like(self.data)
@@ -120,7 +121,7 @@ class ParamArena:
             # clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1 (tiny scalar math; stays on device, no sync)
             scale = torch.clamp(max_norm / (ss.sqrt() + 1e-6), max=1.0)
         ops.adam_step(self.data, self.grad, self.adam_m, self.adam_v, self.shadow, lr, betas[0], betas[1], eps, weight_decay,
-                      self.step_count, scale)
+                      self.step_count, scale, step_state)
 
 
 class _ShadowCache:

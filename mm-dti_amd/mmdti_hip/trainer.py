@@ -62,6 +62,7 @@ class FineTuner:
         self.warmup = int(total_steps * warmup_ratio)
         self.sched_step = 0
         self.arena = ParamArena(model.parameters(), adjacent=_qkv_groups(model))
+        self._graphs, self._state, self._salt = {}, None, None
         self.world = 1
         self.reducer = None
         remove_grad_ready_hook(self)
@@ -136,6 +137,74 @@ class FineTuner:
         lr = linear_warmup_lr(self.lr, self.sched_step, self.warmup, self.total_steps)
         self.arena.adam_step(lr, eps=self.eps, max_norm=self.max_norm)
         self.sched_step += 1
+
+    # ------------------------------------------------------------------ the whole step as ONE HIP graph
+    def graphed_step(self, net_input: dict, net_target: torch.Tensor, epoch: int = 0, use_weight: bool = False, **kw) -> StepOutput:
+        """step() replayed from a captured HIP graph: ~900 kernel launches become one graph launch, which is what the step
+        costs at the reference's real batch sizes (16-32: launch-bound, DESIGN.md "small batches").  One graph per input
+        shape signature (keep the number of distinct padded shapes small: bucketed batches, lengths rounded up).
+        What changes from step to step lives on the device: the optimizer-step counter, the learning rate of the HF schedule,
+        Adam's bias corrections and the dropout salt (ops.step_state_advance is the first node of the graph); the inputs
+        are copied into the graph's static buffers before each replay.  Returned tensors are the graph's static outputs --
+        read them before the next call.  Not available under data parallelism (collectives are left out of graphs here)."""
+        if self.reducer is not None:
+            raise RuntimeError("graphed_step: not supported with distributed=True (use step())")
+        key = (epoch >= getattr(getattr(self.model, "fds_cfg", None), "start_smooth", 1 << 30), bool(use_weight), tuple(sorted(kw.items())),
+               tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(net_input.items())), tuple(net_target.shape), net_target.dtype)
+        ent = self._graphs.get(key)
+        if ent is None:
+            ent = self._capture(net_input, net_target, epoch, use_weight, kw)
+            self._graphs[key] = ent
+        static_in, static_tgt, graph, out = ent
+        for k, v in net_input.items():
+            static_in[k].copy_(v, non_blocking=True)
+        static_tgt.copy_(net_target, non_blocking=True)
+        graph.replay()
+        self.sched_step += 1
+        self.arena.step_count += 1
+        return out
+
+    def _state_step(self, net_input, net_target, epoch, use_weight, kw):
+        """The body that is captured: advance the device state, then forward / backward / clip + Adam reading it."""
+        from . import ops
+        ops.step_state_advance(self._state, self._salt, self.lr, self.warmup, self.total_steps)
+        out = self.forward_backward(net_input, net_target, epoch, use_weight, **kw)
+        self.arena.adam_step(0.0, eps=self.eps, max_norm=self.max_norm, step_state=self._state)
+        self.arena.step_count -= 1                   # (the host-side counter is advanced by graphed_step, once per replay)
+        return out
+
+    def _capture(self, net_input, net_target, epoch, use_weight, kw):
+        dev = net_target.device
+        if self._state is None:
+            self._state = torch.zeros(4, device=dev, dtype=torch.float32)
+            self._salt = torch.zeros(2, device=dev, dtype=torch.int64)
+            self._salt[0] = dropout_state.base & 0x7FFFFFFFFFFFFFFF
+        # the device counter continues from wherever the eager path (or another graph) left the schedule
+        self._state[0] = float(self.sched_step)
+        if self.arena.adam_m is None:
+            self.arena.adam_m = torch.zeros_like(self.arena.data)
+            self.arena.adam_v = torch.zeros_like(self.arena.data)
+        static_in = {k: v.clone() for k, v in net_input.items()}
+        static_tgt = net_target.clone()
+        # warm-up on a side stream (lazy stream / buffer creation must not happen inside the capture), with a throw-away copy of
+        # the state this step mutates
+        saved = (self.arena.data.clone(), self.arena.adam_m.clone(), self.arena.adam_v.clone(), self._state.clone(), self._salt.clone(),
+                 self.arena.step_count)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self._state_step(static_in, static_tgt, epoch, use_weight, kw)
+        torch.cuda.current_stream().wait_stream(s)
+        self.arena.data.copy_(saved[0]); self.arena.adam_m.copy_(saved[1]); self.arena.adam_v.copy_(saved[2])
+        self._state.copy_(saved[3]); self._salt.copy_(saved[4])
+        self.arena.step_count = saved[5]
+        self.arena.refresh_shadow()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self._state_step(static_in, static_tgt, epoch, use_weight, kw)
+        return static_in, static_tgt, graph, out
 
     def step(self, net_input: dict, net_target: torch.Tensor, epoch: int = 0, use_weight: bool = False, **kw) -> StepOutput:
         out = self.forward_backward(net_input, net_target, epoch, use_weight, **kw)

@@ -365,3 +365,46 @@ def test_arena_shadow_follows_load_state_dict():
         m1.encoder.layers[0].fc1.weight.copy_(m2.encoder.layers[0].fc1.weight * 1.5)
         m2.encoder.layers[0].fc1.weight.mul_(1.5)
         torch.testing.assert_close(m1(**dev), m2(**dev), rtol=1e-4, atol=1e-5)
+
+
+def test_graphed_step_matches_eager_and_redraws_dropout():
+    """FineTuner.graphed_step: the whole step (zero-grad, forward, three losses, backward, clip, Adam with the HF schedule)
+    replayed from ONE captured HIP graph.  (1) with every dropout probability 0 it is the eager step: same losses step by
+    step, same parameters after 4 steps (learning-rate warm-up and Adam bias corrections advance on the device);
+    (2) with dropout on and lr 0 the losses CHANGE from replay to replay (the masks are re-drawn from the device salt
+    although seed and site are frozen in the graph) while eval-mode logits of the model stay put (nothing else moves)."""
+    from mmdti_hip.trainer import FineTuner
+    from mmdti_hip import ops
+    from g9util import product_model, tiny_cfg
+    ocfg = tiny_cfg("classification", 40)
+    m1, m2 = product_model(ocfg).cuda().train(), product_model(ocfg).cuda().train()
+    m2.load_state_dict(m1.state_dict())
+    batches = [O.synth_batch(8, 10, 14, ocfg, seed=20 + i, ragged=False) for i in range(4)]
+    t1 = FineTuner(m1, "classification", learning_rate=1e-3, warmup_ratio=0.5, total_steps=6, max_norm=5.0)
+    t2 = FineTuner(m2, "classification", learning_rate=1e-3, warmup_ratio=0.5, total_steps=6, max_norm=5.0)
+    try:
+        for b, y in batches:
+            dev = {k: v.cuda() for k, v in b.items()}
+            o1 = t1.step(dev, y.cuda())
+            o2 = t2.graphed_step(dev, y.cuda())
+            assert abs(float(o1.loss) - float(o2.loss)) <= 2e-4 * abs(float(o1.loss)) + 1e-6, (float(o1.loss), float(o2.loss))
+            assert abs(float(o1.infonce_loss) - float(o2.infonce_loss)) <= 2e-4 * abs(float(o1.infonce_loss))
+        assert len(t2._graphs) == 1 and t2.sched_step == 4 and float(t2._state[0]) == 4.0
+        # (parameters whose gradient is analytically zero -- key.bias, gbf_proj.linear2.bias -- take sign-noise Adam steps on both sides)
+        errs = [float((p1 - p2).norm() / (p1.norm() + 1e-12)) for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters())
+                if p1.requires_grad and not any(z in n for z in ("key.bias", "gbf_proj.linear2.bias", "pooler"))]
+        assert float(np.median(errs)) < 1e-4 and max(errs) < 5e-2, (float(np.median(errs)), max(errs))
+        # (2) dropout on, learning rate 0: only the masks can move the loss
+        m3 = product_model(ocfg, dropout=True).cuda().train()
+        t3 = FineTuner(m3, "classification", learning_rate=0.0, total_steps=100, max_norm=None)
+        b, y = batches[0]
+        dev = {k: v.cuda() for k, v in b.items()}
+        losses = [float(t3.graphed_step(dev, y.cuda()).loss) for _ in range(4)]
+        assert len({round(l, 6) for l in losses}) == 4, losses
+        m3.eval()
+        with torch.no_grad():
+            a = m3(**dev).clone()
+            t3.model.train(); t3.graphed_step(dev, y.cuda()); m3.eval()
+            assert torch.equal(a, m3(**dev))
+    finally:
+        ops.seed_salt_reset()
