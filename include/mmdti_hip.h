@@ -151,7 +151,8 @@ int mmdti_gbf_features_bwd(mmdti_stream_t stream, const float* dist, const long 
  * H=64.  feat/u/h (nullable, together): the [B*N*N, 128] bf16 basis / pre-activation / hidden rows for the backward.
  * tiled != 0: out is [B,H,nt,nt,256] (nt = ceil(N/16); 16x16 tiles in MFMA accumulator order, the layout the pair-attention
  * kernels stream -- see mmdti_pair_attn_fwd) and every pad slot (query or key >= N) is written -inf. */
-int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, const long long* edge_type, const float* mul,
+int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, const void* edge_type,
+                       int edge_bytes /* 8, 4 or 2: int64 as the reference collates (mm_model.py:657-660), or narrowed */, const float* mul,
                        const float* bias, const float* means, const float* stds, const void* w1_bf16, const float* b1,
                        const void* w2_bf16, const float* b2, int B, int N, int ld, int K, int F, int H, int E, float* out,
                        void* feat_bf16, void* u_bf16, void* h_bf16, int flags /* bit 0: tiled pair layout; bit 1: u_bf16 receives
@@ -160,10 +161,19 @@ int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, const long long
  * do_bf16 [B*N*N, 64] = bf16(g re-laid out) and du_bf16 [B*N*N, 128] = bf16((do.W2) * gelu'(u)) -- the A operands of the two
  * weight-gradient GEMMs (dW2 = do^T.h, dW1 = du^T.feat; bias gradients are their column sums) -- and accumulates the
  * Gaussian-layer gradients dmul/dbias [E] and dmeans/dstds [128] (fp32, +=).  E <= 4096. */
-int mmdti_gbf_bias_bwd(mmdti_stream_t stream, const float* g, const float* dist, const long long* edge_type, const float* mul,
-                       const float* bias, const float* means, const float* stds, const void* w1_bf16, const void* w2_bf16,
-                       const void* u_bf16, int B, int N, int ld, int K, int F, int H, int E, int flags, void* do_bf16,
-                       void* du_bf16, float* dmul, float* dbias, float* dmeans, float* dstds);
+int mmdti_gbf_bias_bwd(mmdti_stream_t stream, const float* g, const float* dist, const void* edge_type, int edge_bytes,
+                       const float* mul, const float* bias, const float* means, const float* stds, const void* w1_bf16,
+                       const void* w2_bf16, const void* u_bf16, int B, int N, int ld, int K, int F, int H, int E, int flags,
+                       void* do_bf16, void* du_bf16, float* dmul, float* dbias, float* dmeans, float* dstds);
+/* The WHOLE backward of mmdti_gbf_bias_fwd in one persistent kernel (autograd of mm_model.py:553-556 through gbf_proj
+ * :190-208 and GaussianLayer :211-236): the forward saves nothing -- each 128-pair block recomputes basis / pre-activation /
+ * hidden from dist and edge_type, forms do and du, and accumulates ALL parameter gradients on chip (MFMA, contraction over the
+ * pairs staged transposed in LDS), flushing once per workgroup: dw1 [128,128], db1 [128], dw2 [64,128], db2 [64], dmul/dbias [E],
+ * dmeans/dstds [128] (fp32, +=).  g: dL/d(out) in the layout of flags bit 0.  K=128, F=128, H=64, E <= 1536. */
+int mmdti_gbf_bias_bwd_full(mmdti_stream_t stream, const float* g, const float* dist, const void* edge_type, int edge_bytes,
+                            const float* mul, const float* bias, const float* means, const float* stds, const void* w1_bf16,
+                            const float* b1, const void* w2_bf16, int B, int N, int ld, int K, int F, int H, int E, int flags,
+                            float* dw1, float* db1, float* dw2, float* db2, float* dmul, float* dbias, float* dmeans, float* dstds);
 /* [B,N,N,H] fp32 -> [B,H,N,ld] fp32 (mm_model.py:555-556 permute(0,3,1,2).contiguous()) and its gradient
  * [B,H,N,ld] fp32 (or, tiled != 0, the [B,H,nt,nt,256] tile layout of mmdti_gbf_bias_fwd) -> [B,N,N,H] bf16 */
 int mmdti_pair_permute_fwd(mmdti_stream_t stream, const float* x, float* out, int B, int N, int H, int ld);

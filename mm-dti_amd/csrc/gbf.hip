@@ -201,8 +201,19 @@ __device__ __forceinline__ uint2 gbf_pack4(const gf32x4& a) {
   return pk;
 }
 
+// Edge types as the reference collates them (int64) or narrowed on the host (int32 / int16: SURVEY 8f-3 -- 961 types fit
+// 16 bits).  Branch-free so that a software-pipelined caller keeps the load in flight: one aligned 32-bit load (the low
+// word of an int64 keeps sign and value of anything an embedding index can be), the int16 case picks its half.
+__device__ __forceinline__ int gbf_edge(const void* et, long long base, unsigned off, int esz) {
+  const char* pb = reinterpret_cast<const char*>(et) + base * esz;
+  const unsigned bo = off * (unsigned)esz;
+  const int w = *reinterpret_cast<const int*>(pb + (bo & ~3u));
+  return esz == 2 ? (int)(short)(w >> ((bo & 2u) * 8u)) : w;
+}
+__device__ __forceinline__ int gbf_edge(const void* et, long long p, int esz) { return gbf_edge(et, p, 0u, esz); }
+
 template <bool SAVE, bool TILED>
-__global__ __launch_bounds__(256) void gbf_bias_fwd_kernel(const float* __restrict__ dist, const long long* __restrict__ et,
+__global__ __launch_bounds__(256) void gbf_bias_fwd_kernel(const float* __restrict__ dist, const void* __restrict__ et, int esz,
                                                            const float* __restrict__ mul, const float* __restrict__ bias,
                                                            const float* __restrict__ means, const float* __restrict__ stds,
                                                            const bf16_t* __restrict__ W1, const float* __restrict__ b1,
@@ -274,7 +285,7 @@ __global__ __launch_bounds__(256) void gbf_bias_fwd_kernel(const float* __restri
     const long long p = ((long long)b * N + (valid ? ii : 0)) * N + (valid ? jj : 0);
     float y = 0.f;
     {
-      long long e = et[p];
+      int e = gbf_edge(et, p, esz);
       e = e < 0 ? 0 : (e >= E ? E - 1 : e);
       y = mul[e] * dist[p] + bias[e];
     }
@@ -366,7 +377,7 @@ constexpr int GBF_W2S = 72;   // LDS row stride of W2^T [128 f][64 h]: 144-B row
 
 template <bool TILED>
 __global__ __launch_bounds__(256, 2) void gbf_bias_bwd_kernel(const float* __restrict__ gsrc, const float* __restrict__ dist,
-                                                           const long long* __restrict__ et, const float* __restrict__ mul,
+                                                           const void* __restrict__ et, int esz, const float* __restrict__ mul,
                                                            const float* __restrict__ bias, const float* __restrict__ means,
                                                            const float* __restrict__ stds, const bf16_t* __restrict__ W1,
                                                            const bf16_t* __restrict__ W2, const bf16_t* __restrict__ u_in,
@@ -442,8 +453,8 @@ __global__ __launch_bounds__(256, 2) void gbf_bias_bwd_kernel(const float* __res
     act = true;
     valid = ii < N && jj < N;
     p = ((long long)b * N + (valid ? ii : 0)) * N + (valid ? jj : 0);
-    long long e64 = et[p];
-    e = (int)(e64 < 0 ? 0 : (e64 >= E ? E - 1 : e64));
+    const int e32 = gbf_edge(et, p, esz);
+    e = e32 < 0 ? 0 : (e32 >= E ? E - 1 : e32);
     d = dist[p];
     const float* gp = gsrc + (long long)b * GBF_H * plane + (valid ? q : 0);
 #pragma unroll
@@ -568,6 +579,373 @@ __global__ __launch_bounds__(256, 2) void gbf_bias_bwd_kernel(const float* __res
   }
 }
 
+// =====================================================================================================================
+// Fused pair-bias backward, COMPLETE: everything mm_model.py:553-556 owes its parameters, from G = dL/d(bias) and the
+// batch's distances / edge types alone.  The forward saves NOTHING (its three [P,128] bf16 intermediates were 768 of its
+// 1 036 bytes per atom pair, and the two weight-gradient GEMMs then read 3.9 GB more): the Gaussian basis, the hidden
+// pre-activation and GELU are recomputed here (cheaper than the 1.5 KB per pair they replace), and the weight gradients,
+// whose contraction runs over ALL pairs, are accumulated in registers by the same workgroups.
+//
+// One persistent workgroup of 8 waves per CU.  Iteration = 128 pairs (a 16-pair tile per wave, same tile enumeration and
+// transposed-operand scheme as the forward kernel):
+//   phase A (wave = its 16 pairs):  y -> basis^T (B operand) -> rows of LDS tile T0;  dO^T = bf16(G);  per 16 hidden
+//                        features: du_raw^T = W2^T.dO^T, u^T = W1.basis^T + b1, (h, gelu') = GELU(u),
+//                        du^T = du_raw^T * gelu' -> rows of LDS tile T1; h stays packed in registers
+//   phase B1 (wave w = feature / kernel block w, all 128 pairs):
+//                        dW1[16w.., :] += du^T x basis and db1 (contraction over the pairs: transposing reads of T1 / T0);
+//                        dbasis^T[16w.., pairs] = W1^T.du^T (A by transposing reads of the W1 image, B = rows of T1), then
+//                        the Gaussian backward on the accumulator: d means / d stds of the wave's 16 kernels stay in 8
+//                        registers, the per-pair dy partials meet in an LDS row
+//   phase B2:            T0 / T1 refilled with h and dO;  dW2[:, 16w..] += dO^T x h, db2;  dy -> per-edge-type histogram.
+// The [pair][feature] tiles have 288-byte rows with the feature index XOR-ed by 64 on odd 8-row groups: writes are 8/16
+// bytes per lane, the transposing reads of a half-wave hit 32 distinct bank pairs.
+constexpr int GBF_LW = 144;       // LDS row stride (elements) of W1 [128 f][144] and of the two pair tiles [128 pairs][144]
+constexpr int GBF_FULL_MAXE = 1536;   // 4 per-edge-type fp32 tables next to 126 KB of tiles in the CU's 160 KB
+constexpr size_t gbf_full_smem(int E) {
+  return (size_t)(GBF_F * GBF_LW + GBF_F * GBF_W2S + 2 * 128 * GBF_LW) * 2 + (size_t)(3 * GBF_K + GBF_F + 2 * 128 + 4 * E) * 4;
+}
+
+typedef short gs16x4 __attribute__((ext_vector_type(4)));
+typedef short gs16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) gs16x4 glds_s16x4;
+__device__ __forceinline__ gbf16x8 gbf_tr8(const bf16_t* a0, const bf16_t* a1) {
+  const gs16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((glds_s16x4*)a0);
+  const gs16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((glds_s16x4*)a1);
+  const gs16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(gbf16x8, v);
+}
+
+// TILED: a tile is one 4x4 block of pairs, tpm = ceil(N/4)^2 per molecule (only blocks that hold a real pair are enumerated).
+template <bool TILED>
+__global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
+    const float* __restrict__ gsrc, const float* __restrict__ dist, const void* __restrict__ et, int esz, const float* __restrict__ mul,
+    const float* __restrict__ bias, const float* __restrict__ means, const float* __restrict__ stds, const bf16_t* __restrict__ W1,
+    const float* __restrict__ b1, const bf16_t* __restrict__ W2, float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2,
+    float* __restrict__ db2, float* __restrict__ dmul, float* __restrict__ dbias, float* __restrict__ dmeans, float* __restrict__ dstds, int B,
+    int N, int ld, int E, int tpm) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gbf_smem[];
+  bf16_t* sW1 = reinterpret_cast<bf16_t*>(gbf_smem);            // [128 f][144]  W1[f][k]
+  bf16_t* sW2T = sW1 + GBF_F * GBF_LW;                           // [128 f][72]   W2^T[f][h]
+  bf16_t* T0 = sW2T + GBF_F * GBF_W2S;                           // [128 pairs][144]: basis, later hidden
+  bf16_t* T1 = T0 + 128 * GBF_LW;                                // [128 pairs][144]: du, later dO
+  float* sMu = reinterpret_cast<float*>(T1 + 128 * GBF_LW);
+  float* sIs = sMu + GBF_K;
+  float* sCf = sIs + GBF_K;
+  float* sB1 = sCf + GBF_K;
+  float* sY = sB1 + GBF_F;                                       // [128] y of the iteration's pairs
+  float* sDy = sY + 128;                                         // [128] dL/dy partial sums
+  float* hist = sDy + 128;                                       // [2][E]
+  float* sMul = hist + 2 * E;                                    // [E]
+  float* sBia = sMul + E;                                        // [E]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < E; c += 512) {
+    sMul[c] = mul[c];
+    sBia[c] = bias[c];
+  }
+  for (int c = tid; c < GBF_F * (GBF_K / 8); c += 512) {
+    const int row = c >> 4, col = (c & 15) * 8;
+    *reinterpret_cast<uint4*>(sW1 + row * GBF_LW + col) = *reinterpret_cast<const uint4*>(W1 + row * GBF_K + col);
+  }
+  for (int c = tid; c < GBF_H * GBF_F; c += 512) {
+    const int h = c >> 7, f = c & 127;
+    sW2T[f * GBF_W2S + h] = W2[c];
+  }
+  if (tid < GBF_K) {
+    const float sg = fabsf(stds[tid]) + 1e-5f;
+    sMu[tid] = means[tid];
+    sIs[tid] = 1.0f / sg;
+    sCf[tid] = 1.0f / (GBF_A * sg);
+    sB1[tid] = b1[tid];
+    sDy[tid] = 0.f;
+  }
+  for (int c = tid; c < 2 * E; c += 512) hist[c] = 0.f;
+  __syncthreads();
+  const int g = lane >> 4, i = lane & 15;
+  const int ploc = 16 * wave + i;                                 // this lane's row in the pair tiles
+  const int pswz = ((ploc >> 3) & 1) << 6;
+  // Swizzled column c ^ swz (swz = 0 or 64) = (c < 64 ? c + swz : c - 64 + (64 ^ swz)): two bases, compile-time offsets --
+  // the compiler would otherwise hoist one address register per access out of the loop and spill them.
+#define GBF_SWZ(lo, hi, c) ((c) < 64 ? (lo) + (c) : (hi) + ((c) - 64))
+  bf16_t* const r0lo = T0 + ploc * GBF_LW + pswz;               // this lane's pair row of T0 / T1
+  bf16_t* const r0hi = T0 + ploc * GBF_LW + (64 ^ pswz);
+  bf16_t* const r1lo = r0lo + 128 * GBF_LW;                      // (T1 = T0 + 128 rows: the same registers, immediate offsets)
+  bf16_t* const r1hi = r0hi + 128 * GBF_LW;
+  const int tswz = (g & 1) << 6;                                 // transposing reads: pair rows 32s + 8g + (i>>2) [+4]
+  const int trow = (8 * g + (i >> 2)) * GBF_LW + 4 * (i & 3);
+  const bf16_t* const t0lo = T0 + trow + tswz;
+  const bf16_t* const t0hi = T0 + trow + (64 ^ tswz);
+  const bf16_t* const t1lo = t0lo + 128 * GBF_LW;
+  const bf16_t* const t0w = T0 + trow + ((16 * wave) ^ tswz);   // column block = this wave
+  const bf16_t* const t1w = t0w + 128 * GBF_LW;
+  const int rswz = ((i >> 3) & 1) << 6;                          // row reads of T1: pair row 16j + i
+  const bf16_t* const d1lo = T1 + i * GBF_LW + 8 * g + rswz;
+  const bf16_t* const d1hi = T1 + i * GBF_LW + 8 * g + (64 ^ rswz);
+  // byte offsets (from the start of the LDS block) of the loop-invariant images; see the laundering note in the loop
+  unsigned o_w1row = (unsigned)(i * GBF_LW + 8 * g) * 2;                                   // A fragments of W1 (rows 16ft + i)
+  unsigned o_w2row = (unsigned)(GBF_F * GBF_LW + i * GBF_W2S + 8 * g) * 2;                 // ... and of W2^T
+  unsigned o_w1tr = (unsigned)((8 * g + (i >> 2)) * GBF_LW + 16 * wave + 4 * (i & 3)) * 2; // W1^T fragment, k block = wave
+  const unsigned o_f32 = (unsigned)(GBF_F * GBF_LW + GBF_F * GBF_W2S + 2 * 128 * GBF_LW) * 2;  // sMu
+  unsigned o_gconst = o_f32 + (unsigned)(8 * g) * 4;             // Gaussian constants of kernels 32c + 8g + 0..7 (phase A)
+  unsigned o_b1row = o_f32 + (unsigned)(3 * GBF_K + 4 * g) * 4;
+  unsigned o_kconst = o_f32 + (unsigned)(16 * wave + 4 * g) * 4; // phase B1's Gaussian constants: kernels k = 16*wave + 4g + r
+  const int ntiles = B * tpm;
+  const int nt = (N + 15) >> 4, nb = (N + 3) >> 2;
+  const long long plane = TILED ? (long long)nt * nt * 256 : (long long)N * ld;
+  gf32x4 amu = {0.f, 0.f, 0.f, 0.f}, asg = {0.f, 0.f, 0.f, 0.f};
+  gf32x4 aW1[8], aW2[4], aB1 = {0.f, 0.f, 0.f, 0.f}, aB2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 8; ++t) aW1[t] = gf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) aW2[t] = gf32x4{0.f, 0.f, 0.f, 0.f};
+  const gs16x8 o16 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  const gbf16x8 ones = __builtin_bit_cast(gbf16x8, o16);
+
+  // Branch-free: a tile past the end is clamped to the last one and flagged inactive, a pad lane reads pair (0, 0) of its
+  // molecule -- so every load of the NEXT iteration is in flight, unconditionally, while this one computes.
+  auto fetch = [&](int tile, bool& act, bool& valid, float& d, int& e, float (&gv)[16]) {
+    tile = __builtin_amdgcn_readfirstlane(tile);          // (wave-uniform: tile = 8 * workgroup + wave)
+    act = tile < ntiles;
+    tile = act ? tile : ntiles - 1;
+    const int b = (int)((unsigned)tile / (unsigned)tpm);
+    const int tq = tile - b * tpm;
+    int q, ii, jj;
+    if (TILED) {
+      const int rb = (int)((unsigned)tq / (unsigned)nb), cb = tq - rb * nb;
+      ii = 4 * rb + (i >> 2);
+      jj = 4 * cb + (i & 3);
+      q = ((rb >> 2) * nt + (cb >> 2)) * 256 + (cb & 3) * 64 + (rb & 3) * 16 + i;
+    } else {
+      q = tq * 16 + i;
+      ii = (int)((unsigned)q / (unsigned)ld);
+      jj = q - ii * ld;
+    }
+    valid = act && ii < N && jj < N;
+    // scalar base of the molecule + 32-bit lane offsets (host: N*N and 64*plane fit 31 bits)
+    const long long mol = (long long)b * N * N;
+    const unsigned pl = (unsigned)((valid ? ii : 0) * N + (valid ? jj : 0));
+    const int e32 = gbf_edge(et, mol, pl, esz);
+    e = e32 < 0 ? 0 : (e32 >= E ? E - 1 : e32);
+    d = (dist + mol)[pl];
+    const float* mb = gsrc + (long long)b * GBF_H * plane;
+    const unsigned voff = (unsigned)(8 * g) * (unsigned)plane + (unsigned)(valid ? q : 0);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gv[c * 8 + j] = (mb + (long long)(32 * c + j) * plane)[voff];
+  };
+
+  bool act, valid, n_act, n_valid;
+  float d, n_d, gv[16], n_gv[16];
+  int e, n_e;
+  const int stride = (int)gridDim.x * 8;
+  int tile = (int)blockIdx.x * 8 + wave;
+  fetch(tile, act, valid, d, e, gv);
+  // (every wave of the workgroup runs the same number of iterations: the loop bound is on the workgroup's first tile)
+  for (int base = (int)blockIdx.x * 8; base < ntiles; base += stride, tile += stride) {
+    // The weight / constant images in LDS never change inside the loop, and the compiler knows: left alone it hoists some
+    // 300 registers' worth of their reads out of the loop and spills them.  Laundering the (integer) offsets pins the
+    // reads where they are written and keeps the pointers in the LDS address space.
+    asm volatile("" : "+v"(o_w1row), "+v"(o_w2row), "+v"(o_w1tr), "+v"(o_gconst), "+v"(o_b1row), "+v"(o_kconst));
+    const bf16_t* w1row = reinterpret_cast<const bf16_t*>(gbf_smem + o_w1row);
+    const bf16_t* w2row = reinterpret_cast<const bf16_t*>(gbf_smem + o_w2row);
+    const bf16_t* w1tr = reinterpret_cast<const bf16_t*>(gbf_smem + o_w1tr);
+    const float* gconst = reinterpret_cast<const float*>(gbf_smem + o_gconst);
+    const float* b1row = reinterpret_cast<const float*>(gbf_smem + o_b1row);
+    const float* kconst = reinterpret_cast<const float*>(gbf_smem + o_kconst);
+    fetch(tile + stride, n_act, n_valid, n_d, n_e, n_gv);
+    // ------------------------------------------------------------------------------------------------ phase A
+    gbf16x8 oB[2], hB[4];
+    if (!valid) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) gv[j] = 0.f;
+    }
+    oB[0] = gbf_pack8(gv);
+    oB[1] = gbf_pack8(gv + 8);
+    const float y = sMul[e] * d + sBia[e];
+    if (g == 0) sY[ploc] = y;
+    if (act) {
+      gbf16x8 fB[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float v[8];
+        const float* gc = gconst + 32 * c;
+        const gf32x4 m0 = *reinterpret_cast<const gf32x4*>(gc), m1 = *reinterpret_cast<const gf32x4*>(gc + 4);
+        const gf32x4 s0 = *reinterpret_cast<const gf32x4*>(gc + GBF_K), s1 = *reinterpret_cast<const gf32x4*>(gc + GBF_K + 4);
+        const gf32x4 c0 = *reinterpret_cast<const gf32x4*>(gc + 2 * GBF_K), c1 = *reinterpret_cast<const gf32x4*>(gc + 2 * GBF_K + 4);
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) {
+          const float z0 = (y - m0[ee]) * s0[ee], z1 = (y - m1[ee]) * s1[ee];
+          v[ee] = __expf(-0.5f * z0 * z0) * c0[ee];
+          v[4 + ee] = __expf(-0.5f * z1 * z1) * c1[ee];
+        }
+        fB[c] = gbf_pack8(v);
+        *reinterpret_cast<gbf16x8*>(GBF_SWZ(r0lo, r0hi, 32 * c) + 8 * g) = fB[c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        gf32x4 hv[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int ft = 2 * u + hf;
+          gf32x4 acc = {0.f, 0.f, 0.f, 0.f}, ua = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const gbf16x8 wf = *reinterpret_cast<const gbf16x8*>(w2row + 16 * ft * GBF_W2S + 32 * c);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, oB[c], acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const gbf16x8 wf = *reinterpret_cast<const gbf16x8*>(w1row + 16 * ft * GBF_LW + 32 * c);
+            ua = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, fB[c], ua, 0, 0, 0);
+          }
+          ua += *reinterpret_cast<const gf32x4*>(b1row + 16 * ft);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float yv, gq;
+            gelu_erf_both(ua[r], yv, gq);
+            // the hidden / gelu' pass through bf16 exactly where the unfused chain's saved tensors did
+            hv[hf][r] = yv;
+            acc[r] *= __uint_as_float(((uint32_t)f2bf(gq)) << 16);
+          }
+          *reinterpret_cast<uint2*>(GBF_SWZ(r1lo, r1hi, 16 * ft) + 4 * g) = gbf_pack4(acc);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        float w[8] = {hv[0][0], hv[0][1], hv[0][2], hv[0][3], hv[1][0], hv[1][1], hv[1][2], hv[1][3]};
+        hB[u] = gbf_pack8(w);      // slots 8g' + 4hf + e <-> features 32u + 16hf + 4g + e
+      }
+    } else {                       // tile past the end: its rows of the pair tiles contribute nothing
+      const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        *reinterpret_cast<uint4*>(GBF_SWZ(r0lo, r0hi, 32 * c) + 8 * g) = z4;
+        *reinterpret_cast<uint4*>(GBF_SWZ(r1lo, r1hi, 32 * c) + 8 * g) = z4;
+        hB[c] = __builtin_bit_cast(gbf16x8, z4);
+      }
+    }
+    __syncthreads();                                   // T0 = basis, T1 = du, sY = y of the workgroup's 128 pairs
+    // ------------------------------------------------------------------------------------------------ phase B1
+    // operand fragment (rows / columns fb*16 .., contraction = pairs 32s + 8g + 0..7) of a pair tile, transposing reads
+#define GBF_TFRAG(P, S) gbf_tr8((P) + 32 * (S) * GBF_LW, (P) + (32 * (S) + 4) * GBF_LW)
+#pragma unroll
+    for (int sstep = 0; sstep < 4; ++sstep) {
+      const gbf16x8 fa = GBF_TFRAG(t1w, sstep);                // du^T rows 16*wave ..
+      aB1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, ones, aB1, 0, 0, 0);
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) {
+        const gbf16x8 fb = GBF_TFRAG(GBF_SWZ(t0lo, t0hi, 16 * kb), sstep);
+        aW1[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, aW1[kb], 0, 0, 0);
+      }
+    }
+    {
+      // dbasis^T[k = 16*wave + .., pair] = sum_f W1[f][k] du[pair][f]; A: W1^T fragment (contraction f = 32u + 8g + 0..7)
+      gbf16x8 wfr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        wfr[u] = gbf_tr8(w1tr + 32 * u * GBF_LW, w1tr + (32 * u + 4) * GBF_LW);
+      }
+      const gf32x4 kmu = *reinterpret_cast<const gf32x4*>(kconst);
+      const gf32x4 kis = *reinterpret_cast<const gf32x4*>(kconst + GBF_K);
+      const gf32x4 kcf = *reinterpret_cast<const gf32x4*>(kconst + 2 * GBF_K);
+#pragma unroll 1                                           // (unrolled, the scheduler interleaves all 8 sub-tiles and spills 70 registers)
+      for (int j = 0; j < 8; ++j) {
+        gf32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const gbf16x8 dub = *reinterpret_cast<const gbf16x8*>(GBF_SWZ(d1lo, d1hi, 32 * u) + 16 * j * GBF_LW);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[u], dub, acc, 0, 0, 0);
+        }
+        const float yj = sY[16 * j + i];
+        float dy = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float dvr = __uint_as_float(((uint32_t)f2bf(acc[r])) << 16);   // dbasis passes through bf16 like the unfused chain
+          const float z = (yj - kmu[r]) * kis[r];
+          const float val = __expf(-0.5f * z * z) * kcf[r];
+          const float t = dvr * val;                     // (du, hence dbasis, is exactly 0 for pad pairs)
+          const float zs = z * kis[r];
+          dy -= t * zs;
+          amu[r] += t * zs;
+          asg[r] += t * (z * zs - kis[r]);
+        }
+        dy += __shfl_xor(dy, 16, 64);
+        dy += __shfl_xor(dy, 32, 64);
+        if (g == 0) atomicAdd(&sDy[16 * j + i], dy);
+      }
+    }
+    __syncthreads();                                   // every wave has read basis / du; sDy complete
+    // ------------------------------------------------------------------------------------------------ phase B2
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint4 hw = __builtin_bit_cast(uint4, hB[u]);
+      *reinterpret_cast<uint2*>(GBF_SWZ(r0lo, r0hi, 32 * u) + 4 * g) = make_uint2(hw.x, hw.y);
+      *reinterpret_cast<uint2*>(GBF_SWZ(r0lo, r0hi, 32 * u + 16) + 4 * g) = make_uint2(hw.z, hw.w);
+    }
+    *reinterpret_cast<gbf16x8*>(r1lo + 8 * g) = oB[0];              // dO: heads 32c + 8g ..
+    *reinterpret_cast<gbf16x8*>(r1lo + 32 + 8 * g) = oB[1];
+    if (g == 0) {
+      const float dyv = sDy[ploc];
+      sDy[ploc] = 0.f;
+      if (valid) {
+        atomicAdd(&hist[e], dyv * d);
+        atomicAdd(&hist[E + e], dyv);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sstep = 0; sstep < 4; ++sstep) {
+      const gbf16x8 fb = GBF_TFRAG(t0w, sstep);                // hidden columns 16*wave ..
+#pragma unroll
+      for (int hb = 0; hb < 4; ++hb) {
+        const gbf16x8 fa = GBF_TFRAG(t1lo + 16 * hb, sstep);   // dO^T rows 16*hb .. (heads < 64: the low swizzle half)
+        aW2[hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, aW2[hb], 0, 0, 0);
+      }
+      // db2 of head block wave & 3 (waves 4..7 repeat it and drop it at the flush).  Unconditional on purpose: MFMA ignores
+      // EXEC, a predicated one would still run -- on operands whose masked-off set-up did not.
+      const gbf16x8 fo = GBF_TFRAG(t1lo + 16 * (wave & 3), sstep);
+      aB2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fo, ones, aB2, 0, 0, 0);
+    }
+#undef GBF_TFRAG
+#undef GBF_SWZ
+    __syncthreads();                                   // tiles free for the next iteration
+    act = n_act; valid = n_valid; d = n_d; e = n_e;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) gv[j] = n_gv[j];
+  }
+  // ---- flush.  Accumulator tile: rows 4g + r, column i.
+#pragma unroll
+  for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(dW1 + (long long)(16 * wave + 4 * g + r) * GBF_K + 16 * kb + i, aW1[kb][r]);
+#pragma unroll
+  for (int hb = 0; hb < 4; ++hb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(dW2 + (long long)(16 * hb + 4 * g + r) * GBF_F + 16 * wave + i, aW2[hb][r]);
+  if (i == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      atomicAdd(db1 + 16 * wave + 4 * g + r, aB1[r]);
+      if (wave < 4) atomicAdd(db2 + 16 * wave + 4 * g + r, aB2[r]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float a = amu[r], sgv = asg[r];
+    a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64); a += __shfl_xor(a, 8, 64);
+    sgv += __shfl_xor(sgv, 1, 64); sgv += __shfl_xor(sgv, 2, 64); sgv += __shfl_xor(sgv, 4, 64); sgv += __shfl_xor(sgv, 8, 64);
+    if (i == 0) {
+      const int k = 16 * wave + 4 * g + r;
+      atomicAdd(dmeans + k, a);
+      atomicAdd(dstds + k, stds[k] < 0.f ? -sgv : sgv);   // d|std|/dstd
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < E; c += 512) {
+    const float a = hist[c], bb = hist[E + c];
+    if (a != 0.f) atomicAdd(dmul + c, a);
+    if (bb != 0.f) atomicAdd(dbias + c, bb);
+  }
+}
+
 // Tiled G ([B,H,nt,nt,256], tiles in accumulator order) -> [B,N,N,H] bf16.  One block per (molecule, query block, key
 // tile): the 64 head tiles are 64 contiguous KiB reads; the 16x16 pairs x H heads are regrouped in LDS so that each of
 // the 16 query rows leaves as one contiguous run of 16 keys x H heads.
@@ -661,12 +1039,15 @@ extern "C" int mmdti_pair_permute_bwd(mmdti_stream_t stream, const float* g, voi
   return MMDTI_OK;
 }
 
-extern "C" int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, const long long* edge_type, const float* mul,
+static int edge_bytes_ok(int eb) { return eb == 8 || eb == 4 || eb == 2; }
+
+extern "C" int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, const void* edge_type, int edge_bytes, const float* mul,
                                   const float* bias, const float* means, const float* stds, const void* w1_bf16,
                                   const float* b1, const void* w2_bf16, const float* b2, int B, int N, int ld, int K, int F,
                                   int H, int E, float* out, void* feat_bf16, void* u_bf16, void* h_bf16, int flags) {
   const int tiled = flags & 1, ugrad = (flags >> 1) & 1;   // bit 0: tiled pair layout; bit 1: u_bf16 receives gelu'(u) instead of u
   MMDTI_REQUIRE(dist && edge_type && mul && bias && means && stds && w1_bf16 && b1 && w2_bf16 && b2 && out, "gbf_bias_fwd: null argument");
+  MMDTI_REQUIRE(edge_bytes_ok(edge_bytes), "gbf_bias_fwd: edge types must be int64, int32 or int16 (edge_bytes=%d)", edge_bytes);
   MMDTI_REQUIRE(K == GBF_K && F == GBF_F && H == GBF_H, "gbf_bias_fwd: built for %d gaussians, %d hidden, %d heads (got %d,%d,%d)",
                 GBF_K, GBF_F, GBF_H, K, F, H);
   MMDTI_REQUIRE(B > 0 && N > 0 && ld >= N && ld % 4 == 0 && E > 0, "gbf_bias_fwd: bad shape");
@@ -680,7 +1061,7 @@ extern "C" int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, cons
   const int grid = (int)(ntiles / 4 + 1 < 2048 ? ntiles / 4 + 1 : 2048);
   const size_t smem = (size_t)(GBF_F + GBF_H) * GBF_WS * 2 + (size_t)(3 * GBF_K + GBF_F + GBF_H) * 4;
 #define GBF_L(SAVE, TILED)                                                                                                          \
-  hipLaunchKernelGGL((gbf_bias_fwd_kernel<SAVE, TILED>), dim3(grid), dim3(256), smem, (hipStream_t)stream, dist, edge_type, mul, bias, \
+  hipLaunchKernelGGL((gbf_bias_fwd_kernel<SAVE, TILED>), dim3(grid), dim3(256), smem, (hipStream_t)stream, dist, edge_type, edge_bytes, mul, bias, \
                      means, stds, (const bf16_t*)w1_bf16, b1, (const bf16_t*)w2_bf16, b2, out, (bf16_t*)feat_bf16, (bf16_t*)u_bf16, \
                      (bf16_t*)h_bf16, B, N, ld, E, tpm, ugrad)
   if (save) { if (tiled) GBF_L(true, true); else GBF_L(true, false); }
@@ -690,7 +1071,7 @@ extern "C" int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, cons
   return MMDTI_OK;
 }
 
-extern "C" int mmdti_gbf_bias_bwd(mmdti_stream_t stream, const float* g, const float* dist, const long long* edge_type,
+extern "C" int mmdti_gbf_bias_bwd(mmdti_stream_t stream, const float* g, const float* dist, const void* edge_type, int edge_bytes,
                                   const float* mul, const float* bias, const float* means, const float* stds,
                                   const void* w1_bf16, const void* w2_bf16, const void* u_bf16, int B, int N, int ld, int K,
                                   int F, int H, int E, int flags, void* do_bf16, void* du_bf16, float* dmul, float* dbias,
@@ -701,6 +1082,7 @@ extern "C" int mmdti_gbf_bias_bwd(mmdti_stream_t stream, const float* g, const f
   MMDTI_REQUIRE(K == GBF_K && F == GBF_F && H == GBF_H, "gbf_bias_bwd: built for %d gaussians, %d hidden, %d heads (got %d,%d,%d)",
                 GBF_K, GBF_F, GBF_H, K, F, H);
   MMDTI_REQUIRE(B > 0 && N > 0 && ld >= N && ld % 4 == 0 && E > 0 && E <= GBF_MAXE, "gbf_bias_bwd: bad shape (E <= %d)", GBF_MAXE);
+  MMDTI_REQUIRE(edge_bytes_ok(edge_bytes), "gbf_bias_bwd: edge types must be int64, int32 or int16 (edge_bytes=%d)", edge_bytes);
   MMDTI_REQUIRE(aligned16(u_bf16) && aligned16(do_bf16) && aligned16(du_bf16), "gbf_bias_bwd: 16-byte alignment required");
   const int nt = (N + 15) / 16;
   const int tpm = tiled ? 16 * nt * nt : cdiv((long long)N * ld, 16);
@@ -718,11 +1100,50 @@ extern "C" int mmdti_gbf_bias_bwd(mmdti_stream_t stream, const float* g, const f
     attr_done = true;
   }
 #define GBF_B(TILED)                                                                                                          \
-  hipLaunchKernelGGL((gbf_bias_bwd_kernel<TILED>), dim3(grid), dim3(256), smem, (hipStream_t)stream, g, dist, edge_type, mul, bias, \
+  hipLaunchKernelGGL((gbf_bias_bwd_kernel<TILED>), dim3(grid), dim3(256), smem, (hipStream_t)stream, g, dist, edge_type, edge_bytes, mul, bias, \
                      means, stds, (const bf16_t*)w1_bf16, (const bf16_t*)w2_bf16, (const bf16_t*)u_bf16, (bf16_t*)do_bf16,    \
                      (bf16_t*)du_bf16, dmul, dbias, dmeans, dstds, B, N, ld, E, tpm, ugrad)
   if (tiled) GBF_B(true); else GBF_B(false);
 #undef GBF_B
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_gbf_bias_bwd_full(mmdti_stream_t stream, const float* g, const float* dist, const void* edge_type, int edge_bytes,
+                                       const float* mul, const float* bias, const float* means, const float* stds, const void* w1_bf16,
+                                       const float* b1, const void* w2_bf16, int B, int N, int ld, int K, int F, int H, int E, int flags,
+                                       float* dw1, float* db1, float* dw2, float* db2, float* dmul, float* dbias, float* dmeans,
+                                       float* dstds) {
+  const int tiled = flags & 1;
+  MMDTI_REQUIRE(g && dist && edge_type && mul && bias && means && stds && w1_bf16 && b1 && w2_bf16 && dw1 && db1 && dw2 && db2 && dmul && dbias &&
+                    dmeans && dstds, "gbf_bias_bwd_full: null argument");
+  MMDTI_REQUIRE(edge_bytes_ok(edge_bytes), "gbf_bias_bwd_full: edge types must be int64, int32 or int16 (edge_bytes=%d)", edge_bytes);
+  MMDTI_REQUIRE(K == GBF_K && F == GBF_F && H == GBF_H, "gbf_bias_bwd_full: built for %d gaussians, %d hidden, %d heads (got %d,%d,%d)",
+                GBF_K, GBF_F, GBF_H, K, F, H);
+  MMDTI_REQUIRE(B > 0 && N > 0 && ld >= N && ld % 4 == 0 && E > 0 && E <= GBF_FULL_MAXE, "gbf_bias_bwd_full: bad shape (E <= %d)", GBF_FULL_MAXE);
+  MMDTI_REQUIRE((long long)N * ld * GBF_H < (1ll << 29) && (long long)B * N * ld / 16 < (1ll << 30), "gbf_bias_bwd_full: batch too large for 32-bit tile offsets");
+  MMDTI_REQUIRE(aligned16(w1_bf16), "gbf_bias_bwd_full: W1 must be 16-byte aligned");
+  const int nb = (N + 3) / 4;
+  const int tpm = tiled ? nb * nb : cdiv((long long)N * ld, 16);
+  const long long ntiles = (long long)B * tpm;
+  const int grid = (int)((ntiles + 7) / 8 < 256 ? (ntiles + 7) / 8 : 256);
+  const size_t smem = gbf_full_smem(E);
+  static bool attr_done = false;
+  if (!attr_done) {
+    const int cap = (int)gbf_full_smem(GBF_FULL_MAXE);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gbf_bias_bwd_full_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gbf_bias_bwd_full_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess) {
+      set_error("gbf_bias_bwd_full: hipFuncSetAttribute failed");
+      return MMDTI_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+#define GBF_FB(TILED)                                                                                                              \
+  hipLaunchKernelGGL((gbf_bias_bwd_full_kernel<TILED>), dim3(grid), dim3(512), smem, (hipStream_t)stream, g, dist, edge_type, edge_bytes, mul, \
+                     bias, means, stds, (const bf16_t*)w1_bf16, b1, (const bf16_t*)w2_bf16, dw1, db1, dw2, db2, dmul, dbias, dmeans, dstds, B, \
+                     N, ld, E, tpm)
+  if (tiled) GBF_FB(true); else GBF_FB(false);
+#undef GBF_FB
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }

@@ -280,10 +280,15 @@ class PairBiasFn(torch.autograd.Function):
         dist, edge_type = dist.contiguous(), edge_type.contiguous()
         args = [gbf.mul.weight.view(-1), gbf.bias.weight.view(-1), gbf.means.weight.view(-1), gbf.stds.weight.view(-1)]
         fused = ops.gbf_bias_eligible(args[2].numel(), proj.linear1.weight.shape[0], H, ld)
+        # the complete backward kernel recomputes basis / hidden from the inputs: the forward then saves nothing
+        full = fused and ops.GBF_FULL_BWD and args[0].numel() <= ops.GBF_FULL_MAXE
+        if edge_type.dtype != torch.int64 and not fused:
+            edge_type = edge_type.long()      # (the unfused kernels read the reference's int64)
         if fused:
-            # one kernel from distances to the [B,H,N,ld] bias; the three [P,128] intermediates are saved for the backward
-            # (tiled pair layout whenever the MFMA pair-attention kernels can take it: their loads become contiguous KiBs)
-            keep = any(ctx.needs_input_grad)  # inference: the kernel does not even write the [P,128] intermediates
+            # one kernel from distances to the [B,H,N,ld] bias (tiled pair layout whenever the MFMA pair-attention kernels can
+            # take it: their loads become contiguous KiBs); without the complete backward kernel the three [P,128] intermediates
+            # are kept for the backward
+            keep = any(ctx.needs_input_grad) and not full  # inference: the kernel does not even write the intermediates
             out, saved = ops.gbf_bias_fwd(dist, edge_type, *args, wbf16(proj.linear1.weight), proj.linear1.bias,
                                           wbf16(proj.linear2.weight), proj.linear2.bias, ld, save=keep, tiled=ops.pair_tiled_ok(N),
                                           save_grad=ops.GELU_SAVE_GRAD)
@@ -296,7 +301,7 @@ class PairBiasFn(torch.autograd.Function):
             ugrad = ops.GELU_SAVE_GRAD
             o = ops.linear_fwd(h, wbf16(proj.linear2.weight), proj.linear2.bias, out_dtype=F32)
             out = ops.pair_permute_fwd(o, B, N, H, ld)
-        ctx.st = SimpleNamespace(dist=dist, et=edge_type, feat=feat, u=u, h=h, B=B, N=N, H=H, ld=ld, fused=fused, ugrad=ugrad)
+        ctx.st = SimpleNamespace(dist=dist, et=edge_type, feat=feat, u=u, h=h, B=B, N=N, H=H, ld=ld, fused=fused, ugrad=ugrad, full=full)
         ctx.gbf, ctx.proj = gbf, proj
         return out
 
@@ -304,7 +309,14 @@ class PairBiasFn(torch.autograd.Function):
     def backward(ctx, g):
         st, gbf, proj = ctx.st, ctx.gbf, ctx.proj
         ps = [gbf.mul.weight, gbf.bias.weight, gbf.means.weight, gbf.stds.weight]
-        if st.fused and ps[0].numel() <= 4096:
+        if st.full:
+            # ONE kernel: recompute, both dX products, GELU', the Gaussian backward and all four weight / bias gradients
+            l1, l2 = proj.linear1, proj.linear2
+            allp = [l1.weight, l1.bias, l2.weight, l2.bias] + ps
+            grads = [gbuf(p) if p.requires_grad else torch.zeros_like(p) for p in allp]
+            ops.gbf_bias_bwd_full(g.contiguous(), st.dist, st.et, *[p.view(-1) for p in ps], wbf16(l1.weight), l1.bias, wbf16(l2.weight),
+                                  st.ld, *[gr.view(-1) for gr in grads])
+        elif st.fused and ps[0].numel() <= 4096:
             # one pass over G: re-layout, both dX products, GELU' and the Gaussian backward; only the two weight-gradient
             # GEMMs (contraction over all pairs) and their column sums remain
             grads = [gbuf(p) if p.requires_grad else torch.zeros_like(p) for p in ps]

@@ -17,6 +17,9 @@ F32 = torch.float32
 ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_TANH, ACT_GELU_G, ACT_MUL_AUX = 0, 1, 2, 3, 4, 5
 # forward GELU that saves gelu'(u) instead of u, backward = one multiply (MMDTI_GELU_SAVE_GRAD=0: save u, evaluate gelu' in the backward)
 GELU_SAVE_GRAD = os.environ.get("MMDTI_GELU_SAVE_GRAD", "1") != "0"
+# pair bias: the forward saves nothing and ONE kernel does the whole backward (0: the round-1 chain -- fused per-pair half,
+# three saved [P,128] tensors and two weight-gradient GEMMs)
+GBF_FULL_BWD = os.environ.get("MMDTI_GBF_FULL_BWD", "1") != "0"
 ACT_GELU_FWD = ACT_GELU_G if GELU_SAVE_GRAD else ACT_GELU
 ACT_GELU_DX = ACT_MUL_AUX if GELU_SAVE_GRAD else ACT_GELU_BWD
 DT_F32, DT_BF16, DT_F32_ATOMIC = 0, 1, 2
@@ -286,6 +289,14 @@ def roberta_position_ids(ids, pad_idx):
 
 
 # --------------------------------------------------------------------------------------------- Gaussian basis / pair layout
+EDGE_DTYPES = (torch.int64, torch.int32, torch.int16)
+
+
+def _chk_edge(edge_type):
+    if edge_type.dtype not in EDGE_DTYPES or not edge_type.is_contiguous():
+        raise TypeError(f"gbf.edge_type must be a contiguous int64 / int32 / int16 tensor, got {edge_type.dtype}")
+
+
 def gbf_features_fwd(dist, edge_type, mul, bias, means, stds):
     _chk(dist, F32, "gbf.dist"); _chk(edge_type, torch.int64, "gbf.edge_type")
     P, K, E = dist.numel(), means.numel(), mul.numel()
@@ -306,14 +317,14 @@ def gbf_features_bwd(dist, edge_type, mul, bias, means, stds, dfeat, dmul, dbias
 
 def gbf_bias_fwd(dist, edge_type, mul, bias, means, stds, w1, b1, w2, b2, ld, save=True, tiled=False, save_grad=False):
     """Fused gbf + gbf_proj + permute -> (out [B,H,N,ld] fp32 -- or the tiled pair layout --, (feat, u, h) [P,128] bf16 or None)."""
-    _chk(dist, F32, "gbf.dist"); _chk(edge_type, torch.int64, "gbf.edge_type"); _chk(w1, BF16, "gbf.w1"); _chk(w2, BF16, "gbf.w2")
+    _chk(dist, F32, "gbf.dist"); _chk_edge(edge_type); _chk(w1, BF16, "gbf.w1"); _chk(w2, BF16, "gbf.w2")
     B, N, _ = dist.shape
     Hh, Fh = w2.shape
     K = w1.shape[1]
     out = pair_empty(B, Hh, N, dist.device, tiled) if tiled else torch.empty(B, Hh, N, ld, device=dist.device, dtype=F32)
     saved = tuple(torch.empty(B * N * N, 128, device=dist.device, dtype=BF16) for _ in range(3)) if save else None
     t0 = kernel_timer.begin("gbf_bias_fwd")
-    lib().mmdti_gbf_bias_fwd(_stream(), dist.data_ptr(), edge_type.data_ptr(), mul.data_ptr(), bias.data_ptr(), means.data_ptr(), stds.data_ptr(),
+    lib().mmdti_gbf_bias_fwd(_stream(), dist.data_ptr(), edge_type.data_ptr(), edge_type.element_size(), mul.data_ptr(), bias.data_ptr(), means.data_ptr(), stds.data_ptr(),
                              w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), B, N, ld, K, Fh, Hh, mul.numel(), out.data_ptr(),
                              *([t.data_ptr() for t in saved] if save else [0, 0, 0]), int(tiled) | (2 if save_grad else 0))
     # algorithmic bytes per atom pair: 4 (distance) + edge type in, 64 heads x 4 B of bias out (+ 3 x 256 B kept for the backward)
@@ -329,13 +340,35 @@ def gbf_bias_bwd(g, dist, edge_type, mul, bias, means, stds, w1, w2, u, ld, dmul
     do = torch.empty(P, Hh, device=g.device, dtype=BF16)
     du = torch.empty(P, Fh, device=g.device, dtype=BF16)
     t0 = kernel_timer.begin("gbf_bias_bwd")
-    lib().mmdti_gbf_bias_bwd(_stream(), g.data_ptr(), dist.data_ptr(), edge_type.data_ptr(), mul.data_ptr(), bias.data_ptr(), means.data_ptr(),
+    _chk_edge(edge_type)
+    lib().mmdti_gbf_bias_bwd(_stream(), g.data_ptr(), dist.data_ptr(), edge_type.data_ptr(), edge_type.element_size(), mul.data_ptr(), bias.data_ptr(), means.data_ptr(),
                              stds.data_ptr(), w1.data_ptr(), w2.data_ptr(), u.data_ptr(), B, N, ld, w1.shape[1], Fh, Hh, mul.numel(),
                              int(pair_is_tiled(g)) | (2 if u_is_grad else 0), do.data_ptr(), du.data_ptr(), dmul.data_ptr(), dbias.data_ptr(), dmeans.data_ptr(),
                              dstds.data_ptr())
     # per pair: G 64 x 4 B + saved gelu' 256 B + distance / edge type in, do 128 B + du 256 B out
     kernel_timer.end("gbf_bias_bwd", t0, float(P) * (Hh * g.element_size() + 256 + 4 + edge_type.element_size() + 2 * Hh + 2 * Fh))
     return do, du
+
+
+GBF_FULL_MAXE = 1536       # edge-type tables the complete backward kernel keeps in LDS (gbf.hip GBF_FULL_MAXE)
+
+
+def gbf_bias_bwd_full(g, dist, edge_type, mul, bias, means, stds, w1, b1, w2, ld, dw1, db1, dw2, db2, dmul, dbias, dmeans, dstds):
+    """The whole backward of :func:`gbf_bias_fwd` in one kernel, nothing saved by the forward: all eight parameter gradients
+    (fp32) are accumulated (+=) into the given buffers."""
+    _chk(g, F32, "gbf.g"); _chk(dist, F32, "gbf.dist"); _chk_edge(edge_type); _chk(w1, BF16, "gbf.w1"); _chk(w2, BF16, "gbf.w2")
+    for t, nm in ((dw1, "dw1"), (db1, "db1"), (dw2, "dw2"), (db2, "db2"), (dmul, "dmul"), (dbias, "dbias"), (dmeans, "dmeans"), (dstds, "dstds")):
+        _chk(t, F32, "gbf." + nm)
+    B, N, _ = dist.shape
+    Hh, Fh = w2.shape
+    P = B * N * N
+    t0 = kernel_timer.begin("gbf_bias_bwd")
+    lib().mmdti_gbf_bias_bwd_full(_stream(), g.data_ptr(), dist.data_ptr(), edge_type.data_ptr(), edge_type.element_size(), mul.data_ptr(),
+                                  bias.data_ptr(), means.data_ptr(), stds.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), B, N, ld,
+                                  w1.shape[1], Fh, Hh, mul.numel(), int(pair_is_tiled(g)), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(),
+                                  db2.data_ptr(), dmul.data_ptr(), dbias.data_ptr(), dmeans.data_ptr(), dstds.data_ptr())
+    # algorithmic bytes per atom pair: G 64 x 4 B + distance + edge type in; the parameter gradients are O(1)
+    kernel_timer.end("gbf_bias_bwd", t0, float(P) * (Hh * g.element_size() + 4 + edge_type.element_size()))
 
 
 def gbf_bias_eligible(K, Fh, Hh, ld):

@@ -703,6 +703,77 @@ def test_gbf_bias_bwd_fused_matches_unfused_chain(ops, B, N, tiled):
         assert r < 2e-2, (name, r)
 
 
+@pytest.mark.parametrize("edge_dtype", [torch.int64, torch.int32, torch.int16])
+@pytest.mark.parametrize("tiled", [False, True])
+@pytest.mark.parametrize("B,N", [(2, 13), (3, 37), (1, 130), (9, 21), (1, 1)])
+def test_gbf_bias_complete_backward_matches_chain_and_autograd(ops, B, N, tiled, edge_dtype):
+    """ONE kernel (nothing saved by the forward: basis / hidden recomputed, every parameter gradient accumulated on chip)
+    vs the round-1 chain (fused per-pair half + two weight-gradient GEMMs) and vs fp32 autograd of the bf16-rounded chain.
+    Edge types as int64 (the reference's collate), int32 or int16 must give the same gradients."""
+    K, Fh, H, E = 128, 128, 64, 31 * 31
+    ld = ops.pair_ld(N)
+    gen = G(23)
+    dist = torch.rand(B, N, N, generator=gen) * 8
+    et = torch.randint(0, E, (B, N, N), generator=gen)
+    mul, bias = 1 + 0.1 * torch.randn(E, generator=gen), 0.1 * torch.randn(E, generator=gen)
+    means, stds = torch.rand(K, generator=gen) * 3, torch.rand(K, generator=gen) * 3 - 1.5
+    w1f, w2f = rt(torch.randn(Fh, K, generator=gen) * 0.2), rt(torch.randn(H, Fh, generator=gen) * 0.2)
+    b1f, b2f = torch.randn(Fh, generator=gen) * 0.1, torch.randn(H, generator=gen) * 0.1
+    w1, w2, b1, b2 = dev(bf(w1f)), dev(bf(w2f)), dev(b1f), dev(b2f)
+    d = [dev(t) for t in (dist, et, mul, bias, means, stds)]
+    dn = list(d); dn[1] = d[1].to(edge_dtype)
+    g_std = torch.zeros(B, H, N, ld); g_std[..., :N] = torch.randn(B, H, N, N, generator=gen)
+    g = ops.pair_tile(dev(g_std), N, 0.0) if tiled else dev(g_std)
+    # the forward with narrowed edge types is the same forward
+    out64, _ = ops.gbf_bias_fwd(*d, w1, b1, w2, b2, ld, save=False, tiled=tiled)
+    outn, _ = ops.gbf_bias_fwd(*dn, w1, b1, w2, b2, ld, save=False, tiled=tiled)
+    assert torch.equal(out64, outn)
+    # round-1 chain
+    _, (feat, u, h) = ops.gbf_bias_fwd(*d, w1, b1, w2, b2, ld, save=True, tiled=tiled)
+    gr_r = [torch.zeros_like(t) for t in d[2:]]
+    do, du = ops.gbf_bias_bwd(g, *d, w1, w2, u, ld, *gr_r)
+    ref = {"dw2": do.float().T @ h.float(), "db2": do.float().sum(0), "dw1": du.float().T @ feat.float(), "db1": du.float().sum(0),
+           "dmul": gr_r[0], "dbias": gr_r[1], "dmeans": gr_r[2], "dstds": gr_r[3]}
+    # complete kernel; buffers start non-zero: the kernel accumulates
+    names = ("dw1", "db1", "dw2", "db2", "dmul", "dbias", "dmeans", "dstds")
+    shapes = ((Fh, K), (Fh,), (H, Fh), (H,), (E,), (E,), (K,), (K,))
+    got = {n: torch.full(sh, 0.5, device="cuda") for n, sh in zip(names, shapes)}
+    ops.gbf_bias_bwd_full(g, *dn, w1, b1, w2, ld, *[got[n].view(-1) for n in names])
+    for n in names:
+        a, b_ = got[n] - 0.5, ref[n]
+        r = float((a - b_).norm() / (b_.norm() + 1e-12))
+        assert r < (2e-2 if n in ("dmul", "dbias", "dmeans", "dstds") else 6e-3), (n, r)
+    # fp32 autograd of the same chain with the same operand rounding
+    P = {k: v.clone().requires_grad_(True) for k, v in (("mul", mul), ("bias", bias), ("means", means), ("stds", stds), ("w1", w1f), ("b1", b1f),
+                                                         ("w2", w2f), ("b2", b2f))}
+    y = P["mul"][et] * dist + P["bias"][et]
+    sg = P["stds"].abs() + 1e-5
+    basis = torch.exp(-0.5 * ((y[..., None] - P["means"]) / sg) ** 2) / ((2 * 3.14159) ** 0.5 * sg)
+    hid = torch.nn.functional.gelu(basis @ P["w1"].T + P["b1"])
+    o = (hid @ P["w2"].T + P["b2"]).permute(0, 3, 1, 2)
+    (o * rt(g_std[..., :N])).sum().backward()
+    want = {"dw1": P["w1"].grad, "db1": P["b1"].grad, "dw2": P["w2"].grad, "db2": P["b2"].grad, "dmul": P["mul"].grad, "dbias": P["bias"].grad,
+            "dmeans": P["means"].grad, "dstds": P["stds"].grad}
+    for n in names:
+        a, b_ = (got[n] - 0.5).cpu(), want[n]
+        r = float((a - b_).norm() / (b_.norm() + 1e-12))
+        assert r < 3e-2, (n, "vs autograd", r)
+
+
+def test_gbf_bias_complete_backward_rejects_bad_arguments(ops):
+    from mmdti_hip._abi import MMDTIError
+    K, Fh, H, E, B, N = 128, 128, 64, 2000, 1, 8
+    ld = ops.pair_ld(N)
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    args = [z(B, H, N, ld), z(B, N, N), torch.zeros(B, N, N, device="cuda", dtype=torch.int64), z(E), z(E), z(K), z(K) + 1,
+            z(Fh, K).bfloat16(), z(Fh), z(H, Fh).bfloat16(), ld, z(Fh * K), z(Fh), z(H * Fh), z(H), z(E), z(E), z(K), z(K)]
+    with pytest.raises(MMDTIError):            # E beyond the tables the kernel keeps in LDS
+        ops.gbf_bias_bwd_full(*args)
+    with pytest.raises(TypeError):
+        args[2] = args[2].to(torch.int8)
+        ops.gbf_bias_bwd_full(*args)
+
+
 @pytest.mark.parametrize("M,N,K,out_dtype", [(300, 128, 64, torch.bfloat16), (1000, 256, 192, torch.float32), (129, 64, 128, torch.bfloat16)])
 def test_gemm_epilogue_column_sums(ops, M, N, K, out_dtype):
     """colsum_out: the bias gradient of the producing Linear, accumulated (+=) by the epilogue from the STORED values."""
