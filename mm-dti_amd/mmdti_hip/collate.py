@@ -59,3 +59,66 @@ def stack_labels(samples):
 def tokenize(tokenizer, smiles, truncation=True):
     enc = tokenizer(list(smiles), padding=True, truncation=truncation, return_tensors="pt")
     return enc['input_ids'], enc['attention_mask']
+
+
+def collate_batch(samples, padding_idx, tokenizer):
+    """The whole of ``MM_Model.batch_collate_fn`` (models/mm_model.py:645-682) as a free function: list of
+    (feature dict, label) -> (batch dict, label tensor | None).  A key without a layout rule re-uses the previous field's
+    value, as the reference's loop variable does (and raises if it comes first)."""
+    feats = [s[0] for s in samples]
+    batch, last = {}, None
+    for key in feats[0]:
+        if key == 'smile':
+            continue
+        v = collate_field(key, (f[key] for f in feats), padding_idx)
+        if v is None:
+            if last is None:
+                raise UnboundLocalError(f"batch_collate_fn: no layout rule for the first feature key {key!r}")
+            v = last
+        batch[key] = last = v
+    if 'smile' in feats[0]:
+        batch['input_ids'], batch['attention_mask'] = tokenize(tokenizer, (f['smile'] for f in feats))
+    return batch, stack_labels(samples)
+
+
+# -------------------------------------------------------------------------------------------------- device payload (8f-3)
+NEVER_CONSUMED = ('src_coord',)     # collated by the reference, swallowed by **kwargs in MM_Model.forward (mm_model.py:540)
+INT16_MAX = 32767
+
+
+def device_payload(net_input, n_edge_types=None):
+    """What of a collated batch actually has to cross PCIe: drops the fields no kernel reads and narrows
+    ``src_edge_type`` from int64 to int16 (8 -> 2 bytes per atom pair; the pair-bias kernels take either width) when every
+    index fits -- ``n_edge_types`` (= len(dictionary)**2, 961 for the reference's dictionary) decides without a scan, else
+    the tensor's own min / max do.  Values are unchanged; host tensors in, host tensors out."""
+    out = {k: v for k, v in net_input.items() if k not in NEVER_CONSUMED}
+    et = out.get('src_edge_type')
+    if et is not None and et.dtype == torch.int64:
+        if n_edge_types is not None:
+            fits = n_edge_types <= INT16_MAX + 1
+        else:
+            fits = et.numel() == 0 or (int(et.min()) >= -INT16_MAX - 1 and int(et.max()) <= INT16_MAX)
+        if fits:
+            out['src_edge_type'] = et.to(torch.int16)
+    return out
+
+
+class HostCollate:
+    """``collate_fn`` for a ``DataLoader`` with worker processes: the model's collate (same tensors as
+    ``model.batch_collate_fn``) followed by :func:`device_payload`, holding only the pad index, the tokenizer and the
+    edge-type count -- so the workers never receive a copy of the model."""
+
+    def __init__(self, padding_idx, tokenizer, n_edge_types=None, narrow=True):
+        self.padding_idx, self.tokenizer, self.n_edge_types, self.narrow = padding_idx, tokenizer, n_edge_types, narrow
+
+    @classmethod
+    def of(cls, model, narrow=True):
+        n = None
+        d = getattr(model, 'dictionary', None)
+        if d is not None:
+            n = len(d) * len(d)
+        return cls(model.padding_idx, getattr(model, 'tokenizer', None), n, narrow)
+
+    def __call__(self, samples):
+        batch, label = collate_batch(samples, self.padding_idx, self.tokenizer)
+        return (device_payload(batch, self.n_edge_types) if self.narrow else batch), label

@@ -95,13 +95,15 @@ class DevicePrefetcher:
     The reference moves each batch with synchronous ``.cuda()`` calls inside the step loop (tasks/trainer.py:181-183).
     Here every host tensor is staged through a pinned buffer (re-used while the shapes repeat), copied with
     ``non_blocking=True`` on ``self.stream``, and the consumer's stream waits on the copy's event only when it takes the
-    batch -- so a step never waits for PCIe unless the loader itself is the bottleneck.  Values and dtypes are untouched
-    (the kernels take the reference's int64 / fp32 inputs as they are: 2.4 MB per 256-molecule batch).
+    batch -- so a step never waits for PCIe unless the loader itself is the bottleneck.  ``narrow`` (default): only what the
+    kernels read is copied (``collate.device_payload``: ``src_edge_type`` as int16, no ``src_coord``) -- at 256 molecules of
+    130 atoms the int64 edge types alone are 34.6 MB per batch, 8.7 MB as int16; values are unchanged.
     """
 
-    def __init__(self, batches, device):
+    def __init__(self, batches, device, narrow=True, n_edge_types=None):
         import torch
         self._torch = torch
+        self.narrow, self.n_edge_types = narrow, n_edge_types
         self.batches = batches
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
@@ -122,6 +124,9 @@ class DevicePrefetcher:
     def _launch(self, item):
         torch = self._torch
         net_input, label = item
+        if self.narrow:
+            from .collate import device_payload
+            net_input = device_payload(net_input, self.n_edge_types)
         if self.stream is None:
             return {k: self._stage(k, v) for k, v in net_input.items()}, self._stage("__label__", label), None
         with torch.cuda.stream(self.stream):

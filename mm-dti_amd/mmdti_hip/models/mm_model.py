@@ -29,7 +29,7 @@ import torch.nn as nn
 from ..unicore_compat import Dictionary, init_bert_params, get_activation_fn
 from ..functional import PairBiasFn, EmbeddingFn, DropoutFn, MaskedPoolFn, LinearF32Fn
 from .. import ops
-from ..collate import right_pad, collate_field, stack_labels, tokenize
+from ..collate import right_pad, collate_batch
 from .transformers import TransformerEncoderWithPair
 from .bert_layers import BertCrossEncoder, RobertaTower
 from .infonce import InfoNCE
@@ -383,17 +383,4 @@ class MM_Model(nn.Module):
         """samples: list of (feature dict, label) as DataHub / TorchDataset yield them -> (batch dict, label tensor|None).
         Layout rules: ``mmdti_hip.collate``.  A key without a layout rule re-uses the previous field's value, as the
         reference's loop variable does (and raises if it comes first)."""
-        feats = [s[0] for s in samples]
-        batch, last = {}, None
-        for key in feats[0]:
-            if key == 'smile':
-                continue
-            v = collate_field(key, (f[key] for f in feats), self.padding_idx)
-            if v is None:
-                if last is None:
-                    raise UnboundLocalError(f"batch_collate_fn: no layout rule for the first feature key {key!r}")
-                v = last
-            batch[key] = last = v
-        if 'smile' in feats[0]:
-            batch['input_ids'], batch['attention_mask'] = tokenize(self.tokenizer, (f['smile'] for f in feats))
-        return batch, stack_labels(samples)
+        return collate_batch(samples, self.padding_idx, self.tokenizer)

@@ -32,6 +32,7 @@ import torch
 from torch.utils.data import DataLoader as TorchDataLoader
 
 from ..trainer import FineTuner
+from ..collate import HostCollate, device_payload
 
 logger = logging.getLogger("mmdti_hip")
 
@@ -124,6 +125,11 @@ class Trainer(object):
         self.beta = params.get('beta', 0.1)
         self.fds = params.get('fds', False)
         self.distributed = bool(params.get('distributed', False))
+        # input pipeline (not reference parameters, defaults keep the reference's in-process loader):
+        #   num_workers > 0 -> collate runs in DataLoader worker processes (HostCollate: no model copy in the workers) into
+        #   pinned memory; narrow_inputs -> src_edge_type crosses PCIe as int16 and the never-read src_coord stays on the host
+        self.num_workers = int(params.get('num_workers', 0))
+        self.narrow_inputs = bool(params.get('narrow_inputs', True))
         self.rank = torch.distributed.get_rank() if (self.distributed and torch.distributed.is_initialized()) else 0
 
     # -------------------------------------------------------------- batches
@@ -134,6 +140,8 @@ class Trainer(object):
         """Host -> device move of a collated batch and the target dtype rule (tasks/trainer.py:101-120)."""
         net_input, net_target = batch
         if isinstance(net_input, dict):
+            if self.narrow_inputs:
+                net_input = device_payload(net_input, self._n_edge_types)
             net_input = {k: v.to(self.device, non_blocking=True) for k, v in net_input.items()}
             if self.distributed:
                 from ..parallel import pad_to_global_lengths
@@ -148,6 +156,25 @@ class Trainer(object):
         else:
             net_target = net_target.float()
         return net_input, net_target
+
+    _n_edge_types = None
+
+    def _collate_for(self, model):
+        """The model's own ``batch_collate_fn`` in-process; with worker processes, the same collate as a small picklable
+        object (the workers get the pad index and the tokenizer, not the model)."""
+        d = getattr(model, 'dictionary', None)
+        self._n_edge_types = len(d) * len(d) if d is not None else None
+        from ..models.mm_model import MM_Model
+        if self.num_workers > 0 and type(model).batch_collate_fn is MM_Model.batch_collate_fn:
+            return HostCollate.of(model, narrow=self.narrow_inputs)
+        return model.batch_collate_fn
+
+    def _loader_kwargs(self):
+        if self.num_workers <= 0:
+            return {}
+        # (not persistent: a persistent iterator skips the per-epoch base-seed draw, and the shuffle stream would then differ
+        # from the in-process loader's -- the epoch order is part of what the G10 fixtures pin)
+        return dict(num_workers=self.num_workers, pin_memory=self.device.type == "cuda")
 
     def _require_device(self):
         if self.device.type != "cuda":
@@ -165,10 +192,10 @@ class Trainer(object):
             from torch.utils.data.distributed import DistributedSampler
             sampler = DistributedSampler(train_dataset, shuffle=True, seed=self.seed, drop_last=True)
             train_dataloader = TorchDataLoader(dataset=train_dataset, batch_size=self.batch_size, sampler=sampler,
-                                               collate_fn=model.batch_collate_fn, drop_last=True)
+                                               collate_fn=self._collate_for(model), drop_last=True, **self._loader_kwargs())
         else:
             train_dataloader = NNDataLoader(feature_name=feature_name, dataset=train_dataset, batch_size=self.batch_size, shuffle=True,
-                                            collate_fn=model.batch_collate_fn, drop_last=True)
+                                            collate_fn=self._collate_for(model), drop_last=True, **self._loader_kwargs())
         min_val_loss, max_score, wait = float("inf"), float("-inf"), 0
         num_training_steps = len(train_dataloader) * self.max_epochs
         engine = FineTuner(model, self.task, learning_rate=self.learning_rate, adam_eps=1e-6, warmup_ratio=0.0,
@@ -250,7 +277,7 @@ class Trainer(object):
             sd = torch.load(os.path.join(dump_dir, f'model_{fold}.pth'), map_location=self.device, weights_only=True)["model_state_dict"]
             model.load_state_dict(sd)           # (an arena-bound model re-casts its bf16 weight shadow on the next GEMM: runtime._fresh)
         dataloader = NNDataLoader(feature_name=feature_name, dataset=dataset, batch_size=self.batch_size, shuffle=False,
-                                  collate_fn=model.batch_collate_fn)
+                                  collate_fn=self._collate_for(model), **self._loader_kwargs())
         model = model.eval()
         val_loss, y_preds, y_truths = [], [], []
         builtin = _is_builtin_loss(loss_func, self.task)
@@ -307,6 +334,6 @@ def _is_builtin_loss(loss_func, task):
     return False
 
 
-def NNDataLoader(feature_name=None, dataset=None, batch_size=None, shuffle=False, collate_fn=None, drop_last=False):
-    """tasks/trainer.py:540-556."""
-    return TorchDataLoader(dataset=dataset, batch_size=batch_size, shuffle=shuffle, collate_fn=collate_fn, drop_last=drop_last)
+def NNDataLoader(feature_name=None, dataset=None, batch_size=None, shuffle=False, collate_fn=None, drop_last=False, **loader_kwargs):
+    """tasks/trainer.py:540-556 (``loader_kwargs``: num_workers / pin_memory / persistent_workers, not in the reference)."""
+    return TorchDataLoader(dataset=dataset, batch_size=batch_size, shuffle=shuffle, collate_fn=collate_fn, drop_last=drop_last, **loader_kwargs)

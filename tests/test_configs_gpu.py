@@ -195,3 +195,44 @@ def test_c1_esol_like_epoch_through_trainer(tmp_path):
     assert abs(steps[0, 2] - float(ref["infonce"])) <= 1e-3 * abs(float(ref["infonce"]))
     assert steps[-10:, 0].mean() < steps[:10, 0].mean(), (steps[:10, 0].mean(), steps[-10:, 0].mean())
     assert os.path.exists(os.path.join(str(tmp_path), "model_0.pth"))
+
+
+def test_worker_side_collate_and_narrowed_inputs_train_the_same_steps(tmp_path):
+    """``Trainer(num_workers=2)`` collates in DataLoader workers (HostCollate: int16 edge types, no src_coord,
+    pinned memory) -- the epoch it drives must be the epoch of the in-process int64 path: same batch order, same losses
+    (atomics aside), same predictions."""
+    from mmdti_hip.tasks import Trainer
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "g9_collate.npz"), allow_pickle=False))
+    tok_json = str(g["tok_json"])
+    tok = tokenizer_from(tok_json, 254)
+    ocfg = tiny_cfg("regression", len(tok))
+    P = O.init_params(ocfg, seed=5, std=0.05)
+    rng = np.random.default_rng(7)
+    alphabet = [c for c in __import__("json").loads(tok_json)["model"]["vocab"] if len(c) == 1]
+    samples = []
+    for _ in range(72):
+        na = int(rng.integers(4, 20))
+        atoms = rng.choice(np.arange(4, 30), size=na)
+        d = O.coords2unimol(atoms, rng.normal(0, 3.0, size=(na, 3)), 31)
+        d["smile"] = "".join(rng.choice(alphabet, size=int(rng.integers(3, 20))))
+        samples.append((d, np.array([0.1 * float((atoms == 4).sum())], dtype=np.float32)))
+    runs = []
+    for workers, narrow in ((0, False), (2, True)):
+        model = product_model(ocfg, tok, dropout=False)
+        load_fixture_weights(model, P)
+        seen = []
+        if workers == 0:
+            real = model.batch_collate_fn
+            model.batch_collate_fn = lambda s, real=real: (seen.append(None), real(s))[1]
+        trainer = Trainer(save_path=str(tmp_path / str(workers)), task="regression", metrics="mse", learning_rate=1e-3, batch_size=8, epochs=2,
+                          warmup_ratio=0.1, patience=20, use_cuda=True, alpha=1, beta=0.1, seed=11, num_workers=workers, narrow_inputs=narrow)
+        y = trainer.fit_predict(model, samples[:64], samples[64:], torch.nn.MSELoss(), lambda x: x, str(tmp_path / str(workers)), 0, None,
+                                return_infonce_loss=True, return_ct_loss=True)
+        runs.append((np.stack([h["steps"] for h in trainer.history]), np.asarray(y)))
+        if workers == 0:
+            assert len(seen) > 0                       # the in-process run went through model.batch_collate_fn
+    (s0, y0), (s1, y1) = runs
+    assert s0.shape == s1.shape == (2, 8, 4)
+    np.testing.assert_allclose(s1, s0, rtol=2e-3, atol=1e-5)
+    np.testing.assert_allclose(y1, y0, rtol=5e-3, atol=1e-4)

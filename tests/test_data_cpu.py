@@ -85,3 +85,66 @@ def test_bucket_sampler_drop_last_is_not_size_biased():
         dropped += [atoms[i] for i in range(203) if i not in kept]
     # dropped molecules look like the population, not like its largest members
     assert np.mean(dropped) < np.mean(atoms) + 1.0 * np.std(atoms) and min(dropped) <= np.median(atoms)
+
+
+# ------------------------------------------------------------------------------------------------ 8f-3: what crosses PCIe
+def _mols(n, seed):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        a = int(rng.integers(3, 12))
+        tok = rng.integers(4, 30, size=a + 2)
+        out.append(({"src_tokens": tok, "src_distance": rng.random((a + 2, a + 2)).astype("float32"),
+                     "src_coord": rng.random((a + 2, 3)).astype("float32"), "src_edge_type": tok[:, None] * 31 + tok[None, :],
+                     "smile": "C" * int(rng.integers(2, 9))}, [float(i)]))
+    return out
+
+
+class _Tok:
+    """stand-in for the HF tokenizer call signature (padding=True, truncation=True, return_tensors='pt')"""
+    def __call__(self, smiles, padding=True, truncation=True, return_tensors="pt"):
+        import torch
+        L = max(len(s) for s in smiles) + 2
+        ids = torch.ones(len(smiles), L, dtype=torch.long)
+        att = torch.zeros(len(smiles), L, dtype=torch.long)
+        for r, s in enumerate(smiles):
+            ids[r, :len(s) + 2] = torch.tensor([0] + [5 + (ord(c) % 7) for c in s] + [2])
+            att[r, :len(s) + 2] = 1
+        return {"input_ids": ids, "attention_mask": att}
+
+
+def test_device_payload_drops_unread_fields_and_narrows_edge_types_without_changing_values():
+    import torch
+    from mmdti_hip.collate import collate_batch, device_payload
+    batch, label = collate_batch(_mols(5, 1), 0, _Tok())
+    assert batch["src_edge_type"].dtype == torch.int64 and "src_coord" in batch          # the reference's collate, untouched
+    out = device_payload(batch, n_edge_types=31 * 31)
+    assert "src_coord" not in out and out["src_edge_type"].dtype == torch.int16
+    assert torch.equal(out["src_edge_type"].long(), batch["src_edge_type"])
+    assert all(out[k] is batch[k] for k in out if k != "src_edge_type")
+    # without the dictionary size the tensor's own range decides; an index that does not fit keeps int64
+    assert device_payload(batch)["src_edge_type"].dtype == torch.int16
+    big = dict(batch, src_edge_type=batch["src_edge_type"] + 40000)
+    assert device_payload(big)["src_edge_type"].dtype == torch.int64
+    assert device_payload(big, n_edge_types=50000)["src_edge_type"].dtype == torch.int64
+    assert device_payload(device_payload(batch))["src_edge_type"].dtype == torch.int16   # idempotent
+
+
+def test_worker_side_collate_yields_the_batches_of_the_in_process_collate():
+    """HostCollate in DataLoader worker processes == the model-side collate in the main process (same order, same tensors,
+    edge types narrowed); the collate object carries no model."""
+    import pickle
+    import torch
+    from torch.utils.data import DataLoader
+    from mmdti_hip.collate import HostCollate, collate_batch
+    data = _mols(23, 3)
+    hc = HostCollate(0, _Tok(), n_edge_types=961)
+    assert len(pickle.dumps(hc)) < 2000
+    ref = list(DataLoader(data, batch_size=4, shuffle=False, collate_fn=lambda s: collate_batch(s, 0, _Tok())))
+    got = list(DataLoader(data, batch_size=4, shuffle=False, collate_fn=hc, num_workers=2))
+    assert len(ref) == len(got) == 6
+    for (rb, rl), (gb, gl) in zip(ref, got):
+        assert list(gb) == [k for k in rb if k != "src_coord"]
+        assert torch.equal(gl, rl) and gb["src_edge_type"].dtype == torch.int16
+        assert all(torch.equal(gb[k].long() if k == "src_edge_type" else gb[k], rb[k]) for k in gb)

@@ -325,10 +325,15 @@ def test_device_prefetcher_feeds_the_step():
     from mmdti_hip.trainer import FineTuner
     ocfg = _ocfg("classification", 2)
     host = [O.synth_batch(8, 10, 14, ocfg, seed=20 + i, ragged=True) for i in range(3)] + [O.synth_batch(6, 7, 9, ocfg, seed=30, ragged=True)]
-    got = list(DevicePrefetcher(host, "cuda"))
+    got = list(DevicePrefetcher(host, "cuda", narrow=False))
     assert len(got) == 4
     for (bi, li), (bo, lo) in zip(host, got):
         assert all(bo[k].is_cuda and bo[k].dtype == bi[k].dtype and torch.equal(bo[k].cpu(), bi[k]) for k in bi) and torch.equal(lo.cpu(), li)
+    # default: only what the kernels read crosses PCIe -- int16 edge types (same values), no src_coord
+    for (bi, li), (bo, lo) in zip(host, DevicePrefetcher(host, "cuda")):
+        assert "src_coord" not in bo and bo["src_edge_type"].dtype == torch.int16
+        assert torch.equal(bo["src_edge_type"].cpu().long(), bi["src_edge_type"])
+        assert all(torch.equal(bo[k].cpu(), bi[k]) for k in bo if k != "src_edge_type")
     m1, m2 = _model("classification", 2).eval(), _model("classification", 2).eval()
     m2.load_state_dict(m1.state_dict())
     t1, t2 = FineTuner(m1, "classification"), FineTuner(m2, "classification")
