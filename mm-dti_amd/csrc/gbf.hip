@@ -212,29 +212,59 @@ __device__ __forceinline__ int gbf_edge(const void* et, long long base, unsigned
 }
 __device__ __forceinline__ int gbf_edge(const void* et, long long p, int esz) { return gbf_edge(et, p, 0u, esz); }
 
+typedef float gf32x2 __attribute__((ext_vector_type(2)));
+constexpr float GBF_SQ = 0.84932180028801907f;   // sqrt(log2(e) / 2): exp(-z^2 / 2) = exp2(-(GBF_SQ * z)^2)
+
+// Eight consecutive Gaussian kernels of one pair, in MFMA B-operand form.  mu / isq / cf: the kernels' mean, GBF_SQ / sigma
+// and 1 / (a sigma).  Two kernels per instruction (v_pk_add/mul_f32), one v_exp_f32 each.
+__device__ __forceinline__ gbf16x8 gbf_basis8(float y, const float* mu, const float* isq, const float* cf) {
+  const gf32x4 m0 = *reinterpret_cast<const gf32x4*>(mu), m1 = *reinterpret_cast<const gf32x4*>(mu + 4);
+  const gf32x4 s0 = *reinterpret_cast<const gf32x4*>(isq), s1 = *reinterpret_cast<const gf32x4*>(isq + 4);
+  const gf32x4 c0 = *reinterpret_cast<const gf32x4*>(cf), c1 = *reinterpret_cast<const gf32x4*>(cf + 4);
+  const gf32x2 yy = {y, y};
+  float v[8];
+#define GBF_B2(M, S, C, LO, OUT)                                                       \
+  {                                                                                    \
+    const gf32x2 z = (yy - gf32x2{M[LO], M[LO + 1]}) * gf32x2{S[LO], S[LO + 1]};       \
+    const gf32x2 q = -(z * z);                                                         \
+    const gf32x2 e = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};     \
+    const gf32x2 r = e * gf32x2{C[LO], C[LO + 1]};                                     \
+    v[OUT] = r[0]; v[OUT + 1] = r[1];                                                  \
+  }
+  GBF_B2(m0, s0, c0, 0, 0) GBF_B2(m0, s0, c0, 2, 2) GBF_B2(m1, s1, c1, 0, 4) GBF_B2(m1, s1, c1, 2, 6)
+#undef GBF_B2
+  return gbf_pack8(v);
+}
+
+// 8 waves per workgroup, two workgroups per CU (the weight images are 52 KB); grid-stride over 16-pair tiles with the
+// NEXT tile's index math and loads (edge type, distance) issued before the current tile is computed.  ltab: the per-edge-
+// type tables sit in LDS (E <= GBF_FWD_MAXE) -- a dependent global gather would put two round trips on every tile.
+constexpr int GBF_FWD_MAXE = 4096;
 template <bool SAVE, bool TILED>
-__global__ __launch_bounds__(256) void gbf_bias_fwd_kernel(const float* __restrict__ dist, const void* __restrict__ et, int esz,
-                                                           const float* __restrict__ mul, const float* __restrict__ bias,
-                                                           const float* __restrict__ means, const float* __restrict__ stds,
-                                                           const bf16_t* __restrict__ W1, const float* __restrict__ b1,
-                                                           const bf16_t* __restrict__ W2, const float* __restrict__ b2,
-                                                           float* __restrict__ out, bf16_t* __restrict__ feat_out,
-                                                           bf16_t* __restrict__ u_out, bf16_t* __restrict__ h_out, int B, int N,
-                                                           int ld, int E, int tpm, int ugrad) {
+__global__ __launch_bounds__(512, 2) void gbf_bias_fwd_kernel(const float* __restrict__ dist, const void* __restrict__ et, int esz,
+                                                              const float* __restrict__ mul, const float* __restrict__ bias,
+                                                              const float* __restrict__ means, const float* __restrict__ stds,
+                                                              const bf16_t* __restrict__ W1, const float* __restrict__ b1,
+                                                              const bf16_t* __restrict__ W2, const float* __restrict__ b2,
+                                                              float* __restrict__ out, bf16_t* __restrict__ feat_out,
+                                                              bf16_t* __restrict__ u_out, bf16_t* __restrict__ h_out, int B, int N,
+                                                              int ld, int E, int tpm, int ugrad, int ltab) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gbf_smem[];
   bf16_t* sW1 = reinterpret_cast<bf16_t*>(gbf_smem);       // [128][136]   W1[f][k]
   bf16_t* sW2 = sW1 + GBF_F * GBF_WS;                       // [64][136]    W2[h][f], f in k-slot order
-  float* sMu = reinterpret_cast<float*>(sW2 + GBF_H * GBF_WS);  // [128] means, [128] 1/sigma, [128] 1/(a*sigma), [128] b1, [64] b2
-  float* sIs = sMu + GBF_K;
-  float* sCf = sIs + GBF_K;
+  float* sMu = reinterpret_cast<float*>(sW2 + GBF_H * GBF_WS);  // [128] means, [128] GBF_SQ/sigma, [128] 1/(a*sigma), [128] b1, [64] b2
+  float* sIq = sMu + GBF_K;
+  float* sCf = sIq + GBF_K;
   float* sB1 = sCf + GBF_K;
   float* sB2 = sB1 + GBF_F;
+  float* sMul = sB2 + GBF_H;                                // [E], [E] when ltab
+  float* sBia = sMul + E;
   const int tid = threadIdx.x, lane = tid & 63;
-  for (int c = tid; c < GBF_F * (GBF_K / 8); c += 256) {
+  for (int c = tid; c < GBF_F * (GBF_K / 8); c += 512) {
     const int row = c >> 4, col = (c & 15) * 8;
     *reinterpret_cast<uint4*>(sW1 + row * GBF_WS + col) = *reinterpret_cast<const uint4*>(W1 + row * GBF_K + col);
   }
-  for (int c = tid; c < GBF_H * 32; c += 256) {  // 8-byte pieces: slot 32u+8g+4hf.. <- feature 32u+16hf+4g..
+  for (int c = tid; c < GBF_H * 32; c += 512) {  // 8-byte pieces: slot 32u+8g+4hf.. <- feature 32u+16hf+4g..
     const int row = c >> 5, pc = c & 31, u = pc >> 3, g = (pc >> 1) & 3, hf = pc & 1;
     *reinterpret_cast<uint2*>(sW2 + row * GBF_WS + 32 * u + 8 * g + 4 * hf) =
         *reinterpret_cast<const uint2*>(W2 + row * GBF_F + 32 * u + 16 * hf + 4 * g);
@@ -242,69 +272,74 @@ __global__ __launch_bounds__(256) void gbf_bias_fwd_kernel(const float* __restri
   if (tid < GBF_K) {
     const float sg = fabsf(stds[tid]) + 1e-5f;
     sMu[tid] = means[tid];
-    sIs[tid] = 1.0f / sg;
+    sIq[tid] = GBF_SQ / sg;
     sCf[tid] = 1.0f / (GBF_A * sg);
     sB1[tid] = b1[tid];
     if (tid < GBF_H) sB2[tid] = b2[tid];
   }
+  if (ltab)
+    for (int c = tid; c < E; c += 512) {
+      sMul[c] = mul[c];
+      sBia[c] = bias[c];
+    }
   __syncthreads();
   const int g = lane >> 4, i = lane & 15;
-  const long long ntiles = (long long)B * tpm;
-  const long long nwaves = (long long)gridDim.x * 4;
+  const int ntiles = B * tpm;
+  const int nwaves = (int)gridDim.x * 8;
   // Pair tiles of 16.  Row-major planes: 16 consecutive q = i*ld + j (64 contiguous bytes of every head plane).  Tiled
   // planes ([nt][nt][256], 16x16 tiles in MFMA accumulator order -- the layout the pair-attention kernels stream): a
   // 4x4 (query, key) block, which is again 64 contiguous bytes; blocks past N are visited too so that EVERY pad slot of
   // the plane holds -inf (the attention kernels then need no masking of pad keys / rows).
   const int nt = (N + 15) >> 4, nblk = nt * 4;
   const long long plane = TILED ? (long long)nt * nt * 256 : (long long)N * ld;
-  for (long long tile = (long long)blockIdx.x * 4 + (tid >> 6); tile < ntiles; tile += nwaves) {
-    const int b = (int)(tile / tpm);
-    const int tq = (int)(tile - (long long)b * tpm);
-    int q, ii, jj;
-    bool inplane, past = false;
+  // flags: bit 0 valid pair, bit 1 slot inside the plane, bit 2 whole block past N
+  auto fetch = [&](int tile, int& b, int& q, int& flags, unsigned& pl, int& e, float& d) {
+    tile = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : ntiles - 1);
+    b = (int)((unsigned)tile / (unsigned)tpm);
+    const int tq = tile - b * tpm;
+    int ii, jj;
+    bool inplane = true, past = false;
     if (TILED) {
-      const int rb = tq / nblk, cb = tq - rb * nblk;
-      past = 4 * rb >= N || 4 * cb >= N;   // whole block past N (the same for every lane of the wave)
+      const int rb = (int)((unsigned)tq / (unsigned)nblk), cb = tq - rb * nblk;
+      past = 4 * rb >= N || 4 * cb >= N;   // (the same for every lane of the wave)
       ii = 4 * rb + (i >> 2);
       jj = 4 * cb + (i & 3);
       q = ((rb >> 2) * nt + (cb >> 2)) * 256 + (cb & 3) * 64 + (rb & 3) * 16 + i;
-      inplane = true;
     } else {
       q = tq * 16 + i;
-      ii = q / ld;
+      ii = (int)((unsigned)q / (unsigned)ld);
       jj = q - ii * ld;
       inplane = q < plane;
     }
     const bool valid = ii < N && jj < N;
+    flags = (valid ? 1 : 0) | (inplane ? 2 : 0) | (past ? 4 : 0);
+    pl = (unsigned)((valid ? ii : 0) * N + (valid ? jj : 0));
+    const long long mol = (long long)b * N * N;
+    const int e32 = gbf_edge(et, mol, pl, esz);
+    e = e32 < 0 ? 0 : (e32 >= E ? E - 1 : e32);
+    d = (dist + mol)[pl];
+  };
+  int b, q, flags, e, n_b, n_q, n_flags, n_e;
+  unsigned pl, n_pl;
+  float d, n_d;
+  int tile = (int)blockIdx.x * 8 + (tid >> 6);
+  fetch(tile, b, q, flags, pl, e, d);
+  for (; tile < ntiles; tile += nwaves) {
+    fetch(tile + nwaves, n_b, n_q, n_flags, n_pl, n_e, n_d);
+    const bool valid = flags & 1, inplane = flags & 2, past = flags & 4;
     const float padv = TILED ? -INFINITY : 0.f;
     float* ob = out + (long long)b * GBF_H * plane + q;
     if (TILED && past) {
       for (int hh = 0; hh < GBF_H; ++hh) ob[(long long)hh * plane] = padv;
-      continue;
-    }
-    const long long p = ((long long)b * N + (valid ? ii : 0)) * N + (valid ? jj : 0);
-    float y = 0.f;
-    {
-      int e = gbf_edge(et, p, esz);
-      e = e < 0 ? 0 : (e >= E ? E - 1 : e);
-      y = mul[e] * dist[p] + bias[e];
-    }
+    } else {
+    const long long p = (long long)b * N * N + pl;
+    const float y = ltab ? sMul[e] * d + sBia[e] : mul[e] * d + bias[e];
     // Gaussian basis in B-operand form: lane (g, pair i) holds k = 32c + 8g + 0..7
     gbf16x8 fB[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int k0 = 32 * c + 8 * g;
-      float v[8];
-      const gf32x4 m0 = *reinterpret_cast<const gf32x4*>(sMu + k0), m1 = *reinterpret_cast<const gf32x4*>(sMu + k0 + 4);
-      const gf32x4 s0 = *reinterpret_cast<const gf32x4*>(sIs + k0), s1 = *reinterpret_cast<const gf32x4*>(sIs + k0 + 4);
-      const gf32x4 c0 = *reinterpret_cast<const gf32x4*>(sCf + k0), c1 = *reinterpret_cast<const gf32x4*>(sCf + k0 + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float z0 = (y - m0[e]) * s0[e], z1 = (y - m1[e]) * s1[e];
-        v[e] = __expf(-0.5f * z0 * z0) * c0[e];
-        v[4 + e] = __expf(-0.5f * z1 * z1) * c1[e];
-      }
-      fB[c] = gbf_pack8(v);
+      fB[c] = gbf_basis8(y, sMu + k0, sIq + k0, sCf + k0);
       if (SAVE && valid) *reinterpret_cast<gbf16x8*>(feat_out + p * GBF_K + k0) = fB[c];
     }
     // hidden^T = W1 . basis^T (+ b1), GELU; pairs of accumulator tiles become the K=32 operands of the second product
@@ -325,19 +360,16 @@ __global__ __launch_bounds__(256) void gbf_bias_fwd_kernel(const float* __restri
         acc += bb;
         if (SAVE && ugrad) {   // the saved tensor holds gelu'(pre-activation): the erf and the Gaussian are in hand here, and the
                                // backward kernel -- alone on the chip at the very end of the step -- is left with a multiply
-          gf32x4 gq;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float yv, gv;
-            gelu_erf_both(acc[r], yv, gv);
-            acc[r] = yv;
-            gq[r] = gv;
-          }
+          f32x2_t y0, g0, y1, g1;
+          gelu_erf_both2(f32x2_t{acc[0], acc[1]}, y0, g0);
+          gelu_erf_both2(f32x2_t{acc[2], acc[3]}, y1, g1);
+          acc = gf32x4{y0[0], y0[1], y1[0], y1[1]};
+          const gf32x4 gq = {g0[0], g0[1], g1[0], g1[1]};
           if (valid) *reinterpret_cast<uint2*>(u_out + p * GBF_F + 16 * ft + 4 * g) = gbf_pack4(gq);
         } else {
           if (SAVE && valid) *reinterpret_cast<uint2*>(u_out + p * GBF_F + 16 * ft + 4 * g) = gbf_pack4(acc);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[r] = gelu_erf(acc[r]);
+          const f32x2_t y0 = gelu_erf2(f32x2_t{acc[0], acc[1]}), y1 = gelu_erf2(f32x2_t{acc[2], acc[3]});
+          acc = gf32x4{y0[0], y0[1], y1[0], y1[1]};
         }
         if (SAVE && valid) *reinterpret_cast<uint2*>(h_out + p * GBF_F + 16 * ft + 4 * g) = gbf_pack4(acc);
         hv[hf] = acc;
@@ -362,6 +394,8 @@ __global__ __launch_bounds__(256) void gbf_bias_fwd_kernel(const float* __restri
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    }
+    b = n_b; q = n_q; flags = n_flags; pl = n_pl; e = n_e; d = n_d;
   }
 }
 
@@ -602,7 +636,7 @@ __global__ __launch_bounds__(256, 2) void gbf_bias_bwd_kernel(const float* __res
 constexpr int GBF_LW = 144;       // LDS row stride (elements) of W1 [128 f][144] and of the two pair tiles [128 pairs][144]
 constexpr int GBF_FULL_MAXE = 1536;   // 4 per-edge-type fp32 tables next to 126 KB of tiles in the CU's 160 KB
 constexpr size_t gbf_full_smem(int E) {
-  return (size_t)(GBF_F * GBF_LW + GBF_F * GBF_W2S + 2 * 128 * GBF_LW) * 2 + (size_t)(3 * GBF_K + GBF_F + 2 * 128 + 4 * E) * 4;
+  return (size_t)(GBF_F * GBF_LW + GBF_F * GBF_W2S + 2 * 128 * GBF_LW) * 2 + (size_t)(4 * GBF_K + GBF_F + 2 * 128 + 4 * E) * 4;
 }
 
 typedef short gs16x4 __attribute__((ext_vector_type(4)));
@@ -631,7 +665,8 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
   float* sMu = reinterpret_cast<float*>(T1 + 128 * GBF_LW);
   float* sIs = sMu + GBF_K;
   float* sCf = sIs + GBF_K;
-  float* sB1 = sCf + GBF_K;
+  float* sIq = sCf + GBF_K;                                      // GBF_SQ / sigma (phase A's exp2 form)
+  float* sB1 = sIq + GBF_K;
   float* sY = sB1 + GBF_F;                                       // [128] y of the iteration's pairs
   float* sDy = sY + 128;                                         // [128] dL/dy partial sums
   float* hist = sDy + 128;                                       // [2][E]
@@ -655,6 +690,7 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
     sMu[tid] = means[tid];
     sIs[tid] = 1.0f / sg;
     sCf[tid] = 1.0f / (GBF_A * sg);
+    sIq[tid] = GBF_SQ / sg;
     sB1[tid] = b1[tid];
     sDy[tid] = 0.f;
   }
@@ -686,7 +722,7 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
   unsigned o_w1tr = (unsigned)((8 * g + (i >> 2)) * GBF_LW + 16 * wave + 4 * (i & 3)) * 2; // W1^T fragment, k block = wave
   const unsigned o_f32 = (unsigned)(GBF_F * GBF_LW + GBF_F * GBF_W2S + 2 * 128 * GBF_LW) * 2;  // sMu
   unsigned o_gconst = o_f32 + (unsigned)(8 * g) * 4;             // Gaussian constants of kernels 32c + 8g + 0..7 (phase A)
-  unsigned o_b1row = o_f32 + (unsigned)(3 * GBF_K + 4 * g) * 4;
+  unsigned o_b1row = o_f32 + (unsigned)(4 * GBF_K + 4 * g) * 4;
   unsigned o_kconst = o_f32 + (unsigned)(16 * wave + 4 * g) * 4; // phase B1's Gaussian constants: kernels k = 16*wave + 4g + r
   const int ntiles = B * tpm;
   const int nt = (N + 15) >> 4, nb = (N + 3) >> 2;
@@ -767,18 +803,8 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
       gbf16x8 fB[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        float v[8];
         const float* gc = gconst + 32 * c;
-        const gf32x4 m0 = *reinterpret_cast<const gf32x4*>(gc), m1 = *reinterpret_cast<const gf32x4*>(gc + 4);
-        const gf32x4 s0 = *reinterpret_cast<const gf32x4*>(gc + GBF_K), s1 = *reinterpret_cast<const gf32x4*>(gc + GBF_K + 4);
-        const gf32x4 c0 = *reinterpret_cast<const gf32x4*>(gc + 2 * GBF_K), c1 = *reinterpret_cast<const gf32x4*>(gc + 2 * GBF_K + 4);
-#pragma unroll
-        for (int ee = 0; ee < 4; ++ee) {
-          const float z0 = (y - m0[ee]) * s0[ee], z1 = (y - m1[ee]) * s1[ee];
-          v[ee] = __expf(-0.5f * z0 * z0) * c0[ee];
-          v[4 + ee] = __expf(-0.5f * z1 * z1) * c1[ee];
-        }
-        fB[c] = gbf_pack8(v);
+        fB[c] = gbf_basis8(y, gc, gc + 3 * GBF_K, gc + 2 * GBF_K);
         *reinterpret_cast<gbf16x8*>(GBF_SWZ(r0lo, r0hi, 32 * c) + 8 * g) = fB[c];
       }
 #pragma unroll
@@ -799,13 +825,17 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
             ua = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, fB[c], ua, 0, 0, 0);
           }
           ua += *reinterpret_cast<const gf32x4*>(b1row + 16 * ft);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float yv, gq;
-            gelu_erf_both(ua[r], yv, gq);
-            // the hidden / gelu' pass through bf16 exactly where the unfused chain's saved tensors did
-            hv[hf][r] = yv;
-            acc[r] *= __uint_as_float(((uint32_t)f2bf(gq)) << 16);
+          {
+            f32x2_t y0, g0, y1, g1;
+            gelu_erf_both2(f32x2_t{ua[0], ua[1]}, y0, g0);
+            gelu_erf_both2(f32x2_t{ua[2], ua[3]}, y1, g1);
+            hv[hf] = gf32x4{y0[0], y0[1], y1[0], y1[1]};
+            // gelu' passes through bf16 exactly where the unfused chain's saved tensor did
+            const uint2 gb = gbf_pack4(gf32x4{g0[0], g0[1], g1[0], g1[1]});
+            acc[0] *= __uint_as_float(gb.x << 16);
+            acc[1] *= __uint_as_float(gb.x & 0xffff0000u);
+            acc[2] *= __uint_as_float(gb.y << 16);
+            acc[3] *= __uint_as_float(gb.y & 0xffff0000u);
           }
           *reinterpret_cast<uint2*>(GBF_SWZ(r1lo, r1hi, 16 * ft) + 4 * g) = gbf_pack4(acc);
           __builtin_amdgcn_sched_barrier(0);
@@ -855,18 +885,27 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[u], dub, acc, 0, 0, 0);
         }
         const float yj = sY[16 * j + i];
-        float dy = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float dvr = __uint_as_float(((uint32_t)f2bf(acc[r])) << 16);   // dbasis passes through bf16 like the unfused chain
-          const float z = (yj - kmu[r]) * kis[r];
-          const float val = __expf(-0.5f * z * z) * kcf[r];
-          const float t = dvr * val;                     // (du, hence dbasis, is exactly 0 for pad pairs)
-          const float zs = z * kis[r];
-          dy -= t * zs;
-          amu[r] += t * zs;
-          asg[r] += t * (z * zs - kis[r]);
+        const gf32x2 yy = {yj, yj};
+        const uint2 db = gbf_pack4(acc);                 // dbasis passes through bf16 like the unfused chain
+        gf32x2 dy2 = {0.f, 0.f};
+#define GBF_G2(LO, DV0, DV1)                                                                                   \
+        {                                                                                                      \
+          const gf32x2 is2 = {kis[LO], kis[LO + 1]};                                                           \
+          const gf32x2 z = (yy - gf32x2{kmu[LO], kmu[LO + 1]}) * is2;                                          \
+          const gf32x2 qq = (z * z) * (-0.72134752044448170f);           /* -log2(e) / 2 */                    \
+          const gf32x2 val = gf32x2{__builtin_amdgcn_exp2f(qq[0]), __builtin_amdgcn_exp2f(qq[1])} * gf32x2{kcf[LO], kcf[LO + 1]}; \
+          const gf32x2 t = gf32x2{DV0, DV1} * val;       /* (du, hence dbasis, is exactly 0 for pad pairs) */   \
+          const gf32x2 zs = z * is2;                                                                           \
+          const gf32x2 tz = t * zs;                                                                            \
+          dy2 -= tz;                                                                                           \
+          amu[LO] += tz[0]; amu[LO + 1] += tz[1];                                                              \
+          const gf32x2 w = t * (z * zs - is2);                                                                 \
+          asg[LO] += w[0]; asg[LO + 1] += w[1];                                                                \
         }
+        GBF_G2(0, __uint_as_float(db.x << 16), __uint_as_float(db.x & 0xffff0000u))
+        GBF_G2(2, __uint_as_float(db.y << 16), __uint_as_float(db.y & 0xffff0000u))
+#undef GBF_G2
+        float dy = dy2[0] + dy2[1];
         dy += __shfl_xor(dy, 16, 64);
         dy += __shfl_xor(dy, 32, 64);
         if (g == 0) atomicAdd(&sDy[16 * j + i], dy);
@@ -1058,12 +1097,26 @@ extern "C" int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, cons
   const int nt = (N + 15) / 16;
   const int tpm = tiled ? 16 * nt * nt : cdiv((long long)N * ld, 16);
   const long long ntiles = (long long)B * tpm;
-  const int grid = (int)(ntiles / 4 + 1 < 2048 ? ntiles / 4 + 1 : 2048);
-  const size_t smem = (size_t)(GBF_F + GBF_H) * GBF_WS * 2 + (size_t)(3 * GBF_K + GBF_F + GBF_H) * 4;
+  MMDTI_REQUIRE(ntiles < (1ll << 30) && (long long)N * N < (1ll << 30), "gbf_bias_fwd: batch too large for 32-bit tile indices");
+  const int grid = (int)((ntiles + 7) / 8 < 512 ? (ntiles + 7) / 8 : 512);     // two resident workgroups per CU
+  const int ltab = E <= GBF_FWD_MAXE ? 1 : 0;
+  const size_t smem = (size_t)(GBF_F + GBF_H) * GBF_WS * 2 + (size_t)(3 * GBF_K + GBF_F + GBF_H + (ltab ? 2 * E : 0)) * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    const int cap = (int)((size_t)(GBF_F + GBF_H) * GBF_WS * 2 + (size_t)(3 * GBF_K + GBF_F + GBF_H + 2 * GBF_FWD_MAXE) * 4);
+    const void* fns[4] = {reinterpret_cast<const void*>(gbf_bias_fwd_kernel<true, true>), reinterpret_cast<const void*>(gbf_bias_fwd_kernel<true, false>),
+                          reinterpret_cast<const void*>(gbf_bias_fwd_kernel<false, true>), reinterpret_cast<const void*>(gbf_bias_fwd_kernel<false, false>)};
+    for (int f = 0; f < 4; ++f)
+      if (hipFuncSetAttribute(fns[f], hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess) {
+        set_error("gbf_bias_fwd: hipFuncSetAttribute failed");
+        return MMDTI_ERR_LAUNCH;
+      }
+    attr_done = true;
+  }
 #define GBF_L(SAVE, TILED)                                                                                                          \
-  hipLaunchKernelGGL((gbf_bias_fwd_kernel<SAVE, TILED>), dim3(grid), dim3(256), smem, (hipStream_t)stream, dist, edge_type, edge_bytes, mul, bias, \
+  hipLaunchKernelGGL((gbf_bias_fwd_kernel<SAVE, TILED>), dim3(grid), dim3(512), smem, (hipStream_t)stream, dist, edge_type, edge_bytes, mul, bias, \
                      means, stds, (const bf16_t*)w1_bf16, b1, (const bf16_t*)w2_bf16, b2, out, (bf16_t*)feat_bf16, (bf16_t*)u_bf16, \
-                     (bf16_t*)h_bf16, B, N, ld, E, tpm, ugrad)
+                     (bf16_t*)h_bf16, B, N, ld, E, tpm, ugrad, ltab)
   if (save) { if (tiled) GBF_L(true, true); else GBF_L(true, false); }
   else      { if (tiled) GBF_L(false, true); else GBF_L(false, false); }
 #undef GBF_L
