@@ -186,6 +186,14 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return 0.5f * (1.0f + erfv) + x * kInvSqrt2Pi * e;
 }
 
+// XCD-aware bijective remap of a linear workgroup id (cdna guide T1): hardware workgroup ids go round-robin over the 8 XCDs
+// (each with its own L2), so id -> chunk index gives every XCD a CONTIGUOUS range of the work list -- neighbours in the list
+// (tiles of one row block, heads of one molecule) then share an L2 instead of each pulling the same lines into eight.
+__device__ __forceinline__ int xcd_chunk(int orig, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
 // gelu(x) and gelu'(x) from one erf / one exponential (scalar form)
 __device__ __forceinline__ void gelu_erf_both(float x, float& y, float& dy) {
   const float kInvSqrt2Pi = 0.39894228040143267794f;

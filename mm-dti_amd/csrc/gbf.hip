@@ -300,7 +300,9 @@ __global__ __launch_bounds__(512, 2) void gbf_bias_fwd_kernel(const float* __res
     int ii, jj;
     bool inplane = true, past = false;
     if (TILED) {
-      const int rb = (int)((unsigned)tq / (unsigned)nblk), cb = tq - rb * nblk;
+      // (query block fastest: inside a 16x16 tile the 64-byte segments of rb & 3 = 0..3 are consecutive in memory, so the
+      //  eight waves of a workgroup write -- and the backward reads -- whole 128-byte lines together)
+      const int cb = (int)((unsigned)tq / (unsigned)nblk), rb = tq - cb * nblk;
       past = 4 * rb >= N || 4 * cb >= N;   // (the same for every lane of the wave)
       ii = 4 * rb + (i >> 2);
       jj = 4 * cb + (i & 3);
@@ -746,7 +748,7 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
     const int tq = tile - b * tpm;
     int q, ii, jj;
     if (TILED) {
-      const int rb = (int)((unsigned)tq / (unsigned)nb), cb = tq - rb * nb;
+      const int cb = (int)((unsigned)tq / (unsigned)nb), rb = tq - cb * nb;   // query block fastest: see the forward kernel
       ii = 4 * rb + (i >> 2);
       jj = 4 * cb + (i & 3);
       q = ((rb >> 2) * nt + (cb >> 2)) * 256 + (cb & 3) * 64 + (rb & 3) * 16 + i;

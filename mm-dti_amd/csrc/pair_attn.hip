@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void pair_attn_fwd_kernel(const bf16_t* __rest
                                                             int ld, float scale, uint32_t thresh, float dscale,
                                                             uint64_t seed, uint32_t site) {
   __shared__ __attribute__((aligned(16))) float sq[NCH * 64][HD];
-  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  // (the 64 heads of a token share 128-byte q / k / v lines, 8 heads per line: keep a molecule's heads on one XCD)
+  const int bh = xcd_chunk(blockIdx.x, gridDim.x), b = bh / H, h = bh - b * H;
   const int D = H * HD, D3 = 3 * D;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bf16_t* base = qkv + (long long)b * N * D3 + h * HD;
@@ -143,7 +144,8 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_kernel(const bf16_t* __rest
   __shared__ __attribute__((aligned(16))) float sq[NCH * 64][HD];
   __shared__ __attribute__((aligned(16))) float sdo[NCH * 64][HD];
   __shared__ __attribute__((aligned(16))) float red[NCH * 64][2 * HD];
-  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  // (the 64 heads of a token share 128-byte q / k / v lines, 8 heads per line: keep a molecule's heads on one XCD)
+  const int bh = xcd_chunk(blockIdx.x, gridDim.x), b = bh / H, h = bh - b * H;
   const int D = H * HD, D3 = 3 * D;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bf16_t* base = qkv + (long long)b * N * D3 + h * HD;
@@ -326,7 +328,8 @@ __global__ __launch_bounds__(256, NT > 13 ? 2 : 4) void pair_attn_fwd_mfma_kerne
   __shared__ __attribute__((aligned(16))) bf16_t sK[NP * 8];
   __shared__ __attribute__((aligned(16))) bf16_t sVT[8 * KSTR];
   __shared__ __attribute__((aligned(16))) float sM[NP];
-  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  // (the 64 heads of a token share 128-byte q / k / v lines, 8 heads per line: keep a molecule's heads on one XCD)
+  const int bh = xcd_chunk(blockIdx.x, gridDim.x), b = bh / H, h = bh - b * H;
   const int D = H * HD, D3 = 3 * D;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int nKB = (N + 15) >> 4;
@@ -501,7 +504,8 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
   // parts: with two patches instead of four the workgroup stays under 40 KB -> four per CU); the 8-byte slot s of row q
   // sits at slot s ^ (2 * (q >> 3)), which makes both the row writes and the transposing reads conflict-free
   __shared__ __attribute__((aligned(16))) bf16_t patch[NW][2][256];
-  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  // (the 64 heads of a token share 128-byte q / k / v lines, 8 heads per line: keep a molecule's heads on one XCD)
+  const int bh = xcd_chunk(blockIdx.x, gridDim.x), b = bh / H, h = bh - b * H;
   const int D = H * HD, D3 = 3 * D;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int nKB = (N + 15) >> 4;

@@ -75,29 +75,39 @@ def pmc(fetch_dir, write_dir, dst):
             w.writerow([r[0], r[1], f"{r[2]:.1f}", f"{r[3]:.1f}", f"{r[4]:.0f}"])
 
 
-def rdreq(src, dst):
+def rdreq(src, dst, src2=None):
     """Second view of the read traffic (is FETCH_SIZE x 2 right for the tiled pair reads?): the L2's memory-side
     read REQUEST counters.  TCC_EA0_RDREQ counts every request, TCC_EA0_RDREQ_32B the 32-byte ones; FETCH_SIZE is
     RDREQ x 64 B (MI355X_MICROARCH.md, HBM): if the remaining requests are 128 B wide the bytes read are
-    32 * n32 + 128 * (n - n32), if 64 B wide 32 * n32 + 64 * (n - n32) -- both are listed."""
+    32 * n32 + 128 * (n - n32), if 64 B wide 32 * n32 + 64 * (n - n32) -- both are listed.  With a second pass
+    (``src2``: TCC_EA0_RDREQ_64B_sum, TCC_EA0_RDREQ_128B_sum) the split is measured and ``read_bytes_by_size`` =
+    32 n32 + 64 n64 + 128 n128 is the read traffic itself."""
     n_all, n32 = counter_means(src, "TCC_EA0_RDREQ_sum"), counter_means(src, "TCC_EA0_RDREQ_32B_sum")
+    n64 = n128 = {}
+    if src2:
+        n64, n128 = counter_means(src2, "TCC_EA0_RDREQ_64B_sum"), counter_means(src2, "TCC_EA0_RDREQ_128B_sum")
     rows = []
     for k, (v, n) in n_all.items():
         v32 = n32.get(k, (0.0, 0))[0]
-        rows.append((k, n, v, v32, 32 * v32 + 64 * (v - v32), 32 * v32 + 128 * (v - v32)))
+        v64, v128 = n64.get(k, (None, 0))[0], n128.get(k, (None, 0))[0]
+        by_size = None if v64 is None or v128 is None else 32 * v32 + 64 * v64 + 128 * v128
+        rows.append((k, n, v, v32, 32 * v32 + 64 * (v - v32), 32 * v32 + 128 * (v - v32), v64, v128, by_size))
     rows.sort(key=lambda r: -r[5] * r[1])
     with open(dst, "w") as f:
-        f.write("# rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-rooflines\n")
+        f.write("# rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum (+ a pass with TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum)"
+                " -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-rooflines\n")
         w = csv.writer(f)
-        w.writerow(["kernel", "launches", "RDREQ_mean", "RDREQ_32B_mean", "read_bytes_if_64B_requests", "read_bytes_if_128B_requests"])
+        w.writerow(["kernel", "launches", "RDREQ_mean", "RDREQ_32B_mean", "read_bytes_if_64B_requests", "read_bytes_if_128B_requests",
+                    "RDREQ_64B_mean", "RDREQ_128B_mean", "read_bytes_by_size"])
+        fmt = lambda x: "" if x is None else f"{x:.0f}"
         for r in rows[:30]:
-            w.writerow([r[0], r[1], f"{r[2]:.0f}", f"{r[3]:.0f}", f"{r[4]:.0f}", f"{r[5]:.0f}"])
+            w.writerow([r[0], r[1], fmt(r[2]), fmt(r[3]), fmt(r[4]), fmt(r[5]), fmt(r[6]), fmt(r[7]), fmt(r[8])])
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "rdreq":
-        rdreq(sys.argv[2], sys.argv[3])
+        rdreq(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
