@@ -111,7 +111,9 @@ FAMILIES = {
     "pair_attn_fwd": ("pair_attn_fwd_mfma_kernel", "hbm"),
     "pair_attn_bwd": ("pair_attn_bwd_mfma_kernel", "hbm"),
     "gbf_bias_fwd": ("gbf_bias_fwd_kernel", "hbm"),        # "the pair-distance kernel" of the north star
-    "gbf_bias_bwd": ("gbf_bias_bwd_kernel", "hbm"),
+    # (the complete backward kernel recomputes instead of re-reading: its work unit is MFMA flops, see ops.gbf_bias_bwd_full;
+    #  with MMDTI_GBF_FULL_BWD=0 the round-1 per-pair kernel runs and the unit is bytes again)
+    "gbf_bias_bwd": ("gbf_bias_bwd_full_kernel", "mfma") if os.environ.get("MMDTI_GBF_FULL_BWD", "1") != "0" else ("gbf_bias_bwd_kernel", "hbm"),
     "ln_fwd": ("ln_fwd_kernel", "hbm"),
     "ln_bwd": ("ln_bwd_kernel", "hbm"),
     "attn_fwd": ("attn_fwd_kernel", "mfma"),
@@ -130,7 +132,7 @@ def family_rooflines(summary, steps):
         rate = d["work"] / (d["total_ms"] * 1e-3)
         peak = HBM_PEAK_GBS if bound == "hbm" else MFMA_PEAK_TFS
         ach = rate / 1e9 if bound == "hbm" else rate / 1e12
-        traffic, src = pmc_traffic(prefix) if bound == "hbm" else (None, None)
+        traffic, src = pmc_traffic(prefix) if name != "gemm" else (None, None)   # (one family, many kernels and shapes: no single figure)
         rows.append({"kernel": name, "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
                      "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": src,
                      ("algorithmic_bytes_per_launch" if bound == "hbm" else "algorithmic_flop_per_launch"): int(per_launch),

@@ -367,8 +367,10 @@ def gbf_bias_bwd_full(g, dist, edge_type, mul, bias, means, stds, w1, b1, w2, ld
                                   bias.data_ptr(), means.data_ptr(), stds.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), B, N, ld,
                                   w1.shape[1], Fh, Hh, mul.numel(), int(pair_is_tiled(g)), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(),
                                   db2.data_ptr(), dmul.data_ptr(), dbias.data_ptr(), dmeans.data_ptr(), dstds.data_ptr())
-    # algorithmic bytes per atom pair: G 64 x 4 B + distance + edge type in; the parameter gradients are O(1)
-    kernel_timer.end("gbf_bias_bwd", t0, float(P) * (Hh * g.element_size() + 4 + edge_type.element_size()))
+    # Work unit: MFMA flops (the kernel reads 268 B per atom pair and is nowhere near HBM): per pair the recomputed
+    # pre-activation (2*F*K), dO.W2 (2*H*F), du.W1 (2*F*K) and the two weight-gradient products (2*F*K + 2*H*F)
+    K = w1.shape[1]
+    kernel_timer.end("gbf_bias_bwd", t0, float(P) * (6.0 * Fh * K + 4.0 * Hh * Fh))
 
 
 def gbf_bias_eligible(K, Fh, Hh, ld):
