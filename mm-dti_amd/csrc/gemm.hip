@@ -1059,8 +1059,14 @@ __global__ __launch_bounds__(512, 1) void gemm_big_grouped_kernel(GroupArgs g) {
   a.splitk = g.splitk; a.alpha = 1.f; a.beta = 0.f; a.bias = nullptr; a.residual = nullptr; a.ldr = 0; a.act = MMDTI_ACT_NONE;
   a.aux_in = nullptr; a.aux_out = nullptr; a.ld_aux = 0; a.c_dtype = MMDTI_DT_F32; a.drop_thresh = 0; a.drop_scale = 1.f; a.seed = 0; a.site = 0;
   a.vec_ok = 1; a.colsum = nullptr; a.stream_c = 0; a.dbg = 0; a.slab = (long long)pr.M * pr.N; a.arowsum = pr.arowsum;
-  const int t = wg - pr.tile0, tm = t / pr.tiles_n;
-  big_tile<true, true>(a, tm, t - tm * pr.tiles_n, blockIdx.z, smem);
+  // Tile order inside a problem: the SHORT side of the tile grid runs fastest, so the ~6 consecutive tiles an XCD gets (per
+  // K-split) form a compact 2 x 3 block of the output -- 5 operand pieces through that L2 instead of 7 for a 1 x 6 strip.
+  const int t = wg - pr.tile0;
+  const int tiles_m = (pr.M + BBM - 1) / BBM;
+  int tm, tn;
+  if (tiles_m < pr.tiles_n) { tn = t / tiles_m; tm = t - tn * tiles_m; }
+  else { tm = t / pr.tiles_n; tn = t - tm * pr.tiles_n; }
+  big_tile<true, true>(a, tm, tn, blockIdx.z, smem);
 }
 
 // dW_i += sum over splits of slab_i[s]   (all problems of a group in one launch; blockIdx.y = problem)
