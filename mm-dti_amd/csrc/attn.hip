@@ -45,14 +45,21 @@ __device__ __forceinline__ uint32_t attn_rng_key(uint64_t seed, uint32_t site, u
   seed = salted(seed);
   return mix32((mix32((uint32_t)seed ^ (site * 0x9E3779B9u)) ^ (uint32_t)(seed >> 32)) + bh * 0x85EBCA6Bu);
 }
-// keep iff a 16-bit uniform >= thresh16 (p quantised to 1/65536).  idx = query * key_stride + key.
-__device__ __forceinline__ bool attn_keep(uint32_t key, uint32_t idx, uint32_t thresh16) {
-  uint32_t h = (idx * 0x9E3779B1u) ^ key;
-  h ^= h >> 16;
-  h *= 0x7FEB352Du;
-  h ^= h >> 15;
-  return (h >> 16) >= thresh16;
+// Dropout of the probabilities.  Element (query, key) belongs to QUAD = query * (key_stride / 4) + key / 4 (four consecutive
+// keys of one query), bit key & 3 of that quad's 4-bit keep mask: two avalanche hashes give four 16-bit uniforms, kept iff
+// >= thresh16 (p quantised to 1/65536).  One call per accumulator quad instead of one two-multiply hash per ELEMENT: 32-bit
+// integer multiplies issue at quarter rate, and that hash was over half of the forward kernel's VALU time.
+__device__ __forceinline__ uint32_t attn_keep4(uint32_t key, uint32_t quad, uint32_t thresh16) {
+  const uint32_t a = mix32(quad ^ key);
+  const uint32_t b = mix32(a ^ 0xB5297A4Du);
+  return ((a & 0xffffu) >= thresh16 ? 1u : 0u) | ((a >> 16) >= thresh16 ? 2u : 0u) | ((b & 0xffffu) >= thresh16 ? 4u : 0u) |
+         ((b >> 16) >= thresh16 ? 8u : 0u);
 }
+// Logits are carried in base-2 units (scale * log2 e folded into the scale and the additive key mask), so that the softmax
+// exponential is a bare v_exp_f32.  A finite "minus infinity" mask (finfo.min) stays finite: a fully masked row then softmaxes
+// to uniform, as it does in the unfused path.
+constexpr float ATTN_LOG2E = 1.4426950408889634f;
+__device__ __forceinline__ float attn_mask2(float ka) { return fmaxf(ka * ATTN_LOG2E, -3.4028234663852886e38f); }
 
 template <int HD>
 __device__ __forceinline__ void attn_fill_rows(bf16_t* lds, const bf16_t* g, int L, int rows, int ld, int tid, int nthreads) {
@@ -115,9 +122,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   attn_fill_rows<HD>(sK, k + (long long)b * Lk * ldk + h * HD, Lk, NP, ldk, tid, blockDim.x);
   attn_fill_rows<HD>(sV, v + (long long)b * Lk * ldk + h * HD, Lk, NP, ldk, tid, blockDim.x);
-  for (int t = tid; t < NP; t += blockDim.x) sKA[t] = t < Lk ? (key_add ? key_add[(long long)b * Lk + t] : 0.f) : -INFINITY;
+  for (int t = tid; t < NP; t += blockDim.x) sKA[t] = t < Lk ? (key_add ? attn_mask2(key_add[(long long)b * Lk + t]) : 0.f) : -INFINITY;
   __syncthreads();
   const uint32_t rkey = attn_rng_key(seed, site, (uint32_t)bh);
+  const float scale2 = scale * ATTN_LOG2E;
   const int g = lane >> 4, i = lane & 15;
   const int nqt = (Lq + 15) >> 4;
   for (int qt = wave; qt < nqt; qt += nw) {
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
       for (int c = 0; c < KC; ++c) acc = ATTN_MFMA(attn_frag_rm<HD>(sK, t * 16, c, lane), qf[c], acc);
       const f32x4 ka = *reinterpret_cast<const f32x4*>(&sKA[t * 16 + 4 * g]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = acc[r] * scale + ka[r];
+      for (int r = 0; r < 4; ++r) acc[r] = acc[r] * scale2 + ka[r];
       m = fmaxf(fmaxf(m, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
       S[t] = acc;
       __builtin_amdgcn_sched_barrier(0);  // keep the unrolled tiles in order: hoisted LDS fragments would spill
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = __expf(S[t][r] - m);
+        const float e = __builtin_amdgcn_exp2f(S[t][r] - m);
         S[t][r] = e;
         lsum += e;
       }
@@ -159,15 +167,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
     f32x4 o[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) o[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float invd = thresh16 ? inv * dscale : inv;
 #pragma unroll
     for (int u = 0; u < NT / 2; ++u) {
-      f32x4 p0 = S[2 * u] * inv, p1 = S[2 * u + 1] * inv;
+      f32x4 p0 = S[2 * u] * invd, p1 = S[2 * u + 1] * invd;
       if (thresh16) {
-        const uint32_t i0 = (uint32_t)qi * NP + (2 * u) * 16 + 4 * g;
+        const uint32_t q4 = (uint32_t)qi * (NP / 4) + (2 * u) * 4 + g;
+        const uint32_t k0 = attn_keep4(rkey, q4, thresh16), k1 = attn_keep4(rkey, q4 + 4, thresh16);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          p0[r] = attn_keep(rkey, i0 + r, thresh16) ? p0[r] * dscale : 0.f;
-          p1[r] = attn_keep(rkey, i0 + 16 + r, thresh16) ? p1[r] * dscale : 0.f;
+          p0[r] = (k0 >> r) & 1u ? p0[r] : 0.f;
+          p1[r] = (k1 >> r) & 1u ? p1[r] : 0.f;
         }
       }
       const bf16x8 pf = attn_pack(p0, p1);
@@ -200,9 +210,10 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const bf16_t* __restric
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   attn_fill_rows<HD>(sK, k + (long long)b * Lk * ldk + h * HD, Lk, NP, ldk, tid, blockDim.x);
   attn_fill_rows<HD>(sV, v + (long long)b * Lk * ldk + h * HD, Lk, NP, ldk, tid, blockDim.x);
-  for (int t = tid; t < NP; t += blockDim.x) sKA[t] = t < Lk ? (key_add ? key_add[(long long)b * Lk + t] : 0.f) : -INFINITY;
+  for (int t = tid; t < NP; t += blockDim.x) sKA[t] = t < Lk ? (key_add ? attn_mask2(key_add[(long long)b * Lk + t]) : 0.f) : -INFINITY;
   __syncthreads();
   const uint32_t rkey = attn_rng_key(seed, site, (uint32_t)bh);
+  const float scale2 = scale * ATTN_LOG2E;
   const int g = lane >> 4, i = lane & 15;
   const int nqt = (Lq + 15) >> 4;
   for (int qt = wave; qt < nqt; qt += nw) {
@@ -230,11 +241,11 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const bf16_t* __restric
         dacc = ATTN_MFMA(attn_frag_rm<HD>(sV, t * 16, c, lane), dof[c], dacc);
       }
       const f32x4 ka = *reinterpret_cast<const f32x4*>(&sKA[t * 16 + 4 * g]);
-      const uint32_t i0 = (uint32_t)qi * NP + t * 16 + 4 * g;
+      const uint32_t km = thresh16 ? attn_keep4(rkey, (uint32_t)qi * (NP / 4) + t * 4 + g, thresh16) : 15u;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = __expf(acc[r] * scale + ka[r] - st.x) * st.y;
-        const bool keep = !thresh16 || attn_keep(rkey, i0 + r, thresh16);
+        const float p = __builtin_amdgcn_exp2f(acc[r] * scale2 + ka[r] - st.x) * st.y;
+        const bool keep = (km >> r) & 1u;
         dsum += keep ? dacc[r] * p : 0.f;
         acc[r] = keep ? p : -p;
       }
@@ -323,7 +334,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv_kernel(const bf16_t* __res
       kf[c] = attn_frag_global<HD>(krow, kv, c, lane);
       vf[c] = attn_frag_global<HD>(vrow, kv, c, lane);
     }
-    const float ka = kv ? (key_add ? key_add[(long long)b * Lk + key] : 0.f) : -INFINITY;
+    const float ka = kv ? (key_add ? attn_mask2(key_add[(long long)b * Lk + key]) : 0.f) : -INFINITY;
+    const float scale2 = scale * ATTN_LOG2E;
+    const uint32_t kquad = (uint32_t)(key >> 2), kbit = (uint32_t)(i & 3), qstride4 = (uint32_t)key_stride >> 2;
     f32x4 dka[NB], dva[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -345,16 +358,22 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv_kernel(const bf16_t* __res
         const f32x4 m4 = *reinterpret_cast<const f32x4*>(&sM[r0 + 4 * g]);
         const f32x4 i4 = *reinterpret_cast<const f32x4*>(&sI[r0 + 4 * g]);
         const f32x4 d4 = *reinterpret_cast<const f32x4*>(&sD[r0 + 4 * g]);
+        // keep masks: the four lanes of a key quad need the masks of the same four (query, key-quad) pairs -- lane i & 3 = r
+        // computes the one of query r0 + 4g + r, and the four are exchanged inside the lane quad (DPP quad_perm broadcasts)
+        uint32_t kb = 15u;                             // bit r: element (query r0 + 4g + r, this lane's key) kept
+        if (thresh16) {
+          const int own = (int)attn_keep4(rkey, (uint32_t)(r0 + 4 * g + (int)kbit) * qstride4 + kquad, thresh16);
+          kb = (((uint32_t)__builtin_amdgcn_update_dpp(0, own, 0x00, 0xf, 0xf, false) >> kbit) & 1u) |
+               ((((uint32_t)__builtin_amdgcn_update_dpp(0, own, 0x55, 0xf, 0xf, false) >> kbit) & 1u) << 1) |
+               ((((uint32_t)__builtin_amdgcn_update_dpp(0, own, 0xAA, 0xf, 0xf, false) >> kbit) & 1u) << 2) |
+               ((((uint32_t)__builtin_amdgcn_update_dpp(0, own, 0xFF, 0xf, 0xf, false) >> kbit) & 1u) << 3);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __expf(acc[r] * scale + ka - m4[r]) * i4[r];
-          float w = dacc[r], pk = p;
-          if (thresh16) {
-            const bool keep = attn_keep(rkey, (uint32_t)(r0 + 4 * g + r) * key_stride + key, thresh16);
-            w = keep ? w * dscale : 0.f;
-            pk = keep ? p * dscale : 0.f;
-          }
-          pd[hf][r] = pk;
+          const float p = __builtin_amdgcn_exp2f(acc[r] * scale2 + ka - m4[r]) * i4[r];
+          const bool keep = (kb >> r) & 1u;
+          const float w = keep ? dacc[r] * dscale : 0.f;     // (dscale = 1 without dropout)
+          pd[hf][r] = keep ? p * dscale : 0.f;
           ds[hf][r] = p * (w - d4[r]) * scale;
         }
       }
