@@ -190,8 +190,9 @@ def test_full_size_step_properties():
         lg1, inf1, ct1 = model(**dev, return_infonce_loss=True, return_ct_loss=True, net_target=y)
         lg2, inf2, ct2 = model(**dev, return_infonce_loss=True, return_ct_loss=True, net_target=y)
         assert torch.equal(lg1, lg2)                                   # no atomics between the inputs and the logits
-        # (the two scalar losses are atomic sums over rows: equal up to summation order)
-        assert abs(float(inf1) - float(inf2)) <= 1e-6 * abs(float(inf1)) and abs(float(ct1) - float(ct2)) <= 1e-6 * abs(float(ct1))
+        # (the two scalar losses are atomic sums over 256 rows: equal up to summation order -- the running sum reaches ~1.4e3,
+        #  where one fp32 ulp is 1.2e-4, i.e. 5e-7 of the mean per reordering; a handful of those is the bound)
+        assert abs(float(inf1) - float(inf2)) <= 5e-6 * abs(float(inf1)) and abs(float(ct1) - float(ct2)) <= 5e-6 * abs(float(ct1))
         perm = torch.randperm(256, generator=torch.Generator().manual_seed(3)).cuda()
         devp = {k: v[perm] for k, v in dev.items()}
         lgp, infp, ctp = model(**devp, return_infonce_loss=True, return_ct_loss=True, net_target=y[perm])
