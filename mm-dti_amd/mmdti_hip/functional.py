@@ -102,13 +102,10 @@ _wgrad_keep = []
 
 def _launch_deferred_wgrads(deferred, layers):
     """deferred: argument tuples of _lin_bwd_params whose operands must stay alive until the stream is joined."""
-    global _wgrad_stream_obj
     if not deferred:
         return
     main = torch.cuda.current_stream()
-    if _wgrad_stream_obj is None:
-        _wgrad_stream_obj = torch.cuda.Stream()
-    ws = _wgrad_stream_obj
+    ws = _wgrad_stream()
     ws.wait_stream(main)
     with torch.cuda.stream(ws):
         for group in deferred:                      # one list of _lin_bwd_params calls per layer
@@ -120,6 +117,49 @@ def _launch_deferred_wgrads(deferred, layers):
     def _join(stream=ws):
         torch.cuda.current_stream().wait_stream(stream)
         _wgrad_keep.clear()                             # operands may be recycled now: later work is ordered behind the join
+
+    torch.autograd.Variable._execution_engine.queue_callback(_join)
+
+
+# Option (default off, MMDTI_WGRAD_SIDE=1): weight gradients of the pair encoder on their OWN stream, layer by layer.  They
+# are leaves of the backward graph (only the optimizer reads them) and MFMA-bound, and the next thing on the main stream is the
+# layer below's pair-attention backward -- HBM-bound, matrix pipes idle -- so the grouped launch of layer l could run
+# underneath it.  Measured (same box, r02): 57.4 vs 57.5 ms/step, nothing: a workgroup of the grouped kernel holds 128 KB of
+# a CU's 160 KB of LDS and a pair-attention workgroup needs 40 KB, so the two kernels take turns on a CU instead of sharing it.
+# Operands stay referenced until the launch's event has completed (or the streams are joined at the end of backward).
+WGRAD_SIDE = os.environ.get("MMDTI_WGRAD_SIDE", "0") == "1"
+_wgrad_inflight = []
+
+
+def _wgrad_stream():
+    global _wgrad_stream_obj
+    if _wgrad_stream_obj is None:
+        _wgrad_stream_obj = torch.cuda.Stream()
+    return _wgrad_stream_obj
+
+
+def _launch_side_wgrads(pending, layer):
+    main = torch.cuda.current_stream()
+    ws = _wgrad_stream()
+    ws.wait_stream(main)                         # every operand of `pending` has been produced on `main` by now
+    with torch.cuda.stream(ws):
+        _lin_bwd_params_many(pending)
+        notify_grads_ready(layer.parameters())     # (recorded on this stream: the reducer's event sits behind the GEMMs)
+        ev = torch.cuda.Event()
+        ev.record(ws)
+    _wgrad_inflight.append((ev, pending))
+    while _wgrad_inflight and _wgrad_inflight[0][0].query():
+        _wgrad_inflight.pop(0)                     # that launch is done: its operands may be recycled
+
+
+def _join_side_wgrads():
+    """queue (once per backward) the join of the weight-gradient stream into whatever stream ends the backward pass"""
+    if not _wgrad_inflight:
+        return
+
+    def _join(stream=_wgrad_stream()):
+        torch.cuda.current_stream().wait_stream(stream)
+        _wgrad_inflight.clear()
 
     torch.autograd.Variable._execution_engine.queue_callback(_join)
 
@@ -249,13 +289,16 @@ class PairEncoderFn(torch.autograd.Function):
                                              bf16_copy=(st.p_res, below[li - 1], gbuf(mod.layers[li - 1].fc2.bias)))
             else:
                 dx, dx16 = ops.layernorm_bwd(dh1, L.x, ln1.weight, L.m1, L.r1, gbuf(ln1.weight), gbuf(ln1.bias), dres=dx), None
+            side = WGRAD_SIDE and dout.is_cuda and not hold
             if hold:
                 deferred.append(pending)
                 deferred_layers.append(layer)
+            elif side:
+                _launch_side_wgrads(pending, layer)
             else:
                 _lin_bwd_params_many(pending)
             L.__dict__.clear()       # release this layer's activations (S_l is ~1 GB at the bench shape)
-            if not hold:
+            if not hold and not side:
                 notify_grads_ready(layer.parameters())
         eln = mod.emb_layer_norm
         demb = ops.layernorm_bwd(dx, st.emb.view(M, D), eln.weight, st.emb_mean, st.emb_rstd, gbuf(eln.weight), gbuf(eln.bias),
@@ -264,6 +307,7 @@ class PairEncoderFn(torch.autograd.Function):
         if G is None:
             G = torch.zeros_like(st.bias0)
         _launch_deferred_wgrads(deferred, deferred_layers)
+        _join_side_wgrads()
         _join_stream_after_backward()
         return demb.view(B, N, D), G, None, None, None
 

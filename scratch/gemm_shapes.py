@@ -9,7 +9,7 @@ from mmdti_hip import functional as Fn
 from mmdti_hip.trainer import FineTuner
 model, _ = bench.build_model()
 model = model.cuda().train()
-model.overlap_towers = False; model.infonce_on_side_stream = False; model.cross_modal_module.two_streams = False; Fn.DEFER_WGRAD_LAYERS = 0
+model.overlap_towers = False; model.infonce_on_side_stream = False; model.cross_modal_module.two_streams = False; Fn.DEFER_WGRAD_LAYERS = 0; Fn.WGRAD_SIDE = False
 tuner = FineTuner(model, "classification", total_steps=1000)
 _, batch, label = bench.synth(256, 128, 256, seed=1234)
 batch = {k: v.cuda() for k, v in batch.items()}; label = label.cuda()
