@@ -760,6 +760,33 @@ def test_gbf_bias_complete_backward_matches_chain_and_autograd(ops, B, N, tiled,
         assert r < 3e-2, (n, "vs autograd", r)
 
 
+@pytest.mark.parametrize("E", [1600, 5000])
+def test_gbf_bias_forward_with_large_edge_type_tables(ops, E):
+    """E = 1600 (a 40-token dictionary): tables in LDS, but more than the complete backward kernel keeps (1536), so the model
+    falls back to the round-1 backward chain; E = 5000: beyond the forward's LDS tables too (global gathers).  Same numbers as
+    the unfused chain in both."""
+    K, Fh, H, B, N = 128, 128, 64, 2, 21
+    ld = ops.pair_ld(N)
+    gen = G(41)
+    dist = torch.rand(B, N, N, generator=gen) * 8
+    et = torch.randint(0, E, (B, N, N), generator=gen)
+    et[0, 0, :4] = torch.tensor([0, E - 1, E + 7, -3])            # out-of-range indices clamp, as in the unfused kernel
+    mul, bias = 1 + 0.1 * torch.randn(E, generator=gen), 0.1 * torch.randn(E, generator=gen)
+    means, stds = torch.rand(K, generator=gen) * 3, torch.rand(K, generator=gen) * 3 - 1.5
+    w1, b1 = dev(bf(torch.randn(Fh, K, generator=gen) * 0.2)), dev(torch.randn(Fh, generator=gen) * 0.1)
+    w2, b2 = dev(bf(torch.randn(H, Fh, generator=gen) * 0.2)), dev(torch.randn(H, generator=gen) * 0.1)
+    d = [dev(t) for t in (dist, et, mul, bias, means, stds)]
+    feat = ops.gbf_features_fwd(*d)
+    h = ops.linear_fwd(feat, w1, b1, act=ops.ACT_GELU)
+    o = ops.linear_fwd(h, w2, b2, out_dtype=torch.float32)
+    ref = ops.pair_permute_fwd(o, B, N, H, ld)
+    for dt in (torch.int64, torch.int32):
+        dn = list(d); dn[1] = d[1].to(dt)
+        out, _ = ops.gbf_bias_fwd(*dn, w1, b1, w2, b2, ld, save=False)
+        close(out[..., :N], ref[..., :N], 2e-2, 3e-2)
+        assert float((out[..., :N] - ref[..., :N]).abs().mean()) < 2e-3 * float(ref[..., :N].abs().mean()) + 1e-5
+
+
 def test_gbf_bias_complete_backward_rejects_bad_arguments(ops):
     from mmdti_hip._abi import MMDTIError
     K, Fh, H, E, B, N = 128, 128, 64, 2000, 1, 8
