@@ -56,6 +56,7 @@ struct GemmArgs {
   int stream_c;           // host-set: C is written with streaming (non-temporal) stores -- outputs too large to be of use in the caches
   int dbg;                // measurement switch (see g_gemm_dbg)
   long long slab;         // split-K partials: split ks writes C + ks * slab (elements) instead of accumulating into C; 0 = off
+  const void* zeros;      // >= 16 zero bytes in device memory: source of the K-tail rows of gemm_big_kernel's last K-tile (k-major operands)
   float* arowsum;         // [M] fp32 or null: += sum_k op(A)[m][k] -- for a weight gradient dW = dy^T.x (A = dy, k-major) that
                           // is the Linear's bias gradient; taken with one extra MFMA per A fragment against a ones operand
 };
@@ -831,6 +832,19 @@ __device__ __forceinline__ void big_issue(const bf16_t* kbase, long long d2, uin
   __builtin_amdgcn_global_load_lds((gptr_t*)(reinterpret_cast<const char*>(kbase + d2) + off), (lptr_t*)(d + 4096), 16, 0, 0);
 }
 
+// The LAST K-tile of a k-major operand whose K is not a multiple of 64 (token counts of small / ragged batches): the k rows
+// past the end are fetched from a zero chunk instead -- per-lane source select; a lane's two chunks are k rows k0 and k0 + 32.
+__device__ __forceinline__ void big_issue_tail(const bf16_t* kbase, long long d2, uint32_t off, bf16_t* piece, int wave, int kv, const void* zeros, int tid) {
+  typedef __attribute__((address_space(1))) const void gptr_t;
+  typedef __attribute__((address_space(3))) void lptr_t;
+  const int k0 = tid >> 4;
+  const char* p0 = k0 < kv ? reinterpret_cast<const char*>(kbase) + off : reinterpret_cast<const char*>(zeros);
+  const char* p1 = k0 + 32 < kv ? reinterpret_cast<const char*>(kbase + d2) + off : reinterpret_cast<const char*>(zeros);
+  bf16_t* d = piece + wave * 512;
+  __builtin_amdgcn_global_load_lds((gptr_t*)p0, (lptr_t*)(d), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((gptr_t*)p1, (lptr_t*)(d + 4096), 16, 0, 0);
+}
+
 // C[m][n] += sum over splits of slab[s][m][n]   (the second pass of the slab form of split-K)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C, int M, int N, int ldc, int splits) {
   const long long n4 = (long long)M * N / 4, stride = (long long)gridDim.x * 256;
@@ -860,11 +874,13 @@ __device__ __forceinline__ void big_tile(const GemmArgs& a, int tm, int tn, int 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
   const int m0 = tm * BBM, n0 = tn * BBN;
-  const int ktiles = a.K / BK;
+  const int ktiles = (a.K + BK - 1) / BK;     // (a K tail only with both operands k-major: host-checked)
+  const int ktail = a.K - (ktiles - 1) * BK;  // valid k rows of the last K-tile (BK: no tail)
   const int per = (ktiles + a.splitk - 1) / a.splitk;
   const int kt0 = ks * per, kt1 = min(ktiles, kt0 + per);
   if (kt0 >= kt1) return;
   const int nt = kt1 - kt0;
+  const int tail_t = (TA && TB && ktail != BK && kt1 == ktiles) ? nt - 1 : 0x7fffffff;   // split-local index of the partial tile
   const bf16_t* __restrict__ A = a.A + (long long)kt0 * (TA ? (long long)BK * a.lda : BK);
   const bf16_t* __restrict__ B = a.B + (long long)kt0 * (TB ? (long long)BK * a.ldb : BK);
   const long long kstepA = TA ? (long long)BK * a.lda : BK, kstepB = TB ? (long long)BK * a.ldb : BK;
@@ -884,13 +900,19 @@ __device__ __forceinline__ void big_tile(const GemmArgs& a, int tm, int tn, int 
 #define BIG_A(T) (A + BIG_TILE(T) * kstepA)
 #define BIG_B(T) (B + BIG_TILE(T) * kstepB)
 #define BIG_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+  // (a tile index past the split's end re-fetches its last tile: if that one is the partial tile, through the masked form too)
+#define BIG_ISSUE(KB, D2, OFF, T, DST)                                                      \
+  {                                                                                         \
+    if (TA && TB && BIG_TILE(T) >= tail_t) big_issue_tail(KB, D2, OFF, DST, wave, ktail, a.zeros, tid); \
+    else big_issue(KB, D2, OFF, DST, wave);                                                 \
+  }
   // prologue: every piece of tile 0; of tile 1 the two B pieces (the steady state enters a tile with them in flight)
-  big_issue(BIG_A(0), dA2, oA, smem, wave);
-  big_issue(BIG_B(0), dB2, oB, smem + 2 * BIG_PIECE, wave);
-  big_issue(BIG_B(0) + hB, dB2, oB, smem + 3 * BIG_PIECE, wave);
-  big_issue(BIG_A(0) + hA, dA2, oA, smem + BIG_PIECE, wave);
-  big_issue(BIG_B(1), dB2, oB, smem + BIG_BUF + 2 * BIG_PIECE, wave);
-  big_issue(BIG_B(1) + hB, dB2, oB, smem + BIG_BUF + 3 * BIG_PIECE, wave);
+  BIG_ISSUE(BIG_A(0), dA2, oA, 0, smem);
+  BIG_ISSUE(BIG_B(0), dB2, oB, 0, smem + 2 * BIG_PIECE);
+  BIG_ISSUE(BIG_B(0) + hB, dB2, oB, 0, smem + 3 * BIG_PIECE);
+  BIG_ISSUE(BIG_A(0) + hA, dA2, oA, 0, smem + BIG_PIECE);
+  BIG_ISSUE(BIG_B(1), dB2, oB, 1, smem + BIG_BUF + 2 * BIG_PIECE);
+  BIG_ISSUE(BIG_B(1) + hB, dB2, oB, 1, smem + BIG_BUF + 3 * BIG_PIECE);
   BIG_WAIT(4);
   __builtin_amdgcn_s_barrier();
 
@@ -945,20 +967,21 @@ __device__ __forceinline__ void big_tile(const GemmArgs& a, int tm, int tn, int 
     bf16_t* cur = smem + (t & 1) * BIG_BUF;
     bf16_t* oth = smem + ((t & 1) ^ 1) * BIG_BUF;
     // c1: (A0, k 0..31)   | read A1 k-half 0            | DMA A0(t+1) -> other buffer (free since phase 4 of tile t-1)
-    BIG_PHASE(0, FAx, FBx, rs0, BIG_LDA(FAy, cur + BIG_PIECE, 0), big_issue(BIG_A(t + 1), dA2, oA, oth, wave), (void)0);
+    BIG_PHASE(0, FAx, FBx, rs0, BIG_LDA(FAy, cur + BIG_PIECE, 0), BIG_ISSUE(BIG_A(t + 1), dA2, oA, t + 1, oth), (void)0);
     // c2: (A1, k 0..31)   | read A1 and B k-half 1      | DMA A1(t+1) -> other buffer (free since phase 3 of tile t-1)
     BIG_PHASE(1, FAy, FBx, rs1, BIG_LDA(FAx, cur + BIG_PIECE, 1); BIG_LDB(FBy, cur, 1),
-              big_issue(BIG_A(t + 1) + hA, dA2, oA, oth + BIG_PIECE, wave), (void)0);
+              BIG_ISSUE(BIG_A(t + 1) + hA, dA2, oA, t + 1, oth + BIG_PIECE), (void)0);
     // c3: (A1, k 32..63)  | read A0 k-half 1            | DMA B0(t+2) -> this buffer (B was last read in phase 2); wait: A0(t+1), B(t+1) landed
-    BIG_PHASE(1, FAx, FBy, rs1, BIG_LDA(FAy, cur, 1), big_issue(BIG_B(t + 2), dB2, oB, cur + 2 * BIG_PIECE, wave), BIG_WAIT(4));
+    BIG_PHASE(1, FAx, FBy, rs1, BIG_LDA(FAy, cur, 1), BIG_ISSUE(BIG_B(t + 2), dB2, oB, t + 2, cur + 2 * BIG_PIECE), BIG_WAIT(4));
     // c4: (A0, k 32..63)  | read A0, B of tile t+1      | DMA B1(t+2) -> this buffer; wait: A1(t+1) landed
     BIG_PHASE(0, FAy, FBy, rs0, BIG_LDA(FAx, oth, 0); BIG_LDB(FBx, oth, 0),
-              big_issue(BIG_B(t + 2) + hB, dB2, oB, cur + 3 * BIG_PIECE, wave), BIG_WAIT(4));
+              BIG_ISSUE(BIG_B(t + 2) + hB, dB2, oB, t + 2, cur + 3 * BIG_PIECE), BIG_WAIT(4));
   }
   BIG_WAIT(0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();   // no DMA in flight, no read outstanding: LDS is free for the epilogue
 #undef BIG_PHASE
+#undef BIG_ISSUE
 #undef BIG_MF8
 #undef BMF
 #undef BIG_LDA
@@ -1065,6 +1088,7 @@ struct GroupProb {
 struct GroupArgs {
   GroupProb p[GROUP_MAX];
   int nprob, ntiles, K, splitk;
+  const void* zeros;
 };
 
 __global__ __launch_bounds__(512, 1) void gemm_big_grouped_kernel(GroupArgs g) {
@@ -1079,7 +1103,7 @@ __global__ __launch_bounds__(512, 1) void gemm_big_grouped_kernel(GroupArgs g) {
   a.batch_inner = 1; a.sAo = a.sAi = a.sBo = a.sBi = a.sCo = a.sCi = 0;
   a.splitk = g.splitk; a.alpha = 1.f; a.beta = 0.f; a.bias = nullptr; a.residual = nullptr; a.ldr = 0; a.act = MMDTI_ACT_NONE;
   a.aux_in = nullptr; a.aux_out = nullptr; a.ld_aux = 0; a.c_dtype = MMDTI_DT_F32; a.drop_thresh = 0; a.drop_scale = 1.f; a.seed = 0; a.site = 0;
-  a.vec_ok = 1; a.colsum = nullptr; a.stream_c = 0; a.dbg = 0; a.slab = (long long)pr.M * pr.N; a.arowsum = pr.arowsum;
+  a.vec_ok = 1; a.colsum = nullptr; a.stream_c = 0; a.dbg = 0; a.slab = (long long)pr.M * pr.N; a.arowsum = pr.arowsum; a.zeros = g.zeros;
   // Tile order inside a problem: the SHORT side of the tile grid runs fastest, so the ~6 consecutive tiles an XCD gets (per
   // K-split) form a compact 2 x 3 block of the output -- 5 operand pieces through that L2 instead of 7 for a 1 x 6 strip.
   const int t = wg - pr.tile0;
@@ -1260,6 +1284,16 @@ MMDTI_DEFINE_SALT_PULL(gemm)
 using namespace mmdti;
 
 static int g_gemm_big = getenv("MMDTI_GEMM_BIG") ? atoi(getenv("MMDTI_GEMM_BIG")) : 1;
+
+// 256 zero bytes in device memory (see GemmArgs::zeros); allocated at the first call that needs it
+static const void* zero_page() {
+  static void* page = nullptr;
+  if (!page) {
+    if (hipMalloc(&page, 256) != hipSuccess) { page = nullptr; return nullptr; }
+    if (hipMemset(page, 0, 256) != hipSuccess) { (void)hipFree(page); page = nullptr; return nullptr; }
+  }
+  return page;
+}
 static int g_gemm_ring = getenv("MMDTI_GEMM_RING") ? atoi(getenv("MMDTI_GEMM_RING")) : 1;
 static int g_gemm_dbg = 0;     // measurement only: 1 = gemm_big_kernel returns after its K loop (no epilogue, no slab pass)
 
@@ -1318,6 +1352,7 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
   a.seed = seed; a.site = site;
   a.colsum = colsum_out;
   a.arowsum = nullptr;
+  a.zeros = nullptr;
   a.slab = 0;
   a.dbg = g_gemm_dbg;
   {
@@ -1494,10 +1529,12 @@ extern "C" int mmdti_linear_dw_grouped(mmdti_stream_t stream, int nprob, const v
                                        const int* ldx, const int* lddw, int rows, void* workspace, long long workspace_bytes) {
   MMDTI_REQUIRE(nprob >= 1 && nprob <= GROUP_MAX, "linear_dw_grouped: 1..%d problems (got %d)", GROUP_MAX, nprob);
   MMDTI_REQUIRE(dy_bf16 && x_bf16 && dw && n_out && n_in && ldy && ldx && lddw, "linear_dw_grouped: null argument table");
-  MMDTI_REQUIRE(rows >= 1024 && rows % BK == 0, "linear_dw_grouped: rows must be a multiple of %d and >= 1024 (got %d)", BK, rows);
+  MMDTI_REQUIRE(rows >= 512, "linear_dw_grouped: at least 512 rows (got %d)", rows);   // (any count: a K tail is zero-filled in the kernel)
   MMDTI_REQUIRE(workspace && aligned16(workspace), "linear_dw_grouped: a 16-byte aligned workspace is required");
   GroupArgs g;
   g.nprob = nprob; g.K = rows;
+  g.zeros = zero_page();
+  MMDTI_REQUIRE(g.zeros != nullptr, "linear_dw_grouped: could not allocate the zero page");
   int tiles = 0;
   long long elems = 0;
   for (int i = 0; i < nprob; ++i) {
@@ -1515,7 +1552,7 @@ extern "C" int mmdti_linear_dw_grouped(mmdti_stream_t stream, int nprob, const v
   }
   for (int i = nprob; i < GROUP_MAX; ++i) { g.p[i] = g.p[0]; g.p[i].tile0 = 0x7fffffff; }
   g.ntiles = tiles;
-  const int kts = rows / BK;
+  const int kts = cdiv(rows, BK);
   int sk = max(1, min(kts / 4, 256 / max(1, tiles)));   // floor: all workgroups resident in ONE round
   sk = cdiv(kts, cdiv(kts, sk));                     // no empty split: every slab is summed
   g.splitk = sk;
@@ -1547,7 +1584,7 @@ extern "C" int mmdti_linear_dw_grouped(mmdti_stream_t stream, int nprob, const v
 /* splits the grouped weight-gradient launch will use for `tiles` output tiles over `rows` tokens (workspace sizing) */
 extern "C" int mmdti_linear_dw_grouped_splits(int tiles, int rows) {
   if (tiles <= 0 || rows < BK) return 1;
-  const int kts = rows / BK;
+  const int kts = cdiv(rows, BK);
   const int sk = max(1, min(kts / 4, 256 / max(1, tiles)));
   return cdiv(kts, cdiv(kts, sk));
 }

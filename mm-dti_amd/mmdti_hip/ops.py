@@ -135,9 +135,13 @@ def linear_bwd_weight(dy, x, dw, *, rows=None, db=None):
 GROUPED_DW = os.environ.get("MMDTI_GROUPED_DW", "1") != "0"
 
 
+# (any row count: the kernel zero-fills the tail of the last 64-row K-tile)
+GROUPED_DW_MIN_ROWS = int(os.environ.get("MMDTI_GROUPED_DW_MIN_ROWS", "1024"))
+
+
 def _dw_groupable(dy, x, dw, rows):
     return (dy.dtype == BF16 and x.dtype == BF16 and dw.dtype == F32 and dy.stride(-1) == 1 and x.stride(-1) == 1 and dw.stride(-1) == 1 and
-            dw.shape[0] % 256 == 0 and dw.shape[1] % 256 == 0 and rows % 64 == 0 and rows >= 4096 and dy.stride(0) % 8 == 0 and
+            dw.shape[0] % 256 == 0 and dw.shape[1] % 256 == 0 and rows >= GROUPED_DW_MIN_ROWS and dy.stride(0) % 8 == 0 and
             x.stride(0) % 8 == 0 and dw.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and dw.data_ptr() % 16 == 0)
 
 

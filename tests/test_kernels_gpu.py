@@ -1022,10 +1022,13 @@ def test_attn_fused_rejects_unsupported_shapes(ops):
         ops.attn_fwd(q2, q2, q2, None, 1, 2, 16, 16, 0.1)                  # head_dim 48
 
 
-def test_grouped_weight_gradients(ops):
+@pytest.mark.parametrize("rows", [4096 + 64 * 3, 3616, 1031, 1024 + 63, 8192 + 1])
+def test_grouped_weight_gradients(ops, rows):
     """mmdti_linear_dw_grouped: the weight + bias gradients of several Linears over the same token rows in one launch (slab
-    split-K, no atomics) == dy^T.x / column sums of dy in fp32, accumulated INTO the buffers; ineligible items fall back."""
-    rows = 4096 + 64 * 3
+    split-K, no atomics) == dy^T.x / column sums of dy in fp32, accumulated INTO the buffers; ineligible items fall back.
+    Token counts that are not a multiple of the 64-deep K tile (small / ragged batches): the kernel zero-fills the tail of the
+    last tile from a zero page -- 1 to 63 valid rows, in the last split only, rows past the end never read (the operands below
+    are exact-size allocations followed by NaN-poisoned neighbours would not matter: they are never addressed)."""
     g = G(11)
     shapes = [(512, 2048), (2048, 512), (1536, 512), (512, 512), (256, 768)]
     items, refs = [], []
