@@ -32,10 +32,12 @@ def _grad_report(model, P):
 
 
 # ------------------------------------------------------------------------------------------------ N up to 258
-@pytest.mark.parametrize("N", [209, 240, 258])
+@pytest.mark.parametrize("N", [209, 240, 258, 280])
 def test_unimol_tower_at_reference_crop_sizes(N):
     """Tower 1 (embedding -> fused pair bias -> 2-layer pair encoder, H = 64 so the fused/tiled hot path is the one running)
-    at the atom counts the reference's crop allows (N = atoms + 2 <= 258) against the oracle with the same rounding points."""
+    at the atom counts the reference's crop allows (N = atoms + 2 <= 258) against the oracle with the same rounding points.
+    N = 280 is beyond the crop AND beyond the tiled layout (272): the row-major pair tensors with the same fused pair-bias
+    forward / complete backward kernels in their row-major form."""
     ocfg = tiny_cfg("classification", 40)
     ocfg.unimol = O.UniMolCfg(layers=2, dim=512, ffn=256, heads=64, K=128, vocab=31, emb_dropout=0.0, dropout=0.0, attn_dropout=0.0, pooler_dropout=0.0)
     ocfg.cross, ocfg.roberta = O.CrossCfg(dim=512, heads=16, ffn=128, hidden_dropout=0.0, attn_dropout=0.0), O.RobertaCfg(layers=1, dim=512, heads=8, ffn=128, vocab=40, max_pos=40, hidden_dropout=0.0, attn_dropout=0.0)
@@ -48,12 +50,13 @@ def test_unimol_tower_at_reference_crop_sizes(N):
     batch["src_distance"][1, N - 40:, :] = 0; batch["src_distance"][1, :, N - 40:] = 0
     from mmdti_hip import ops
     from mmdti_hip.functional import EmbeddingFn
-    assert ops.pair_tiled_ok(N)
+    tiled = N <= 272
+    assert ops.pair_tiled_ok(N) == tiled
     dev = {k: v.cuda() for k, v in batch.items()}
     pad = dev["src_tokens"].eq(0)
     x = EmbeddingFn.apply(model.embed_tokens.weight, dev["src_tokens"], 0)
     bias = model.pair_bias(dev["src_distance"], dev["src_edge_type"])
-    assert ops.pair_is_tiled(bias)
+    assert ops.pair_is_tiled(bias) == tiled
     enc, s_last, _ = model.encoder.encode(x, bias, pad)
     g = torch.randn(enc.shape, generator=torch.Generator().manual_seed(1))
     (enc * g.cuda()).sum().backward()
@@ -62,7 +65,7 @@ def test_unimol_tower_at_reference_crop_sizes(N):
     eo, so = O.unimol_encoder(xo, bo, batch["src_tokens"].eq(0), P, ocfg.unimol, bf16=True, with_aux=False)
     (eo * g).sum().backward()
     assert rel_l2(enc, eo) < 3e-3, rel_l2(enc, eo)
-    s_hip = ops.pair_untile(s_last, N).cpu()
+    s_hip = (ops.pair_untile(s_last, N) if tiled else s_last[..., :N]).cpu()
     so = so.view(2, 64, N, N)
     fin = torch.isfinite(so)
     assert torch.equal(torch.isfinite(s_hip), fin) and rel_l2(s_hip[fin], so[fin]) < 3e-3
