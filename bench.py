@@ -247,7 +247,7 @@ def main():
             roofline["note"] = ("dominant kernel family by GPU time; HIP events on the launch stream around every launch of 2 extra steps after the timed "
                                 "region with every stream-level overlap off (each launch alone on the chip); achieved = algorithmic work / summed launch time")
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # (rank 0 at N = 1 only: the other ranks of a multi-GPU run would sit in a collective for a minute)
             cpu = cpu_baseline(args.atoms, args.tokens, args.cpu_sample)
         mols = args.batch * world * args.steps
         shape = "mixed lengths padded to the batch maximum" if args.ragged else "all at max length"
