@@ -1308,14 +1308,16 @@ extern "C" int mmdti_set_option(const char* name, int value) {
 
 // Shapes on which the 256 x 256 kernel (one workgroup per CU) beats the 128 x 128 ones (four per CU): enough tiles to fill
 // the 256 CUs with little waste in the last round (measured table: DESIGN.md section 4 "GEMM").
-static bool big_shape_pays(int M, int N, int K, int splitk, int transA, int transB) {
+static bool big_shape_pays(int M, int N, int K, int splitk, int transA, int transB, bool reads_aux) {
   // Measured on MI355X against the 128 x 128 kernels (scratch/gemm_big_test.py, profiles/r02_gemm_big_ab.json).  The K loop
   // of this kernel runs at 900-1300 TF/s, but with ONE workgroup per CU nothing overlaps a tile's epilogue (an HBM / VALU
   // burst of 15-20 us for a 256 x 256 fp32 / GELU tile) with another tile's loop, and 33 280-row outputs quantise badly on
   // 256 CUs (130 row tiles).  It pays where the loop dominates and the tile count divides the chip:
   const long long tiles = (long long)cdiv(M, 256) * cdiv(N, 256);
   if (splitk > 1) return K >= 16384 && 256 % tiles == 0 && tiles >= 4;     // long-K weight gradients: 4 or 16 output tiles (x1.02...1.25)
-  return tiles % 256 == 0 && !transB && K >= 512 && N <= 2048 && M >= 65536;   // tower-2 forward shapes in whole rounds (x1.03...1.10)
+  // tower-2 shapes in whole rounds: forward x1.03...1.10; input gradients (k-major B) x1.09...1.10 when the epilogue reads nothing
+  // (with the saved-activation multiply the 128 x 128 kernels win, 266 vs 304 us); 512 x 512 x 512 stays with them too (72 vs 77 us)
+  return tiles % 256 == 0 && K >= 512 && N <= 2048 && M >= 65536 && (long long)N * K >= 512 * 1024 && !(transB && reads_aux);
 }
 
 extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void* B, void* C, int M, int N, int K,
@@ -1445,7 +1447,7 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
   const int use_big = g_gemm_big;
   const bool big_ok = fast && use_big && batch_outer * batch_inner == 1 && !colsum_out && M >= 256 && N >= 256 &&
                       (c_dtype == MMDTI_DT_F32_ATOMIC || a.vec_ok) && M % 256 == 0 && N % 256 == 0;
-  if (big_ok && (use_big == 2 || big_shape_pays(M, N, K, splitk, transA, transB))) {
+  if (big_ok && (use_big == 2 || big_shape_pays(M, N, K, splitk, transA, transB, aux_in != nullptr))) {
     typedef void (*bkern_t)(GemmArgs);
     static const bkern_t bkerns[2][2] = {{gemm_big_kernel<false, false>, gemm_big_kernel<false, true>},
                                          {gemm_big_kernel<true, false>, gemm_big_kernel<true, true>}};
