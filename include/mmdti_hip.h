@@ -238,7 +238,9 @@ int mmdti_l2norm_bwd(mmdti_stream_t stream, const float* dxhat, const float* xha
 /* One direction of the symmetric CE (infonce.py:93-98) for anchors rows [row0,row0+Bl) of qh_all against all
  * Bg keys kh_all (global negatives under DDP).  loss_sum += sum_i CE_i (atomic); dq_all rows [row0,row0+Bl) and all
  * Bg rows of dk_all are accumulated (+=, caller zero-initialises).  Gradients are of (1/(2*Bg)) * sum_i CE_i.
- * scratch: Bl*Bg floats (the logit-gradient matrix handed from the row pass to the column pass). */
+ * scratch: Bl*Bg floats (the logit-gradient matrix handed from the row pass to the column pass).
+ * Feature width D <= 64 (the reference's 50): the Bl x Bg similarity matrix and both gradient products run as fp32 MFMAs
+ * (v_mfma_f32_16x16x4_f32 -- fp32 products and accumulation, the loss keeps fp32 precision); wider D takes scalar kernels. */
 int mmdti_infonce_dir(mmdti_stream_t stream, const float* qh_all, const float* kh_all, int Bg, int D, int row0,
                       int Bl, float temperature, float* loss_sum, float* dq_all, float* dk_all, float* scratch);
 

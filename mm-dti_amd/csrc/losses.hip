@@ -168,6 +168,175 @@ __global__ __launch_bounds__(64) void infonce_cols_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------- InfoNCE on the matrix pipe (feature width <= 64)
+// The B x B_global similarity matrix and both gradient products as fp32 MFMAs (v_mfma_f32_16x16x4_f32: fp32 products, fp32
+// accumulation -- the loss keeps fp32 precision; bf16 operands would cost 1e-3 on a temperature-0.1 softmax):
+//   rows kernel, one workgroup per 16 anchors, the waves share the key tiles:
+//     pass 1  L^tile = Q_a . K_t^T  (13 k-steps at D = 50)  ->  online (max, sum) per anchor
+//     pass 2  L^tile again -> gl = (softmax - onehot) * scale -> scratch;  dQ_a += gl . K_t  (gl transposed through a 16 x 17
+//             LDS patch per wave: the accumulator layout has anchors on registers, the A operand wants them on lanes)
+//   cols kernel, one workgroup per 16 keys:  dK_t += gl^T . Q  over the rank's anchors.
+// At the 8-GPU global batch (2048 keys) the scalar kernels below walk 2048-long serial loops per thread; these do not.
+typedef float nce_f32x4 __attribute__((ext_vector_type(4)));
+#define NCE_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32(A, B, C, 0, 0, 0)
+constexpr int NCE_MAXD = 64;
+
+__device__ __forceinline__ void nce_combine(float& m, float& s, float m2, float s2) {
+  const float mn = fmaxf(m, m2);
+  if (mn == -INFINITY) { m = mn; s = 0.f; return; }
+  s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+  m = mn;
+}
+
+__global__ __launch_bounds__(256) void infonce_rows_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k, int Bg, int D, int row0,
+                                                                int Bl, float invT, float* __restrict__ loss_sum, float* __restrict__ dq,
+                                                                float* __restrict__ gl_out) {
+  extern __shared__ float sm[];
+  const int DP = (D + 3) & ~3;
+  float* sQ = sm;                        // [16][DP]
+  float* sStat = sQ + 16 * DP;           // [4 waves][16 anchors][2]
+  float* sLse = sStat + 4 * 16 * 2;      // [16]
+  float* patch = sLse + 16;              // [4 waves][16][17]
+  float* sDq = patch + 4 * 16 * 17;      // [4 waves][16 anchors][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+  const int il0 = blockIdx.x * 16;
+  for (int c = tid; c < 16 * DP; c += 256) {
+    const int a = c / DP, d = c - a * DP;
+    sQ[c] = (il0 + a < Bl && d < D) ? q[(long long)(row0 + il0 + a) * D + d] : 0.f;
+  }
+  __syncthreads();
+  const int nkt = (Bg + 15) >> 4, nks = DP >> 2, NU = (D + 15) >> 4;
+  auto logits = [&](int t) -> nce_f32x4 {      // rows = anchors 4g + r, column = key 16t + i (unscaled)
+    const int key = 16 * t + i;
+    const float* kr = k + (long long)(key < Bg ? key : 0) * D;
+    nce_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s4 = 0; s4 < nks; ++s4) {
+      const int d = 4 * s4 + g;
+      const float bv = (key < Bg && d < D) ? kr[d] : 0.f;
+      acc = NCE_MFMA(sQ[i * DP + d], bv, acc);
+    }
+    return acc;
+  };
+  // ---- pass 1: row max / sum
+  float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, sum[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int t = wave; t < nkt; t += 4) {
+    const nce_f32x4 acc = logits(t);
+    if (16 * t + i < Bg) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) nce_combine(m[r], sum[r], acc[r] * invT, 1.0f);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      const float m2 = __shfl_xor(m[r], o, 64), s2 = __shfl_xor(sum[r], o, 64);
+      nce_combine(m[r], sum[r], m2, s2);
+    }
+    if (i == 0) {
+      sStat[(wave * 16 + 4 * g + r) * 2] = m[r];
+      sStat[(wave * 16 + 4 * g + r) * 2 + 1] = sum[r];
+    }
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float mm = -INFINITY, ss = 0.f;
+    for (int w = 0; w < 4; ++w) nce_combine(mm, ss, sStat[(w * 16 + tid) * 2], sStat[(w * 16 + tid) * 2 + 1]);
+    sLse[tid] = mm + __logf(ss);
+  }
+  __syncthreads();
+  // ---- pass 2: logit gradients, loss, dQ
+  const float gscale = 0.5f / (float)Bg;     // d[(CE_a + CE_b)/2 mean over Bg]/d CE_i
+  nce_f32x4 dacc[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) dacc[u] = nce_f32x4{0.f, 0.f, 0.f, 0.f};
+  float* pw = patch + wave * 16 * 17;
+  for (int t = wave; t < nkt; t += 4) {
+    const nce_f32x4 acc = logits(t);
+    const int key = 16 * t + i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int a = 4 * g + r, il = il0 + a;
+      float gl = 0.f;
+      if (key < Bg && il < Bl) {
+        const float l = acc[r] * invT, lse = sLse[a];
+        const bool diag = key == row0 + il;
+        gl = (__expf(l - lse) - (diag ? 1.f : 0.f)) * gscale * invT;
+        gl_out[(long long)il * Bg + key] = gl;
+        if (diag) atomicAdd(loss_sum, lse - l);
+      }
+      pw[a * 17 + i] = gl;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int sp = 0; sp < 4; ++sp) {
+      const float av = pw[i * 17 + 4 * sp + g];                 // A: anchor i, key 4 sp + g of the tile
+      const int kk = 16 * t + 4 * sp + g;
+      const float* kr = k + (long long)(kk < Bg ? kk : 0) * D;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (u < NU) {
+          const int d = 16 * u + i;
+          const float bv = (kk < Bg && d < D) ? kr[d] : 0.f;     // B: key 4 sp + g, feature 16 u + i
+          dacc[u] = NCE_MFMA(av, bv, dacc[u]);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                              // the next tile overwrites the patch
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sDq[(wave * 16 + 4 * g + r) * 64 + 16 * u + i] = dacc[u][r];
+  __syncthreads();
+  for (int c = tid; c < 16 * 64; c += 256) {
+    const int a = c >> 6, d = c & 63;
+    if (il0 + a < Bl && d < D)
+      dq[(long long)(row0 + il0 + a) * D + d] += sDq[c] + sDq[16 * 64 + c] + sDq[2 * 16 * 64 + c] + sDq[3 * 16 * 64 + c];
+  }
+}
+
+__global__ __launch_bounds__(256) void infonce_cols_mfma_kernel(const float* __restrict__ q, const float* __restrict__ gl, int Bg, int D, int row0,
+                                                                int Bl, float* __restrict__ dk) {
+  __shared__ float sDk[4 * 16 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+  const int j0 = blockIdx.x * 16, NU = (D + 15) >> 4;
+  const int key = j0 + i;
+  nce_f32x4 dacc[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) dacc[u] = nce_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nat = (Bl + 15) >> 4;
+  for (int at = wave; at < nat; at += 4) {
+#pragma unroll
+    for (int sp = 0; sp < 4; ++sp) {
+      const int il = 16 * at + 4 * sp + g;
+      const float av = (il < Bl && key < Bg) ? gl[(long long)il * Bg + key] : 0.f;     // A: key i, anchor 4 sp + g of the tile
+      const float* qr = q + (long long)(row0 + (il < Bl ? il : 0)) * D;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (u < NU) {
+          const int d = 16 * u + i;
+          const float bv = (il < Bl && d < D) ? qr[d] : 0.f;                            // B: anchor 4 sp + g, feature 16 u + i
+          dacc[u] = NCE_MFMA(av, bv, dacc[u]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sDk[(wave * 16 + 4 * g + r) * 64 + 16 * u + i] = dacc[u][r];
+  __syncthreads();
+  for (int c = tid; c < 16 * 64; c += 256) {
+    const int a = c >> 6, d = c & 63;
+    if (j0 + a < Bg && d < D) dk[(long long)(j0 + a) * D + d] += sDk[c] + sDk[16 * 64 + c] + sDk[2 * 16 * 64 + c] + sDk[3 * 16 * 64 + c];
+  }
+}
+
 // ---------------------------------------------------------------- ConR / SupCon
 // block per anchor i.  prod_ij = <f_i,f_j>/t.  See contrastive.py for the masks.
 __global__ __launch_bounds__(256) void ct_fwd_kernel(int mode, const float* __restrict__ fh, int B, int D, const float* __restrict__ lab_f,
@@ -531,6 +700,16 @@ extern "C" int mmdti_infonce_dir(mmdti_stream_t stream, const float* qh_all, con
   MMDTI_REQUIRE(qh_all && kh_all && loss_sum && dq_all && dk_all && scratch, "infonce_dir: null pointer");
   MMDTI_REQUIRE(Bg > 0 && D > 0 && row0 >= 0 && Bl > 0 && row0 + Bl <= Bg, "infonce_dir: bad sizes (Bg=%d row0=%d Bl=%d)", Bg, row0, Bl);
   MMDTI_REQUIRE(temperature > 0.f, "infonce_dir: temperature must be positive");
+  if (D <= NCE_MAXD) {     // similarity matrix and both gradient products as fp32 MFMAs
+    const int DP = (D + 3) & ~3;
+    const size_t smem_m = ((size_t)16 * DP + 4 * 16 * 2 + 16 + 4 * 16 * 17 + 4 * 16 * 64) * sizeof(float);
+    hipLaunchKernelGGL(infonce_rows_mfma_kernel, dim3(cdiv(Bl, 16)), dim3(256), smem_m, (hipStream_t)stream, qh_all, kh_all, Bg, D, row0, Bl,
+                       1.0f / temperature, loss_sum, dq_all, scratch);
+    MMDTI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(infonce_cols_mfma_kernel, dim3(cdiv(Bg, 16)), dim3(256), 0, (hipStream_t)stream, qh_all, scratch, Bg, D, row0, Bl, dk_all);
+    MMDTI_LAUNCH_CHECK();
+    return MMDTI_OK;
+  }
   const size_t smem = ((size_t)D + Bg + 4) * sizeof(float);
   MMDTI_REQUIRE(smem <= 64 * 1024, "infonce_dir: global batch %d too large for the LDS logits row", Bg);
   hipLaunchKernelGGL(infonce_rows_kernel, dim3(Bl), dim3(256), smem, (hipStream_t)stream, qh_all, kh_all, Bg, D, row0,

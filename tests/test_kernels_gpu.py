@@ -425,6 +425,26 @@ def test_infonce_sharded_rows_equal_full(ops):
     close(full[0] / (2 * B), ref.reshape(1), 1e-5, 1e-6)
 
 
+@pytest.mark.parametrize("Bg,Bl,row0,D", [(300, 300, 0, 50), (2048, 256, 512, 50), (77, 30, 40, 64), (40, 40, 0, 96)])
+def test_infonce_matrix_pipe_kernels_vs_autograd(ops, Bg, Bl, row0, D):
+    """The similarity matrix and both gradient products on fp32 MFMAs (feature width <= 64; 96 takes the scalar kernels): one
+    direction of the symmetric CE for the anchors [row0, row0 + Bl) of a (global) batch of Bg -- ragged tile counts, the 8-GPU
+    global batch -- against fp32 autograd of the same expression."""
+    q = torch.nn.functional.normalize(torch.randn(Bg, D, generator=G(5)), dim=-1)
+    k = torch.nn.functional.normalize(torch.randn(Bg, D, generator=G(6)), dim=-1)
+    qr, kr = q.clone().requires_grad_(), k.clone().requires_grad_()
+    logits = qr[row0:row0 + Bl] @ kr.t() / 0.1
+    ce = torch.nn.functional.cross_entropy(logits, torch.arange(row0, row0 + Bl), reduction="sum")
+    (ce / (2 * Bg)).backward()
+    loss = torch.zeros(1, device="cuda")
+    dq, dk = torch.zeros(Bg, D, device="cuda"), torch.zeros(Bg, D, device="cuda")
+    ops.infonce_dir(dev(q), dev(k), row0, Bl, 0.1, loss, dq, dk)
+    close(loss, ce.detach().reshape(1), 2e-5, 1e-4)
+    close(dq, qr.grad, 1e-4, 1e-7)
+    close(dk, kr.grad, 1e-4, 1e-7)
+    assert float(dq[:row0].abs().max() if row0 else 0.0) == 0.0 and float(dq[row0 + Bl:].abs().max() if row0 + Bl < Bg else 0.0) == 0.0
+
+
 def test_seq_mean(ops):
     B, S, D, ld = 3, 11, 50, 64
     x = torch.zeros(B, S, ld); x[..., :D] = torch.randn(B, S, D, generator=G(1))
