@@ -130,6 +130,11 @@ int mmdti_embedding_fwd(mmdti_stream_t stream, const long long* ids, const float
 /* dtable[ids[i]] += dout[i] (atomic), rows with ids==padding_idx skipped (padding_idx<0: none) */
 int mmdti_embedding_bwd(mmdti_stream_t stream, const long long* ids, const float* dout, long long n, int D,
                         int vocab, long long padding_idx, float* dtable);
+/* out[i] = table_a[ids_a[i]] + table_b[ids_b[i]] + table_c[ids_c[i]] in one pass (HF RobertaEmbeddings.forward,
+ * modeling_roberta.py:75-122: word + position + token-type, summed in that order); ids_c == NULL: row 0 of table_c. */
+int mmdti_embedding_fwd3(mmdti_stream_t stream, const long long* ids_a, const float* table_a, int vocab_a, const long long* ids_b,
+                         const float* table_b, int vocab_b, const long long* ids_c, const float* table_c, int vocab_c, long long n, int D,
+                         float* out);
 /* One-hot rows for the embedding backward: out[i, ids[i]] = 1 (bf16), everything else 0; rows with ids == padding_idx or
  * out of range are all-zero.  out is [n, ld] with ld >= vocab, ld % 8 == 0.  dtable = onehot^T . dout is then ONE split-K
  * MFMA GEMM (mmdti_gemm_bf16, both operands k-major) instead of n*D contended atomics on a few hundred table rows. */

@@ -157,6 +157,26 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const long long* __r
   }
 }
 
+// word + position + token-type embeddings summed in one pass (HF RobertaEmbeddings.forward, modeling_roberta.py:75-122): one
+// 16-byte store per element instead of a store and two read-modify-write passes.  ids_c == null: row 0 of table_c (token type 0).
+__global__ __launch_bounds__(256) void embedding_fwd3_kernel(const long long* __restrict__ ids_a, const float* __restrict__ ta, int va,
+                                                             const long long* __restrict__ ids_b, const float* __restrict__ tb, int vb,
+                                                             const long long* __restrict__ ids_c, const float* __restrict__ tc, int vc,
+                                                             long long n, int D4, float* __restrict__ out) {
+  const long long total = n * D4;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const long long i = t / D4;
+    const int c = (int)(t - i * D4);
+    long long ia = ids_a[i], ib = ids_b[i], ic = ids_c ? ids_c[i] : 0;
+    ia = ia < 0 ? 0 : (ia >= va ? va - 1 : ia);
+    ib = ib < 0 ? 0 : (ib >= vb ? vb - 1 : ib);
+    ic = ic < 0 ? 0 : (ic >= vc ? vc - 1 : ic);
+    const float4 a = reinterpret_cast<const float4*>(ta)[ia * D4 + c], b = reinterpret_cast<const float4*>(tb)[ib * D4 + c],
+                 d = reinterpret_cast<const float4*>(tc)[ic * D4 + c];
+    reinterpret_cast<float4*>(out)[t] = make_float4(a.x + b.x + d.x, a.y + b.y + d.y, a.z + b.z + d.z, a.w + b.w + d.w);   // (a + b) + c, the reference's order
+  }
+}
+
 // one-hot rows (bf16) for the embedding backward GEMM: thread per 8-column chunk
 __global__ __launch_bounds__(256) void onehot_bf16_kernel(const long long* __restrict__ ids, long long n, int vocab, int ld8,
                                                           long long padding_idx, bf16_t* __restrict__ out) {
@@ -521,6 +541,18 @@ extern "C" int mmdti_embedding_bwd(mmdti_stream_t stream, const long long* ids, 
   MMDTI_REQUIRE(ids && dout && dtable && n > 0 && D > 0 && vocab > 0, "embedding_bwd: bad arguments");
   hipLaunchKernelGGL(embedding_bwd_kernel, dim3(grid_for(n * D, 256)), dim3(256), 0, (hipStream_t)stream, ids, dout,
                      n, D, vocab, padding_idx, dtable);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_embedding_fwd3(mmdti_stream_t stream, const long long* ids_a, const float* table_a, int vocab_a, const long long* ids_b,
+                                    const float* table_b, int vocab_b, const long long* ids_c, const float* table_c, int vocab_c, long long n,
+                                    int D, float* out) {
+  MMDTI_REQUIRE(ids_a && table_a && ids_b && table_b && table_c && out && n > 0 && D > 0 && D % 4 == 0 && vocab_a > 0 && vocab_b > 0 && vocab_c > 0,
+                "embedding_fwd3: bad arguments");
+  MMDTI_REQUIRE(aligned16(table_a) && aligned16(table_b) && aligned16(table_c) && aligned16(out), "embedding_fwd3: alignment");
+  hipLaunchKernelGGL(embedding_fwd3_kernel, dim3(grid_for(n * (D / 4), 256)), dim3(256), 0, (hipStream_t)stream, ids_a, table_a, vocab_a, ids_b,
+                     table_b, vocab_b, ids_c, table_c, vocab_c, n, D / 4, out);
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }

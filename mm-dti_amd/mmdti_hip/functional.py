@@ -550,10 +550,8 @@ class RobertaEncoderFn(torch.autograd.Function):
         p_att = cfg.attn_dropout if training else 0.0
         ids = input_ids.contiguous()
         pos = ops.roberta_position_ids(ids, cfg.pad_idx)
-        e = ops.embedding_fwd(ids, mod.word)
-        ops.embedding_fwd(pos, mod.position, out=e, accumulate=True)
-        zeros = torch.zeros_like(ids)
-        ops.embedding_fwd(zeros, mod.token_type, out=e, accumulate=True)
+        e = ops.embedding_fwd3(ids, mod.word, pos, mod.position, mod.token_type)      # word + position + token type 0, one pass
+        zeros = None
         st = SimpleNamespace(B=B, Lq=Lq, Lk=Lq, D=D, seed=seed, ids=ids, pos=pos, zeros=zeros, e=e, layers=[], p_hid=p_hid)
         keep = any(ctx.needs_input_grad)      # inference: no per-layer activations are kept
         st.site_emb = sites.next()
@@ -581,9 +579,11 @@ class RobertaEncoderFn(torch.autograd.Function):
                                drop_p=st.p_hid, seed=st.seed, site=st.site_emb)
         cfg = mod.cfg
         de16 = ops.cast_bf16(de)
-        for ids, w, pad in ((st.ids, mod.word, cfg.pad_idx), (st.pos, mod.position, cfg.pad_idx), (st.zeros, mod.token_type, -1)):
+        for ids, w, pad in ((st.ids, mod.word, cfg.pad_idx), (st.pos, mod.position, cfg.pad_idx), (None, mod.token_type, -1)):
             g = gbuf(w)
             if g is not None:
+                if ids is None:        # token type 0 everywhere: a one-row table is a column sum (ids unused), else explicit zeros
+                    ids = st.ids if w.shape[0] == 1 else torch.zeros_like(st.ids)
                 ops.embedding_bwd_gemm(ids, de16, g, pad)
         notify_grads_ready(mod.embeddings.parameters())
         _join_stream_after_backward()   # (MM_Model runs this tower on a side stream)

@@ -262,6 +262,18 @@ def embedding_fwd(ids, table, out=None, accumulate=False):
     return out
 
 
+def embedding_fwd3(ids_a, table_a, ids_b, table_b, table_c, ids_c=None):
+    """table_a[ids_a] + table_b[ids_b] + table_c[ids_c or 0] in one pass (RoBERTa word + position + token-type embeddings)."""
+    _chk(ids_a, torch.int64, "embedding.ids_a"); _chk(ids_b, torch.int64, "embedding.ids_b")
+    for t in (table_a, table_b, table_c):
+        _chk(t, F32, "embedding.table")
+    D = table_a.shape[1]
+    out = torch.empty(*ids_a.shape, D, device=table_a.device, dtype=F32)
+    lib().mmdti_embedding_fwd3(_stream(), ids_a.data_ptr(), table_a.data_ptr(), table_a.shape[0], ids_b.data_ptr(), table_b.data_ptr(),
+                               table_b.shape[0], _p(ids_c), table_c.data_ptr(), table_c.shape[0], ids_a.numel(), D, out.data_ptr())
+    return out
+
+
 def embedding_bwd(ids, dout, dtable, padding_idx=-1):
     V, D = dtable.shape
     lib().mmdti_embedding_bwd(_stream(), ids.data_ptr(), dout.data_ptr(), ids.numel(), D, V, int(padding_idx), dtable.data_ptr())

@@ -392,6 +392,21 @@ def test_embedding_and_position_ids(ops, golden):
     close(one, rt(dout).view(-1, 32).sum(0, keepdim=True), 1e-4, 1e-3)
 
 
+def test_roberta_embedding_sum_in_one_pass(ops):
+    """word + position + token-type embeddings (HF RobertaEmbeddings.forward) as ONE gather-add kernel == three nn.Embedding
+    lookups summed in the reference's order; out-of-range ids clamp like the single-table kernel."""
+    gen = G(3)
+    Vw, Vp, D, B, L = 600, 258, 512, 5, 37
+    word, pos_t, typ = torch.randn(Vw, D, generator=gen), torch.randn(Vp, D, generator=gen), torch.randn(1, D, generator=gen)
+    ids, pos = torch.randint(0, Vw, (B, L), generator=gen), torch.randint(0, Vp, (B, L), generator=gen)
+    out = ops.embedding_fwd3(dev(ids), dev(word), dev(pos), dev(pos_t), dev(typ))
+    ref = (word[ids] + pos_t[pos]) + typ[0]
+    assert torch.equal(out.cpu(), ref)
+    one = ops.embedding_fwd(dev(ids), dev(word)); ops.embedding_fwd(dev(pos), dev(pos_t), out=one, accumulate=True)
+    ops.embedding_fwd(dev(torch.zeros_like(ids)), dev(typ), out=one, accumulate=True)
+    assert torch.equal(out, one)
+
+
 # ------------------------------------------------------------------------------------------- InfoNCE (golden G1)
 @pytest.mark.parametrize("B", [2, 16])
 def test_infonce_golden(ops, golden, B):
