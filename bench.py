@@ -176,7 +176,13 @@ def main():
         model.split_tower1 = int(os.environ["MMDTI_SPLIT_TOWER1"])
     tuner = FineTuner(model, "classification", total_steps=10_000, distributed=(world > 1 or os.environ.get("MMDTI_FORCE_DDP") == "1"))
     _, batch, label = synth(args.batch, args.atoms, args.tokens, seed=1234 + rank, ragged=args.ragged)
+    counts = None
+    if args.ragged:
+        from mmdti_hip.collate import atom_counts
+        counts = atom_counts(batch["src_tokens"], 0)        # host-side lengths: the pair kernels skip all-padding key tiles
     batch = {k: v.to(dev) for k, v in batch.items()}
+    if counts is not None:
+        batch["atom_counts"] = counts
     label = label.to(dev)
 
     def barrier():

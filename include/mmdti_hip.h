@@ -190,12 +190,18 @@ int mmdti_pair_permute_bwd(mmdti_stream_t stream, const float* g, void* out_bf16
  * O = dropout(softmax(S)).v.   qkv: [B,N,3*H*8] bf16 (q|k|v);  bias_in/s_out: [B,H,N,ld] fp32. */
 int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, const float* bias_in, float* s_out,
                         void* o_bf16, const unsigned char* key_pad, int B, int N, int H, int ld, float scale,
-                        float drop_p, unsigned long long seed, unsigned int site, int tiled);
+                        float drop_p, unsigned long long seed, unsigned int site, int tiled,
+                        const int* key_tiles /* nullable, tiled layout only: [B] int32, number of 16-key tiles of each molecule that
+                        hold a real key (ragged batches, right-padded by mm_model.py:645-682).  The key tiles past it are all padding:
+                        they are not loaded, not computed, and not stored unless rag_store != 0 (then written as -inf: pass it for the
+                        last layer, whose S goes back to the caller).  Pad QUERY rows are computed as ever. */,
+                        int rag_store);
 /* g (in/out, [B,H,N,ld] fp32): on entry dL/dS_l from the layers above (ignored if g_in_zero), on exit
- * dL/dS_l total = dL/d(bias_in).  dqkv: [B,N,3*H*8] bf16. */
+ * dL/dS_l total = dL/d(bias_in).  dqkv: [B,N,3*H*8] bf16.  key_tiles: as in the forward; the skipped tiles of g are neither
+ * read nor written (hand in a zero-initialised g for a ragged batch). */
 int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, const float* s, const void* do_bf16, float* g,
                         void* dqkv_bf16, int B, int N, int H, int ld, float scale, int g_in_zero, float drop_p,
-                        unsigned long long seed, unsigned int site, int tiled);
+                        unsigned long long seed, unsigned int site, int tiled, const int* key_tiles);
 
 /* ---- Row softmax over materialised scores (HF eager_attention_forward :158-183; BertCoAttention
  * mm_module.py:497-514) ------------------------------------------------------------------------

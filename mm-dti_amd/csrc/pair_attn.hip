@@ -315,12 +315,16 @@ __device__ __forceinline__ void pa_split4(const f32x4& v, pa_s16x4& hi, pa_s16x4
 }
 #define PA_MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A, B, C, 0, 0, 0)
 
-template <int NT, bool TILED, bool FULL>
+// RAG (ragged batches): key_tiles[b] = number of 16-key tiles of molecule b that hold a real key.  The tiles past it are all
+// padding -- -inf in every S of the chain, 0 in G -- so they are neither loaded nor computed nor (rag_store == 0) stored; pad
+// QUERY rows are still computed (the reference's unmasked InfoNCE mean reads the encoder output at padded positions).
+// rag_store != 0: the skipped tiles are written as -inf (the last layer, whose S is returned to the caller).
+template <int NT, bool TILED, bool FULL, bool RAG>
 __global__ __launch_bounds__(256, NT > 13 ? 2 : 4) void pair_attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_in,
                                                                  float* __restrict__ s_out, bf16_t* __restrict__ o,
                                                                  const unsigned char* __restrict__ key_pad, int N, int H, int ld,
                                                                  float scale, uint32_t thresh, float dscale, uint64_t seed,
-                                                                 uint32_t site) {
+                                                                 uint32_t site, const int* __restrict__ key_tiles, int rag_store) {
   constexpr int NP = NT * 16;
   constexpr int KSTR = NP + 8;   // row stride (elements) of the d-major V image (see the backward kernel's sKT)
   // raw bf16 images, exactly as loaded: sQ / sK [row][8], sVT [d][key]
@@ -333,6 +337,7 @@ __global__ __launch_bounds__(256, NT > 13 ? 2 : 4) void pair_attn_fwd_mfma_kerne
   const int D = H * HD, D3 = 3 * D;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int nKB = (N + 15) >> 4;
+  const int kt = RAG ? min(max(__builtin_amdgcn_readfirstlane(key_tiles[b]), 1), nKB) : nKB;   // (wave-uniform: one molecule per workgroup)
   const bf16_t* base = qkv + (long long)b * N * D3 + h * HD;
   for (int t = tid; t < NP; t += blockDim.x) {
     uint4 q = make_uint4(0u, 0u, 0u, 0u), kk = q, vv = q;
@@ -385,7 +390,9 @@ __global__ __launch_bounds__(256, NT > 13 ? 2 : 4) void pair_attn_fwd_mfma_kerne
     f32x4 S[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      if (TILED && !EDGE && (FULL ? t < NT - 1 : false)) {
+      if (RAG && t >= kt) {
+        S[t] = f32x4{NEG_INF, NEG_INF, NEG_INF, NEG_INF};
+      } else if (TILED && !EDGE && (FULL ? t < NT - 1 : false)) {
         S[t] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(bin + t * TSTEP + goff));
       } else {
         const bool pr = PA_PRED(t);
@@ -396,7 +403,16 @@ __global__ __launch_bounds__(256, NT > 13 ? 2 : 4) void pair_attn_fwd_mfma_kerne
     float m = NEG_INF;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      {
+      if (RAG && t >= kt) {
+        if (rag_store) {
+          const f32x4 ninf = {NEG_INF, NEG_INF, NEG_INF, NEG_INF};
+          if (TILED && !EDGE && (FULL ? t < NT - 1 : false)) {
+            __builtin_nontemporal_store(ninf, reinterpret_cast<f32x4*>(sout + t * TSTEP + goff));
+          } else if (PA_PRED(t)) {
+            __builtin_nontemporal_store(ninf, reinterpret_cast<f32x4*>(sout + t * TSTEP + goff));
+          }
+        }
+      } else {
         const int kcol = t * 16 + 4 * g;
         f32x4 c = S[t];
         const pa_s16x4 ka = g < 2 ? *reinterpret_cast<const pa_s16x4*>(sK + (t * 16 + c16) * 8 + 4 * g) : zero4;
@@ -438,7 +454,7 @@ __global__ __launch_bounds__(256, NT > 13 ? 2 : 4) void pair_attn_fwd_mfma_kerne
     f32x4 oacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      {
+      if (!(RAG && t >= kt)) {
         f32x4 p = S[t] * inv;
         if (thresh) {
           const uint32_t kb = keep4_u16(seed, site, (uint64_t)(rowoff + t * 16 + 4 * g) >> 2, thresh >> 16);
@@ -482,12 +498,14 @@ __global__ __launch_bounds__(256, NT > 13 ? 2 : 4) void pair_attn_fwd_mfma_kerne
 // quarter of the matrix-pipe time and a third of the LDS instructions of the fp32 16x16x4 form this replaces.
 // Each (query block, key tile) contribution to dK/dV is added to an LDS image owned by the wave.
 
-template <int NT, bool TILED, bool FULL, int NW>
+// RAG: see the forward kernel.  Skipped key tiles contribute nothing (P = 0, G = 0) and their G is NOT written: the caller
+// hands in a zero-initialised G when the batch is ragged.
+template <int NT, bool TILED, bool FULL, int NW, bool RAG>
 __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ s_in,
                                                                  const bf16_t* __restrict__ dO, const float* __restrict__ gin, float* __restrict__ gout,
                                                                  bf16_t* __restrict__ dqkv, int N, int H, int ld, float scale,
                                                                  int g_in_zero, uint32_t thresh, float dscale, uint64_t seed,
-                                                                 uint32_t site) {
+                                                                 uint32_t site, const int* __restrict__ key_tiles) {
   constexpr int NP = NT * 16;
   constexpr int KSTR = NP + 8;   // row stride (elements) of the d-major K image: 8-byte reads of 8 rows x 2 key groups hit 16 distinct bank pairs
   // raw bf16 images, exactly as loaded.  sQ / sD / sV: [row][8]; the +16 elements are the tail that tr-reads of the last
@@ -509,6 +527,7 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
   const int D = H * HD, D3 = 3 * D;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int nKB = (N + 15) >> 4;
+  const int kt = RAG ? min(max(__builtin_amdgcn_readfirstlane(key_tiles[b]), 1), nKB) : nKB;
   const bf16_t* base = qkv + (long long)b * N * D3 + h * HD;
   for (int t = tid; t < NP + 2; t += blockDim.x) {
     uint4 q = make_uint4(0u, 0u, 0u, 0u), kk = q, vv = q, dd = q;
@@ -572,7 +591,9 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
       {
         const int kcol = t * 16 + 4 * g;
         f32x4 c;
-        if (PA_FAST(t)) {
+        if (RAG && t >= kt) {
+          c = f32x4{NEG_INF, NEG_INF, NEG_INF, NEG_INF};
+        } else if (PA_FAST(t)) {
           c = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sin_p + t * TSTEP + goff));
         } else {
           const bool inrow = PA_PRED(t);
@@ -609,7 +630,7 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
     float dl = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      {
+      if (!(RAG && t >= kt)) {
         // A of dP^T: V[key 16t + c16][d = 4g..4g+3] (exact bf16 products, fp32 accumulation)
         const pa_s16x4 va = g < 2 ? *reinterpret_cast<const pa_s16x4*>(sV + (t * 16 + c16) * 8 + 4 * g) : zero4;
         f32x4 dp = {0.f, 0.f, 0.f, 0.f};
@@ -638,6 +659,7 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
     // fewer at the 168 cap -- no spills), pinned in place by scheduling barriers
     constexpr int PA_LA = 3;
     auto load_gin = [&](int t) -> f32x4 {
+      if (RAG && t >= kt) return f32x4{0.f, 0.f, 0.f, 0.f};
       if (PA_FAST(t)) {
         const f32x4 ld4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gin_p + (g_in_zero ? 0 : t * TSTEP + goff)));
         return g_in_zero ? f32x4{0.f, 0.f, 0.f, 0.f} : ld4;
@@ -657,6 +679,7 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
       const f32x4 Gin = Gq[t % PA_LA];
       if (t + PA_LA < NT) Gq[t % PA_LA] = load_gin(t + PA_LA);
       __builtin_amdgcn_sched_barrier(0);
+      if (RAG && t >= kt) continue;      // (wave-uniform: nothing of this tile exists)
       const pa_s16x4 va = g < 2 ? *reinterpret_cast<const pa_s16x4*>(sV + (t * 16 + c16) * 8 + 4 * g) : zero4;
       f32x4 dp = {0.f, 0.f, 0.f, 0.f};
       dp = PA_MFMA16(va, dob, dp);
@@ -770,8 +793,10 @@ static int check_common(const char* fn, int B, int N, int H, int ld) {
 
 extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, const float* bias_in, float* s_out,
                                    void* o_bf16, const unsigned char* key_pad, int B, int N, int H, int ld,
-                                   float scale, float drop_p, unsigned long long seed, unsigned int site, int tiled) {
+                                   float scale, float drop_p, unsigned long long seed, unsigned int site, int tiled,
+                                   const int* key_tiles, int rag_store) {
   if (int e = check_common("pair_attn_fwd", B, N, H, ld)) return e;
+  MMDTI_REQUIRE(!key_tiles || tiled, "pair_attn_fwd: key_tiles (ragged batches) needs the tiled pair layout");
   MMDTI_REQUIRE(!tiled || (ld % 4 == 0 && N <= 16 * PA_MAX_NT), "pair_attn_fwd: the tiled pair layout needs ld %% 4 == 0 and N <= 272");
   MMDTI_REQUIRE(qkv_bf16 && bias_in && s_out && o_bf16, "pair_attn_fwd: null pointer");
   MMDTI_REQUIRE(aligned16(qkv_bf16), "pair_attn_fwd: qkv must be 16-byte aligned");
@@ -784,14 +809,15 @@ extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, 
   if (ld % 4 == 0 && aligned16(bias_in) && aligned16(s_out) && N <= 16 * PA_MAX_NT) {
     const int nqb = (N + 15) / 16;
     dim3 blk(nqb % 3 == 0 ? 192 : (nqb < 4 ? 64 * nqb : 256));
-#define PA_M(NT, TL, FL)                                                                                                    \
-  hipLaunchKernelGGL((pair_attn_fwd_mfma_kernel<NT, TL, FL>), grid, blk, 0, s, (const bf16_t*)qkv_bf16, bias_in, s_out,         \
-                     (bf16_t*)o_bf16, key_pad, N, H, ld, scale, th, sc, (uint64_t)seed, (uint32_t)site)
+#define PA_M(NT, TL, FL, RG)                                                                                                \
+  hipLaunchKernelGGL((pair_attn_fwd_mfma_kernel<NT, TL, FL, RG>), grid, blk, 0, s, (const bf16_t*)qkv_bf16, bias_in, s_out,     \
+                     (bf16_t*)o_bf16, key_pad, N, H, ld, scale, th, sc, (uint64_t)seed, (uint32_t)site, key_tiles, rag_store)
 #define PA_MT(NT)                                                                           \
   do {                                                                                      \
-    if (!tiled) PA_M(NT, false, false);                                                     \
-    else if (nqb == NT) PA_M(NT, true, true);                                               \
-    else PA_M(NT, true, false);                                                             \
+    if (!tiled) PA_M(NT, false, false, false);                                              \
+    else if (key_tiles) { if (nqb == NT) PA_M(NT, true, true, true); else PA_M(NT, true, false, true); } \
+    else if (nqb == NT) PA_M(NT, true, true, false);                                        \
+    else PA_M(NT, true, false, false);                                                      \
   } while (0)
     if (nqb <= 5) PA_MT(5); else if (nqb <= 9) PA_MT(9); else if (nqb <= 13) PA_MT(13); else PA_MT(17);
 #undef PA_MT
@@ -816,8 +842,10 @@ extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, 
 
 extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, const float* s, const void* do_bf16,
                                    float* g, void* dqkv_bf16, int B, int N, int H, int ld, float scale,
-                                   int g_in_zero, float drop_p, unsigned long long seed, unsigned int site, int tiled) {
+                                   int g_in_zero, float drop_p, unsigned long long seed, unsigned int site, int tiled,
+                                   const int* key_tiles) {
   if (int e = check_common("pair_attn_bwd", B, N, H, ld)) return e;
+  MMDTI_REQUIRE(!key_tiles || tiled, "pair_attn_bwd: key_tiles (ragged batches) needs the tiled pair layout");
   MMDTI_REQUIRE(!tiled || (ld % 4 == 0 && N <= 16 * PA_MAX_NT), "pair_attn_bwd: the tiled pair layout needs ld %% 4 == 0 and N <= 272");
   MMDTI_REQUIRE(qkv_bf16 && s && do_bf16 && g && dqkv_bf16, "pair_attn_bwd: null pointer");
   MMDTI_REQUIRE(aligned16(qkv_bf16) && aligned16(do_bf16) && aligned16(dqkv_bf16), "pair_attn_bwd: alignment");
@@ -828,19 +856,20 @@ extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, 
   if (ld % 4 == 0 && aligned16(s) && aligned16(g) && N <= 16 * PA_MAX_NT) {
     const int nqb = (N + 15) / 16;
     dim3 blk(nqb % 3 == 0 ? 192 : (nqb < 4 ? 64 * nqb : 256));
-#define PA_MB(NT, TL, FL, NWV)                                                                                             \
-  hipLaunchKernelGGL((pair_attn_bwd_mfma_kernel<NT, TL, FL, NWV>), grid, blk, 0, st, (const bf16_t*)qkv_bf16, s,             \
+#define PA_MB(NT, TL, FL, NWV, RG)                                                                                             \
+  hipLaunchKernelGGL((pair_attn_bwd_mfma_kernel<NT, TL, FL, NWV, RG>), grid, blk, 0, st, (const bf16_t*)qkv_bf16, s,         \
                      (const bf16_t*)do_bf16, g, g, (bf16_t*)dqkv_bf16, N, H, ld, scale, g_in_zero, th, sc,                   \
-                     (uint64_t)seed, (uint32_t)site)
-#define PA_MBW(NT, TL, FL)                                                                  \
+                     (uint64_t)seed, (uint32_t)site, key_tiles)
+#define PA_MBW(NT, TL, FL, RG)                                                              \
   do {                                                                                      \
-    if (blk.x == 192) PA_MB(NT, TL, FL, 3); else PA_MB(NT, TL, FL, 4);                      \
+    if (blk.x == 192) PA_MB(NT, TL, FL, 3, RG); else PA_MB(NT, TL, FL, 4, RG);              \
   } while (0)
 #define PA_MBT(NT)                                                                          \
   do {                                                                                      \
-    if (!tiled) PA_MBW(NT, false, false);                                                   \
-    else if (nqb == NT) PA_MBW(NT, true, true);                                             \
-    else PA_MBW(NT, true, false);                                                           \
+    if (!tiled) PA_MBW(NT, false, false, false);                                            \
+    else if (key_tiles) { if (nqb == NT) PA_MBW(NT, true, true, true); else PA_MBW(NT, true, false, true); } \
+    else if (nqb == NT) PA_MBW(NT, true, true, false);                                      \
+    else PA_MBW(NT, true, false, false);                                                    \
   } while (0)
     if (nqb <= 5) PA_MBT(5); else if (nqb <= 9) PA_MBT(9); else if (nqb <= 13) PA_MBT(13); else PA_MBT(17);
 #undef PA_MBW

@@ -83,10 +83,24 @@ def collate_batch(samples, padding_idx, tokenizer):
 
 # -------------------------------------------------------------------------------------------------- device payload (8f-3)
 NEVER_CONSUMED = ('src_coord',)     # collated by the reference, swallowed by **kwargs in MM_Model.forward (mm_model.py:540)
+HOST_FIELDS = ('atom_counts',)      # stay on the host: MM_Model reads them to pick kernels without a device sync
 INT16_MAX = 32767
 
 
-def device_payload(net_input, n_edge_types=None):
+def atom_counts(src_tokens, pad_idx=0):
+    """[B] int32: position of each molecule's last non-pad token + 1 (its real length for a right-padded batch; with holes in
+    the mask, still an upper bound of every real key's index -- which is all the ragged pair kernels rely on)."""
+    real = src_tokens.ne(pad_idx)
+    pos = torch.arange(1, src_tokens.shape[1] + 1, dtype=torch.int64, device=src_tokens.device)
+    return (real.to(torch.int64) * pos).amax(dim=1).to(torch.int32)
+
+
+def to_device(net_input, device, non_blocking=True):
+    """.to(device) for every field of a collated batch except the host-side ones."""
+    return {k: (v if k in HOST_FIELDS else v.to(device, non_blocking=non_blocking)) for k, v in net_input.items()}
+
+
+def device_payload(net_input, n_edge_types=None, pad_idx=0):
     """What of a collated batch actually has to cross PCIe: drops the fields no kernel reads and narrows
     ``src_edge_type`` from int64 to int16 (8 -> 2 bytes per atom pair; the pair-bias kernels take either width) when every
     index fits -- ``n_edge_types`` (= len(dictionary)**2, 961 for the reference's dictionary) decides without a scan, else
@@ -100,6 +114,9 @@ def device_payload(net_input, n_edge_types=None):
             fits = et.numel() == 0 or (int(et.min()) >= -INT16_MAX - 1 and int(et.max()) <= INT16_MAX)
         if fits:
             out['src_edge_type'] = et.to(torch.int16)
+    st = out.get('src_tokens')
+    if st is not None and st.device.type == 'cpu' and 'atom_counts' not in out:
+        out['atom_counts'] = atom_counts(st, pad_idx)
     return out
 
 
@@ -121,4 +138,4 @@ class HostCollate:
 
     def __call__(self, samples):
         batch, label = collate_batch(samples, self.padding_idx, self.tokenizer)
-        return (device_payload(batch, self.n_edge_types) if self.narrow else batch), label
+        return (device_payload(batch, self.n_edge_types, self.padding_idx) if self.narrow else batch), label

@@ -10,6 +10,8 @@ from __future__ import annotations
 
 from typing import Iterator, List, Sequence
 
+HOST_FIELDS = ('atom_counts',)      # (collate.HOST_FIELDS; repeated here so that this module keeps importing without torch)
+
 import numpy as np
 
 
@@ -100,10 +102,10 @@ class DevicePrefetcher:
     130 atoms the int64 edge types alone are 34.6 MB per batch, 8.7 MB as int16; values are unchanged.
     """
 
-    def __init__(self, batches, device, narrow=True, n_edge_types=None):
+    def __init__(self, batches, device, narrow=True, n_edge_types=None, pad_idx=0):
         import torch
         self._torch = torch
-        self.narrow, self.n_edge_types = narrow, n_edge_types
+        self.narrow, self.n_edge_types, self.pad_idx = narrow, n_edge_types, pad_idx
         self.batches = batches
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
@@ -126,11 +128,11 @@ class DevicePrefetcher:
         net_input, label = item
         if self.narrow:
             from .collate import device_payload
-            net_input = device_payload(net_input, self.n_edge_types)
+            net_input = device_payload(net_input, self.n_edge_types, self.pad_idx)
         if self.stream is None:
-            return {k: self._stage(k, v) for k, v in net_input.items()}, self._stage("__label__", label), None
+            return {k: (v if k in HOST_FIELDS else self._stage(k, v)) for k, v in net_input.items()}, self._stage("__label__", label), None
         with torch.cuda.stream(self.stream):
-            dev_in = {k: self._stage(k, v) for k, v in net_input.items()}
+            dev_in = {k: (v if k in HOST_FIELDS else self._stage(k, v)) for k, v in net_input.items()}
             dev_lab = self._stage("__label__", label)
             ev = torch.cuda.Event()
             ev.record(self.stream)
@@ -147,7 +149,7 @@ class DevicePrefetcher:
             dev_in, dev_lab, ev = nxt
             if ev is not None:
                 torch.cuda.current_stream(self.device).wait_event(ev)
-                for t in list(dev_in.values()) + [dev_lab]:
+                for t in [v for k, v in dev_in.items() if k not in HOST_FIELDS] + [dev_lab]:
                     t.record_stream(torch.cuda.current_stream(self.device))
                 # (the staging buffers are rewritten by the next _launch: its host-side copy_ must not race the DMA)
                 ev.synchronize()

@@ -186,10 +186,12 @@ class PairEncoderFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, emb, bias, padding_mask, mod, training):
+    def forward(ctx, emb, bias, padding_mask, mod, training, key_tiles=None):
         B, N, D = emb.shape
         H = mod.attention_heads
         tiled = ops.pair_is_tiled(bias)        # [B,H,nt,nt,256] tile layout (see ops.pair_tile) or row-major [B,H,N,ld]
+        if not tiled:
+            key_tiles = None                   # (the row-major kernels have no ragged form)
         ld = ops.pair_ld(N) if tiled else bias.shape[-1]
         M = B * N
         p_emb = mod.emb_dropout if training else 0.0
@@ -197,7 +199,7 @@ class PairEncoderFn(torch.autograd.Function):
         p_att = mod.attention_dropout if training else 0.0
         seed = dropout_state.next_seed()
         sites = _Sites()
-        st = SimpleNamespace(B=B, N=N, D=D, H=H, ld=ld, M=M, seed=seed, p_emb=p_emb, p_res=p_res, p_att=p_att, layers=[])
+        st = SimpleNamespace(B=B, N=N, D=D, H=H, ld=ld, M=M, seed=seed, p_emb=p_emb, p_res=p_res, p_att=p_att, layers=[], kt=key_tiles)
         keep = any(ctx.needs_input_grad)      # inference (torch.no_grad / frozen inputs): nothing is kept for a backward --
                                               # the 15 per-layer logit tensors are freed as the stack advances
         emb = emb.contiguous()
@@ -218,7 +220,9 @@ class PairEncoderFn(torch.autograd.Function):
             _, L.h1, L.m1, L.r1 = ops.layernorm_fwd(x, ln1.weight, ln1.bias, ln1.eps)
             L.qkv = ops.linear_fwd(L.h1, wbf16(att.in_proj.weight), att.in_proj.bias)
             L.site_att = sites.next()
-            L.s, L.o = ops.pair_attn_fwd(L.qkv, s_prev, padding_mask if li == 0 else None, B, N, H, ld, scale, p_att, seed, L.site_att)
+            # (ragged batches: all-padding key tiles are skipped; the last layer writes them as -inf because its S is returned)
+            L.s, L.o = ops.pair_attn_fwd(L.qkv, s_prev, padding_mask if li == 0 else None, B, N, H, ld, scale, p_att, seed, L.site_att,
+                                         key_tiles=key_tiles, rag_store=li == len(mod.layers) - 1)
             s_prev = L.s
             L.site_o = sites.next()
             L.x1 = ops.linear_fwd(L.o, wbf16(att.out_proj.weight), att.out_proj.bias, residual=x, out_dtype=F32, drop_p=p_res, seed=seed, site=L.site_o)
@@ -280,8 +284,8 @@ class PairEncoderFn(torch.autograd.Function):
             do = ops.linear_bwd_input(dy1, wbf16(att.out_proj.weight))
             g_zero = G is None
             if g_zero:
-                G = torch.empty_like(L.s)
-            dqkv = ops.pair_attn_bwd(L.qkv, L.s, do, G, B, N, H, ld, scale, g_zero, st.p_att, seed, L.site_att)
+                G = torch.empty_like(L.s) if st.kt is None else torch.zeros_like(L.s)     # (skipped key tiles of G are never written)
+            dqkv = ops.pair_attn_bwd(L.qkv, L.s, do, G, B, N, H, ld, scale, g_zero, st.p_att, seed, L.site_att, key_tiles=st.kt)
             _wgrad(dqkv, L.h1, att.in_proj.weight, att.in_proj.bias)
             dh1 = ops.linear_bwd_input(dqkv, wbf16(att.in_proj.weight))
             if li > 0:
@@ -309,7 +313,7 @@ class PairEncoderFn(torch.autograd.Function):
         _launch_deferred_wgrads(deferred, deferred_layers)
         _join_side_wgrads()
         _join_stream_after_backward()
-        return demb.view(B, N, D), G, None, None, None
+        return demb.view(B, N, D), G, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------- Gaussian pair bias

@@ -30,6 +30,8 @@ from ..unicore_compat import Dictionary, init_bert_params, get_activation_fn
 from ..functional import PairBiasFn, EmbeddingFn, DropoutFn, MaskedPoolFn, LinearF32Fn
 from .. import ops
 from ..collate import right_pad, collate_batch
+
+PAIR_RAGGED = os.environ.get("MMDTI_PAIR_RAGGED", "1") != "0"
 from .transformers import TransformerEncoderWithPair
 from .bert_layers import BertCrossEncoder, RobertaTower
 from .infonce import InfoNCE
@@ -286,8 +288,16 @@ class MM_Model(nn.Module):
 
     def forward(self, src_tokens, src_distance, src_edge_type, input_ids, attention_mask, weights=None,
                 return_infonce_loss=False, return_ct_loss=False, return_feature=False, net_target=None, use_weight=None,
-                epoch=0, **kwargs):
+                epoch=0, atom_counts=None, **kwargs):
         padding_mask = src_tokens.eq(self.padding_idx)
+        # Ragged batches.  atom_counts ([B] ints ON THE HOST: position of each molecule's last real token + 1, attached by
+        # collate.device_payload) tells, without a device sync, whether some molecule is shorter than the padded length; then the
+        # pair-attention kernels skip the all-padding key tiles (a third to a half of the pair traffic on a drug-like batch).
+        key_tiles = None
+        if atom_counts is not None and PAIR_RAGGED and src_tokens.is_cuda:
+            kt = (torch.as_tensor(atom_counts, device="cpu").to(torch.int64) + 15) // 16
+            if int(kt.min()) < (src_tokens.shape[1] + 15) // 16:
+                key_tiles = kt.clamp_(min=1).to(torch.int32).to(src_tokens.device, non_blocking=True)
         img_mask = ~padding_mask
         attention_mask = attention_mask.bool().to(src_tokens.device)
         # NOTE: the reference sets padding_mask=None when nothing is padded (:548-549), which costs a host sync
@@ -306,7 +316,7 @@ class MM_Model(nn.Module):
         def tower1(sl):
             xs = EmbeddingFn.apply(self.embed_tokens.weight, src_tokens[sl], self.padding_idx)
             bias_s = self.pair_bias(src_distance[sl], src_edge_type[sl])
-            return self.encoder.encode(xs, bias_s, padding_mask[sl])[0]
+            return self.encoder.encode(xs, bias_s, padding_mask[sl], None if key_tiles is None else key_tiles[sl])[0]
 
         Bm = src_tokens.shape[0]
         parts = int(self.split_tower1)

@@ -459,28 +459,30 @@ def pair_untile(t, N):
     return t.reshape(B, H, -1)[:, :, _tile_index(N, t.device).reshape(-1)].view(B, H, N, N)
 
 
-def pair_attn_fwd(qkv, bias_in, key_pad, B, N, H, ld, scale, drop_p=0.0, seed=0, site=0):
+def pair_attn_fwd(qkv, bias_in, key_pad, B, N, H, ld, scale, drop_p=0.0, seed=0, site=0, key_tiles=None, rag_store=False):
     _chk(qkv, BF16, "pair_attn.qkv"); _chk(bias_in, F32, "pair_attn.bias")
     tiled = pair_is_tiled(bias_in)
     s_out = torch.empty_like(bias_in) if tiled else torch.empty(B, H, N, ld, device=qkv.device, dtype=F32)
     o = torch.empty(B * N, H * 8, device=qkv.device, dtype=BF16)
     kp = _u8(key_pad)
     t0 = kernel_timer.begin("pair_attn_fwd")
+    if key_tiles is not None:
+        _chk(key_tiles, torch.int32, "pair_attn.key_tiles")
     lib().mmdti_pair_attn_fwd(_stream(), qkv.data_ptr(), bias_in.data_ptr(), s_out.data_ptr(), o.data_ptr(), _p(kp), B, N, H, ld,
-                              float(scale), float(drop_p), int(seed), int(site), int(tiled))
+                              float(scale), float(drop_p), int(seed), int(site), int(tiled), _p(key_tiles), int(rag_store))
     # per (pair, head): read the bias / previous logits 4 B, write S 4 B; per (token, head): q|k|v in (48 B), o out (16 B)
     kernel_timer.end("pair_attn_fwd", t0, float(B) * H * (N * N * 8.0 + N * 64.0))
     return s_out, o
 
 
-def pair_attn_bwd(qkv, s, do, g, B, N, H, ld, scale, g_in_zero, drop_p=0.0, seed=0, site=0):
+def pair_attn_bwd(qkv, s, do, g, B, N, H, ld, scale, g_in_zero, drop_p=0.0, seed=0, site=0, key_tiles=None):
     dqkv = torch.empty_like(qkv)
     tiled = pair_is_tiled(s)
     if pair_is_tiled(g) != tiled:
         raise MMDTIError("pair_attn_bwd: S and G must share one pair layout")
     t0 = kernel_timer.begin("pair_attn_bwd")
     lib().mmdti_pair_attn_bwd(_stream(), qkv.data_ptr(), s.data_ptr(), do.data_ptr(), g.data_ptr(), dqkv.data_ptr(), B, N, H, ld,
-                              float(scale), int(g_in_zero), float(drop_p), int(seed), int(site), int(tiled))
+                              float(scale), int(g_in_zero), float(drop_p), int(seed), int(site), int(tiled), _p(key_tiles))
     # per (pair, head): read S 4 B, read + write G (4 B each; the first layer reads none); per (token, head): 7 x 16 B rows
     kernel_timer.end("pair_attn_bwd", t0, float(B) * H * (N * N * (4.0 + g.element_size() * (1 if g_in_zero else 2)) + N * 112.0))
     return dqkv

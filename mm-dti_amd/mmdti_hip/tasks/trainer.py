@@ -32,7 +32,7 @@ import torch
 from torch.utils.data import DataLoader as TorchDataLoader
 
 from ..trainer import FineTuner
-from ..collate import HostCollate, device_payload
+from ..collate import HostCollate, device_payload, to_device
 
 logger = logging.getLogger("mmdti_hip")
 
@@ -141,8 +141,8 @@ class Trainer(object):
         net_input, net_target = batch
         if isinstance(net_input, dict):
             if self.narrow_inputs:
-                net_input = device_payload(net_input, self._n_edge_types)
-            net_input = {k: v.to(self.device, non_blocking=True) for k, v in net_input.items()}
+                net_input = device_payload(net_input, self._n_edge_types, self._pad_idx)
+            net_input = to_device(net_input, self.device)
             if self.distributed:
                 from ..parallel import pad_to_global_lengths
                 net_input = pad_to_global_lengths(net_input)        # the unmasked InfoNCE mean needs one padded length on all ranks
@@ -158,12 +158,14 @@ class Trainer(object):
         return net_input, net_target
 
     _n_edge_types = None
+    _pad_idx = 0
 
     def _collate_for(self, model):
         """The model's own ``batch_collate_fn`` in-process; with worker processes, the same collate as a small picklable
         object (the workers get the pad index and the tokenizer, not the model)."""
         d = getattr(model, 'dictionary', None)
         self._n_edge_types = len(d) * len(d) if d is not None else None
+        self._pad_idx = getattr(model, 'padding_idx', 0)
         from ..models.mm_model import MM_Model
         if self.num_workers > 0 and type(model).batch_collate_fn is MM_Model.batch_collate_fn:
             return HostCollate.of(model, narrow=self.narrow_inputs)

@@ -73,6 +73,52 @@ def test_unimol_tower_at_reference_crop_sizes(N):
     assert worst[1] < 6e-2 and cos_min > 0.995, (worst, cos_min)
 
 
+# ------------------------------------------------------------------------------------------------ ragged batches: key-tile skipping
+def test_ragged_batch_step_with_and_without_key_tile_skipping_is_the_same_step():
+    """A training step (dropout live) of the whole model on a batch of mixed-length molecules at the reference head count
+    (64 heads: the tiled pair kernels), once as collated (dense: every key tile of the padded length) and once with the
+    host-side ``atom_counts`` that ``collate.device_payload`` attaches (the pair-attention kernels then skip each
+    molecule's all-padding key tiles).  Skipping changes what is read and written, not what is computed: losses and every
+    parameter gradient must be bit-identical."""
+    from mmdti_hip import collate
+    from mmdti_hip.runtime import dropout_state
+    from mmdti_hip.functional import CELossFn
+    ocfg = tiny_cfg("classification", 40)
+    ocfg.unimol = O.UniMolCfg(layers=3, dim=512, ffn=256, heads=64, K=128, vocab=31)
+    ocfg.cross, ocfg.roberta = O.CrossCfg(dim=512, heads=16, ffn=128), O.RobertaCfg(layers=1, dim=512, heads=8, ffn=128, vocab=40, max_pos=40)
+    P = O.init_params(ocfg, seed=12, std=0.05)
+    model = product_model(ocfg).cuda().train()
+    load_fixture_weights(model, P)
+    batch, label = O.synth_batch(6, 75, 20, ocfg, seed=21, ragged=True)
+    counts = collate.atom_counts(batch["src_tokens"], 0)
+    N = batch["src_tokens"].shape[1]
+    assert int(counts.max()) == N and (int(counts.min()) + 15) // 16 < (N + 15) // 16          # at least one molecule has tiles to skip
+    dev = {k: v.cuda() for k, v in batch.items()}
+
+    def step(**extra):
+        dropout_state.reseed(77)
+        model.zero_grad(set_to_none=True)
+        logits, infonce, ct = model(**dev, **extra, return_infonce_loss=True, return_ct_loss=True, net_target=label.cuda())
+        loss = CELossFn.apply(logits, label.cuda()) + 0.1 * infonce + 0.1 * ct
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), infonce.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    dense = step()
+    again = step()
+    ragged = step(atom_counts=counts)
+    # forward: deterministic -> bit-identical.  Gradients: several are accumulated with fp32 atomics (split-K slabs aside:
+    # LayerNorm gamma/beta, embedding rows, pair-bias tables), so two runs of the SAME step differ in the last bits; the
+    # ragged run must sit inside that noise.
+    assert torch.equal(dense[0], again[0]) and torch.equal(dense[1], again[1])
+    assert torch.equal(ragged[0], dense[0]) and torch.equal(ragged[1], dense[1])
+    assert ragged[2].keys() == dense[2].keys()
+    names = [n for n in dense[2] if float(dense[2][n].abs().max()) > 0 and not any(z in n for z in ZERO_GRADS)]     # (analytically zero: pure rounding noise)
+    noise = max(rel_l2(again[2][n], dense[2][n]) for n in names)
+    worst = max(((n, rel_l2(ragged[2][n], dense[2][n])) for n in names), key=lambda t: t[1])
+    assert noise < 1e-5 and worst[1] < 1e-5, (noise, worst)
+
+
 # ------------------------------------------------------------------------------------------------ C3 at the reference architecture
 def test_c3_regression_conr_fds_at_reference_architecture():
     """BASELINE config 3 (docking-score-like regression + ConR + FDS, bf16, 1 GPU) at 15L/512/64h through FineTuner: an FDS

@@ -122,7 +122,11 @@ def test_device_payload_drops_unread_fields_and_narrows_edge_types_without_chang
     out = device_payload(batch, n_edge_types=31 * 31)
     assert "src_coord" not in out and out["src_edge_type"].dtype == torch.int16
     assert torch.equal(out["src_edge_type"].long(), batch["src_edge_type"])
-    assert all(out[k] is batch[k] for k in out if k != "src_edge_type")
+    assert all(out[k] is batch[k] for k in out if k not in ("src_edge_type", "atom_counts"))
+    # host-side lengths for the ragged pair kernels: last non-pad position + 1 of every molecule
+    st = batch["src_tokens"]
+    want = torch.tensor([max(j + 1 for j in range(st.shape[1]) if int(st[b, j]) != 0) for b in range(st.shape[0])], dtype=torch.int32)
+    assert torch.equal(out["atom_counts"], want) and out["atom_counts"].device.type == "cpu"
     # without the dictionary size the tensor's own range decides; an index that does not fit keeps int64
     assert device_payload(batch)["src_edge_type"].dtype == torch.int16
     big = dict(batch, src_edge_type=batch["src_edge_type"] + 40000)
@@ -145,6 +149,6 @@ def test_worker_side_collate_yields_the_batches_of_the_in_process_collate():
     got = list(DataLoader(data, batch_size=4, shuffle=False, collate_fn=hc, num_workers=2))
     assert len(ref) == len(got) == 6
     for (rb, rl), (gb, gl) in zip(ref, got):
-        assert list(gb) == [k for k in rb if k != "src_coord"]
+        assert list(gb) == [k for k in rb if k != "src_coord"] + ["atom_counts"]
         assert torch.equal(gl, rl) and gb["src_edge_type"].dtype == torch.int16
-        assert all(torch.equal(gb[k].long() if k == "src_edge_type" else gb[k], rb[k]) for k in gb)
+        assert all(torch.equal(gb[k].long() if k == "src_edge_type" else gb[k], rb[k]) for k in gb if k != "atom_counts")

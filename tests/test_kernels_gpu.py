@@ -288,6 +288,65 @@ def test_pair_tile_roundtrip(ops):
     assert t[1, 2, 1, 2, ((35 % 16) // 4 * 16 + 20 % 16) * 4 + 35 % 4].item() == x[1, 2, 20, 35].item()
 
 
+@pytest.mark.parametrize("B,N,H,lens,p", [(4, 130, 8, (130, 37, 64, 5), 0.0), (3, 100, 64, (100, 17, 81), 0.1), (2, 258, 8, (40, 258), 0.0), (2, 16, 8, (3, 16), 0.0)])
+def test_pair_attn_ragged_key_tile_skipping_equals_dense(ops, B, N, H, lens, p):
+    """Ragged batches (tiled layout): with key_tiles = ceil(length / 16) per molecule the kernels neither load, compute nor store
+    the all-padding key tiles.  Everything that is defined must equal the dense run bit for bit: O, dqkv, S and G on the kept
+    tiles; rag_store writes -inf into the skipped S tiles (the dense run has -inf there too); skipped G tiles stay as handed in
+    (zero).  Pad QUERY rows are computed in both."""
+    D, ld, scale = H * 8, ops.pair_ld(N), 8 ** -0.5
+    nt = ops.pair_tiles(N)
+    qkv = dev(bf(torch.randn(B, N, 3 * D, generator=G(1)))).view(B * N, 3 * D)
+    dO = dev(bf(torch.randn(B, N, D, generator=G(3)))).view(B * N, D)
+    key_pad = torch.zeros(B, N, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        key_pad[b, n:] = True
+    bias = torch.zeros(B, H, N, ld); bias[..., :N] = torch.randn(B, H, N, N, generator=G(2))
+    bias_t = ops.pair_tile(dev(bias), N, float("-inf"))
+    kt = torch.tensor([(n + 15) // 16 for n in lens], dtype=torch.int32, device="cuda")
+    kw = dict(drop_p=p, seed=5, site=3)
+
+    def rows(t):                                                                # -> [B,H,N,nt,16]: the N x N block by key tile (slots with q >= N or k >= N are never written or read)
+        u = torch.zeros(B, H, N, nt * 16, device=t.device)
+        u[..., :N] = ops.pair_untile(t, N)
+        return u.view(B, H, N, nt, 16).transpose(2, 3)                          # [B,H,nt(key tile),N,16]: index 2 = key tile like the raw layout's index 3
+
+    s_d, o_d = ops.pair_attn_fwd(qkv, bias_t, dev(key_pad), B, N, H, ld, scale, **kw)
+    s_r, o_r = ops.pair_attn_fwd(qkv, bias_t, dev(key_pad), B, N, H, ld, scale, key_tiles=kt, rag_store=True, **kw)
+    assert torch.equal(o_r, o_d) and torch.equal(rows(s_r), rows(s_d))          # (skipped tiles: -inf in both)
+    s_n, o_n = ops.pair_attn_fwd(qkv, bias_t, dev(key_pad), B, N, H, ld, scale, key_tiles=kt, rag_store=False, **kw)
+    assert torch.equal(o_n, o_d)
+    for b in range(B):
+        k = int(kt[b])
+        assert torch.equal(rows(s_n)[b, :, :k], rows(s_d)[b, :, :k])
+    # second layer on top of the not-stored S: the skipped tiles are never read
+    s2_d, o2_d = ops.pair_attn_fwd(qkv, s_d, None, B, N, H, ld, scale, **kw)
+    s_poison = s_n.clone()
+    for b in range(B):
+        s_poison[b, :, :, int(kt[b]):] = float("nan")
+    s2_r, o2_r = ops.pair_attn_fwd(qkv, s_poison, None, B, N, H, ld, scale, key_tiles=kt, rag_store=True, **kw)
+    assert torch.equal(o2_r, o2_d) and torch.equal(rows(s2_r), rows(s2_d))
+    # backward
+    g_in = torch.zeros(B, H, N, ld); g_in[..., :N] = torch.randn(B, H, N, N, generator=G(4)).masked_fill(key_pad.view(B, 1, 1, N), 0.0)
+    g_d = ops.pair_tile(dev(g_in), N, 0.0); g_r = g_d.clone()
+    dq_d = ops.pair_attn_bwd(qkv, s_d, dO, g_d, B, N, H, ld, scale, False, **kw)
+    dq_r = ops.pair_attn_bwd(qkv, s_poison, dO, g_r, B, N, H, ld, scale, False, key_tiles=kt, **kw)
+    assert torch.equal(dq_r, dq_d)
+    for b in range(B):
+        k = int(kt[b])
+        assert torch.equal(rows(g_r)[b, :, :k], rows(g_d)[b, :, :k])
+        if k < nt:
+            assert float(rows(g_d)[b, :, k:].abs().max()) == 0.0                   # (what the dense run computes there is exactly 0 ...)
+            assert torch.equal(rows(g_r)[b, :, k:], rows(ops.pair_tile(dev(g_in), N, 0.0))[b, :, k:])      # (... and the ragged run leaves them untouched)
+    gz = torch.zeros_like(g_d)
+    dq_z = ops.pair_attn_bwd(qkv, s_poison, dO, gz, B, N, H, ld, scale, True, key_tiles=kt, **kw)
+    gz_d = torch.full_like(g_d, 7.0)
+    dq_zd = ops.pair_attn_bwd(qkv, s_d, dO, gz_d, B, N, H, ld, scale, True, **kw)
+    assert torch.equal(dq_z, dq_zd)
+    for b in range(B):
+        assert torch.equal(rows(gz)[b, :, :int(kt[b])], rows(gz_d)[b, :, :int(kt[b])])
+
+
 def test_pair_attn_dropout(ops):
     B, N, H = 2, 64, 8
     D, ld, scale = H * 8, 64, 8 ** -0.5

@@ -334,7 +334,8 @@ def test_device_prefetcher_feeds_the_step():
     for (bi, li), (bo, lo) in zip(host, DevicePrefetcher(host, "cuda")):
         assert "src_coord" not in bo and bo["src_edge_type"].dtype == torch.int16
         assert torch.equal(bo["src_edge_type"].cpu().long(), bi["src_edge_type"])
-        assert all(torch.equal(bo[k].cpu(), bi[k]) for k in bo if k != "src_edge_type")
+        assert all(torch.equal(bo[k].cpu(), bi[k]) for k in bo if k not in ("src_edge_type", "atom_counts"))
+        assert bo["atom_counts"].device.type == "cpu" and bo["atom_counts"].dtype == torch.int32            # host-side lengths
     m1, m2 = _model("classification", 2).eval(), _model("classification", 2).eval()
     m2.load_state_dict(m1.state_dict())
     t1, t2 = FineTuner(m1, "classification"), FineTuner(m2, "classification")
