@@ -296,8 +296,11 @@ class MM_Model(nn.Module):
         key_tiles = None
         if atom_counts is not None and PAIR_RAGGED and src_tokens.is_cuda:
             kt = (torch.as_tensor(atom_counts, device="cpu").to(torch.int64) + 15) // 16
-            if int(kt.min()) < (src_tokens.shape[1] + 15) // 16:
-                key_tiles = kt.clamp_(min=1).to(torch.int32).to(src_tokens.device, non_blocking=True)
+            nt = (src_tokens.shape[1] + 15) // 16
+            if int(kt.min()) < nt:
+                kt = kt.clamp_(min=1, max=nt)
+                ops.set_pair_kept(float(kt.sum()) / (kt.numel() * nt))
+                key_tiles = kt.to(torch.int32).to(src_tokens.device, non_blocking=True)
         img_mask = ~padding_mask
         attention_mask = attention_mask.bool().to(src_tokens.device)
         # NOTE: the reference sets padding_mask=None when nothing is padded (:548-549), which costs a host sync

@@ -459,6 +459,16 @@ def pair_untile(t, N):
     return t.reshape(B, H, -1)[:, :, _tile_index(N, t.device).reshape(-1)].view(B, H, N, N)
 
 
+_pair_kept = 1.0       # fraction of the padded key columns the ragged kernels keep (work accounting of the timers only)
+
+
+def set_pair_kept(frac):
+    """MM_Model tells the kernel timers what share of the pair tiles a ragged step touches, so that bench.py's achieved
+    bytes are the bytes of the tiles actually read and written (1.0 = dense)."""
+    global _pair_kept
+    _pair_kept = float(frac)
+
+
 def pair_attn_fwd(qkv, bias_in, key_pad, B, N, H, ld, scale, drop_p=0.0, seed=0, site=0, key_tiles=None, rag_store=False):
     _chk(qkv, BF16, "pair_attn.qkv"); _chk(bias_in, F32, "pair_attn.bias")
     tiled = pair_is_tiled(bias_in)
@@ -471,7 +481,8 @@ def pair_attn_fwd(qkv, bias_in, key_pad, B, N, H, ld, scale, drop_p=0.0, seed=0,
     lib().mmdti_pair_attn_fwd(_stream(), qkv.data_ptr(), bias_in.data_ptr(), s_out.data_ptr(), o.data_ptr(), _p(kp), B, N, H, ld,
                               float(scale), float(drop_p), int(seed), int(site), int(tiled), _p(key_tiles), int(rag_store))
     # per (pair, head): read the bias / previous logits 4 B, write S 4 B; per (token, head): q|k|v in (48 B), o out (16 B)
-    kernel_timer.end("pair_attn_fwd", t0, float(B) * H * (N * N * 8.0 + N * 64.0))
+    kept = _pair_kept if key_tiles is not None else 1.0
+    kernel_timer.end("pair_attn_fwd", t0, float(B) * H * (N * N * (4.0 * kept + 4.0 * (1.0 if rag_store else kept)) + N * 64.0))
     return s_out, o
 
 
@@ -484,7 +495,8 @@ def pair_attn_bwd(qkv, s, do, g, B, N, H, ld, scale, g_in_zero, drop_p=0.0, seed
     lib().mmdti_pair_attn_bwd(_stream(), qkv.data_ptr(), s.data_ptr(), do.data_ptr(), g.data_ptr(), dqkv.data_ptr(), B, N, H, ld,
                               float(scale), int(g_in_zero), float(drop_p), int(seed), int(site), int(tiled), _p(key_tiles))
     # per (pair, head): read S 4 B, read + write G (4 B each; the first layer reads none); per (token, head): 7 x 16 B rows
-    kernel_timer.end("pair_attn_bwd", t0, float(B) * H * (N * N * (4.0 + g.element_size() * (1 if g_in_zero else 2)) + N * 112.0))
+    kept = _pair_kept if key_tiles is not None else 1.0
+    kernel_timer.end("pair_attn_bwd", t0, float(B) * H * (N * N * kept * (4.0 + g.element_size() * (1 if g_in_zero else 2)) + N * 112.0))
     return dqkv
 
 

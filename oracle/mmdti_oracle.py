@@ -253,6 +253,8 @@ def unimol_layer(x: Tensor, bias: Tensor, P: Params, pre: str, cfg: UniMolCfg,
     k = heads(k)
     v = heads(v)
     S = torch.bmm(q, k.transpose(1, 2)) + bias
+    if bf16 and "s16" in BF16_SITES:
+        S = S.to(torch.float16).to(torch.float32)      # pair logits carried between layers as fp16 (what the reference's AMP path does)
     Pm = dropout(torch.softmax(S, dim=-1), cfg.attn_dropout, training)
     o = torch.bmm(Pm, v).view(B, H, N, hd).transpose(1, 2).contiguous().view(B, N, D)
     o = linear(o, P[pre + "self_attn.out_proj.weight"], P[pre + "self_attn.out_proj.bias"], bf16)
