@@ -159,14 +159,17 @@ int mmdti_gbf_features_bwd(mmdti_stream_t stream, const float* dist, const long 
 int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, const void* edge_type,
                        int edge_bytes /* 8, 4 or 2: int64 as the reference collates (mm_model.py:657-660), or narrowed */, const float* mul,
                        const float* bias, const float* means, const float* stds, const void* w1_bf16, const float* b1,
-                       const void* w2_bf16, const float* b2, int B, int N, int ld, int K, int F, int H, int E, float* out,
+                       const void* w2_bf16, const float* b2, int B, int N, int ld, int K, int F, int H, int E, void* out,
                        void* feat_bf16, void* u_bf16, void* h_bf16, int flags /* bit 0: tiled pair layout; bit 1: u_bf16 receives
-                       gelu'(pre-activation) instead of the pre-activation (then pass the same bit to mmdti_gbf_bias_bwd) */);
+                       gelu'(pre-activation) instead of the pre-activation (then pass the same bit to mmdti_gbf_bias_bwd); bit 2 (with
+                       bit 0): the pair tensor of the call is a 16-bit plane -- out is fp16 here (layout 3 of mmdti_pair_attn_fwd,
+                       which explains the type); g of the two backward entry points is bf16 (layout 7 of mmdti_pair_attn_bwd).
+                       Without bit 2 out and g are fp32 */);
 /* Per-pair half of the backward of mmdti_gbf_bias_fwd, one pass over g = dL/d(out) (same layout flag): writes
  * do_bf16 [B*N*N, 64] = bf16(g re-laid out) and du_bf16 [B*N*N, 128] = bf16((do.W2) * gelu'(u)) -- the A operands of the two
  * weight-gradient GEMMs (dW2 = do^T.h, dW1 = du^T.feat; bias gradients are their column sums) -- and accumulates the
  * Gaussian-layer gradients dmul/dbias [E] and dmeans/dstds [128] (fp32, +=).  E <= 4096. */
-int mmdti_gbf_bias_bwd(mmdti_stream_t stream, const float* g, const float* dist, const void* edge_type, int edge_bytes,
+int mmdti_gbf_bias_bwd(mmdti_stream_t stream, const void* g, const float* dist, const void* edge_type, int edge_bytes,
                        const float* mul, const float* bias, const float* means, const float* stds, const void* w1_bf16,
                        const void* w2_bf16, const void* u_bf16, int B, int N, int ld, int K, int F, int H, int E, int flags,
                        void* do_bf16, void* du_bf16, float* dmul, float* dbias, float* dmeans, float* dstds);
@@ -174,8 +177,8 @@ int mmdti_gbf_bias_bwd(mmdti_stream_t stream, const float* g, const float* dist,
  * :190-208 and GaussianLayer :211-236): the forward saves nothing -- each 128-pair block recomputes basis / pre-activation /
  * hidden from dist and edge_type, forms do and du, and accumulates ALL parameter gradients on chip (MFMA, contraction over the
  * pairs staged transposed in LDS), flushing once per workgroup: dw1 [128,128], db1 [128], dw2 [64,128], db2 [64], dmul/dbias [E],
- * dmeans/dstds [128] (fp32, +=).  g: dL/d(out) in the layout of flags bit 0.  K=128, F=128, H=64, E <= 1536. */
-int mmdti_gbf_bias_bwd_full(mmdti_stream_t stream, const float* g, const float* dist, const void* edge_type, int edge_bytes,
+ * dmeans/dstds [128] (fp32, +=).  g: dL/d(out) in the layout of flags bits 0 and 2.  K=128, F=128, H=64, E <= 1536. */
+int mmdti_gbf_bias_bwd_full(mmdti_stream_t stream, const void* g, const float* dist, const void* edge_type, int edge_bytes,
                             const float* mul, const float* bias, const float* means, const float* stds, const void* w1_bf16,
                             const float* b1, const void* w2_bf16, int B, int N, int ld, int K, int F, int H, int E, int flags,
                             float* dw1, float* db1, float* dw2, float* db2, float* dmul, float* dbias, float* dmeans, float* dstds);
@@ -187,21 +190,30 @@ int mmdti_pair_permute_bwd(mmdti_stream_t stream, const float* g, void* out_bf16
 /* ---- Pair-bias attention, head_dim 8 (unicore SelfMultiheadAttention + softmax_dropout with
  * return_attn=True, reached from transformers.py:137-139; key-padding merge :122-135) ------------
  * S = scale*q.k^T + bias_in (+ -inf at padded keys); s_out = S (next layer's bias AND the saved activation);
- * O = dropout(softmax(S)).v.   qkv: [B,N,3*H*8] bf16 (q|k|v);  bias_in/s_out: [B,H,N,ld] fp32. */
-int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, const float* bias_in, float* s_out,
+ * O = dropout(softmax(S)).v.   qkv: [B,N,3*H*8] bf16 (q|k|v).
+ * layout (of bias_in / s_out, and of s / g in the backward):
+ *   0  row-major planes [B,H,N,ld] fp32;
+ *   1  tiled planes [B,H,nt,nt,256] fp32 (nt = ceil(N/16); 16x16 tiles in MFMA accumulator order, N <= 272);
+ *   3  COMPACT tiled planes: same element order, the logits chain as fp16 -- half the bytes of the forward's dominant traffic,
+ *      a sixth less in the backward.  The reference carries these logits as fp16 itself when it runs under AMP (autocast makes
+ *      attn_weights fp16; tasks/trainer.py:266-282).  Each layer rounds S once (to nearest even, saturating at 65504) and its own
+ *      softmax runs on the rounded value, so forward and backward see the same logits.  The gradient chain g stays fp32;
+ *   7  (backward only, opt-in) as 3 with g as bf16: another third less traffic, at a cost in gradient fidelity wherever sums
+ *      over pairs cancel (measured: DESIGN.md); no ragged form. */
+int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, const void* bias_in, void* s_out,
                         void* o_bf16, const unsigned char* key_pad, int B, int N, int H, int ld, float scale,
-                        float drop_p, unsigned long long seed, unsigned int site, int tiled,
-                        const int* key_tiles /* nullable, tiled layout only: [B] int32, number of 16-key tiles of each molecule that
+                        float drop_p, unsigned long long seed, unsigned int site, int layout,
+                        const int* key_tiles /* nullable, layout 3 only: [B] int32, number of 16-key tiles of each molecule that
                         hold a real key (ragged batches, right-padded by mm_model.py:645-682).  The key tiles past it are all padding:
                         they are not loaded, not computed, and not stored unless rag_store != 0 (then written as -inf: pass it for the
                         last layer, whose S goes back to the caller).  Pad QUERY rows are computed as ever. */,
                         int rag_store);
-/* g (in/out, [B,H,N,ld] fp32): on entry dL/dS_l from the layers above (ignored if g_in_zero), on exit
- * dL/dS_l total = dL/d(bias_in).  dqkv: [B,N,3*H*8] bf16.  key_tiles: as in the forward; the skipped tiles of g are neither
+/* g (in/out, same layout as s; fp32, or bf16 for layout 7): on entry dL/dS_l from the layers above (ignored if g_in_zero), on
+ * exit dL/dS_l total = dL/d(bias_in).  dqkv: [B,N,3*H*8] bf16.  key_tiles: as in the forward; the skipped tiles of g are neither
  * read nor written (hand in a zero-initialised g for a ragged batch). */
-int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, const float* s, const void* do_bf16, float* g,
+int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, const void* s, const void* do_bf16, void* g,
                         void* dqkv_bf16, int B, int N, int H, int ld, float scale, int g_in_zero, float drop_p,
-                        unsigned long long seed, unsigned int site, int tiled, const int* key_tiles);
+                        unsigned long long seed, unsigned int site, int layout, const int* key_tiles);
 
 /* ---- Row softmax over materialised scores (HF eager_attention_forward :158-183; BertCoAttention
  * mm_module.py:497-514) ------------------------------------------------------------------------

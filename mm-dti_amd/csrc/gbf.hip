@@ -240,15 +240,25 @@ __device__ __forceinline__ gbf16x8 gbf_basis8(float y, const float* mu, const fl
 // NEXT tile's index math and loads (edge type, distance) issued before the current tile is computed.  ltab: the per-edge-
 // type tables sit in LDS (E <= GBF_FWD_MAXE) -- a dependent global gather would put two round trips on every tile.
 constexpr int GBF_FWD_MAXE = 4096;
-template <bool SAVE, bool TILED>
+// Element types of the pair planes (see pair_attn.hip): fp32, or -- compact tiled planes -- the bias as fp16 (saturating at
+// 65504, -inf in the pad slots stays -inf) and the incoming gradient as bf16.
+__device__ __forceinline__ void gbf_put(float* p, float v) { *p = v; }
+__device__ __forceinline__ void gbf_put(_Float16* p, float v) { *p = (_Float16)fminf(v, 65504.f); }
+__device__ __forceinline__ float gbf_get(const float* p) { return *p; }
+__device__ __forceinline__ float gbf_get(const __bf16* p) {
+  return __builtin_bit_cast(float, (uint32_t)(*reinterpret_cast<const unsigned short*>(p)) << 16);
+}
+
+template <bool SAVE, bool TILED, typename OT>
 __global__ __launch_bounds__(512, 2) void gbf_bias_fwd_kernel(const float* __restrict__ dist, const void* __restrict__ et, int esz,
                                                               const float* __restrict__ mul, const float* __restrict__ bias,
                                                               const float* __restrict__ means, const float* __restrict__ stds,
                                                               const bf16_t* __restrict__ W1, const float* __restrict__ b1,
                                                               const bf16_t* __restrict__ W2, const float* __restrict__ b2,
-                                                              float* __restrict__ out, bf16_t* __restrict__ feat_out,
+                                                              OT* __restrict__ out, bf16_t* __restrict__ feat_out,
                                                               bf16_t* __restrict__ u_out, bf16_t* __restrict__ h_out, int B, int N,
                                                               int ld, int E, int tpm, int ugrad, int ltab) {
+  static_assert(TILED || sizeof(OT) == 4, "compact pair planes exist in the tiled layout only");
   extern __shared__ __attribute__((aligned(16))) unsigned char gbf_smem[];
   bf16_t* sW1 = reinterpret_cast<bf16_t*>(gbf_smem);       // [128][136]   W1[f][k]
   bf16_t* sW2 = sW1 + GBF_F * GBF_WS;                       // [64][136]    W2[h][f], f in k-slot order
@@ -330,9 +340,9 @@ __global__ __launch_bounds__(512, 2) void gbf_bias_fwd_kernel(const float* __res
     fetch(tile + nwaves, n_b, n_q, n_flags, n_pl, n_e, n_d);
     const bool valid = flags & 1, inplane = flags & 2, past = flags & 4;
     const float padv = TILED ? -INFINITY : 0.f;
-    float* ob = out + (long long)b * GBF_H * plane + q;
+    OT* ob = out + (long long)b * GBF_H * plane + q;
     if (TILED && past) {
-      for (int hh = 0; hh < GBF_H; ++hh) ob[(long long)hh * plane] = padv;
+      for (int hh = 0; hh < GBF_H; ++hh) gbf_put(ob + (long long)hh * plane, padv);
     } else {
     const long long p = (long long)b * N * N + pl;
     const float y = ltab ? sMul[e] * d + sBia[e] : mul[e] * d + bias[e];
@@ -392,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void gbf_bias_fwd_kernel(const float* __res
       const gf32x4 bb = *reinterpret_cast<const gf32x4*>(sB2 + 16 * ht + 4 * g);
       if (inplane) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ob[(long long)(16 * ht + 4 * g + r) * plane] = valid ? acc[r] + bb[r] : padv;
+        for (int r = 0; r < 4; ++r) gbf_put(ob + (long long)(16 * ht + 4 * g + r) * plane, valid ? acc[r] + bb[r] : padv);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -411,8 +421,8 @@ __global__ __launch_bounds__(512, 2) void gbf_bias_fwd_kernel(const float* __res
 // the two weight-gradient GEMMs (contraction over the 4.3 M pairs) stay on the GEMM kernel.
 constexpr int GBF_W2S = 72;   // LDS row stride of W2^T [128 f][64 h]: 144-B rows, conflict-free ds_read_b128 fragments
 
-template <bool TILED>
-__global__ __launch_bounds__(256, 2) void gbf_bias_bwd_kernel(const float* __restrict__ gsrc, const float* __restrict__ dist,
+template <bool TILED, typename GT>
+__global__ __launch_bounds__(256, 2) void gbf_bias_bwd_kernel(const GT* __restrict__ gsrc, const float* __restrict__ dist,
                                                            const void* __restrict__ et, int esz, const float* __restrict__ mul,
                                                            const float* __restrict__ bias, const float* __restrict__ means,
                                                            const float* __restrict__ stds, const bf16_t* __restrict__ W1,
@@ -492,11 +502,11 @@ __global__ __launch_bounds__(256, 2) void gbf_bias_bwd_kernel(const float* __res
     const int e32 = gbf_edge(et, p, esz);
     e = e32 < 0 ? 0 : (e32 >= E ? E - 1 : e32);
     d = dist[p];
-    const float* gp = gsrc + (long long)b * GBF_H * plane + (valid ? q : 0);
+    const GT* gp = gsrc + (long long)b * GBF_H * plane + (valid ? q : 0);
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) gv[c * 8 + j] = valid ? gp[(long long)(32 * c + 8 * g + j) * plane] : 0.f;
+      for (int j = 0; j < 8; ++j) gv[c * 8 + j] = valid ? gbf_get(gp + (long long)(32 * c + 8 * g + j) * plane) : 0.f;
 #pragma unroll
     for (int ft = 0; ft < 8; ++ft) {
       up[ft] = make_uint2(0u, 0u);
@@ -652,9 +662,9 @@ __device__ __forceinline__ gbf16x8 gbf_tr8(const bf16_t* a0, const bf16_t* a1) {
 }
 
 // TILED: a tile is one 4x4 block of pairs, tpm = ceil(N/4)^2 per molecule (only blocks that hold a real pair are enumerated).
-template <bool TILED>
+template <bool TILED, typename GT>
 __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
-    const float* __restrict__ gsrc, const float* __restrict__ dist, const void* __restrict__ et, int esz, const float* __restrict__ mul,
+    const GT* __restrict__ gsrc, const float* __restrict__ dist, const void* __restrict__ et, int esz, const float* __restrict__ mul,
     const float* __restrict__ bias, const float* __restrict__ means, const float* __restrict__ stds, const bf16_t* __restrict__ W1,
     const float* __restrict__ b1, const bf16_t* __restrict__ W2, float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2,
     float* __restrict__ db2, float* __restrict__ dmul, float* __restrict__ dbias, float* __restrict__ dmeans, float* __restrict__ dstds, int B,
@@ -764,12 +774,12 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
     const int e32 = gbf_edge(et, mol, pl, esz);
     e = e32 < 0 ? 0 : (e32 >= E ? E - 1 : e32);
     d = (dist + mol)[pl];
-    const float* mb = gsrc + (long long)b * GBF_H * plane;
+    const GT* mb = gsrc + (long long)b * GBF_H * plane;
     const unsigned voff = (unsigned)(8 * g) * (unsigned)plane + (unsigned)(valid ? q : 0);
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) gv[c * 8 + j] = (mb + (long long)(32 * c + j) * plane)[voff];
+      for (int j = 0; j < 8; ++j) gv[c * 8 + j] = gbf_get(mb + (long long)(32 * c + j) * plane + voff);
   };
 
   bool act, valid, n_act, n_valid;
@@ -1085,8 +1095,10 @@ static int edge_bytes_ok(int eb) { return eb == 8 || eb == 4 || eb == 2; }
 extern "C" int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, const void* edge_type, int edge_bytes, const float* mul,
                                   const float* bias, const float* means, const float* stds, const void* w1_bf16,
                                   const float* b1, const void* w2_bf16, const float* b2, int B, int N, int ld, int K, int F,
-                                  int H, int E, float* out, void* feat_bf16, void* u_bf16, void* h_bf16, int flags) {
-  const int tiled = flags & 1, ugrad = (flags >> 1) & 1;   // bit 0: tiled pair layout; bit 1: u_bf16 receives gelu'(u) instead of u
+                                  int H, int E, void* out, void* feat_bf16, void* u_bf16, void* h_bf16, int flags) {
+  // bit 0: tiled pair layout; bit 1: u_bf16 receives gelu'(u) instead of u; bit 2: compact planes (out is fp16; tiled only)
+  const int tiled = flags & 1, ugrad = (flags >> 1) & 1, compact = (flags >> 2) & 1;
+  MMDTI_REQUIRE(!compact || tiled, "gbf_bias_fwd: compact planes (flags bit 2) exist in the tiled layout only");
   MMDTI_REQUIRE(dist && edge_type && mul && bias && means && stds && w1_bf16 && b1 && w2_bf16 && b2 && out, "gbf_bias_fwd: null argument");
   MMDTI_REQUIRE(edge_bytes_ok(edge_bytes), "gbf_bias_fwd: edge types must be int64, int32 or int16 (edge_bytes=%d)", edge_bytes);
   MMDTI_REQUIRE(K == GBF_K && F == GBF_F && H == GBF_H, "gbf_bias_fwd: built for %d gaussians, %d hidden, %d heads (got %d,%d,%d)",
@@ -1106,32 +1118,36 @@ extern "C" int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, cons
   static bool attr_done = false;
   if (!attr_done) {
     const int cap = (int)((size_t)(GBF_F + GBF_H) * GBF_WS * 2 + (size_t)(3 * GBF_K + GBF_F + GBF_H + 2 * GBF_FWD_MAXE) * 4);
-    const void* fns[4] = {reinterpret_cast<const void*>(gbf_bias_fwd_kernel<true, true>), reinterpret_cast<const void*>(gbf_bias_fwd_kernel<true, false>),
-                          reinterpret_cast<const void*>(gbf_bias_fwd_kernel<false, true>), reinterpret_cast<const void*>(gbf_bias_fwd_kernel<false, false>)};
-    for (int f = 0; f < 4; ++f)
+    const void* fns[6] = {reinterpret_cast<const void*>(gbf_bias_fwd_kernel<true, true, float>), reinterpret_cast<const void*>(gbf_bias_fwd_kernel<true, false, float>),
+                          reinterpret_cast<const void*>(gbf_bias_fwd_kernel<false, true, float>), reinterpret_cast<const void*>(gbf_bias_fwd_kernel<false, false, float>),
+                          reinterpret_cast<const void*>(gbf_bias_fwd_kernel<true, true, _Float16>), reinterpret_cast<const void*>(gbf_bias_fwd_kernel<false, true, _Float16>)};
+    for (int f = 0; f < 6; ++f)
       if (hipFuncSetAttribute(fns[f], hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess) {
         set_error("gbf_bias_fwd: hipFuncSetAttribute failed");
         return MMDTI_ERR_LAUNCH;
       }
     attr_done = true;
   }
-#define GBF_L(SAVE, TILED)                                                                                                          \
-  hipLaunchKernelGGL((gbf_bias_fwd_kernel<SAVE, TILED>), dim3(grid), dim3(512), smem, (hipStream_t)stream, dist, edge_type, edge_bytes, mul, bias, \
-                     means, stds, (const bf16_t*)w1_bf16, b1, (const bf16_t*)w2_bf16, b2, out, (bf16_t*)feat_bf16, (bf16_t*)u_bf16, \
+#define GBF_L(SAVE, TILED, OT)                                                                                                      \
+  hipLaunchKernelGGL((gbf_bias_fwd_kernel<SAVE, TILED, OT>), dim3(grid), dim3(512), smem, (hipStream_t)stream, dist, edge_type, edge_bytes, mul, bias, \
+                     means, stds, (const bf16_t*)w1_bf16, b1, (const bf16_t*)w2_bf16, b2, (OT*)out, (bf16_t*)feat_bf16, (bf16_t*)u_bf16, \
                      (bf16_t*)h_bf16, B, N, ld, E, tpm, ugrad, ltab)
-  if (save) { if (tiled) GBF_L(true, true); else GBF_L(true, false); }
-  else      { if (tiled) GBF_L(false, true); else GBF_L(false, false); }
+  if (compact) { if (save) GBF_L(true, true, _Float16); else GBF_L(false, true, _Float16); }
+  else if (save) { if (tiled) GBF_L(true, true, float); else GBF_L(true, false, float); }
+  else           { if (tiled) GBF_L(false, true, float); else GBF_L(false, false, float); }
 #undef GBF_L
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }
 
-extern "C" int mmdti_gbf_bias_bwd(mmdti_stream_t stream, const float* g, const float* dist, const void* edge_type, int edge_bytes,
+extern "C" int mmdti_gbf_bias_bwd(mmdti_stream_t stream, const void* g, const float* dist, const void* edge_type, int edge_bytes,
                                   const float* mul, const float* bias, const float* means, const float* stds,
                                   const void* w1_bf16, const void* w2_bf16, const void* u_bf16, int B, int N, int ld, int K,
                                   int F, int H, int E, int flags, void* do_bf16, void* du_bf16, float* dmul, float* dbias,
                                   float* dmeans, float* dstds) {
-  const int tiled = flags & 1, ugrad = (flags >> 1) & 1;   // bit 0: tiled pair layout; bit 1: u_bf16 holds gelu'(u)
+  // bit 0: tiled pair layout; bit 1: u_bf16 holds gelu'(u); bit 2: compact planes (g is bf16; tiled only)
+  const int tiled = flags & 1, ugrad = (flags >> 1) & 1, compact = (flags >> 2) & 1;
+  MMDTI_REQUIRE(!compact || tiled, "gbf_bias_bwd: compact planes (flags bit 2) exist in the tiled layout only");
   MMDTI_REQUIRE(g && dist && edge_type && mul && bias && means && stds && w1_bf16 && w2_bf16 && u_bf16 && do_bf16 && du_bf16 && dmul &&
                     dbias && dmeans && dstds, "gbf_bias_bwd: null argument");
   MMDTI_REQUIRE(K == GBF_K && F == GBF_F && H == GBF_H, "gbf_bias_bwd: built for %d gaussians, %d hidden, %d heads (got %d,%d,%d)",
@@ -1147,29 +1163,31 @@ extern "C" int mmdti_gbf_bias_bwd(mmdti_stream_t stream, const float* g, const f
   MMDTI_REQUIRE(smem <= 96 * 1024, "gbf_bias_bwd: %d edge types do not fit the LDS tables", E);
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gbf_bias_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gbf_bias_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gbf_bias_bwd_kernel<true, float>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gbf_bias_bwd_kernel<false, float>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gbf_bias_bwd_kernel<true, __bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
       set_error("gbf_bias_bwd: hipFuncSetAttribute failed");
       return MMDTI_ERR_LAUNCH;
     }
     attr_done = true;
   }
-#define GBF_B(TILED)                                                                                                          \
-  hipLaunchKernelGGL((gbf_bias_bwd_kernel<TILED>), dim3(grid), dim3(256), smem, (hipStream_t)stream, g, dist, edge_type, edge_bytes, mul, bias, \
+#define GBF_B(TILED, GT)                                                                                                      \
+  hipLaunchKernelGGL((gbf_bias_bwd_kernel<TILED, GT>), dim3(grid), dim3(256), smem, (hipStream_t)stream, (const GT*)g, dist, edge_type, edge_bytes, mul, bias, \
                      means, stds, (const bf16_t*)w1_bf16, (const bf16_t*)w2_bf16, (const bf16_t*)u_bf16, (bf16_t*)do_bf16,    \
                      (bf16_t*)du_bf16, dmul, dbias, dmeans, dstds, B, N, ld, E, tpm, ugrad)
-  if (tiled) GBF_B(true); else GBF_B(false);
+  if (compact) GBF_B(true, __bf16); else if (tiled) GBF_B(true, float); else GBF_B(false, float);
 #undef GBF_B
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }
 
-extern "C" int mmdti_gbf_bias_bwd_full(mmdti_stream_t stream, const float* g, const float* dist, const void* edge_type, int edge_bytes,
+extern "C" int mmdti_gbf_bias_bwd_full(mmdti_stream_t stream, const void* g, const float* dist, const void* edge_type, int edge_bytes,
                                        const float* mul, const float* bias, const float* means, const float* stds, const void* w1_bf16,
                                        const float* b1, const void* w2_bf16, int B, int N, int ld, int K, int F, int H, int E, int flags,
                                        float* dw1, float* db1, float* dw2, float* db2, float* dmul, float* dbias, float* dmeans,
                                        float* dstds) {
-  const int tiled = flags & 1;
+  const int tiled = flags & 1, compact = (flags >> 2) & 1;   // bit 0: tiled pair layout; bit 2: compact planes (g is bf16; tiled only)
+  MMDTI_REQUIRE(!compact || tiled, "gbf_bias_bwd_full: compact planes (flags bit 2) exist in the tiled layout only");
   MMDTI_REQUIRE(g && dist && edge_type && mul && bias && means && stds && w1_bf16 && b1 && w2_bf16 && dw1 && db1 && dw2 && db2 && dmul && dbias &&
                     dmeans && dstds, "gbf_bias_bwd_full: null argument");
   MMDTI_REQUIRE(edge_bytes_ok(edge_bytes), "gbf_bias_bwd_full: edge types must be int64, int32 or int16 (edge_bytes=%d)", edge_bytes);
@@ -1186,18 +1204,19 @@ extern "C" int mmdti_gbf_bias_bwd_full(mmdti_stream_t stream, const float* g, co
   static bool attr_done = false;
   if (!attr_done) {
     const int cap = (int)gbf_full_smem(GBF_FULL_MAXE);
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gbf_bias_bwd_full_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gbf_bias_bwd_full_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gbf_bias_bwd_full_kernel<true, float>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gbf_bias_bwd_full_kernel<false, float>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gbf_bias_bwd_full_kernel<true, __bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess) {
       set_error("gbf_bias_bwd_full: hipFuncSetAttribute failed");
       return MMDTI_ERR_LAUNCH;
     }
     attr_done = true;
   }
-#define GBF_FB(TILED)                                                                                                              \
-  hipLaunchKernelGGL((gbf_bias_bwd_full_kernel<TILED>), dim3(grid), dim3(512), smem, (hipStream_t)stream, g, dist, edge_type, edge_bytes, mul, \
+#define GBF_FB(TILED, GT)                                                                                                          \
+  hipLaunchKernelGGL((gbf_bias_bwd_full_kernel<TILED, GT>), dim3(grid), dim3(512), smem, (hipStream_t)stream, (const GT*)g, dist, edge_type, edge_bytes, mul, \
                      bias, means, stds, (const bf16_t*)w1_bf16, b1, (const bf16_t*)w2_bf16, dw1, db1, dw2, db2, dmul, dbias, dmeans, dstds, B, \
                      N, ld, E, tpm)
-  if (tiled) GBF_FB(true); else GBF_FB(false);
+  if (compact) GBF_FB(true, __bf16); else if (tiled) GBF_FB(true, float); else GBF_FB(false, float);
 #undef GBF_FB
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;

@@ -315,16 +315,70 @@ __device__ __forceinline__ void pa_split4(const f32x4& v, pa_s16x4& hi, pa_s16x4
 }
 #define PA_MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A, B, C, 0, 0, 0)
 
+// Element types of the pair tensors.  Row-major planes and the round-1 tiled planes hold fp32.  The COMPACT tiled planes
+// hold the logits chain S as fp16 (same [nKB][nKB][256] element order: a lane's 4 keys are 8 contiguous bytes, a tile
+// 512 B): the pair kernels are bound by this traffic -- the forward's halves, the backward's drops from 12 to 10 B per
+// pair and head.  The gradient chain G stays fp32 by default; bf16 is an opt-in (layout bit 2) that costs gradient
+// fidelity where sums over pairs cancel ("tried").
+//   S (fp16, round to nearest even): what the reference's own AMP path carries between layers (its attn_weights are fp16
+//     under autocast); the softmax of the layer that produced a value runs on the ROUNDED value, so the forward and the
+//     backward's recomputation see the same logits.  Values above the fp16 range saturate at 65504 instead of becoming
+//     +inf (a -inf row mask stays -inf).
+//   G (bf16, opt-in): fp16 would flush the small gradients the reference protects with its GradScaler; bf16 keeps fp32's
+//     range.  The dQ / dK products of a layer use the unrounded fp32 G of that layer; only what is handed to the previous
+//     layer is rounded.
+typedef _Float16 pa_f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 pa_load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 pa_load4_nt(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
+__device__ __forceinline__ void pa_store4_nt(float* p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
+__device__ __forceinline__ f32x4 pa_round4(const float*, f32x4 v) { return v; }
+
+__device__ __forceinline__ f32x4 pa_widen_f16(const pa_f16x4& h) {
+  f32x4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = (float)h[r];
+  return v;
+}
+__device__ __forceinline__ pa_f16x4 pa_narrow_f16(const f32x4& v) {
+  pa_f16x4 h;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) h[r] = (_Float16)v[r];
+  return h;
+}
+__device__ __forceinline__ f32x4 pa_load4(const _Float16* p) { return pa_widen_f16(*reinterpret_cast<const pa_f16x4*>(p)); }
+__device__ __forceinline__ f32x4 pa_load4_nt(const _Float16* p) { return pa_widen_f16(__builtin_nontemporal_load(reinterpret_cast<const pa_f16x4*>(p))); }
+__device__ __forceinline__ void pa_store4_nt(_Float16* p, const f32x4& v) {   // (v already went through pa_round4: the conversion is exact)
+  __builtin_nontemporal_store(pa_narrow_f16(v), reinterpret_cast<pa_f16x4*>(p));
+}
+__device__ __forceinline__ f32x4 pa_round4(const _Float16*, const f32x4& v) {
+  f32x4 c;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c[r] = fminf(v[r], 65504.f);
+  return pa_widen_f16(pa_narrow_f16(c));
+}
+
+__device__ __forceinline__ f32x4 pa_widen_bf16(const pa_s16x4& h) {
+  f32x4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = __builtin_bit_cast(float, (uint32_t)(uint16_t)h[r] << 16);
+  return v;
+}
+__device__ __forceinline__ f32x4 pa_load4(const __bf16* p) { return pa_widen_bf16(*reinterpret_cast<const pa_s16x4*>(p)); }
+__device__ __forceinline__ f32x4 pa_load4_nt(const __bf16* p) { return pa_widen_bf16(__builtin_nontemporal_load(reinterpret_cast<const pa_s16x4*>(p))); }
+__device__ __forceinline__ void pa_store4_nt(__bf16* p, const f32x4& v) { __builtin_nontemporal_store(pa_pack4(v), reinterpret_cast<pa_s16x4*>(p)); }
+
 // RAG (ragged batches): key_tiles[b] = number of 16-key tiles of molecule b that hold a real key.  The tiles past it are all
 // padding -- -inf in every S of the chain, 0 in G -- so they are neither loaded nor computed nor (rag_store == 0) stored; pad
 // QUERY rows are still computed (the reference's unmasked InfoNCE mean reads the encoder output at padded positions).
 // rag_store != 0: the skipped tiles are written as -inf (the last layer, whose S is returned to the caller).
-template <int NT, bool TILED, bool FULL, bool RAG>
-__global__ __launch_bounds__(256, NT > 13 ? 2 : 4) void pair_attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_in,
-                                                                 float* __restrict__ s_out, bf16_t* __restrict__ o,
+template <int NT, bool TILED, bool FULL, bool RAG, typename ST>
+__global__ __launch_bounds__(256, NT > 13 ? 2 : 4) void pair_attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, const ST* __restrict__ bias_in,
+                                                                 ST* __restrict__ s_out, bf16_t* __restrict__ o,
                                                                  const unsigned char* __restrict__ key_pad, int N, int H, int ld,
                                                                  float scale, uint32_t thresh, float dscale, uint64_t seed,
                                                                  uint32_t site, const int* __restrict__ key_tiles, int rag_store) {
+  static_assert(TILED || sizeof(ST) == 4, "compact pair tensors exist in the tiled layout only");
+  static_assert(!RAG || sizeof(ST) == 2, "key-tile skipping is built for the compact layout only");
   constexpr int NP = NT * 16;
   constexpr int KSTR = NP + 8;   // row stride (elements) of the d-major V image (see the backward kernel's sKT)
   // raw bf16 images, exactly as loaded: sQ / sK [row][8], sVT [d][key]
@@ -377,8 +431,8 @@ __global__ __launch_bounds__(256, NT > 13 ? 2 : 4) void pair_attn_fwd_mfma_kerne
     const long long tbase = ((long long)bh * nKB + qb) * nKB * 256 + lane * 4;
     // (row-major: the lane's 4 keys of tile t start at rowoff + 16t + 4g; a lane whose predicate is off reads the row's
     //  first 16 bytes instead -- always inside the tensor, unlike "tile 0 + 4g" when ld < 16)
-    const float* bin = bias_in + (TILED ? tbase : rowoff);
-    float* sout = s_out + (TILED ? tbase : rowoff);
+    const ST* bin = bias_in + (TILED ? tbase : rowoff);
+    ST* sout = s_out + (TILED ? tbase : rowoff);
     constexpr int TSTEP = TILED ? 256 : 16;
     const int goff = TILED ? 0 : 4 * g;
 #define PA_PRED(T) (!TILED ? (qvalid && (T) * 16 + 4 * g < N) \
@@ -393,10 +447,10 @@ __global__ __launch_bounds__(256, NT > 13 ? 2 : 4) void pair_attn_fwd_mfma_kerne
       if (RAG && t >= kt) {
         S[t] = f32x4{NEG_INF, NEG_INF, NEG_INF, NEG_INF};
       } else if (TILED && !EDGE && (FULL ? t < NT - 1 : false)) {
-        S[t] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(bin + t * TSTEP + goff));
+        S[t] = pa_load4_nt(bin + t * TSTEP + goff);
       } else {
         const bool pr = PA_PRED(t);
-        const f32x4 ld4 = *reinterpret_cast<const f32x4*>(bin + (pr ? t * TSTEP + goff : 0));
+        const f32x4 ld4 = pa_load4(bin + (pr ? t * TSTEP + goff : 0));
         S[t] = pr ? ld4 : f32x4{fillv, fillv, fillv, fillv};
       }
     }
@@ -407,9 +461,9 @@ __global__ __launch_bounds__(256, NT > 13 ? 2 : 4) void pair_attn_fwd_mfma_kerne
         if (rag_store) {
           const f32x4 ninf = {NEG_INF, NEG_INF, NEG_INF, NEG_INF};
           if (TILED && !EDGE && (FULL ? t < NT - 1 : false)) {
-            __builtin_nontemporal_store(ninf, reinterpret_cast<f32x4*>(sout + t * TSTEP + goff));
+            pa_store4_nt(sout + t * TSTEP + goff, ninf);
           } else if (PA_PRED(t)) {
-            __builtin_nontemporal_store(ninf, reinterpret_cast<f32x4*>(sout + t * TSTEP + goff));
+            pa_store4_nt(sout + t * TSTEP + goff, ninf);
           }
         }
       } else {
@@ -425,10 +479,11 @@ __global__ __launch_bounds__(256, NT > 13 ? 2 : 4) void pair_attn_fwd_mfma_kerne
 #pragma unroll
           for (int r = 0; r < 4; ++r) c[r] = (km[r] != 0.f) ? NEG_INF : c[r];
         }
+        c = pa_round4(sout, c);   // (compact: the fp16 value that is stored is also the one this layer's softmax sees)
         if (TILED && !EDGE && (FULL ? t < NT - 1 : false)) {
-          __builtin_nontemporal_store(c, reinterpret_cast<f32x4*>(sout + t * TSTEP + goff));
+          pa_store4_nt(sout + t * TSTEP + goff, c);
         } else if (PA_PRED(t)) {
-          __builtin_nontemporal_store(c, reinterpret_cast<f32x4*>(sout + t * TSTEP + goff));
+          pa_store4_nt(sout + t * TSTEP + goff, c);
         }
         S[t] = c;
         m = fmaxf(fmaxf(m, fmaxf(c[0], c[1])), fmaxf(c[2], c[3]));
@@ -500,12 +555,14 @@ __global__ __launch_bounds__(256, NT > 13 ? 2 : 4) void pair_attn_fwd_mfma_kerne
 
 // RAG: see the forward kernel.  Skipped key tiles contribute nothing (P = 0, G = 0) and their G is NOT written: the caller
 // hands in a zero-initialised G when the batch is ragged.
-template <int NT, bool TILED, bool FULL, int NW, bool RAG>
-__global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ s_in,
-                                                                 const bf16_t* __restrict__ dO, const float* __restrict__ gin, float* __restrict__ gout,
+template <int NT, bool TILED, bool FULL, int NW, bool RAG, typename ST, typename GT>
+__global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const ST* __restrict__ s_in,
+                                                                 const bf16_t* __restrict__ dO, const GT* __restrict__ gin, GT* __restrict__ gout,
                                                                  bf16_t* __restrict__ dqkv, int N, int H, int ld, float scale,
                                                                  int g_in_zero, uint32_t thresh, float dscale, uint64_t seed,
                                                                  uint32_t site, const int* __restrict__ key_tiles) {
+  static_assert(TILED || (sizeof(ST) == 4 && sizeof(GT) == 4), "compact pair tensors exist in the tiled layout only");
+  static_assert(!RAG || sizeof(ST) == 2, "key-tile skipping is built for the compact layout only");
   constexpr int NP = NT * 16;
   constexpr int KSTR = NP + 8;   // row stride (elements) of the d-major K image: 8-byte reads of 8 rows x 2 key groups hit 16 distinct bank pairs
   // raw bf16 images, exactly as loaded.  sQ / sD / sV: [row][8]; the +16 elements are the tail that tr-reads of the last
@@ -567,9 +624,9 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
     const bool qvalid = EDGE ? qi < N : true;
     const long long rowoff = ((long long)bh * N + (qvalid ? qi : 0)) * ld;   // (also the dropout counter base)
     const long long tbase = ((long long)bh * nKB + qb) * nKB * 256 + lane * 4;
-    const float* sin_p = s_in + (TILED ? tbase : rowoff);     // (predicate-off lanes read the row's first 16 bytes: in bounds)
-    const float* gin_p = gin + (TILED ? tbase : rowoff);
-    float* gout_p = gout + (TILED ? tbase : rowoff);
+    const ST* sin_p = s_in + (TILED ? tbase : rowoff);     // (predicate-off lanes read the row's first 16 bytes: in bounds)
+    const GT* gin_p = gin + (TILED ? tbase : rowoff);
+    GT* gout_p = gout + (TILED ? tbase : rowoff);
     constexpr int TSTEP = TILED ? 256 : 16;
     const int goff = TILED ? 0 : 4 * g;
 #define PA_PRED(T) (!TILED ? (qvalid && (T) * 16 + 4 * g < N) \
@@ -594,10 +651,10 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
         if (RAG && t >= kt) {
           c = f32x4{NEG_INF, NEG_INF, NEG_INF, NEG_INF};
         } else if (PA_FAST(t)) {
-          c = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sin_p + t * TSTEP + goff));
+          c = pa_load4_nt(sin_p + t * TSTEP + goff);
         } else {
           const bool inrow = PA_PRED(t);
-          const f32x4 ld4 = *reinterpret_cast<const f32x4*>(sin_p + (inrow ? t * TSTEP + goff : 0));
+          const f32x4 ld4 = pa_load4(sin_p + (inrow ? t * TSTEP + goff : 0));
           c = inrow ? ld4 : f32x4{NEG_INF, NEG_INF, NEG_INF, NEG_INF};
         }
         if (!TILED) {
@@ -661,11 +718,11 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
     auto load_gin = [&](int t) -> f32x4 {
       if (RAG && t >= kt) return f32x4{0.f, 0.f, 0.f, 0.f};
       if (PA_FAST(t)) {
-        const f32x4 ld4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gin_p + (g_in_zero ? 0 : t * TSTEP + goff)));
+        const f32x4 ld4 = pa_load4_nt(gin_p + (g_in_zero ? 0 : t * TSTEP + goff));
         return g_in_zero ? f32x4{0.f, 0.f, 0.f, 0.f} : ld4;
       }
       const bool inrow = PA_PRED(t) && !g_in_zero;
-      const f32x4 ld4 = *reinterpret_cast<const f32x4*>(gin_p + (inrow ? t * TSTEP + goff : 0));
+      const f32x4 ld4 = pa_load4(gin_p + (inrow ? t * TSTEP + goff : 0));
       return inrow ? ld4 : f32x4{0.f, 0.f, 0.f, 0.f};
     };
     f32x4 Gq[PA_LA];
@@ -692,9 +749,9 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
       }
       if (EDGE && !qvalid) G = f32x4{0.f, 0.f, 0.f, 0.f};
       if (PA_FAST(t)) {
-        __builtin_nontemporal_store(G, reinterpret_cast<f32x4*>(gout_p + t * TSTEP + goff));
+        pa_store4_nt(gout_p + t * TSTEP + goff, G);
       } else if (PA_PRED(t)) {
-        __builtin_nontemporal_store(G, reinterpret_cast<f32x4*>(gout_p + t * TSTEP + goff));
+        pa_store4_nt(gout_p + t * TSTEP + goff, G);
       }
       f32x4 Pd;
 #pragma unroll
@@ -791,15 +848,18 @@ static int check_common(const char* fn, int B, int N, int H, int ld) {
   return MMDTI_OK;
 }
 
-extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, const float* bias_in, float* s_out,
+extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, const void* bias_in, void* s_out,
                                    void* o_bf16, const unsigned char* key_pad, int B, int N, int H, int ld,
-                                   float scale, float drop_p, unsigned long long seed, unsigned int site, int tiled,
+                                   float scale, float drop_p, unsigned long long seed, unsigned int site, int layout,
                                    const int* key_tiles, int rag_store) {
+  const int tiled = layout & 1, compact = (layout >> 1) & 1;   // bit 0: tiled planes; bit 1: compact planes (S fp16; tiled only)
   if (int e = check_common("pair_attn_fwd", B, N, H, ld)) return e;
-  MMDTI_REQUIRE(!key_tiles || tiled, "pair_attn_fwd: key_tiles (ragged batches) needs the tiled pair layout");
+  MMDTI_REQUIRE((layout & ~3) == 0 && (!compact || tiled), "pair_attn_fwd: layout must be 0 (row-major fp32), 1 (tiled fp32) or 3 (tiled, fp16 logits)");
+  MMDTI_REQUIRE(!key_tiles || compact, "pair_attn_fwd: key_tiles (ragged batches) needs the compact tiled pair layout (layout 3)");
   MMDTI_REQUIRE(!tiled || (ld % 4 == 0 && N <= 16 * PA_MAX_NT), "pair_attn_fwd: the tiled pair layout needs ld %% 4 == 0 and N <= 272");
   MMDTI_REQUIRE(qkv_bf16 && bias_in && s_out && o_bf16, "pair_attn_fwd: null pointer");
   MMDTI_REQUIRE(aligned16(qkv_bf16), "pair_attn_fwd: qkv must be 16-byte aligned");
+  MMDTI_REQUIRE(!tiled || (aligned16(bias_in) && aligned16(s_out)), "pair_attn_fwd: tiled pair tensors must be 16-byte aligned");
   MMDTI_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "pair_attn_fwd: dropout p out of range");
   const uint32_t th = dropout_thresh(drop_p);
   const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
@@ -809,15 +869,16 @@ extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, 
   if (ld % 4 == 0 && aligned16(bias_in) && aligned16(s_out) && N <= 16 * PA_MAX_NT) {
     const int nqb = (N + 15) / 16;
     dim3 blk(nqb % 3 == 0 ? 192 : (nqb < 4 ? 64 * nqb : 256));
-#define PA_M(NT, TL, FL, RG)                                                                                                \
-  hipLaunchKernelGGL((pair_attn_fwd_mfma_kernel<NT, TL, FL, RG>), grid, blk, 0, s, (const bf16_t*)qkv_bf16, bias_in, s_out,     \
-                     (bf16_t*)o_bf16, key_pad, N, H, ld, scale, th, sc, (uint64_t)seed, (uint32_t)site, key_tiles, rag_store)
+#define PA_M(NT, TL, FL, RG, ST)                                                                                                     \
+  hipLaunchKernelGGL((pair_attn_fwd_mfma_kernel<NT, TL, FL, RG, ST>), grid, blk, 0, s, (const bf16_t*)qkv_bf16, (const ST*)bias_in, \
+                     (ST*)s_out, (bf16_t*)o_bf16, key_pad, N, H, ld, scale, th, sc, (uint64_t)seed, (uint32_t)site, key_tiles, rag_store)
 #define PA_MT(NT)                                                                           \
   do {                                                                                      \
-    if (!tiled) PA_M(NT, false, false, false);                                              \
-    else if (key_tiles) { if (nqb == NT) PA_M(NT, true, true, true); else PA_M(NT, true, false, true); } \
-    else if (nqb == NT) PA_M(NT, true, true, false);                                        \
-    else PA_M(NT, true, false, false);                                                      \
+    if (!tiled) PA_M(NT, false, false, false, float);                                       \
+    else if (!compact) { if (nqb == NT) PA_M(NT, true, true, false, float); else PA_M(NT, true, false, false, float); } \
+    else if (key_tiles) { if (nqb == NT) PA_M(NT, true, true, true, _Float16); else PA_M(NT, true, false, true, _Float16); } \
+    else if (nqb == NT) PA_M(NT, true, true, false, _Float16);                              \
+    else PA_M(NT, true, false, false, _Float16);                                            \
   } while (0)
     if (nqb <= 5) PA_MT(5); else if (nqb <= 9) PA_MT(9); else if (nqb <= 13) PA_MT(13); else PA_MT(17);
 #undef PA_MT
@@ -826,7 +887,7 @@ extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, 
     return MMDTI_OK;
   }
 #define PA_F(NCH)                                                                                                   \
-  hipLaunchKernelGGL((pair_attn_fwd_kernel<NCH>), grid, block, 0, s, (const bf16_t*)qkv_bf16, bias_in, s_out,      \
+  hipLaunchKernelGGL((pair_attn_fwd_kernel<NCH>), grid, block, 0, s, (const bf16_t*)qkv_bf16, (const float*)bias_in, (float*)s_out, \
                      (bf16_t*)o_bf16, key_pad, N, H, ld, scale, th, sc, (uint64_t)seed, (uint32_t)site)
   switch ((N + 63) / 64) {
     case 1: PA_F(1); break;
@@ -840,15 +901,20 @@ extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, 
   return MMDTI_OK;
 }
 
-extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, const float* s, const void* do_bf16,
-                                   float* g, void* dqkv_bf16, int B, int N, int H, int ld, float scale,
-                                   int g_in_zero, float drop_p, unsigned long long seed, unsigned int site, int tiled,
+extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, const void* s, const void* do_bf16,
+                                   void* g, void* dqkv_bf16, int B, int N, int H, int ld, float scale,
+                                   int g_in_zero, float drop_p, unsigned long long seed, unsigned int site, int layout,
                                    const int* key_tiles) {
+  // bit 0: tiled planes; bit 1: compact planes (s is fp16; tiled only); bit 2: g is bf16 (with bit 1 only; no ragged form)
+  const int tiled = layout & 1, compact = (layout >> 1) & 1, g16 = (layout >> 2) & 1;
   if (int e = check_common("pair_attn_bwd", B, N, H, ld)) return e;
-  MMDTI_REQUIRE(!key_tiles || tiled, "pair_attn_bwd: key_tiles (ragged batches) needs the tiled pair layout");
+  MMDTI_REQUIRE((layout & ~7) == 0 && (!compact || tiled) && (!g16 || compact),
+                "pair_attn_bwd: layout must be 0 (row-major fp32), 1 (tiled fp32), 3 (tiled, fp16 logits) or 7 (tiled, fp16 logits, bf16 gradients)");
+  MMDTI_REQUIRE(!key_tiles || (compact && !g16), "pair_attn_bwd: key_tiles (ragged batches) needs layout 3 (tiled, fp16 logits, fp32 gradients)");
   MMDTI_REQUIRE(!tiled || (ld % 4 == 0 && N <= 16 * PA_MAX_NT), "pair_attn_bwd: the tiled pair layout needs ld %% 4 == 0 and N <= 272");
   MMDTI_REQUIRE(qkv_bf16 && s && do_bf16 && g && dqkv_bf16, "pair_attn_bwd: null pointer");
   MMDTI_REQUIRE(aligned16(qkv_bf16) && aligned16(do_bf16) && aligned16(dqkv_bf16), "pair_attn_bwd: alignment");
+  MMDTI_REQUIRE(!tiled || (aligned16(s) && aligned16(g)), "pair_attn_bwd: tiled pair tensors must be 16-byte aligned");
   const uint32_t th = dropout_thresh(drop_p);
   const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   dim3 grid(B * H), block(256);
@@ -856,20 +922,22 @@ extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, 
   if (ld % 4 == 0 && aligned16(s) && aligned16(g) && N <= 16 * PA_MAX_NT) {
     const int nqb = (N + 15) / 16;
     dim3 blk(nqb % 3 == 0 ? 192 : (nqb < 4 ? 64 * nqb : 256));
-#define PA_MB(NT, TL, FL, NWV, RG)                                                                                             \
-  hipLaunchKernelGGL((pair_attn_bwd_mfma_kernel<NT, TL, FL, NWV, RG>), grid, blk, 0, st, (const bf16_t*)qkv_bf16, s,         \
-                     (const bf16_t*)do_bf16, g, g, (bf16_t*)dqkv_bf16, N, H, ld, scale, g_in_zero, th, sc,                   \
-                     (uint64_t)seed, (uint32_t)site, key_tiles)
-#define PA_MBW(NT, TL, FL, RG)                                                              \
+#define PA_MB(NT, TL, FL, NWV, RG, ST, GT)                                                                                     \
+  hipLaunchKernelGGL((pair_attn_bwd_mfma_kernel<NT, TL, FL, NWV, RG, ST, GT>), grid, blk, 0, st, (const bf16_t*)qkv_bf16,      \
+                     (const ST*)s, (const bf16_t*)do_bf16, (const GT*)g, (GT*)g, (bf16_t*)dqkv_bf16, N, H, ld, scale,           \
+                     g_in_zero, th, sc, (uint64_t)seed, (uint32_t)site, key_tiles)
+#define PA_MBW(NT, TL, FL, RG, ST, GT)                                                      \
   do {                                                                                      \
-    if (blk.x == 192) PA_MB(NT, TL, FL, 3, RG); else PA_MB(NT, TL, FL, 4, RG);              \
+    if (blk.x == 192) PA_MB(NT, TL, FL, 3, RG, ST, GT); else PA_MB(NT, TL, FL, 4, RG, ST, GT); \
   } while (0)
 #define PA_MBT(NT)                                                                          \
   do {                                                                                      \
-    if (!tiled) PA_MBW(NT, false, false, false);                                            \
-    else if (key_tiles) { if (nqb == NT) PA_MBW(NT, true, true, true); else PA_MBW(NT, true, false, true); } \
-    else if (nqb == NT) PA_MBW(NT, true, true, false);                                      \
-    else PA_MBW(NT, true, false, false);                                                    \
+    if (!tiled) PA_MBW(NT, false, false, false, float, float);                              \
+    else if (!compact) { if (nqb == NT) PA_MBW(NT, true, true, false, float, float); else PA_MBW(NT, true, false, false, float, float); } \
+    else if (g16) { if (nqb == NT) PA_MBW(NT, true, true, false, _Float16, __bf16); else PA_MBW(NT, true, false, false, _Float16, __bf16); } \
+    else if (key_tiles) { if (nqb == NT) PA_MBW(NT, true, true, true, _Float16, float); else PA_MBW(NT, true, false, true, _Float16, float); } \
+    else if (nqb == NT) PA_MBW(NT, true, true, false, _Float16, float);                     \
+    else PA_MBW(NT, true, false, false, _Float16, float);                                   \
   } while (0)
     if (nqb <= 5) PA_MBT(5); else if (nqb <= 9) PA_MBT(9); else if (nqb <= 13) PA_MBT(13); else PA_MBT(17);
 #undef PA_MBW
@@ -879,8 +947,8 @@ extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, 
     return MMDTI_OK;
   }
 #define PA_B(NCH)                                                                                                   \
-  hipLaunchKernelGGL((pair_attn_bwd_kernel<NCH>), grid, block, 0, st, (const bf16_t*)qkv_bf16, s,                  \
-                     (const bf16_t*)do_bf16, g, (bf16_t*)dqkv_bf16, N, H, ld, scale, g_in_zero, th, sc,            \
+  hipLaunchKernelGGL((pair_attn_bwd_kernel<NCH>), grid, block, 0, st, (const bf16_t*)qkv_bf16, (const float*)s,    \
+                     (const bf16_t*)do_bf16, (float*)g, (bf16_t*)dqkv_bf16, N, H, ld, scale, g_in_zero, th, sc,            \
                      (uint64_t)seed, (uint32_t)site)
   switch ((N + 63) / 64) {
     case 1: PA_B(1); break;

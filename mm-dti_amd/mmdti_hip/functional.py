@@ -180,8 +180,9 @@ class PairEncoderFn(torch.autograd.Function):
     """TransformerEncoderWithPair.forward (models/transformers.py:96-183) minus the discarded aux outputs:
     emb-LN -> dropout -> zero padded rows -> L x [pre-LN pair-bias attention + FFN, S chained] -> final LN.
 
-    inputs : emb [B,N,D] fp32, bias [B,H,N,ld] fp32 (ld >= N; standard layout is ld == N), padding_mask [B,N] bool|None
-    outputs: x [B,N,D] fp32, S_last [B,H,N,ld] fp32 (pre-softmax logits of the last layer, -inf at padded keys),
+    inputs : emb [B,N,D] fp32, bias [B,H,N,ld] fp32 (ld >= N; standard layout is ld == N) or a tiled pair tensor (fp32, or the
+             compact fp16 planes PairBiasFn produces on the hot path), padding_mask [B,N] bool|None
+    outputs: x [B,N,D] fp32, S_last in the layout and dtype of bias (pre-softmax logits of the last layer, -inf at padded keys),
              x_pre [B,N,D] fp32 (stream before the final LN; only the discarded x_norm aux output reads it)
     """
 
@@ -190,8 +191,15 @@ class PairEncoderFn(torch.autograd.Function):
         B, N, D = emb.shape
         H = mod.attention_heads
         tiled = ops.pair_is_tiled(bias)        # [B,H,nt,nt,256] tile layout (see ops.pair_tile) or row-major [B,H,N,ld]
-        if not tiled:
-            key_tiles = None                   # (the row-major kernels have no ragged form)
+        compact = tiled and bias.dtype == torch.float16     # logits chain as fp16 (ops.PAIR_COMPACT, PairBiasFn)
+        if not compact or ops.PAIR_G_BF16:
+            key_tiles = None                   # (only the compact tiled kernels with fp32 gradients have a ragged form)
+        # The gradient of a compact (fp16) bias is NOT an fp16 tensor (fp32, or bf16 on request), and autograd casts whatever a
+        # backward returns to the dtype of the input.  PairBiasFn therefore hangs a slot on the bias it produces; the backward
+        # below leaves the real gradient chain there and hands autograd a zero-storage placeholder.
+        slot = getattr(bias, "_mmdti_grad_slot", None) if compact else None
+        if compact and slot is None and bias.requires_grad:
+            raise ops.MMDTIError("PairEncoderFn: an fp16 pair bias that needs a gradient must come from PairBiasFn")
         ld = ops.pair_ld(N) if tiled else bias.shape[-1]
         M = B * N
         p_emb = mod.emb_dropout if training else 0.0
@@ -199,7 +207,7 @@ class PairEncoderFn(torch.autograd.Function):
         p_att = mod.attention_dropout if training else 0.0
         seed = dropout_state.next_seed()
         sites = _Sites()
-        st = SimpleNamespace(B=B, N=N, D=D, H=H, ld=ld, M=M, seed=seed, p_emb=p_emb, p_res=p_res, p_att=p_att, layers=[], kt=key_tiles)
+        st = SimpleNamespace(B=B, N=N, D=D, H=H, ld=ld, M=M, seed=seed, p_emb=p_emb, p_res=p_res, p_att=p_att, layers=[], kt=key_tiles, slot=slot)
         keep = any(ctx.needs_input_grad)      # inference (torch.no_grad / frozen inputs): nothing is kept for a backward --
                                               # the 15 per-layer logit tensors are freed as the stack advances
         emb = emb.contiguous()
@@ -284,7 +292,8 @@ class PairEncoderFn(torch.autograd.Function):
             do = ops.linear_bwd_input(dy1, wbf16(att.out_proj.weight))
             g_zero = G is None
             if g_zero:
-                G = torch.empty_like(L.s) if st.kt is None else torch.zeros_like(L.s)     # (skipped key tiles of G are never written)
+                # (fp32, or bf16 under MMDTI_PAIR_G_BF16; skipped key tiles of G are never written)
+                G = (torch.empty if st.kt is None else torch.zeros)(L.s.shape, device=L.s.device, dtype=ops.pair_grad_dtype(L.s))
             dqkv = ops.pair_attn_bwd(L.qkv, L.s, do, G, B, N, H, ld, scale, g_zero, st.p_att, seed, L.site_att, key_tiles=st.kt)
             _wgrad(dqkv, L.h1, att.in_proj.weight, att.in_proj.bias)
             dh1 = ops.linear_bwd_input(dqkv, wbf16(att.in_proj.weight))
@@ -310,6 +319,9 @@ class PairEncoderFn(torch.autograd.Function):
         notify_grads_ready(list(eln.parameters()) + ([] if mod.final_layer_norm is None else list(mod.final_layer_norm.parameters())))
         if G is None:
             G = torch.zeros_like(st.bias0)
+        if st.slot is not None:
+            st.slot.g = G                                                            # -> PairBiasFn.backward (see forward)
+            G = torch.zeros((), device=G.device, dtype=torch.float16).expand(G.shape)
         _launch_deferred_wgrads(deferred, deferred_layers)
         _join_side_wgrads()
         _join_stream_after_backward()
@@ -319,7 +331,10 @@ class PairEncoderFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------- Gaussian pair bias
 class PairBiasFn(torch.autograd.Function):
     """gbf -> gbf_proj -> permute (models/mm_model.py:553-556): (dist [B,N,N] f32, edge_type [B,N,N] i64) ->
-    bias [B,H,N,ld] fp32."""
+    bias [B,H,N,ld] fp32 -- or, on the fused hot path (K = F = 128, H = 64, N <= 272), the tiled pair layout, as fp16 unless
+    MMDTI_PAIR_COMPACT=0.  The gradient chain of a compact bias is fp32 (or bf16), not fp16: PairEncoderFn.backward leaves it
+    in the slot hung on the bias (``_mmdti_grad_slot``) and autograd only carries a placeholder; a gradient that reaches this
+    function through autograd from any other consumer is added on top."""
 
     @staticmethod
     def forward(ctx, anchor, dist, edge_type, gbf, proj, ld):
@@ -337,9 +352,10 @@ class PairBiasFn(torch.autograd.Function):
             # take it: their loads become contiguous KiBs); without the complete backward kernel the three [P,128] intermediates
             # are kept for the backward
             keep = any(ctx.needs_input_grad) and not full  # inference: the kernel does not even write the intermediates
+            tiled = ops.pair_tiled_ok(N)
             out, saved = ops.gbf_bias_fwd(dist, edge_type, *args, wbf16(proj.linear1.weight), proj.linear1.bias,
-                                          wbf16(proj.linear2.weight), proj.linear2.bias, ld, save=keep, tiled=ops.pair_tiled_ok(N),
-                                          save_grad=ops.GELU_SAVE_GRAD)
+                                          wbf16(proj.linear2.weight), proj.linear2.bias, ld, save=keep, tiled=tiled,
+                                          save_grad=ops.GELU_SAVE_GRAD, compact=tiled and ops.PAIR_COMPACT)
             feat, u, h = saved if keep else (None, None, None)
             ugrad = ops.GELU_SAVE_GRAD
         else:
@@ -349,14 +365,27 @@ class PairBiasFn(torch.autograd.Function):
             ugrad = ops.GELU_SAVE_GRAD
             o = ops.linear_fwd(h, wbf16(proj.linear2.weight), proj.linear2.bias, out_dtype=F32)
             out = ops.pair_permute_fwd(o, B, N, H, ld)
-        ctx.st = SimpleNamespace(dist=dist, et=edge_type, feat=feat, u=u, h=h, B=B, N=N, H=H, ld=ld, fused=fused, ugrad=ugrad, full=full)
+        ctx.st = SimpleNamespace(dist=dist, et=edge_type, feat=feat, u=u, h=h, B=B, N=N, H=H, ld=ld, fused=fused, ugrad=ugrad, full=full, slot=None)
         ctx.gbf, ctx.proj = gbf, proj
+        if out.dtype == torch.float16:
+            ctx.st.slot = out._mmdti_grad_slot = SimpleNamespace(g=None)
         return out
 
     @staticmethod
     def backward(ctx, g):
         st, gbf, proj = ctx.st, ctx.gbf, ctx.proj
         ps = [gbf.mul.weight, gbf.bias.weight, gbf.means.weight, gbf.stds.weight]
+        if st.slot is not None:
+            # compact bias: the gradient chain sits in the slot (PairEncoderFn.backward); what autograd delivered is a
+            # zero-storage placeholder unless another consumer of the bias contributed a real fp16 gradient
+            real = any(sd != 0 for sd in g.stride())
+            chain, st.slot.g = st.slot.g, None
+            if chain is None:
+                g = g.float()
+            elif real:
+                g = chain.float().add_(g) if chain.dtype != F32 else chain.add_(g)
+            else:
+                g = chain
         if st.full:
             # ONE kernel: recompute, both dX products, GELU', the Gaussian backward and all four weight / bias gradients
             l1, l2 = proj.linear1, proj.linear2

@@ -13,6 +13,7 @@ from ._abi import lib, MMDTIError
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+F16 = torch.float16
 
 ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_TANH, ACT_GELU_G, ACT_MUL_AUX = 0, 1, 2, 3, 4, 5
 # forward GELU that saves gelu'(u) instead of u, backward = one multiply (MMDTI_GELU_SAVE_GRAD=0: save u, evaluate gelu' in the backward)
@@ -331,20 +332,23 @@ def gbf_features_bwd(dist, edge_type, mul, bias, means, stds, dfeat, dmul, dbias
                                  dstds.data_ptr())
 
 
-def gbf_bias_fwd(dist, edge_type, mul, bias, means, stds, w1, b1, w2, b2, ld, save=True, tiled=False, save_grad=False):
-    """Fused gbf + gbf_proj + permute -> (out [B,H,N,ld] fp32 -- or the tiled pair layout --, (feat, u, h) [P,128] bf16 or None)."""
+def gbf_bias_fwd(dist, edge_type, mul, bias, means, stds, w1, b1, w2, b2, ld, save=True, tiled=False, save_grad=False, compact=False):
+    """Fused gbf + gbf_proj + permute -> (out [B,H,N,ld] fp32 -- or the tiled pair layout, fp32 or (compact) fp16 --,
+    (feat, u, h) [P,128] bf16 or None)."""
+    if compact and not tiled:
+        raise MMDTIError("gbf_bias_fwd: compact pair planes exist in the tiled layout only")
     _chk(dist, F32, "gbf.dist"); _chk_edge(edge_type); _chk(w1, BF16, "gbf.w1"); _chk(w2, BF16, "gbf.w2")
     B, N, _ = dist.shape
     Hh, Fh = w2.shape
     K = w1.shape[1]
-    out = pair_empty(B, Hh, N, dist.device, tiled) if tiled else torch.empty(B, Hh, N, ld, device=dist.device, dtype=F32)
+    out = pair_empty(B, Hh, N, dist.device, tiled, dtype=F16 if compact else F32) if tiled else torch.empty(B, Hh, N, ld, device=dist.device, dtype=F32)
     saved = tuple(torch.empty(B * N * N, 128, device=dist.device, dtype=BF16) for _ in range(3)) if save else None
     t0 = kernel_timer.begin("gbf_bias_fwd")
     lib().mmdti_gbf_bias_fwd(_stream(), dist.data_ptr(), edge_type.data_ptr(), edge_type.element_size(), mul.data_ptr(), bias.data_ptr(), means.data_ptr(), stds.data_ptr(),
                              w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), B, N, ld, K, Fh, Hh, mul.numel(), out.data_ptr(),
-                             *([t.data_ptr() for t in saved] if save else [0, 0, 0]), int(tiled) | (2 if save_grad else 0))
-    # algorithmic bytes per atom pair: 4 (distance) + edge type in, 64 heads x 4 B of bias out (+ 3 x 256 B kept for the backward)
-    kernel_timer.end("gbf_bias_fwd", t0, float(B * N * N) * (4 + edge_type.element_size() + Hh * 4 + (3 * 256 if save else 0)))
+                             *([t.data_ptr() for t in saved] if save else [0, 0, 0]), int(tiled) | (2 if save_grad else 0) | (4 if compact else 0))
+    # algorithmic bytes per atom pair: 4 (distance) + edge type in, 64 heads x 4 B (compact: 2 B) of bias out (+ 3 x 256 B kept for the backward)
+    kernel_timer.end("gbf_bias_fwd", t0, float(B * N * N) * (4 + edge_type.element_size() + Hh * out.element_size() + (3 * 256 if save else 0)))
     return out, saved
 
 
@@ -359,7 +363,7 @@ def gbf_bias_bwd(g, dist, edge_type, mul, bias, means, stds, w1, w2, u, ld, dmul
     _chk_edge(edge_type)
     lib().mmdti_gbf_bias_bwd(_stream(), g.data_ptr(), dist.data_ptr(), edge_type.data_ptr(), edge_type.element_size(), mul.data_ptr(), bias.data_ptr(), means.data_ptr(),
                              stds.data_ptr(), w1.data_ptr(), w2.data_ptr(), u.data_ptr(), B, N, ld, w1.shape[1], Fh, Hh, mul.numel(),
-                             int(pair_is_tiled(g)) | (2 if u_is_grad else 0), do.data_ptr(), du.data_ptr(), dmul.data_ptr(), dbias.data_ptr(), dmeans.data_ptr(),
+                             _pair_layout_g(g, "gbf_bias_bwd") | (2 if u_is_grad else 0), do.data_ptr(), du.data_ptr(), dmul.data_ptr(), dbias.data_ptr(), dmeans.data_ptr(),
                              dstds.data_ptr())
     # per pair: G 64 x 4 B + saved gelu' 256 B + distance / edge type in, do 128 B + du 256 B out
     kernel_timer.end("gbf_bias_bwd", t0, float(P) * (Hh * g.element_size() + 256 + 4 + edge_type.element_size() + 2 * Hh + 2 * Fh))
@@ -372,7 +376,7 @@ GBF_FULL_MAXE = 1536       # edge-type tables the complete backward kernel keeps
 def gbf_bias_bwd_full(g, dist, edge_type, mul, bias, means, stds, w1, b1, w2, ld, dw1, db1, dw2, db2, dmul, dbias, dmeans, dstds):
     """The whole backward of :func:`gbf_bias_fwd` in one kernel, nothing saved by the forward: all eight parameter gradients
     (fp32) are accumulated (+=) into the given buffers."""
-    _chk(g, F32, "gbf.g"); _chk(dist, F32, "gbf.dist"); _chk_edge(edge_type); _chk(w1, BF16, "gbf.w1"); _chk(w2, BF16, "gbf.w2")
+    _chk(dist, F32, "gbf.dist"); _chk_edge(edge_type); _chk(w1, BF16, "gbf.w1"); _chk(w2, BF16, "gbf.w2")
     for t, nm in ((dw1, "dw1"), (db1, "db1"), (dw2, "dw2"), (db2, "db2"), (dmul, "dmul"), (dbias, "dbias"), (dmeans, "dmeans"), (dstds, "dstds")):
         _chk(t, F32, "gbf." + nm)
     B, N, _ = dist.shape
@@ -381,7 +385,7 @@ def gbf_bias_bwd_full(g, dist, edge_type, mul, bias, means, stds, w1, b1, w2, ld
     t0 = kernel_timer.begin("gbf_bias_bwd")
     lib().mmdti_gbf_bias_bwd_full(_stream(), g.data_ptr(), dist.data_ptr(), edge_type.data_ptr(), edge_type.element_size(), mul.data_ptr(),
                                   bias.data_ptr(), means.data_ptr(), stds.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), B, N, ld,
-                                  w1.shape[1], Fh, Hh, mul.numel(), int(pair_is_tiled(g)), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(),
+                                  w1.shape[1], Fh, Hh, mul.numel(), _pair_layout_g(g, "gbf_bias_bwd_full"), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(),
                                   db2.data_ptr(), dmul.data_ptr(), dbias.data_ptr(), dmeans.data_ptr(), dstds.data_ptr())
     # Work unit: MFMA flops (the kernel reads 268 B per atom pair and is nowhere near HBM): per pair the recomputed
     # pre-activation (2*F*K), dO.W2 (2*H*F), du.W1 (2*F*K) and the two weight-gradient products (2*F*K + 2*H*F)
@@ -430,10 +434,44 @@ def pair_tiled_ok(N):
     return N <= 272
 
 
-def pair_empty(B, H, N, device, tiled, zero=False):
+def pair_empty(B, H, N, device, tiled, zero=False, dtype=F32):
     nt = pair_tiles(N)
     shape = (B, H, nt, nt, 256) if tiled else (B, H, N, pair_ld(N))
-    return (torch.zeros if zero else torch.empty)(shape, device=device, dtype=F32)
+    return (torch.zeros if zero else torch.empty)(shape, device=device, dtype=dtype)
+
+
+# Element types.  fp32 everywhere, or -- COMPACT tiled planes, what the hot path runs -- the logits chain as fp16
+# (include/mmdti_hip.h, mmdti_pair_attn_fwd: layout 3).  The gradient chain stays fp32 unless MMDTI_PAIR_G_BF16=1 (layout 7:
+# measured to cost gradient fidelity).  The dtype of a tensor says which form it is.
+PAIR_COMPACT = os.environ.get("MMDTI_PAIR_COMPACT", "1") != "0"
+PAIR_G_BF16 = os.environ.get("MMDTI_PAIR_G_BF16", "0") == "1"
+
+
+def pair_grad_dtype(s):
+    """dtype of the gradient chain G that goes with a logits tensor s."""
+    return BF16 if (s.dtype == F16 and PAIR_G_BF16) else F32
+
+
+def _pair_layout_s(s, what):
+    """layout code of a logits-like pair tensor: 0 row-major fp32, 1 tiled fp32, 3 tiled fp16."""
+    tiled = pair_is_tiled(s)
+    if s.dtype == F16:
+        if not tiled:
+            raise MMDTIError(f"{what}: fp16 pair logits exist in the tiled layout only")
+        return 3
+    _chk(s, F32, what)
+    return int(tiled)
+
+
+def _pair_layout_g(g, what):
+    """layout / flag bits of a gradient pair tensor: 0 row-major fp32, 1 tiled fp32, 5 (bits 0 and 2) tiled bf16."""
+    tiled = pair_is_tiled(g)
+    if g.dtype == BF16:
+        if not tiled:
+            raise MMDTIError(f"{what}: bf16 pair gradients exist in the tiled layout only")
+        return 5
+    _chk(g, F32, what)
+    return int(tiled)
 
 
 def _tile_index(N, device):
@@ -470,7 +508,8 @@ def set_pair_kept(frac):
 
 
 def pair_attn_fwd(qkv, bias_in, key_pad, B, N, H, ld, scale, drop_p=0.0, seed=0, site=0, key_tiles=None, rag_store=False):
-    _chk(qkv, BF16, "pair_attn.qkv"); _chk(bias_in, F32, "pair_attn.bias")
+    _chk(qkv, BF16, "pair_attn.qkv")
+    layout = _pair_layout_s(bias_in, "pair_attn.bias")
     tiled = pair_is_tiled(bias_in)
     s_out = torch.empty_like(bias_in) if tiled else torch.empty(B, H, N, ld, device=qkv.device, dtype=F32)
     o = torch.empty(B * N, H * 8, device=qkv.device, dtype=BF16)
@@ -479,24 +518,29 @@ def pair_attn_fwd(qkv, bias_in, key_pad, B, N, H, ld, scale, drop_p=0.0, seed=0,
     if key_tiles is not None:
         _chk(key_tiles, torch.int32, "pair_attn.key_tiles")
     lib().mmdti_pair_attn_fwd(_stream(), qkv.data_ptr(), bias_in.data_ptr(), s_out.data_ptr(), o.data_ptr(), _p(kp), B, N, H, ld,
-                              float(scale), float(drop_p), int(seed), int(site), int(tiled), _p(key_tiles), int(rag_store))
-    # per (pair, head): read the bias / previous logits 4 B, write S 4 B; per (token, head): q|k|v in (48 B), o out (16 B)
-    kept = _pair_kept if key_tiles is not None else 1.0
-    kernel_timer.end("pair_attn_fwd", t0, float(B) * H * (N * N * (4.0 * kept + 4.0 * (1.0 if rag_store else kept)) + N * 64.0))
+                              float(scale), float(drop_p), int(seed), int(site), layout, _p(key_tiles), int(rag_store))
+    # per (pair, head): read the bias / previous logits, write S (4 B each; compact 2 B); per (token, head): q|k|v in (48 B), o out (16 B)
+    kept, es = _pair_kept if key_tiles is not None else 1.0, float(s_out.element_size())
+    kernel_timer.end("pair_attn_fwd", t0, float(B) * H * (N * N * (es * kept + es * (1.0 if rag_store else kept)) + N * 64.0))
     return s_out, o
 
 
 def pair_attn_bwd(qkv, s, do, g, B, N, H, ld, scale, g_in_zero, drop_p=0.0, seed=0, site=0, key_tiles=None):
     dqkv = torch.empty_like(qkv)
     tiled = pair_is_tiled(s)
-    if pair_is_tiled(g) != tiled:
-        raise MMDTIError("pair_attn_bwd: S and G must share one pair layout")
+    layout = _pair_layout_s(s, "pair_attn_bwd.s")
+    if pair_is_tiled(g) != tiled or not (g.dtype == F32 or (g.dtype == BF16 and s.dtype == F16)):
+        raise MMDTIError("pair_attn_bwd: S and G must share one pair layout (fp32 gradients, or bf16 gradients with fp16 logits)")
+    if g.dtype == BF16:
+        if key_tiles is not None:
+            raise MMDTIError("pair_attn_bwd: the ragged form (key_tiles) needs fp32 gradients")
+        layout |= 4
     t0 = kernel_timer.begin("pair_attn_bwd")
     lib().mmdti_pair_attn_bwd(_stream(), qkv.data_ptr(), s.data_ptr(), do.data_ptr(), g.data_ptr(), dqkv.data_ptr(), B, N, H, ld,
-                              float(scale), int(g_in_zero), float(drop_p), int(seed), int(site), int(tiled), _p(key_tiles))
-    # per (pair, head): read S 4 B, read + write G (4 B each; the first layer reads none); per (token, head): 7 x 16 B rows
+                              float(scale), int(g_in_zero), float(drop_p), int(seed), int(site), layout, _p(key_tiles))
+    # per (pair, head): read S, read + write G (4 B each, compact 2 B; the first layer reads no G); per (token, head): 7 x 16 B rows
     kept = _pair_kept if key_tiles is not None else 1.0
-    kernel_timer.end("pair_attn_bwd", t0, float(B) * H * (N * N * kept * (4.0 + g.element_size() * (1 if g_in_zero else 2)) + N * 112.0))
+    kernel_timer.end("pair_attn_bwd", t0, float(B) * H * (N * N * kept * (s.element_size() + g.element_size() * (1 if g_in_zero else 2)) + N * 112.0))
     return dqkv
 
 

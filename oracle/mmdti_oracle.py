@@ -113,8 +113,25 @@ class ModelCfg:
 # distance between the bf16 path and the fp32 reference): "w" GEMM weights, "x" GEMM inputs (LayerNorm / attention /
 # GELU outputs), "qkv" the stored q|k|v of tower 1, "qkv2" q,k,v of towers 2 / fusion, "p" their attention probabilities,
 # "proj" per-token InfoNCE projections (only when the head projects before pooling).
-ALL_SITES = frozenset({"w", "x", "qkv", "qkv2", "p", "proj"})
+ALL_SITES = frozenset({"w", "x", "qkv", "qkv2", "p", "proj", "s16"})
+# "s16": the pair logits of tower 1 (gbf bias, then every layer's S) are carried as fp16, rounded once per layer, and each
+# layer's softmax runs on the rounded value -- the HIP path's compact pair planes, and what the reference's AMP path does
+# (autocast makes attn_weights fp16).  Cost at the reference depth: profiles/r02_s16_budget_cpu.json.
 BF16_SITES = set(ALL_SITES)
+
+
+class _RoundF16(torch.autograd.Function):
+    """fp16 storage of a value (round to nearest even, saturating at the largest finite fp16; -inf stays -inf) whose
+    gradient is NOT stored as fp16: a plain ``x.half().float()`` would send the gradient back through an fp16 cast and
+    flush the small ones -- the HIP path keeps that chain in fp32."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return torch.clamp(x, max=65504.0).to(torch.float16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
 
 
 def _r(x: Tensor, on: bool, site: str = "x") -> Tensor:
@@ -254,7 +271,7 @@ def unimol_layer(x: Tensor, bias: Tensor, P: Params, pre: str, cfg: UniMolCfg,
     v = heads(v)
     S = torch.bmm(q, k.transpose(1, 2)) + bias
     if bf16 and "s16" in BF16_SITES:
-        S = S.to(torch.float16).to(torch.float32)      # pair logits carried between layers as fp16 (what the reference's AMP path does)
+        S = _RoundF16.apply(S)      # pair logits carried between layers as fp16 (what the reference's AMP path does)
     Pm = dropout(torch.softmax(S, dim=-1), cfg.attn_dropout, training)
     o = torch.bmm(Pm, v).view(B, H, N, hd).transpose(1, 2).contiguous().view(B, N, D)
     o = linear(o, P[pre + "self_attn.out_proj.weight"], P[pre + "self_attn.out_proj.bias"], bf16)
@@ -282,6 +299,8 @@ def unimol_encoder(emb: Tensor, attn_mask: Tensor, padding_mask: Optional[Tensor
         x = x * (1 - padding_mask.unsqueeze(-1).type_as(x))
     input_attn_mask = attn_mask
     bias = attn_mask
+    if bf16 and "s16" in BF16_SITES:
+        bias = _RoundF16.apply(bias)
     if padding_mask is not None:
         bias = bias.view(B, H, N, N).masked_fill(padding_mask.view(B, 1, 1, N).bool(), float("-inf")).view(B * H, N, N)
         input_attn_mask = bias          # reference aliasing: the in-place fill is visible in input_attn_mask too

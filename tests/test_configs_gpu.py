@@ -65,7 +65,8 @@ def test_unimol_tower_at_reference_crop_sizes(N):
     eo, so = O.unimol_encoder(xo, bo, batch["src_tokens"].eq(0), P, ocfg.unimol, bf16=True, with_aux=False)
     (eo * g).sum().backward()
     assert rel_l2(enc, eo) < 3e-3, rel_l2(enc, eo)
-    s_hip = (ops.pair_untile(s_last, N) if tiled else s_last[..., :N]).cpu()
+    s_hip = (ops.pair_untile(s_last, N) if tiled else s_last[..., :N]).float().cpu()
+    assert s_last.dtype == (torch.float16 if tiled else torch.float32)         # compact planes on the tiled hot path
     so = so.view(2, 64, N, N)
     fin = torch.isfinite(so)
     assert torch.equal(torch.isfinite(s_hip), fin) and rel_l2(s_hip[fin], so[fin]) < 3e-3

@@ -288,12 +288,71 @@ def test_pair_tile_roundtrip(ops):
     assert t[1, 2, 1, 2, ((35 % 16) // 4 * 16 + 20 % 16) * 4 + 35 % 4].item() == x[1, 2, 20, 35].item()
 
 
+@pytest.mark.parametrize("B,N,H,p", [(2, 7, 8, 0.0), (3, 70, 4, 0.0), (2, 130, 64, 0.1), (1, 210, 64, 0.0), (2, 240, 8, 0.1), (1, 258, 64, 0.0), (1, 272, 4, 0.0)])
+def test_pair_attn_compact_planes_are_the_fp32_kernels_plus_rounding(ops, B, N, H, p):
+    """COMPACT tiled planes (layout 3: logits chain fp16, gradient chain fp32 -- the hot path; layout 7: gradient chain bf16,
+    opt-in) against the fp32 tiled kernels, which the test above pins to autograd.  The relations are exact, bit for bit:
+      forward   S16 = fp16_rne(S32) when both start from the same fp16 bias;  O16 = the fp32 kernel's O when that is handed
+                the ROUNDED logits (q = 0, bias = S16): the layer's own softmax runs on what is stored;
+      backward  (S16, G fp32) -> dqkv and G identical to the fp32 kernel on S16 widened to fp32;
+                (S16, G bf16) -> dqkv identical too -- the products use the unrounded G of the layer -- and G_out = bf16_rne(G_out32)."""
+    D, ld, scale = H * 8, ops.pair_ld(N), 8 ** -0.5
+    kw = dict(drop_p=p, seed=11, site=2)
+    qkv = dev(bf(torch.randn(B, N, 3 * D, generator=G(1)))).view(B * N, 3 * D)
+    dO = dev(bf(torch.randn(B, N, D, generator=G(3)))).view(B * N, D)
+    key_pad = torch.zeros(B, N, dtype=torch.bool)
+    key_pad[0, N - max(1, N // 3):] = True
+    bias = torch.zeros(B, H, N, ld); bias[..., :N] = 3.0 * torch.randn(B, H, N, N, generator=G(2))
+    b16 = ops.pair_tile(dev(bias), N, float("-inf")).half()
+    b32 = b16.float()
+    s16, o16 = ops.pair_attn_fwd(qkv, b16, dev(key_pad), B, N, H, ld, scale, **kw)
+    s32, o32 = ops.pair_attn_fwd(qkv, b32, dev(key_pad), B, N, H, ld, scale, **kw)
+    assert s16.dtype == torch.float16 and ops.pair_is_tiled(s16) and s32.dtype == torch.float32
+    un = lambda t: ops.pair_untile(t, N)                                           # (slots with q >= N or k >= N are never read)
+    assert torch.equal(un(s16), un(s32).half())
+    assert float((un(s16).float() - un(s32))[torch.isfinite(un(s32))].abs().max()) > 0       # ... and the rounding is really there
+    q0 = qkv.clone(); q0[:, :D] = 0
+    _, o_chk = ops.pair_attn_fwd(q0, s16.float(), None, B, N, H, ld, scale, **kw)
+    assert torch.equal(o16, o_chk)
+    close(o16.float().cpu(), o32.float().cpu(), 3e-2, 3e-2)                                   # (and close to the unrounded layer)
+    # a second layer on top: reads fp16, writes fp16
+    s16b, o16b = ops.pair_attn_fwd(qkv, s16, None, B, N, H, ld, scale, **kw)
+    s32b, _ = ops.pair_attn_fwd(qkv, s16.float(), None, B, N, H, ld, scale, **kw)
+    assert torch.equal(un(s16b), un(s32b).half())
+    # backward
+    g_in = torch.zeros(B, H, N, ld); g_in[..., :N] = torch.randn(B, H, N, N, generator=G(4)).masked_fill(key_pad.view(B, 1, 1, N), 0.0)
+    g16 = ops.pair_tile(dev(g_in), N, 0.0).bfloat16()
+    g32 = g16.float(); g32c = g32.clone()
+    dq16 = ops.pair_attn_bwd(qkv, s16, dO, g16, B, N, H, ld, scale, False, **kw)
+    dq32 = ops.pair_attn_bwd(qkv, s16.float(), dO, g32, B, N, H, ld, scale, False, **kw)
+    dq32c = ops.pair_attn_bwd(qkv, s16, dO, g32c, B, N, H, ld, scale, False, **kw)            # the default pairing: fp16 logits, fp32 gradients
+    assert torch.equal(dq32c, dq32) and torch.equal(un(g32c), un(g32))
+    assert g16.dtype == torch.bfloat16 and torch.equal(dq16, dq32)
+    assert torch.equal(un(g16), un(g32).bfloat16())
+    gz16 = torch.full_like(g16, 7.0); gz32 = torch.full_like(g32, 7.0)
+    dqz16 = ops.pair_attn_bwd(qkv, s16, dO, gz16, B, N, H, ld, scale, True, **kw)
+    dqz32 = ops.pair_attn_bwd(qkv, s16.float(), dO, gz32, B, N, H, ld, scale, True, **kw)
+    assert torch.equal(dqz16, dqz32) and torch.equal(un(gz16), un(gz32).bfloat16())
+    # saturation instead of +inf: logits beyond the fp16 range stay finite
+    big = b16.clone(); big[0, 0, 0, 0, :4] = 65504.0
+    qbig = (qkv.float() * 16).bfloat16()
+    sbig, obig = ops.pair_attn_fwd(qbig, big, None, B, N, H, ld, scale)
+    assert not torch.isnan(obig.float()).any() and not torch.isposinf(un(sbig).float()).any()
+    # mismatched element types are refused
+    with pytest.raises(ops.MMDTIError):
+        ops.pair_attn_bwd(qkv, s32, dO, g16, B, N, H, ld, scale, False)            # bf16 gradients only go with fp16 logits
+    with pytest.raises(ops.MMDTIError):
+        ops.pair_attn_bwd(qkv, s16, dO, g16, B, N, H, ld, scale, False, key_tiles=torch.ones(B, dtype=torch.int32, device="cuda"))
+    with pytest.raises(ops.MMDTIError):
+        ops.pair_attn_fwd(qkv, dev(bias).half(), None, B, N, H, ld, scale)         # fp16 row-major planes do not exist
+
+
 @pytest.mark.parametrize("B,N,H,lens,p", [(4, 130, 8, (130, 37, 64, 5), 0.0), (3, 100, 64, (100, 17, 81), 0.1), (2, 258, 8, (40, 258), 0.0), (2, 16, 8, (3, 16), 0.0)])
 def test_pair_attn_ragged_key_tile_skipping_equals_dense(ops, B, N, H, lens, p):
-    """Ragged batches (tiled layout): with key_tiles = ceil(length / 16) per molecule the kernels neither load, compute nor store
-    the all-padding key tiles.  Everything that is defined must equal the dense run bit for bit: O, dqkv, S and G on the kept
-    tiles; rag_store writes -inf into the skipped S tiles (the dense run has -inf there too); skipped G tiles stay as handed in
-    (zero).  Pad QUERY rows are computed in both."""
+    """Ragged batches (compact tiled planes): with key_tiles = ceil(length / 16) per molecule the kernels neither load, compute
+    nor store the all-padding key tiles.  Everything that is defined must equal the dense run bit for bit: O, dqkv, S and G on
+    the kept tiles; rag_store writes -inf into the skipped S tiles (the dense run has -inf there too); skipped G tiles stay as
+    handed in (zero).  Pad QUERY rows are computed in both."""
     D, ld, scale = H * 8, ops.pair_ld(N), 8 ** -0.5
     nt = ops.pair_tiles(N)
     qkv = dev(bf(torch.randn(B, N, 3 * D, generator=G(1)))).view(B * N, 3 * D)
@@ -302,17 +361,18 @@ def test_pair_attn_ragged_key_tile_skipping_equals_dense(ops, B, N, H, lens, p):
     for b, n in enumerate(lens):
         key_pad[b, n:] = True
     bias = torch.zeros(B, H, N, ld); bias[..., :N] = torch.randn(B, H, N, N, generator=G(2))
-    bias_t = ops.pair_tile(dev(bias), N, float("-inf"))
+    bias_t = ops.pair_tile(dev(bias), N, float("-inf")).half()
     kt = torch.tensor([(n + 15) // 16 for n in lens], dtype=torch.int32, device="cuda")
     kw = dict(drop_p=p, seed=5, site=3)
 
-    def rows(t):                                                                # -> [B,H,N,nt,16]: the N x N block by key tile (slots with q >= N or k >= N are never written or read)
+    def rows(t):                                                                # -> [B,H,nt,N,16]: the N x N block by key tile (slots with q >= N or k >= N are never written or read)
         u = torch.zeros(B, H, N, nt * 16, device=t.device)
-        u[..., :N] = ops.pair_untile(t, N)
-        return u.view(B, H, N, nt, 16).transpose(2, 3)                          # [B,H,nt(key tile),N,16]: index 2 = key tile like the raw layout's index 3
+        u[..., :N] = ops.pair_untile(t, N).float()
+        return u.view(B, H, N, nt, 16).transpose(2, 3)
 
     s_d, o_d = ops.pair_attn_fwd(qkv, bias_t, dev(key_pad), B, N, H, ld, scale, **kw)
     s_r, o_r = ops.pair_attn_fwd(qkv, bias_t, dev(key_pad), B, N, H, ld, scale, key_tiles=kt, rag_store=True, **kw)
+    assert s_r.dtype == torch.float16
     assert torch.equal(o_r, o_d) and torch.equal(rows(s_r), rows(s_d))          # (skipped tiles: -inf in both)
     s_n, o_n = ops.pair_attn_fwd(qkv, bias_t, dev(key_pad), B, N, H, ld, scale, key_tiles=kt, rag_store=False, **kw)
     assert torch.equal(o_n, o_d)
@@ -328,7 +388,8 @@ def test_pair_attn_ragged_key_tile_skipping_equals_dense(ops, B, N, H, lens, p):
     assert torch.equal(o2_r, o2_d) and torch.equal(rows(s2_r), rows(s2_d))
     # backward
     g_in = torch.zeros(B, H, N, ld); g_in[..., :N] = torch.randn(B, H, N, N, generator=G(4)).masked_fill(key_pad.view(B, 1, 1, N), 0.0)
-    g_d = ops.pair_tile(dev(g_in), N, 0.0); g_r = g_d.clone()
+    g_0 = ops.pair_tile(dev(g_in), N, 0.0)
+    g_d = g_0.clone(); g_r = g_0.clone()
     dq_d = ops.pair_attn_bwd(qkv, s_d, dO, g_d, B, N, H, ld, scale, False, **kw)
     dq_r = ops.pair_attn_bwd(qkv, s_poison, dO, g_r, B, N, H, ld, scale, False, key_tiles=kt, **kw)
     assert torch.equal(dq_r, dq_d)
@@ -336,8 +397,8 @@ def test_pair_attn_ragged_key_tile_skipping_equals_dense(ops, B, N, H, lens, p):
         k = int(kt[b])
         assert torch.equal(rows(g_r)[b, :, :k], rows(g_d)[b, :, :k])
         if k < nt:
-            assert float(rows(g_d)[b, :, k:].abs().max()) == 0.0                   # (what the dense run computes there is exactly 0 ...)
-            assert torch.equal(rows(g_r)[b, :, k:], rows(ops.pair_tile(dev(g_in), N, 0.0))[b, :, k:])      # (... and the ragged run leaves them untouched)
+            assert float(rows(g_d)[b, :, k:].abs().max()) == 0.0                # (what the dense run computes there is exactly 0 ...)
+            assert torch.equal(rows(g_r)[b, :, k:], rows(g_0)[b, :, k:])        # (... and the ragged run leaves them untouched)
     gz = torch.zeros_like(g_d)
     dq_z = ops.pair_attn_bwd(qkv, s_poison, dO, gz, B, N, H, ld, scale, True, key_tiles=kt, **kw)
     gz_d = torch.full_like(g_d, 7.0)
@@ -345,6 +406,8 @@ def test_pair_attn_ragged_key_tile_skipping_equals_dense(ops, B, N, H, lens, p):
     assert torch.equal(dq_z, dq_zd)
     for b in range(B):
         assert torch.equal(rows(gz)[b, :, :int(kt[b])], rows(gz_d)[b, :, :int(kt[b])])
+    with pytest.raises(ops.MMDTIError):                                         # the fp32 planes have no ragged form
+        ops.pair_attn_fwd(qkv, bias_t.float(), dev(key_pad), B, N, H, ld, scale, key_tiles=kt)
 
 
 def test_pair_attn_dropout(ops):
@@ -852,6 +915,50 @@ def test_gbf_bias_complete_backward_matches_chain_and_autograd(ops, B, N, tiled,
         a, b_ = (got[n] - 0.5).cpu(), want[n]
         r = float((a - b_).norm() / (b_.norm() + 1e-12))
         assert r < 3e-2, (n, "vs autograd", r)
+
+
+@pytest.mark.parametrize("B,N", [(2, 13), (3, 37), (1, 130), (1, 1)])
+def test_gbf_bias_compact_planes(ops, B, N):
+    """Compact tiled planes at the two ends of the pair chain: the fused pair-bias forward writes fp16 = fp16_rne(its fp32
+    output) with -inf in every pad slot, and both backward forms read the gradient as bf16 exactly as they read the same values
+    in fp32."""
+    K, Fh, H, E = 128, 128, 64, 31 * 31
+    ld = ops.pair_ld(N)
+    gen = G(29)
+    dist = torch.rand(B, N, N, generator=gen) * 8
+    et = torch.randint(0, E, (B, N, N), generator=gen)
+    mul, bias = 1 + 0.1 * torch.randn(E, generator=gen), 0.1 * torch.randn(E, generator=gen)
+    means, stds = torch.rand(K, generator=gen) * 3, torch.rand(K, generator=gen) * 3 - 1.5
+    w1, b1 = dev(bf(torch.randn(Fh, K, generator=gen) * 0.2)), dev(torch.randn(Fh, generator=gen) * 0.1)
+    w2, b2 = dev(bf(torch.randn(H, Fh, generator=gen) * 0.2)), dev(torch.randn(H, generator=gen) * 0.1)
+    d = [dev(t) for t in (dist, et.to(torch.int16), mul, bias, means, stds)]
+    o32, _ = ops.gbf_bias_fwd(*d, w1, b1, w2, b2, ld, save=False, tiled=True)
+    o16, saved = ops.gbf_bias_fwd(*d, w1, b1, w2, b2, ld, save=True, tiled=True, compact=True)
+    assert o16.dtype == torch.float16 and o16.shape == o32.shape
+    assert torch.equal(o16, o32.half())                                # every slot, pads (-inf) included
+    idx = ops._tile_index(N, o16.device).reshape(-1)
+    pads = torch.ones(o16[0, 0].numel(), dtype=torch.bool, device=o16.device); pads[idx] = False
+    assert torch.isneginf(o16.reshape(B, H, -1)[:, :, pads]).all()
+    with pytest.raises(ops.MMDTIError):
+        ops.gbf_bias_fwd(*d, w1, b1, w2, b2, ld, save=False, tiled=False, compact=True)
+    g32 = ops.pair_tile(dev(torch.randn(B, H, N, N, generator=gen)), N, 0.0).bfloat16().float()
+    g16 = g32.bfloat16()
+    # round-1 chain: per-pair half
+    feat, u, h = saved
+    gr_a = [torch.zeros_like(t) for t in d[2:]]; gr_b = [torch.zeros_like(t) for t in d[2:]]
+    do_a, du_a = ops.gbf_bias_bwd(g32, *d, w1, w2, u, ld, *gr_a)
+    do_b, du_b = ops.gbf_bias_bwd(g16, *d, w1, w2, u, ld, *gr_b)
+    assert torch.equal(do_a, do_b) and torch.equal(du_a, du_b)
+    # complete kernel (fp32 atomics at the flush: equal up to summation order)
+    names = ("dw1", "db1", "dw2", "db2", "dmul", "dbias", "dmeans", "dstds")
+    shapes = ((Fh, K), (Fh,), (H, Fh), (H,), (E,), (E,), (K,), (K,))
+    got = {}
+    for tag, g in (("f32", g32), ("bf16", g16)):
+        got[tag] = {n: torch.zeros(sh, device="cuda") for n, sh in zip(names, shapes)}
+        ops.gbf_bias_bwd_full(g, *d, w1, b1, w2, ld, *[got[tag][n].view(-1) for n in names])
+    for n in names:
+        a, b_ = got["bf16"][n], got["f32"][n]
+        assert float((a - b_).norm() / (b_.norm() + 1e-12)) < 1e-5, n
 
 
 @pytest.mark.parametrize("E", [1600, 5000])

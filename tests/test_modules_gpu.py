@@ -234,11 +234,18 @@ def test_pair_bias_vs_oracle(M):
     compare_param_grads(got, P, 4e-2)
 
 
-def test_unimol_tower_hot_path_layout_vs_oracle(M):
+@pytest.mark.parametrize("compact", [True, False, "g16"])
+def test_unimol_tower_hot_path_layout_vs_oracle(M, compact, monkeypatch):
     """Reference-sized head count / basis (64 heads, 128 Gaussians, 128 hidden): the path the benchmark takes -- fused
-    gbf -> MLP -> TILED pair bias, pair attention streaming the tiled layout, tiled G back into the gbf backward."""
+    gbf -> MLP -> TILED pair bias, pair attention streaming the tiled layout, tiled G back into the gbf backward.  compact:
+    the pair logits as fp16 (the default; "g16": with the gradient chain as bf16, MMDTI_PAIR_G_BF16=1) or fp32
+    (MMDTI_PAIR_COMPACT=0); same oracle, same tolerances."""
     from mmdti_hip.functional import PairBiasFn
     from mmdti_hip import ops
+    monkeypatch.setattr(ops, "PAIR_COMPACT", bool(compact))
+    monkeypatch.setattr(ops, "PAIR_G_BF16", compact == "g16")      # (opt-in: gradient chain as bf16)
+    if not compact:
+        monkeypatch.setattr(O, "BF16_SITES", set(O.ALL_SITES) - {"s16"})       # fp32 pair planes: the contract without the fp16 logits site
     B, N, D, H, K, V = 2, 21, 512, 64, 128, 31
     ucfg = O.UniMolCfg(layers=2, dim=D, ffn=128, heads=H, K=K, vocab=V)
     cfg = O.ModelCfg(unimol=ucfg, roberta=O.RobertaCfg(layers=1, dim=64, heads=4, ffn=128, vocab=40, max_pos=40), cross=O.CrossCfg(dim=64, heads=4, ffn=128))
@@ -259,9 +266,9 @@ def test_unimol_tower_hot_path_layout_vs_oracle(M):
     load_params(enc, P, "encoder."); load_params(gbf, P, "gbf."); load_params(proj, P, "gbf_proj.")
     e = emb.cuda().requires_grad_()
     bias = PairBiasFn.apply(gbf.means.weight, dist.cuda(), et.cuda(), gbf, proj, ops.pair_ld(N))
-    assert ops.pair_is_tiled(bias)
+    assert ops.pair_is_tiled(bias) and bias.dtype == (torch.float16 if compact else torch.float32)
     x, s_last, _ = enc.encode(e, bias, pad.cuda())
-    assert ops.pair_is_tiled(s_last)
+    assert ops.pair_is_tiled(s_last) and s_last.dtype == bias.dtype
     check(x, xo, 2e-3, "encoder output (tiled path)")
     (x * dx.cuda()).sum().backward()
     check(e.grad, er.grad, 3e-2, "d emb")

@@ -4,7 +4,9 @@ CPU only: the oracle's emulation of the HIP path's rounding points, one site at 
 a 4-molecule batch.  Result (full table: profiles/r02_rounding_sites_cpu.json, scratch/rounding_sites.py): rounding the
 GEMM WEIGHTS to bf16 moves encoder_rep by ~2.8e-3 relative L2, rounding the GEMM INPUTS by ~2.7e-3, the stored q|k|v by
 ~1.0e-3; attention probabilities and projections are below 4e-4.  They add in quadrature to ~4e-3: the north star's 1e-3
-on embeddings needs more than 8 mantissa bits on BOTH operands of every GEMM -- no single rounding point to fix."""
+on embeddings needs more than 8 mantissa bits on BOTH operands of every GEMM -- no single rounding point to fix.
+Carrying tower 1's pair logits as fp16 (site "s16": the compact pair planes; profiles/r02_s16_budget_cpu.json) is a
+hundred times below that budget: < 1e-4 on encoder_rep on its own, invisible in the total."""
 import torch
 
 from oracle import mmdti_oracle as O
@@ -24,7 +26,8 @@ def test_rounding_budget_at_reference_depth():
         with torch.no_grad():
             ref = O.mm_forward(batch, P, cfg, net_target=label, bf16=False)
             err = {}
-            for name, sites in (("all", O.ALL_SITES), ("w", {"w"}), ("x", {"x"}), ("qkv", {"qkv"}), ("rest", {"p", "qkv2", "proj"})):
+            for name, sites in (("all", O.ALL_SITES), ("w", {"w"}), ("x", {"x"}), ("qkv", {"qkv"}), ("rest", {"p", "qkv2", "proj"}), ("s16", {"s16"}),
+                                ("all_but_s16", O.ALL_SITES - {"s16"})):
                 O.BF16_SITES = set(sites)
                 o = O.mm_forward(batch, P, cfg, net_target=label, bf16=True)
                 err[name] = (_rel(o["enc"], ref["enc"]), _rel(o["bert"], ref["bert"]))
@@ -37,3 +40,5 @@ def test_rounding_budget_at_reference_depth():
     quad = (enc["w"] ** 2 + enc["x"] ** 2 + enc["qkv"] ** 2) ** 0.5
     assert abs(quad - enc["all"]) < 0.35 * enc["all"], (quad, enc)    # independent errors: they add in quadrature
     assert err["all"][1] < 4e-3, err                           # tower 2 (6 post-LN layers): ~2e-3
+    assert enc["s16"] < 1.5e-4 and err["s16"][1] == 0.0, err    # fp16 pair logits alone: two orders below the operand rounding ...
+    assert abs(enc["all"] - enc["all_but_s16"]) < 0.05 * enc["all"], enc     # ... and invisible next to it
