@@ -151,6 +151,20 @@ __device__ __forceinline__ uint32_t keep4_u16(uint64_t seed, uint32_t site, uint
   return ((a & 0xffffu) >= thresh16 ? 1u : 0u) | ((a >> 16) >= thresh16 ? 2u : 0u) | ((b & 0xffffu) >= thresh16 ? 4u : 0u) |
          ((b >> 16) >= thresh16 ? 8u : 0u);
 }
+// The same four uniforms as keep4_u16, left in the halves of two words: element r of the quad is kept iff
+// keep4_half(w, r) >= thresh16 -- callers that select per element compare the halves directly (one SDWA compare each)
+// instead of assembling and then dissecting a bit mask.
+struct Keep4 { uint32_t a, b; };
+__device__ __forceinline__ Keep4 keep4_words(uint64_t seed, uint32_t site, uint64_t ctr) {
+  seed = salted(seed);
+  const uint32_t k = mix32((uint32_t)seed ^ (site * 0x9E3779B9u)) ^ (uint32_t)(seed >> 32);
+  const uint32_t a = mix32(((uint32_t)ctr ^ k) + (uint32_t)(ctr >> 32) * 0x85EBCA6Bu);
+  return Keep4{a, mix32(a ^ 0xB5297A4Du)};
+}
+__device__ __forceinline__ bool keep4_kept(const Keep4& w, int r, uint32_t thresh16) {
+  const uint32_t word = r < 2 ? w.a : w.b;
+  return ((r & 1) ? (word >> 16) : (word & 0xffffu)) >= thresh16;
+}
 // keep-mask for element index `idx` of dropout site `site`: one Philox call covers 4 consecutive
 // elements (idx>>2), lane picks word idx&3.  keep iff u32 >= thresh, thresh = p * 2^32.
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t site, uint64_t idx, uint32_t thresh) {

@@ -314,6 +314,7 @@ __device__ __forceinline__ void pa_split4(const f32x4& v, pa_s16x4& hi, pa_s16x4
   lo = pa_pack4(r);
 }
 #define PA_MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A, B, C, 0, 0, 0)
+#define PA_LOG2E 1.44269504088896340736f
 
 // Element types of the pair tensors.  Row-major planes and the round-1 tiled planes hold fp32.  The COMPACT tiled planes
 // hold the logits chain S as fp16 (same [nKB][nKB][256] element order: a lane's 4 keys are 8 contiguous bytes, a tile
@@ -331,7 +332,7 @@ typedef _Float16 pa_f16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 pa_load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ f32x4 pa_load4_nt(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
 __device__ __forceinline__ void pa_store4_nt(float* p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
-__device__ __forceinline__ f32x4 pa_round4(const float*, f32x4 v) { return v; }
+__device__ __forceinline__ f32x4 pa_round4(f32x4& keep, f32x4 v) { keep = v; return v; }
 
 __device__ __forceinline__ f32x4 pa_widen_f16(const pa_f16x4& h) {
   f32x4 v;
@@ -350,12 +351,16 @@ __device__ __forceinline__ f32x4 pa_load4_nt(const _Float16* p) { return pa_wide
 __device__ __forceinline__ void pa_store4_nt(_Float16* p, const f32x4& v) {   // (v already went through pa_round4: the conversion is exact)
   __builtin_nontemporal_store(pa_narrow_f16(v), reinterpret_cast<pa_f16x4*>(p));
 }
-__device__ __forceinline__ f32x4 pa_round4(const _Float16*, const f32x4& v) {
+// round a quad of logits to its storage type; `keep` receives the stored form so that the store does not convert again.
+// (v_med3_f32 against (-inf, 65504) is min(v, 65504) without fminf's NaN-canonicalising v_max_f32 in front)
+__device__ __forceinline__ f32x4 pa_round4(pa_f16x4& keep, const f32x4& v) {
   f32x4 c;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) c[r] = fminf(v[r], 65504.f);
-  return pa_widen_f16(pa_narrow_f16(c));
+  for (int r = 0; r < 4; ++r) c[r] = __builtin_amdgcn_fmed3f(v[r], -INFINITY, 65504.f);
+  keep = pa_narrow_f16(c);
+  return pa_widen_f16(keep);
 }
+__device__ __forceinline__ void pa_store4_nt(_Float16* p, const pa_f16x4& h) { __builtin_nontemporal_store(h, reinterpret_cast<pa_f16x4*>(p)); }
 
 __device__ __forceinline__ f32x4 pa_widen_bf16(const pa_s16x4& h) {
   f32x4 v;
@@ -372,7 +377,7 @@ __device__ __forceinline__ void pa_store4_nt(__bf16* p, const f32x4& v) { __buil
 // QUERY rows are still computed (the reference's unmasked InfoNCE mean reads the encoder output at padded positions).
 // rag_store != 0: the skipped tiles are written as -inf (the last layer, whose S is returned to the caller).
 template <int NT, bool TILED, bool FULL, bool RAG, typename ST>
-__global__ __launch_bounds__(256, NT > 13 ? 2 : 4) void pair_attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, const ST* __restrict__ bias_in,
+__global__ __launch_bounds__(256, NT > 9 ? 2 : 4) void pair_attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, const ST* __restrict__ bias_in,
                                                                  ST* __restrict__ s_out, bf16_t* __restrict__ o,
                                                                  const unsigned char* __restrict__ key_pad, int N, int H, int ld,
                                                                  float scale, uint32_t thresh, float dscale, uint64_t seed,
@@ -437,6 +442,14 @@ __global__ __launch_bounds__(256, NT > 13 ? 2 : 4) void pair_attn_fwd_mfma_kerne
     const int goff = TILED ? 0 : 4 * g;
 #define PA_PRED(T) (!TILED ? (qvalid && (T) * 16 + 4 * g < N) \
                            : (qvalid && (FULL ? ((T) < NT - 1 || colok) : ((T) < nlast || ((T) == nlast && colok)))))
+    // interior tiles of a complete query block: no predicate (FULL only: as a wave-uniform run-time branch it doubles the unrolled
+    // code and the NT = 13 backward fell out of the instruction cache, 1.2 -> 3.3 ms)
+#define PA_FAST(T) (TILED && !EDGE && (FULL ? (T) < NT - 1 : false))
+    // tiles that are not processed at all: past the molecule's last real key tile (RAG only.  Skipping the tiles past nKB of
+    // a kernel instantiated for more tiles than this N has -- the same test with kt == nKB -- was measured and is SLOWER:
+    // N = 160 backward 1.23 -> 3.26 ms, N = 128 0.80 -> 0.97: the wave-uniform branches around every tile of the unrolled
+    // sweeps stop the loads of later tiles from being issued ahead; predicated-off tiles cost less than that)
+#define PA_SKIP(T) (RAG && (T) >= kt)
     // Phase 1: request every bias tile of this query block (the NT 16-byte loads are issued back to back and stay in
     // flight together).  Slots that are not loaded: -inf (pad keys), or 0 in a pad ROW (keeps that row's softmax finite;
     // nothing of it is stored).
@@ -444,9 +457,9 @@ __global__ __launch_bounds__(256, NT > 13 ? 2 : 4) void pair_attn_fwd_mfma_kerne
     f32x4 S[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      if (RAG && t >= kt) {
+      if (PA_SKIP(t)) {
         S[t] = f32x4{NEG_INF, NEG_INF, NEG_INF, NEG_INF};
-      } else if (TILED && !EDGE && (FULL ? t < NT - 1 : false)) {
+      } else if (PA_FAST(t)) {
         S[t] = pa_load4_nt(bin + t * TSTEP + goff);
       } else {
         const bool pr = PA_PRED(t);
@@ -457,10 +470,10 @@ __global__ __launch_bounds__(256, NT > 13 ? 2 : 4) void pair_attn_fwd_mfma_kerne
     float m = NEG_INF;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      if (RAG && t >= kt) {
-        if (rag_store) {
+      if (PA_SKIP(t)) {
+        if (RAG && rag_store) {   // (a tile past nKB does not exist: PA_FAST / PA_PRED are false for it)
           const f32x4 ninf = {NEG_INF, NEG_INF, NEG_INF, NEG_INF};
-          if (TILED && !EDGE && (FULL ? t < NT - 1 : false)) {
+          if (PA_FAST(t)) {
             pa_store4_nt(sout + t * TSTEP + goff, ninf);
           } else if (PA_PRED(t)) {
             pa_store4_nt(sout + t * TSTEP + goff, ninf);
@@ -479,25 +492,29 @@ __global__ __launch_bounds__(256, NT > 13 ? 2 : 4) void pair_attn_fwd_mfma_kerne
 #pragma unroll
           for (int r = 0; r < 4; ++r) c[r] = (km[r] != 0.f) ? NEG_INF : c[r];
         }
-        c = pa_round4(sout, c);   // (compact: the fp16 value that is stored is also the one this layer's softmax sees)
-        if (TILED && !EDGE && (FULL ? t < NT - 1 : false)) {
-          pa_store4_nt(sout + t * TSTEP + goff, c);
+        typename std::conditional<sizeof(ST) == 2, pa_f16x4, f32x4>::type cs;
+        c = pa_round4(cs, c);   // (compact: the fp16 value that is stored is also the one this layer's softmax sees)
+        if (PA_FAST(t)) {
+          pa_store4_nt(sout + t * TSTEP + goff, cs);
         } else if (PA_PRED(t)) {
-          pa_store4_nt(sout + t * TSTEP + goff, c);
+          pa_store4_nt(sout + t * TSTEP + goff, cs);
         }
         S[t] = c;
-        m = fmaxf(fmaxf(m, fmaxf(c[0], c[1])), fmaxf(c[2], c[3]));
+        m = fmaxf(fmaxf(m, c[0]), c[1]);   // (two v_max3_f32)
+        m = fmaxf(fmaxf(m, c[2]), c[3]);
       }
     }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
+    // exp(S - m) as exp2(S * log2(e) - m * log2(e)): one FMA + v_exp_f32 per element (the backward recomputes it the same way)
+    const float mneg = -m * PA_LOG2E;
     float lsum = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = __expf(S[t][r] - m);
+          const float e = __builtin_amdgcn_exp2f(fmaf(S[t][r], PA_LOG2E, mneg));
           S[t][r] = e;
           lsum += e;
         }
@@ -505,16 +522,16 @@ __global__ __launch_bounds__(256, NT > 13 ? 2 : 4) void pair_attn_fwd_mfma_kerne
     }
     lsum += __shfl_xor(lsum, 16, 64);
     lsum += __shfl_xor(lsum, 32, 64);
-    const float inv = 1.0f / lsum;
+    const float inv = dscale / lsum;   // (dropout's 1 / (1 - p) folded in: dscale == 1 without dropout)
     f32x4 oacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      if (!(RAG && t >= kt)) {
+      if (!PA_SKIP(t)) {
         f32x4 p = S[t] * inv;
         if (thresh) {
-          const uint32_t kb = keep4_u16(seed, site, (uint64_t)(rowoff + t * 16 + 4 * g) >> 2, thresh >> 16);
+          const Keep4 kw = keep4_words(seed, site, (uint64_t)(rowoff + t * 16 + 4 * g) >> 2);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) p[r] = (kb >> r) & 1u ? p[r] * dscale : 0.f;
+          for (int r = 0; r < 4; ++r) p[r] = keep4_kept(kw, r, thresh >> 16) ? p[r] : 0.f;
         }
         // O^T += V^T . P^T : A = V[keys 16t + 4g..4g+3][d = c16 & 7] (rows d >= 8 of the result are never stored), B = P^T as it sits
         const pa_s16x4 va = *reinterpret_cast<const pa_s16x4*>(sVT + (c16 & 7) * KSTR + t * 16 + 4 * g);
@@ -532,6 +549,8 @@ __global__ __launch_bounds__(256, NT > 13 ? 2 : 4) void pair_attn_fwd_mfma_kerne
       *reinterpret_cast<uint2*>(o + ((long long)b * N + qi) * D + h * HD + 4 * g) = pk;
     }
 #undef PA_PRED
+#undef PA_FAST
+#undef PA_SKIP
   };
   for (int qb = wave; qb < nKB; qb += nwaves) {
     if (TILED && qb * 16 + 16 <= N) body(qb, std::false_type{});
@@ -556,7 +575,7 @@ __global__ __launch_bounds__(256, NT > 13 ? 2 : 4) void pair_attn_fwd_mfma_kerne
 // RAG: see the forward kernel.  Skipped key tiles contribute nothing (P = 0, G = 0) and their G is NOT written: the caller
 // hands in a zero-initialised G when the batch is ragged.
 template <int NT, bool TILED, bool FULL, int NW, bool RAG, typename ST, typename GT>
-__global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const ST* __restrict__ s_in,
+__global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : 3) void pair_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const ST* __restrict__ s_in,
                                                                  const bf16_t* __restrict__ dO, const GT* __restrict__ gin, GT* __restrict__ gout,
                                                                  bf16_t* __restrict__ dqkv, int N, int H, int ld, float scale,
                                                                  int g_in_zero, uint32_t thresh, float dscale, uint64_t seed,
@@ -632,6 +651,7 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
 #define PA_PRED(T) (!TILED ? (qvalid && (T) * 16 + 4 * g < N) \
                            : (qvalid && (FULL ? ((T) < NT - 1 || colok) : ((T) < nlast || ((T) == nlast && colok)))))
 #define PA_FAST(T) (TILED && !EDGE && (FULL ? (T) < NT - 1 : false))
+#define PA_SKIP(T) (RAG && (T) >= kt)   // (see the forward kernel)
     // operands of this query block that do not depend on the key tile:
     //   dob : B of dP^T = V.dO^T          -> dO[query c16][d = 4g..4g+3]   (k = d: lane groups 2, 3 carry zeros)
     //   bD  : B of dV  += Pd^T.dO         -> dO[queries 4g..4g+3][d = c16] (transposing read; columns d >= 8 are unused)
@@ -648,7 +668,7 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
       {
         const int kcol = t * 16 + 4 * g;
         f32x4 c;
-        if (RAG && t >= kt) {
+        if (PA_SKIP(t)) {
           c = f32x4{NEG_INF, NEG_INF, NEG_INF, NEG_INF};
         } else if (PA_FAST(t)) {
           c = pa_load4_nt(sin_p + t * TSTEP + goff);
@@ -662,19 +682,21 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
           for (int r = 0; r < 4; ++r) c[r] = (kcol + r < N) ? c[r] : NEG_INF;   // pad columns of the row are not data
         }
         P[t] = c;
-        m = fmaxf(fmaxf(m, fmaxf(c[0], c[1])), fmaxf(c[2], c[3]));
+        m = fmaxf(fmaxf(m, c[0]), c[1]);
+        m = fmaxf(fmaxf(m, c[2]), c[3]);
       }
     }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     if (m == NEG_INF) m = 0.f;   // rows beyond N: everything is -inf, keep the arithmetic finite
+    const float mneg = -m * PA_LOG2E;   // (same exponential as the forward: exp2(S * log2(e) - m * log2(e)))
     float lsum = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = __expf(P[t][r] - m);
+          const float e = __builtin_amdgcn_exp2f(fmaf(P[t][r], PA_LOG2E, mneg));
           P[t][r] = e;
           lsum += e;
         }
@@ -687,17 +709,17 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
     float dl = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      if (!(RAG && t >= kt)) {
+      if (!PA_SKIP(t)) {
         // A of dP^T: V[key 16t + c16][d = 4g..4g+3] (exact bf16 products, fp32 accumulation)
         const pa_s16x4 va = g < 2 ? *reinterpret_cast<const pa_s16x4*>(sV + (t * 16 + c16) * 8 + 4 * g) : zero4;
         f32x4 dp = {0.f, 0.f, 0.f, 0.f};
         dp = PA_MFMA16(va, dob, dp);
         f32x4 pr = P[t] * inv;
         if (thresh) {
-          const uint32_t kb = keep4_u16(seed, site, (uint64_t)(rowoff + t * 16 + 4 * g) >> 2, thresh >> 16);
+          const Keep4 kw = keep4_words(seed, site, (uint64_t)(rowoff + t * 16 + 4 * g) >> 2);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const bool kp = (kb >> r) & 1u;
+            const bool kp = keep4_kept(kw, r, thresh >> 16);
             dp[r] = kp ? dp[r] * dscale : 0.f;
             dl += dp[r] * pr[r];
             pr[r] = kp ? pr[r] : -pr[r];
@@ -716,7 +738,7 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
     // fewer at the 168 cap -- no spills), pinned in place by scheduling barriers
     constexpr int PA_LA = 3;
     auto load_gin = [&](int t) -> f32x4 {
-      if (RAG && t >= kt) return f32x4{0.f, 0.f, 0.f, 0.f};
+      if (PA_SKIP(t)) return f32x4{0.f, 0.f, 0.f, 0.f};
       if (PA_FAST(t)) {
         const f32x4 ld4 = pa_load4_nt(gin_p + (g_in_zero ? 0 : t * TSTEP + goff));
         return g_in_zero ? f32x4{0.f, 0.f, 0.f, 0.f} : ld4;
@@ -736,7 +758,7 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
       const f32x4 Gin = Gq[t % PA_LA];
       if (t + PA_LA < NT) Gq[t % PA_LA] = load_gin(t + PA_LA);
       __builtin_amdgcn_sched_barrier(0);
-      if (RAG && t >= kt) continue;      // (wave-uniform: nothing of this tile exists)
+      if (PA_SKIP(t)) continue;      // (wave-uniform: nothing of this tile exists)
       const pa_s16x4 va = g < 2 ? *reinterpret_cast<const pa_s16x4*>(sV + (t * 16 + c16) * 8 + 4 * g) : zero4;
       f32x4 dp = {0.f, 0.f, 0.f, 0.f};
       dp = PA_MFMA16(va, dob, dp);
@@ -808,6 +830,7 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : (NW == 3 ? 3 : 2)) void pair_
     }
 #undef PA_PRED
 #undef PA_FAST
+#undef PA_SKIP
   };
   for (int qb = wave; qb < nKB; qb += nwaves) {
     if (TILED && qb * 16 + 16 <= N) body(qb, std::false_type{});
@@ -876,11 +899,18 @@ extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, 
   do {                                                                                      \
     if (!tiled) PA_M(NT, false, false, false, float);                                       \
     else if (!compact) { if (nqb == NT) PA_M(NT, true, true, false, float); else PA_M(NT, true, false, false, float); } \
-    else if (key_tiles) { if (nqb == NT) PA_M(NT, true, true, true, _Float16); else PA_M(NT, true, false, true, _Float16); } \
-    else if (nqb == NT) PA_M(NT, true, true, false, _Float16);                              \
-    else PA_M(NT, true, false, false, _Float16);                                            \
   } while (0)
-    if (nqb <= 5) PA_MT(5); else if (nqb <= 9) PA_MT(9); else if (nqb <= 13) PA_MT(13); else PA_MT(17);
+    // The hot path (compact planes) has an instantiation for EVERY tile count: all its tiles exist, the interior ones run
+    // without predicates (FULL).  In a kernel instantiated for more tiles than N has, the surplus tiles are predicated off but
+    // still walked and no tile takes the fast path -- 25-45 % more time per real tile (N = 96 / 113 / 128 on the 9-tile kernel).
+#define PA_MC(NT) case NT: if (key_tiles) PA_M(NT, true, true, true, _Float16); else PA_M(NT, true, true, false, _Float16); break
+    if (compact) {
+      switch (nqb) {
+        PA_MC(1); PA_MC(2); PA_MC(3); PA_MC(4); PA_MC(5); PA_MC(6); PA_MC(7); PA_MC(8); PA_MC(9); PA_MC(10); PA_MC(11); PA_MC(12);
+        PA_MC(13); PA_MC(14); PA_MC(15); PA_MC(16); PA_MC(17);
+      }
+    } else if (nqb <= 5) PA_MT(5); else if (nqb <= 9) PA_MT(9); else if (nqb <= 13) PA_MT(13); else PA_MT(17);
+#undef PA_MC
 #undef PA_MT
 #undef PA_M
     MMDTI_LAUNCH_CHECK();
@@ -934,12 +964,21 @@ extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, 
   do {                                                                                      \
     if (!tiled) PA_MBW(NT, false, false, false, float, float);                              \
     else if (!compact) { if (nqb == NT) PA_MBW(NT, true, true, false, float, float); else PA_MBW(NT, true, false, false, float, float); } \
-    else if (g16) { if (nqb == NT) PA_MBW(NT, true, true, false, _Float16, __bf16); else PA_MBW(NT, true, false, false, _Float16, __bf16); } \
-    else if (key_tiles) { if (nqb == NT) PA_MBW(NT, true, true, true, _Float16, float); else PA_MBW(NT, true, false, true, _Float16, float); } \
-    else if (nqb == NT) PA_MBW(NT, true, true, false, _Float16, float);                     \
-    else PA_MBW(NT, true, false, false, _Float16, float);                                   \
+    else { if (nqb == NT) PA_MBW(NT, true, true, false, _Float16, __bf16); else PA_MBW(NT, true, false, false, _Float16, __bf16); } \
   } while (0)
-    if (nqb <= 5) PA_MBT(5); else if (nqb <= 9) PA_MBT(9); else if (nqb <= 13) PA_MBT(13); else PA_MBT(17);
+    // (compact planes with fp32 gradients -- the hot path -- have one instantiation per tile count: see the forward)
+#define PA_MBC(NT)                                                                                                    \
+  case NT:                                                                                                            \
+    if (key_tiles) PA_MB(NT, true, true, (NT % 3 == 0 ? 3 : 4), true, _Float16, float);                               \
+    else PA_MB(NT, true, true, (NT % 3 == 0 ? 3 : 4), false, _Float16, float);                                        \
+    break
+    if (compact && !g16) {
+      switch (nqb) {
+        PA_MBC(1); PA_MBC(2); PA_MBC(3); PA_MBC(4); PA_MBC(5); PA_MBC(6); PA_MBC(7); PA_MBC(8); PA_MBC(9); PA_MBC(10); PA_MBC(11);
+        PA_MBC(12); PA_MBC(13); PA_MBC(14); PA_MBC(15); PA_MBC(16); PA_MBC(17);
+      }
+    } else if (nqb <= 5) PA_MBT(5); else if (nqb <= 9) PA_MBT(9); else if (nqb <= 13) PA_MBT(13); else PA_MBT(17);
+#undef PA_MBC
 #undef PA_MBW
 #undef PA_MBT
 #undef PA_MB
