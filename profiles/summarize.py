@@ -24,9 +24,33 @@ def find(d, pat):
     return hits[-1]
 
 
+def demangle(name):
+    """rocprofv3 leaves kernels whose template arguments include _Float16 / __bf16 mangled (its demangler predates DF16_ / DF16b).
+    Only what this library's kernel names need: _ZN5mmdti<len><name>I<args>E... with int (Li9E), bool (Lb1E), float (f),
+    _Float16 (DF16_) and __bf16 (DF16b) arguments."""
+    m = re.match(r"_ZN5mmdti(\d+)", name)
+    if not m:
+        return name
+    n = int(m.group(1))
+    base, rest = name[m.end():m.end() + n], name[m.end() + n:]
+    if not rest.startswith("I"):
+        return "mmdti::" + base
+    rest, args = rest[1:], []
+    while rest and not rest.startswith("E"):
+        for pat, fn in ((r"Li(\d+)E", lambda g: g.group(1)), (r"Lb([01])E", lambda g: "true" if g.group(1) == "1" else "false"),
+                        (r"DF16_", lambda g: "_Float16"), (r"DF16b", lambda g: "__bf16"), (r"f", lambda g: "float")):
+            g = re.match(pat, rest)
+            if g:
+                args.append(fn(g)); rest = rest[g.end():]
+                break
+        else:
+            return name
+    return f"mmdti::{base}<{', '.join(args)}>"
+
+
 def short(name):
     name = re.sub(r"\(.*$", "", name)            # drop the argument list, keep template args
-    return name.replace("void ", "").strip()
+    return demangle(name.replace("void ", "").strip())
 
 
 def stats(src, dst):
