@@ -372,10 +372,35 @@ __device__ __forceinline__ f32x4 pa_load4(const __bf16* p) { return pa_widen_bf1
 __device__ __forceinline__ f32x4 pa_load4_nt(const __bf16* p) { return pa_widen_bf16(__builtin_nontemporal_load(reinterpret_cast<const pa_s16x4*>(p))); }
 __device__ __forceinline__ void pa_store4_nt(__bf16* p, const f32x4& v) { __builtin_nontemporal_store(pa_pack4(v), reinterpret_cast<pa_s16x4*>(p)); }
 
-// RAG (ragged batches): key_tiles[b] = number of 16-key tiles of molecule b that hold a real key.  The tiles past it are all
-// padding -- -inf in every S of the chain, 0 in G -- so they are neither loaded nor computed nor (rag_store == 0) stored; pad
-// QUERY rows are still computed (the reference's unmasked InfoNCE mean reads the encoder output at padded positions).
-// rag_store != 0: the skipped tiles are written as -inf (the last layer, whose S is returned to the caller).
+// Ragged batches: the number of key tiles a molecule's sweeps cover is a COMPILE-TIME constant of the code that runs them.  A
+// workgroup reads its molecule's count and branches ONCE into the body unrolled for it; per-tile `if (t >= kt) skip` branches
+// inside one body unrolled for all NT tiles were measured at + 20-40 % per processed tile (they keep the loads of later tiles
+// from being issued ahead).  Supported counts: every k up to 9 tiles, every 2nd up to 13, every 4th beyond, and NT itself -- a
+// count in between runs as the next supported one (the extra tiles are ordinary all-padding tiles: -inf logits, zero gradient,
+// read and written like any other), identically in every layer and in both directions.
+__host__ __device__ constexpr int pa_kt_step(int nt) { return nt <= 9 ? 1 : (nt <= 13 ? 2 : 4); }
+// smallest supported count >= kt
+__host__ __device__ constexpr int pa_kt_effective(int kt, int nt) {
+  const int s = pa_kt_step(nt), k = ((kt < 1 ? 1 : kt) + s - 1) / s * s;
+  return k >= nt ? nt : k;
+}
+// f(std::integral_constant<int, ke>) for a count ke that pa_kt_effective produced (K walks down the supported counts)
+template <int NT, int K, typename F>
+__device__ __forceinline__ void pa_dispatch_kt(int ke, F&& f) {
+  constexpr int step = pa_kt_step(NT);
+  constexpr int below = (K == NT) ? ((NT - 1) / step) * step : K - step;   // the next supported count below K (0: none)
+  if constexpr (below < 1) {
+    f(std::integral_constant<int, K>{});
+  } else {
+    if (ke >= K) f(std::integral_constant<int, K>{});
+    else pa_dispatch_kt<NT, below>(ke, f);
+  }
+}
+
+// RAG (ragged batches): key_tiles[b] = number of 16-key tiles of molecule b that hold a real key.  The tiles past it (past
+// pa_kt_effective of it) are all padding -- -inf in every S of the chain, 0 in G -- so they are neither loaded nor computed nor
+// (rag_store == 0) stored; pad QUERY rows are still computed (the reference's unmasked InfoNCE mean reads the encoder output at
+// padded positions).  rag_store != 0: the skipped tiles are written as -inf (the last layer, whose S is returned to the caller).
 template <int NT, bool TILED, bool FULL, bool RAG, typename ST>
 __global__ __launch_bounds__(256, NT > 9 ? 2 : 4) void pair_attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, const ST* __restrict__ bias_in,
                                                                  ST* __restrict__ s_out, bf16_t* __restrict__ o,
@@ -396,7 +421,8 @@ __global__ __launch_bounds__(256, NT > 9 ? 2 : 4) void pair_attn_fwd_mfma_kernel
   const int D = H * HD, D3 = 3 * D;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int nKB = (N + 15) >> 4;
-  const int kt = RAG ? min(max(__builtin_amdgcn_readfirstlane(key_tiles[b]), 1), nKB) : nKB;   // (wave-uniform: one molecule per workgroup)
+  // (wave-uniform: one molecule per workgroup; rounded up to a count the sweeps are unrolled for)
+  const int kt = RAG ? pa_kt_effective(min(__builtin_amdgcn_readfirstlane(key_tiles[b]), nKB), NT) : NT;
   const bf16_t* base = qkv + (long long)b * N * D3 + h * HD;
   for (int t = tid; t < NP; t += blockDim.x) {
     uint4 q = make_uint4(0u, 0u, 0u, 0u), kk = q, vv = q;
@@ -425,8 +451,9 @@ __global__ __launch_bounds__(256, NT > 9 ? 2 : 4) void pair_attn_fwd_mfma_kernel
   // key tile keep per-lane predicates.  FULL: nKB == NT, so "last tile" is a compile-time index.
   const int nlast = nKB - 1;
   const bool colok = 4 * g < N - 16 * nlast;
-  auto body = [&](int qb, auto edge_c) {
+  auto body = [&](int qb, auto edge_c, auto kt_c) {
     constexpr bool EDGE = decltype(edge_c)::value;
+    constexpr int KT = decltype(kt_c)::value;   // key tiles this molecule's sweeps cover (NT unless RAG)
     const int qi = qb * 16 + c16;
     const bool qvalid = EDGE ? qi < N : true;
     const long long rowoff = ((long long)bh * N + (qvalid ? qi : 0)) * ld;   // (also the dropout counter base)
@@ -445,21 +472,14 @@ __global__ __launch_bounds__(256, NT > 9 ? 2 : 4) void pair_attn_fwd_mfma_kernel
     // interior tiles of a complete query block: no predicate (FULL only: as a wave-uniform run-time branch it doubles the unrolled
     // code and the NT = 13 backward fell out of the instruction cache, 1.2 -> 3.3 ms)
 #define PA_FAST(T) (TILED && !EDGE && (FULL ? (T) < NT - 1 : false))
-    // tiles that are not processed at all: past the molecule's last real key tile (RAG only.  Skipping the tiles past nKB of
-    // a kernel instantiated for more tiles than this N has -- the same test with kt == nKB -- was measured and is SLOWER:
-    // N = 160 backward 1.23 -> 3.26 ms, N = 128 0.80 -> 0.97: the wave-uniform branches around every tile of the unrolled
-    // sweeps stop the loads of later tiles from being issued ahead; predicated-off tiles cost less than that)
-#define PA_SKIP(T) (RAG && (T) >= kt)
     // Phase 1: request every bias tile of this query block (the NT 16-byte loads are issued back to back and stay in
     // flight together).  Slots that are not loaded: -inf (pad keys), or 0 in a pad ROW (keeps that row's softmax finite;
     // nothing of it is stored).
     const float fillv = (TILED && qvalid) ? -INFINITY : 0.f;
-    f32x4 S[NT];
+    f32x4 S[KT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (PA_SKIP(t)) {
-        S[t] = f32x4{NEG_INF, NEG_INF, NEG_INF, NEG_INF};
-      } else if (PA_FAST(t)) {
+    for (int t = 0; t < KT; ++t) {
+      if (PA_FAST(t)) {
         S[t] = pa_load4_nt(bin + t * TSTEP + goff);
       } else {
         const bool pr = PA_PRED(t);
@@ -468,18 +488,20 @@ __global__ __launch_bounds__(256, NT > 9 ? 2 : 4) void pair_attn_fwd_mfma_kernel
       }
     }
     float m = NEG_INF;
+    if (RAG && rag_store) {   // the all-padding tiles past KT: -inf (the last layer: its S goes back to the caller)
+      const f32x4 ninf = {NEG_INF, NEG_INF, NEG_INF, NEG_INF};
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (PA_SKIP(t)) {
-        if (RAG && rag_store) {   // (a tile past nKB does not exist: PA_FAST / PA_PRED are false for it)
-          const f32x4 ninf = {NEG_INF, NEG_INF, NEG_INF, NEG_INF};
-          if (PA_FAST(t)) {
-            pa_store4_nt(sout + t * TSTEP + goff, ninf);
-          } else if (PA_PRED(t)) {
-            pa_store4_nt(sout + t * TSTEP + goff, ninf);
-          }
+      for (int t = KT; t < NT; ++t) {
+        if (PA_FAST(t)) {
+          pa_store4_nt(sout + t * TSTEP + goff, ninf);
+        } else if (PA_PRED(t)) {
+          pa_store4_nt(sout + t * TSTEP + goff, ninf);
         }
-      } else {
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      {
         const int kcol = t * 16 + 4 * g;
         f32x4 c = S[t];
         const pa_s16x4 ka = g < 2 ? *reinterpret_cast<const pa_s16x4*>(sK + (t * 16 + c16) * 8 + 4 * g) : zero4;
@@ -510,7 +532,7 @@ __global__ __launch_bounds__(256, NT > 9 ? 2 : 4) void pair_attn_fwd_mfma_kernel
     const float mneg = -m * PA_LOG2E;
     float lsum = 0.f;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    for (int t = 0; t < KT; ++t) {
       {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -525,8 +547,8 @@ __global__ __launch_bounds__(256, NT > 9 ? 2 : 4) void pair_attn_fwd_mfma_kernel
     const float inv = dscale / lsum;   // (dropout's 1 / (1 - p) folded in: dscale == 1 without dropout)
     f32x4 oacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (!PA_SKIP(t)) {
+    for (int t = 0; t < KT; ++t) {
+      {
         f32x4 p = S[t] * inv;
         if (thresh) {
           const Keep4 kw = keep4_words(seed, site, (uint64_t)(rowoff + t * 16 + 4 * g) >> 2);
@@ -550,12 +572,15 @@ __global__ __launch_bounds__(256, NT > 9 ? 2 : 4) void pair_attn_fwd_mfma_kernel
     }
 #undef PA_PRED
 #undef PA_FAST
-#undef PA_SKIP
   };
-  for (int qb = wave; qb < nKB; qb += nwaves) {
-    if (TILED && qb * 16 + 16 <= N) body(qb, std::false_type{});
-    else body(qb, std::true_type{});
-  }
+  auto run = [&](auto kt_c) {
+    for (int qb = wave; qb < nKB; qb += nwaves) {
+      if (TILED && qb * 16 + 16 <= N) body(qb, std::false_type{}, kt_c);
+      else body(qb, std::true_type{}, kt_c);
+    }
+  };
+  if constexpr (RAG) pa_dispatch_kt<NT, NT>(kt, run);
+  else run(std::integral_constant<int, NT>{});
 }
 
 // =====================================================================================================================
@@ -603,7 +628,7 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : 3) void pair_attn_bwd_mfma_ke
   const int D = H * HD, D3 = 3 * D;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int nKB = (N + 15) >> 4;
-  const int kt = RAG ? min(max(__builtin_amdgcn_readfirstlane(key_tiles[b]), 1), nKB) : nKB;
+  const int kt = RAG ? pa_kt_effective(min(__builtin_amdgcn_readfirstlane(key_tiles[b]), nKB), NT) : NT;   // (see the forward kernel)
   const bf16_t* base = qkv + (long long)b * N * D3 + h * HD;
   for (int t = tid; t < NP + 2; t += blockDim.x) {
     uint4 q = make_uint4(0u, 0u, 0u, 0u), kk = q, vv = q, dd = q;
@@ -637,8 +662,9 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : 3) void pair_attn_bwd_mfma_ke
   //  slot is 0 -- both are preserved by the stores below --, so interior tiles run without predicates or pad masking.)
   const int nlast = nKB - 1;
   const bool colok = 4 * g < N - 16 * nlast;
-  auto body = [&](int qb, auto edge_c) {
+  auto body = [&](int qb, auto edge_c, auto kt_c) {
     constexpr bool EDGE = decltype(edge_c)::value;
+    constexpr int KT = decltype(kt_c)::value;   // key tiles this molecule's sweeps cover (NT unless RAG)
     const int qi = qb * 16 + c16;
     const bool qvalid = EDGE ? qi < N : true;
     const long long rowoff = ((long long)bh * N + (qvalid ? qi : 0)) * ld;   // (also the dropout counter base)
@@ -651,7 +677,6 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : 3) void pair_attn_bwd_mfma_ke
 #define PA_PRED(T) (!TILED ? (qvalid && (T) * 16 + 4 * g < N) \
                            : (qvalid && (FULL ? ((T) < NT - 1 || colok) : ((T) < nlast || ((T) == nlast && colok)))))
 #define PA_FAST(T) (TILED && !EDGE && (FULL ? (T) < NT - 1 : false))
-#define PA_SKIP(T) (RAG && (T) >= kt)   // (see the forward kernel)
     // operands of this query block that do not depend on the key tile:
     //   dob : B of dP^T = V.dO^T          -> dO[query c16][d = 4g..4g+3]   (k = d: lane groups 2, 3 carry zeros)
     //   bD  : B of dV  += Pd^T.dO         -> dO[queries 4g..4g+3][d = c16] (transposing read; columns d >= 8 are unused)
@@ -661,16 +686,14 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : 3) void pair_attn_bwd_mfma_ke
     const pa_s16x4 bD = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pa_lds_s16x4*)(sD + trq));
     const pa_s16x4 bQ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pa_lds_s16x4*)(sQ + trq));
     // ---- sweep 1
-    f32x4 P[NT];
+    f32x4 P[KT];
     float m = NEG_INF;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    for (int t = 0; t < KT; ++t) {
       {
         const int kcol = t * 16 + 4 * g;
         f32x4 c;
-        if (PA_SKIP(t)) {
-          c = f32x4{NEG_INF, NEG_INF, NEG_INF, NEG_INF};
-        } else if (PA_FAST(t)) {
+        if (PA_FAST(t)) {
           c = pa_load4_nt(sin_p + t * TSTEP + goff);
         } else {
           const bool inrow = PA_PRED(t);
@@ -692,7 +715,7 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : 3) void pair_attn_bwd_mfma_ke
     const float mneg = -m * PA_LOG2E;   // (same exponential as the forward: exp2(S * log2(e) - m * log2(e)))
     float lsum = 0.f;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    for (int t = 0; t < KT; ++t) {
       {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -708,8 +731,8 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : 3) void pair_attn_bwd_mfma_ke
     // dropped elements are remembered in the SIGN of P (P >= 0): |P| feeds the softmax gradient, P > 0 selects dropout(P)
     float dl = 0.f;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (!PA_SKIP(t)) {
+    for (int t = 0; t < KT; ++t) {
+      {
         // A of dP^T: V[key 16t + c16][d = 4g..4g+3] (exact bf16 products, fp32 accumulation)
         const pa_s16x4 va = g < 2 ? *reinterpret_cast<const pa_s16x4*>(sV + (t * 16 + c16) * 8 + 4 * g) : zero4;
         f32x4 dp = {0.f, 0.f, 0.f, 0.f};
@@ -738,7 +761,6 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : 3) void pair_attn_bwd_mfma_ke
     // fewer at the 168 cap -- no spills), pinned in place by scheduling barriers
     constexpr int PA_LA = 3;
     auto load_gin = [&](int t) -> f32x4 {
-      if (PA_SKIP(t)) return f32x4{0.f, 0.f, 0.f, 0.f};
       if (PA_FAST(t)) {
         const f32x4 ld4 = pa_load4_nt(gin_p + (g_in_zero ? 0 : t * TSTEP + goff));
         return g_in_zero ? f32x4{0.f, 0.f, 0.f, 0.f} : ld4;
@@ -749,16 +771,15 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : 3) void pair_attn_bwd_mfma_ke
     };
     f32x4 Gq[PA_LA];
 #pragma unroll
-    for (int t = 0; t < PA_LA && t < NT; ++t) Gq[t] = load_gin(t);
+    for (int t = 0; t < PA_LA && t < KT; ++t) Gq[t] = load_gin(t);
     f32x4 dq = {0.f, 0.f, 0.f, 0.f};
     const int dcol = dlane ? c16 : 0;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    for (int t = 0; t < KT; ++t) {
       const int kcol = t * 16 + 4 * g;
       const f32x4 Gin = Gq[t % PA_LA];
-      if (t + PA_LA < NT) Gq[t % PA_LA] = load_gin(t + PA_LA);
+      if (t + PA_LA < KT) Gq[t % PA_LA] = load_gin(t + PA_LA);
       __builtin_amdgcn_sched_barrier(0);
-      if (PA_SKIP(t)) continue;      // (wave-uniform: nothing of this tile exists)
       const pa_s16x4 va = g < 2 ? *reinterpret_cast<const pa_s16x4*>(sV + (t * 16 + c16) * 8 + 4 * g) : zero4;
       f32x4 dp = {0.f, 0.f, 0.f, 0.f};
       dp = PA_MFMA16(va, dob, dp);
@@ -830,12 +851,15 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : 3) void pair_attn_bwd_mfma_ke
     }
 #undef PA_PRED
 #undef PA_FAST
-#undef PA_SKIP
   };
-  for (int qb = wave; qb < nKB; qb += nwaves) {
-    if (TILED && qb * 16 + 16 <= N) body(qb, std::false_type{});
-    else body(qb, std::true_type{});
-  }
+  auto run = [&](auto kt_c) {
+    for (int qb = wave; qb < nKB; qb += nwaves) {
+      if (TILED && qb * 16 + 16 <= N) body(qb, std::false_type{}, kt_c);
+      else body(qb, std::true_type{}, kt_c);
+    }
+  };
+  if constexpr (RAG) pa_dispatch_kt<NT, NT>(kt, run);
+  else run(std::integral_constant<int, NT>{});
   __syncthreads();
   for (int key = tid; key < N; key += blockDim.x) {
     const int t = key >> 4, kg = (key & 15) >> 2, r = key & 3;

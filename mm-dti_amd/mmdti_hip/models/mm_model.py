@@ -299,7 +299,8 @@ class MM_Model(nn.Module):
             nt = (src_tokens.shape[1] + 15) // 16
             if int(kt.min()) < nt:
                 kt = kt.clamp_(min=1, max=nt)
-                ops.set_pair_kept(float(kt.sum()) / (kt.numel() * nt))
+                covered = sum(ops.pair_key_tiles_effective(int(k), nt) for k in kt.tolist())     # (what the kernels cover: ops.pair_key_tiles_effective)
+                ops.set_pair_kept(covered / (kt.numel() * nt))
                 key_tiles = kt.to(torch.int32).to(src_tokens.device, non_blocking=True)
         img_mask = ~padding_mask
         attention_mask = attention_mask.bool().to(src_tokens.device)

@@ -497,6 +497,15 @@ def pair_untile(t, N):
     return t.reshape(B, H, -1)[:, :, _tile_index(N, t.device).reshape(-1)].view(B, H, N, N)
 
 
+def pair_key_tiles_effective(kt, nt):
+    """The key-tile count the ragged kernels actually cover for a molecule with ``kt`` real key tiles out of ``nt``: every count
+    is supported up to 9 tiles, every 2nd up to 13, every 4th beyond (pair_attn.hip, pa_kt_effective); a count in between runs as
+    the next supported one -- the extra tiles are ordinary all-padding tiles."""
+    step = 1 if nt <= 9 else (2 if nt <= 13 else 4)
+    k = (max(int(kt), 1) + step - 1) // step * step
+    return nt if k >= nt else k
+
+
 _pair_kept = 1.0       # fraction of the padded key columns the ragged kernels keep (work accounting of the timers only)
 
 

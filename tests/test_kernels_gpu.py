@@ -347,7 +347,8 @@ def test_pair_attn_compact_planes_are_the_fp32_kernels_plus_rounding(ops, B, N, 
         ops.pair_attn_fwd(qkv, dev(bias).half(), None, B, N, H, ld, scale)         # fp16 row-major planes do not exist
 
 
-@pytest.mark.parametrize("B,N,H,lens,p", [(4, 130, 8, (130, 37, 64, 5), 0.0), (3, 100, 64, (100, 17, 81), 0.1), (2, 258, 8, (40, 258), 0.0), (2, 16, 8, (3, 16), 0.0)])
+@pytest.mark.parametrize("B,N,H,lens,p", [(4, 130, 8, (130, 37, 64, 5), 0.0), (3, 100, 64, (100, 17, 81), 0.1), (2, 258, 8, (40, 258), 0.0), (2, 16, 8, (3, 16), 0.0),
+                                          (5, 200, 4, (200, 33, 90, 150, 177), 0.1), (4, 240, 8, (10, 70, 130, 240), 0.0)])
 def test_pair_attn_ragged_key_tile_skipping_equals_dense(ops, B, N, H, lens, p):
     """Ragged batches (compact tiled planes): with key_tiles = ceil(length / 16) per molecule the kernels neither load, compute
     nor store the all-padding key tiles.  Everything that is defined must equal the dense run bit for bit: O, dqkv, S and G on
@@ -363,6 +364,8 @@ def test_pair_attn_ragged_key_tile_skipping_equals_dense(ops, B, N, H, lens, p):
     bias = torch.zeros(B, H, N, ld); bias[..., :N] = torch.randn(B, H, N, N, generator=G(2))
     bias_t = ops.pair_tile(dev(bias), N, float("-inf")).half()
     kt = torch.tensor([(n + 15) // 16 for n in lens], dtype=torch.int32, device="cuda")
+    ke = [ops.pair_key_tiles_effective(int(k), nt) for k in kt]                # tiles the kernels cover (>= kt: see ops.pair_key_tiles_effective)
+    assert all(int(a) <= b <= nt for a, b in zip(kt, ke))
     kw = dict(drop_p=p, seed=5, site=3)
 
     def rows(t):                                                                # -> [B,H,nt,N,16]: the N x N block by key tile (slots with q >= N or k >= N are never written or read)
@@ -377,13 +380,13 @@ def test_pair_attn_ragged_key_tile_skipping_equals_dense(ops, B, N, H, lens, p):
     s_n, o_n = ops.pair_attn_fwd(qkv, bias_t, dev(key_pad), B, N, H, ld, scale, key_tiles=kt, rag_store=False, **kw)
     assert torch.equal(o_n, o_d)
     for b in range(B):
-        k = int(kt[b])
+        k = ke[b]
         assert torch.equal(rows(s_n)[b, :, :k], rows(s_d)[b, :, :k])
     # second layer on top of the not-stored S: the skipped tiles are never read
     s2_d, o2_d = ops.pair_attn_fwd(qkv, s_d, None, B, N, H, ld, scale, **kw)
     s_poison = s_n.clone()
     for b in range(B):
-        s_poison[b, :, :, int(kt[b]):] = float("nan")
+        s_poison[b, :, :, ke[b]:] = float("nan")
     s2_r, o2_r = ops.pair_attn_fwd(qkv, s_poison, None, B, N, H, ld, scale, key_tiles=kt, rag_store=True, **kw)
     assert torch.equal(o2_r, o2_d) and torch.equal(rows(s2_r), rows(s2_d))
     # backward
@@ -394,7 +397,7 @@ def test_pair_attn_ragged_key_tile_skipping_equals_dense(ops, B, N, H, lens, p):
     dq_r = ops.pair_attn_bwd(qkv, s_poison, dO, g_r, B, N, H, ld, scale, False, key_tiles=kt, **kw)
     assert torch.equal(dq_r, dq_d)
     for b in range(B):
-        k = int(kt[b])
+        k = ke[b]
         assert torch.equal(rows(g_r)[b, :, :k], rows(g_d)[b, :, :k])
         if k < nt:
             assert float(rows(g_d)[b, :, k:].abs().max()) == 0.0                # (what the dense run computes there is exactly 0 ...)
@@ -405,7 +408,7 @@ def test_pair_attn_ragged_key_tile_skipping_equals_dense(ops, B, N, H, lens, p):
     dq_zd = ops.pair_attn_bwd(qkv, s_d, dO, gz_d, B, N, H, ld, scale, True, **kw)
     assert torch.equal(dq_z, dq_zd)
     for b in range(B):
-        assert torch.equal(rows(gz)[b, :, :int(kt[b])], rows(gz_d)[b, :, :int(kt[b])])
+        assert torch.equal(rows(gz)[b, :, :ke[b]], rows(gz_d)[b, :, :ke[b]])
     with pytest.raises(ops.MMDTIError):                                         # the fp32 planes have no ragged form
         ops.pair_attn_fwd(qkv, bias_t.float(), dev(key_pad), B, N, H, ld, scale, key_tiles=kt)
 
