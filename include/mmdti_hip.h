@@ -204,7 +204,8 @@ int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, const void*
                         void* o_bf16, const unsigned char* key_pad, int B, int N, int H, int ld, float scale,
                         float drop_p, unsigned long long seed, unsigned int site, int layout,
                         const int* key_tiles /* nullable, layout 3 only: [B] int32, number of 16-key tiles of each molecule that
-                        hold a real key (ragged batches, right-padded by mm_model.py:645-682).  The key tiles past it are all padding:
+                        hold a real key (ragged batches, right-padded by mm_model.py:645-682).  The key tiles past it (past the next count the
+                        sweeps are built for: every count up to 9 tiles, every 2nd up to 13, every 4th beyond) are all padding:
                         they are not loaded, not computed, and not stored unless rag_store != 0 (then written as -inf: pass it for the
                         last layer, whose S goes back to the caller).  Pad QUERY rows are computed as ever. */,
                         int rag_store);
