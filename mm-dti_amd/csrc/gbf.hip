@@ -257,7 +257,8 @@ __global__ __launch_bounds__(512, 2) void gbf_bias_fwd_kernel(const float* __res
                                                               const bf16_t* __restrict__ W2, const float* __restrict__ b2,
                                                               OT* __restrict__ out, bf16_t* __restrict__ feat_out,
                                                               bf16_t* __restrict__ u_out, bf16_t* __restrict__ h_out, int B, int N,
-                                                              int ld, int E, int tpm, int ugrad, int ltab) {
+                                                              int ld, int E, int tpm, int ugrad, int ltab,
+                                                              const int* __restrict__ tile_prefix) {
   static_assert(TILED || sizeof(OT) == 4, "compact pair planes exist in the tiled layout only");
   extern __shared__ __attribute__((aligned(16))) unsigned char gbf_smem[];
   bf16_t* sW1 = reinterpret_cast<bf16_t*>(gbf_smem);       // [128][136]   W1[f][k]
@@ -294,8 +295,13 @@ __global__ __launch_bounds__(512, 2) void gbf_bias_fwd_kernel(const float* __res
     }
   __syncthreads();
   const int g = lane >> 4, i = lane & 15;
-  const int ntiles = B * tpm;
+  // Ragged batches (tile_prefix, tiled planes only): molecule b covers its first tile_prefix[b+1] - tile_prefix[b] tiles -- with
+  // the column block slowest in a molecule's tile order these are exactly the blocks of its first key tiles; the all-padding
+  // key tiles behind them are never read by the ragged pair-attention kernels and are not written.
+  const bool rag = TILED && tile_prefix != nullptr;
+  const int ntiles = rag ? tile_prefix[B] : B * tpm;
   const int nwaves = (int)gridDim.x * 8;
+  int b_run = 0;   // (fetch is called with increasing tiles: the molecule index only moves forward)
   // Pair tiles of 16.  Row-major planes: 16 consecutive q = i*ld + j (64 contiguous bytes of every head plane).  Tiled
   // planes ([nt][nt][256], 16x16 tiles in MFMA accumulator order -- the layout the pair-attention kernels stream): a
   // 4x4 (query, key) block, which is again 64 contiguous bytes; blocks past N are visited too so that EVERY pad slot of
@@ -305,8 +311,15 @@ __global__ __launch_bounds__(512, 2) void gbf_bias_fwd_kernel(const float* __res
   // flags: bit 0 valid pair, bit 1 slot inside the plane, bit 2 whole block past N
   auto fetch = [&](int tile, int& b, int& q, int& flags, unsigned& pl, int& e, float& d) {
     tile = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : ntiles - 1);
-    b = (int)((unsigned)tile / (unsigned)tpm);
-    const int tq = tile - b * tpm;
+    int tq;
+    if (rag) {
+      while (b_run + 1 < B && tile >= tile_prefix[b_run + 1]) ++b_run;
+      b = b_run;
+      tq = tile - tile_prefix[b];
+    } else {
+      b = (int)((unsigned)tile / (unsigned)tpm);
+      tq = tile - b * tpm;
+    }
     int ii, jj;
     bool inplane = true, past = false;
     if (TILED) {
@@ -668,7 +681,7 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
     const float* __restrict__ bias, const float* __restrict__ means, const float* __restrict__ stds, const bf16_t* __restrict__ W1,
     const float* __restrict__ b1, const bf16_t* __restrict__ W2, float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2,
     float* __restrict__ db2, float* __restrict__ dmul, float* __restrict__ dbias, float* __restrict__ dmeans, float* __restrict__ dstds, int B,
-    int N, int ld, int E, int tpm) {
+    int N, int ld, int E, int tpm, const int* __restrict__ tile_prefix) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gbf_smem[];
   bf16_t* sW1 = reinterpret_cast<bf16_t*>(gbf_smem);            // [128 f][144]  W1[f][k]
   bf16_t* sW2T = sW1 + GBF_F * GBF_LW;                           // [128 f][72]   W2^T[f][h]
@@ -736,7 +749,11 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
   unsigned o_gconst = o_f32 + (unsigned)(8 * g) * 4;             // Gaussian constants of kernels 32c + 8g + 0..7 (phase A)
   unsigned o_b1row = o_f32 + (unsigned)(4 * GBF_K + 4 * g) * 4;
   unsigned o_kconst = o_f32 + (unsigned)(16 * wave + 4 * g) * 4; // phase B1's Gaussian constants: kernels k = 16*wave + 4g + r
-  const int ntiles = B * tpm;
+  // (ragged batches: tile_prefix as in the forward kernel -- here a molecule's tiles are its 4x4 blocks of REAL pairs, column
+  //  block slowest, so a prefix of them covers its first key tiles; the gradient is zero, and never written, behind them)
+  const bool rag = TILED && tile_prefix != nullptr;
+  const int ntiles = rag ? tile_prefix[B] : B * tpm;
+  int b_run = 0;
   const int nt = (N + 15) >> 4, nb = (N + 3) >> 2;
   const long long plane = TILED ? (long long)nt * nt * 256 : (long long)N * ld;
   gf32x4 amu = {0.f, 0.f, 0.f, 0.f}, asg = {0.f, 0.f, 0.f, 0.f};
@@ -754,8 +771,15 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
     tile = __builtin_amdgcn_readfirstlane(tile);          // (wave-uniform: tile = 8 * workgroup + wave)
     act = tile < ntiles;
     tile = act ? tile : ntiles - 1;
-    const int b = (int)((unsigned)tile / (unsigned)tpm);
-    const int tq = tile - b * tpm;
+    int b, tq;
+    if (rag) {
+      while (b_run + 1 < B && tile >= tile_prefix[b_run + 1]) ++b_run;
+      b = b_run;
+      tq = tile - tile_prefix[b];
+    } else {
+      b = (int)((unsigned)tile / (unsigned)tpm);
+      tq = tile - b * tpm;
+    }
     int q, ii, jj;
     if (TILED) {
       const int cb = (int)((unsigned)tq / (unsigned)nb), rb = tq - cb * nb;   // query block fastest: see the forward kernel
@@ -1095,10 +1119,12 @@ static int edge_bytes_ok(int eb) { return eb == 8 || eb == 4 || eb == 2; }
 extern "C" int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, const void* edge_type, int edge_bytes, const float* mul,
                                   const float* bias, const float* means, const float* stds, const void* w1_bf16,
                                   const float* b1, const void* w2_bf16, const float* b2, int B, int N, int ld, int K, int F,
-                                  int H, int E, void* out, void* feat_bf16, void* u_bf16, void* h_bf16, int flags) {
+                                  int H, int E, void* out, void* feat_bf16, void* u_bf16, void* h_bf16, int flags,
+                                  const int* tile_prefix) {
   // bit 0: tiled pair layout; bit 1: u_bf16 receives gelu'(u) instead of u; bit 2: compact planes (out is fp16; tiled only)
   const int tiled = flags & 1, ugrad = (flags >> 1) & 1, compact = (flags >> 2) & 1;
   MMDTI_REQUIRE(!compact || tiled, "gbf_bias_fwd: compact planes (flags bit 2) exist in the tiled layout only");
+  MMDTI_REQUIRE(!tile_prefix || tiled, "gbf_bias_fwd: tile_prefix (ragged batches) needs the tiled pair layout");
   MMDTI_REQUIRE(dist && edge_type && mul && bias && means && stds && w1_bf16 && b1 && w2_bf16 && b2 && out, "gbf_bias_fwd: null argument");
   MMDTI_REQUIRE(edge_bytes_ok(edge_bytes), "gbf_bias_fwd: edge types must be int64, int32 or int16 (edge_bytes=%d)", edge_bytes);
   MMDTI_REQUIRE(K == GBF_K && F == GBF_F && H == GBF_H, "gbf_bias_fwd: built for %d gaussians, %d hidden, %d heads (got %d,%d,%d)",
@@ -1131,7 +1157,7 @@ extern "C" int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, cons
 #define GBF_L(SAVE, TILED, OT)                                                                                                      \
   hipLaunchKernelGGL((gbf_bias_fwd_kernel<SAVE, TILED, OT>), dim3(grid), dim3(512), smem, (hipStream_t)stream, dist, edge_type, edge_bytes, mul, bias, \
                      means, stds, (const bf16_t*)w1_bf16, b1, (const bf16_t*)w2_bf16, b2, (OT*)out, (bf16_t*)feat_bf16, (bf16_t*)u_bf16, \
-                     (bf16_t*)h_bf16, B, N, ld, E, tpm, ugrad, ltab)
+                     (bf16_t*)h_bf16, B, N, ld, E, tpm, ugrad, ltab, tile_prefix)
   if (compact) { if (save) GBF_L(true, true, _Float16); else GBF_L(false, true, _Float16); }
   else if (save) { if (tiled) GBF_L(true, true, float); else GBF_L(true, false, float); }
   else           { if (tiled) GBF_L(false, true, float); else GBF_L(false, false, float); }
@@ -1185,9 +1211,10 @@ extern "C" int mmdti_gbf_bias_bwd_full(mmdti_stream_t stream, const void* g, con
                                        const float* mul, const float* bias, const float* means, const float* stds, const void* w1_bf16,
                                        const float* b1, const void* w2_bf16, int B, int N, int ld, int K, int F, int H, int E, int flags,
                                        float* dw1, float* db1, float* dw2, float* db2, float* dmul, float* dbias, float* dmeans,
-                                       float* dstds) {
+                                       float* dstds, const int* tile_prefix) {
   const int tiled = flags & 1, compact = (flags >> 2) & 1;   // bit 0: tiled pair layout; bit 2: compact planes (g is bf16; tiled only)
   MMDTI_REQUIRE(!compact || tiled, "gbf_bias_bwd_full: compact planes (flags bit 2) exist in the tiled layout only");
+  MMDTI_REQUIRE(!tile_prefix || tiled, "gbf_bias_bwd_full: tile_prefix (ragged batches) needs the tiled pair layout");
   MMDTI_REQUIRE(g && dist && edge_type && mul && bias && means && stds && w1_bf16 && b1 && w2_bf16 && dw1 && db1 && dw2 && db2 && dmul && dbias &&
                     dmeans && dstds, "gbf_bias_bwd_full: null argument");
   MMDTI_REQUIRE(edge_bytes_ok(edge_bytes), "gbf_bias_bwd_full: edge types must be int64, int32 or int16 (edge_bytes=%d)", edge_bytes);
@@ -1215,7 +1242,7 @@ extern "C" int mmdti_gbf_bias_bwd_full(mmdti_stream_t stream, const void* g, con
 #define GBF_FB(TILED, GT)                                                                                                          \
   hipLaunchKernelGGL((gbf_bias_bwd_full_kernel<TILED, GT>), dim3(grid), dim3(512), smem, (hipStream_t)stream, (const GT*)g, dist, edge_type, edge_bytes, mul, \
                      bias, means, stds, (const bf16_t*)w1_bf16, b1, (const bf16_t*)w2_bf16, dw1, db1, dw2, db2, dmul, dbias, dmeans, dstds, B, \
-                     N, ld, E, tpm)
+                     N, ld, E, tpm, tile_prefix)
   if (compact) GBF_FB(true, __bf16); else if (tiled) GBF_FB(true, float); else GBF_FB(false, float);
 #undef GBF_FB
   MMDTI_LAUNCH_CHECK();

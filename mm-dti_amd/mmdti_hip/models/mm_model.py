@@ -281,10 +281,11 @@ class MM_Model(nn.Module):
         return self._side
 
     # ------------------------------------------------------------------ forward
-    def pair_bias(self, src_distance, src_edge_type):
-        """mm_model.py:553-556 fused: -> [B,H,N,ld] fp32."""
+    def pair_bias(self, src_distance, src_edge_type, key_tiles_host=None):
+        """mm_model.py:553-556 fused: -> the pair bias ([B,H,N,ld] fp32, or the tiled pair layout on the hot path).  key_tiles_host
+        (ragged batches): [B] real key tiles per molecule, on the HOST."""
         N = src_distance.shape[-1]
-        return PairBiasFn.apply(self.gbf.means.weight, src_distance.float(), src_edge_type, self.gbf, self.gbf_proj, ops.pair_ld(N))
+        return PairBiasFn.apply(self.gbf.means.weight, src_distance.float(), src_edge_type, self.gbf, self.gbf_proj, ops.pair_ld(N), key_tiles_host)
 
     def forward(self, src_tokens, src_distance, src_edge_type, input_ids, attention_mask, weights=None,
                 return_infonce_loss=False, return_ct_loss=False, return_feature=False, net_target=None, use_weight=None,
@@ -293,7 +294,7 @@ class MM_Model(nn.Module):
         # Ragged batches.  atom_counts ([B] ints ON THE HOST: position of each molecule's last real token + 1, attached by
         # collate.device_payload) tells, without a device sync, whether some molecule is shorter than the padded length; then the
         # pair-attention kernels skip the all-padding key tiles (a third to a half of the pair traffic on a drug-like batch).
-        key_tiles = None
+        key_tiles = kt_host = None
         if atom_counts is not None and PAIR_RAGGED and src_tokens.is_cuda:
             kt = (torch.as_tensor(atom_counts, device="cpu").to(torch.int64) + 15) // 16
             nt = (src_tokens.shape[1] + 15) // 16
@@ -301,6 +302,7 @@ class MM_Model(nn.Module):
                 kt = kt.clamp_(min=1, max=nt)
                 covered = sum(ops.pair_key_tiles_effective(int(k), nt) for k in kt.tolist())     # (what the kernels cover: ops.pair_key_tiles_effective)
                 ops.set_pair_kept(covered / (kt.numel() * nt))
+                kt_host = kt
                 key_tiles = kt.to(torch.int32).to(src_tokens.device, non_blocking=True)
         img_mask = ~padding_mask
         attention_mask = attention_mask.bool().to(src_tokens.device)
@@ -319,7 +321,7 @@ class MM_Model(nn.Module):
 
         def tower1(sl):
             xs = EmbeddingFn.apply(self.embed_tokens.weight, src_tokens[sl], self.padding_idx)
-            bias_s = self.pair_bias(src_distance[sl], src_edge_type[sl])
+            bias_s = self.pair_bias(src_distance[sl], src_edge_type[sl], None if kt_host is None else kt_host[sl])
             return self.encoder.encode(xs, bias_s, padding_mask[sl], None if key_tiles is None else key_tiles[sl])[0]
 
         Bm = src_tokens.shape[0]

@@ -964,6 +964,61 @@ def test_gbf_bias_compact_planes(ops, B, N):
         assert float((a - b_).norm() / (b_.norm() + 1e-12)) < 1e-5, n
 
 
+@pytest.mark.parametrize("B,N,lens", [(4, 130, (130, 37, 64, 5)), (3, 37, (37, 16, 17)), (2, 200, (33, 200)), (3, 21, (21, 21, 21))])
+def test_gbf_bias_ragged_tile_prefixes(ops, B, N, lens):
+    """Ragged batches at the two ends of the pair chain: with the per-molecule tile prefixes the fused pair-bias forward writes only
+    the blocks of each molecule's first key tiles (the ones the ragged pair-attention kernels read; bit-identical there, everything
+    behind them left untouched), and the complete backward visits only those blocks -- the gradient is zero behind them, so all
+    eight parameter gradients agree with the dense run up to the summation order of the fp32 atomics."""
+    K, Fh, H, E = 128, 128, 64, 31 * 31
+    ld, nt = ops.pair_ld(N), ops.pair_tiles(N)
+    gen = G(31)
+    dist = torch.rand(B, N, N, generator=gen) * 8
+    et = torch.randint(1, E, (B, N, N), generator=gen)
+    for b, n in enumerate(lens):                                   # padded as the reference collates: distance 0, edge type 0
+        dist[b, n:, :] = 0; dist[b, :, n:] = 0; et[b, n:, :] = 0; et[b, :, n:] = 0
+    mul, bias = 1 + 0.1 * torch.randn(E, generator=gen), 0.1 * torch.randn(E, generator=gen)
+    means, stds = torch.rand(K, generator=gen) * 3, torch.rand(K, generator=gen) * 3 - 1.5
+    w1, b1 = dev(bf(torch.randn(Fh, K, generator=gen) * 0.2)), dev(torch.randn(Fh, generator=gen) * 0.1)
+    w2, b2 = dev(bf(torch.randn(H, Fh, generator=gen) * 0.2)), dev(torch.randn(H, generator=gen) * 0.1)
+    d = [dev(t) for t in (dist, et.to(torch.int16), mul, bias, means, stds)]
+    kt = torch.tensor([(n + 15) // 16 for n in lens])
+    ke = [ops.pair_key_tiles_effective(int(k), nt) for k in kt]
+    pre_f, pre_b = ops.gbf_tile_prefixes(kt, N, "cuda")
+    assert pre_f.dtype == torch.int32 and pre_f.shape == (B + 1,) and int(pre_f[-1]) == sum(4 * k * 4 * nt for k in ke)
+    dense, _ = ops.gbf_bias_fwd(*d, w1, b1, w2, b2, ld, save=False, tiled=True, compact=True)
+    canary = 123.0
+    import mmdti_hip.ops as O_
+    orig_empty = O_.pair_empty
+    O_.pair_empty = lambda *a, **k: torch.full_like(orig_empty(*a, **k), canary)       # so that "not written" is observable
+    try:
+        rag, _ = ops.gbf_bias_fwd(*d, w1, b1, w2, b2, ld, save=False, tiled=True, compact=True, tile_prefix=pre_f)
+    finally:
+        O_.pair_empty = orig_empty
+    for b in range(B):
+        assert torch.equal(rag[b, :, :, :ke[b]], dense[b, :, :, :ke[b]])             # [B,H,tq,tk,256]: key tiles < ke, every query tile, pads included
+        if ke[b] < nt:
+            assert bool((rag[b, :, :, ke[b]:] == canary).all())        # (the bias of padded keys: the ragged attention kernels never read it)
+    # backward: g is zero behind the kept tiles (as the ragged attention backward leaves it)
+    g = ops.pair_tile(dev(torch.randn(B, H, N, N, generator=gen)), N, 0.0)
+    for b in range(B):
+        g[b, :, :, ke[b]:] = 0.0
+    names = ("dw1", "db1", "dw2", "db2", "dmul", "dbias", "dmeans", "dstds")
+    shapes = ((Fh, K), (Fh,), (H, Fh), (H,), (E,), (E,), (K,), (K,))
+    got = {}
+    for tag, pre in (("dense", None), ("ragged", pre_b)):
+        got[tag] = {n: torch.zeros(sh, device="cuda") for n, sh in zip(names, shapes)}
+        gg = g.clone()
+        if pre is not None:
+            for b in range(B):
+                gg[b, :, :, ke[b]:] = float("nan")                                    # never read
+        ops.gbf_bias_bwd_full(gg, *d, w1, b1, w2, ld, *[got[tag][n].view(-1) for n in names], tile_prefix=pre)
+    for n in names:
+        a, b_ = got["ragged"][n], got["dense"][n]
+        assert torch.isfinite(a).all(), n
+        assert float((a - b_).norm() / (b_.norm() + 1e-12)) < 1e-5, n
+
+
 @pytest.mark.parametrize("E", [1600, 5000])
 def test_gbf_bias_forward_with_large_edge_type_tables(ops, E):
     """E = 1600 (a 40-token dictionary): tables in LDS, but more than the complete backward kernel keeps (1536), so the model
