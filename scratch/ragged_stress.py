@@ -1,0 +1,62 @@
+"""Randomised check of the ragged path through the whole model: for random batch shapes (N from 8 to 258, random molecule
+lengths) the training-mode loss with the host-side atom counts (ragged kernels: compile-time key-tile counts, ragged pair-bias
+kernels) must equal the loss without them (dense kernels) bit for bit, and gradients up to atomics noise."""
+import os, sys, random, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "mm-dti_amd"))
+from oracle import mmdti_oracle as O
+from g9util import tiny_cfg, product_model, load_fixture_weights, rel_l2
+from mmdti_hip import collate
+from mmdti_hip.runtime import dropout_state
+from mmdti_hip.functional import CELossFn
+
+ocfg = tiny_cfg("classification", 40)
+ocfg.unimol = O.UniMolCfg(layers=2, dim=512, ffn=256, heads=64, K=128, vocab=31)
+ocfg.cross, ocfg.roberta = O.CrossCfg(dim=512, heads=16, ffn=128), O.RobertaCfg(layers=1, dim=512, heads=8, ffn=128, vocab=40, max_pos=40)
+P = O.init_params(ocfg, seed=12, std=0.05)
+model = product_model(ocfg).cuda().train()
+load_fixture_weights(model, P)
+if os.environ.get('STRESS_NO_OVERLAP') == '1':
+    model.overlap_towers = False; model.infonce_on_side_stream = False; model.cross_modal_module.two_streams = False
+    from mmdti_hip import functional as Fn
+    Fn.DEFER_WGRAD_LAYERS = 0; Fn.WGRAD_SIDE = False
+rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+bad = 0
+for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
+    B = rng.choice([2, 3, 5, 8])
+    nmax = rng.choice([6, 14, 30, 46, 62, 78, 94, 110, 126, 142, 158, 190, 222, 256])
+    batch, label = O.synth_batch(B, nmax, 20, ocfg, seed=1000 + trial, ragged=True)
+    counts = collate.atom_counts(batch["src_tokens"], 0)
+    N = batch["src_tokens"].shape[1]
+    dev = {k: v.cuda() for k, v in batch.items()}
+    def step(**extra):
+        dropout_state.reseed(77 + trial)
+        model.zero_grad(set_to_none=True)
+        logits, infonce, ct = model(**dev, **extra, return_infonce_loss=True, return_ct_loss=True, net_target=label.cuda())
+        loss = CELossFn.apply(logits, label.cuda()) + 0.1 * infonce + 0.1 * ct
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    ld, gd = step()
+    ld2, gd2 = step()                                     # the dense step against itself: the noise floor (fp32 atomics)
+    lr, gr = step(atom_counts=counts)
+    names = [n for n in gd if float(gd[n].abs().max()) > 0 and not any(z in n for z in ("pooler", "key.bias", "gbf_proj.linear2.bias"))]
+    worst = max(((n, rel_l2(gr[n], gd[n])) for n in names), key=lambda t: t[1])
+    noise = max(((n, rel_l2(gd2[n], gd[n])) for n in names), key=lambda t: t[1])
+    # gbf_proj.linear1.bias / gbf.stds are sums that cancel almost completely (exactly, if gelu' were constant: the rows of G sum
+    # to zero), so a different GROUPING of the fp32 partial sums shows up at 1e-2 relative there; everything else must agree tightly
+    tight = [n for n in names if not n.startswith("gbf")]
+    worst_t = max(((n, rel_l2(gr[n], gd[n])) for n in tight), key=lambda t: t[1])
+    noise_t = max(((n, rel_l2(gd2[n], gd[n])) for n in tight), key=lambda t: t[1])
+    # Two runs of the SAME dense step are not bit-identical either (loss kernels and split-K / table gradients use fp32 atomics:
+    # the loss moves by an ulp, bottom-of-the-network gradients by up to 2e-3 after the bf16 casts of the backward chain amplify
+    # it): the ragged step has to sit inside that band, not at zero.
+    ok = (abs(float(ld) - float(lr)) <= 3e-7 * abs(float(ld)) and worst_t[1] <= max(3 * noise_t[1], 5e-3) and worst[1] < 0.1
+          and bool(torch.isfinite(lr)) and all(bool(torch.isfinite(v).all()) for v in gr.values()))
+    if not torch.equal(ld, ld2): print("   !! dense forward not repeatable:", float(ld), float(ld2))
+    if not torch.equal(ld, lr): print("   !! ragged forward differs:", float(ld), float(lr), float(ld - lr))
+    print(f"      non-gbf worst {worst_t[0]} {worst_t[1]:.1e} (dense vs dense {noise_t[0]} {noise_t[1]:.1e})")
+    bad += not ok
+    print(f"trial {trial:2d} B={B} N={N:3d} lens={counts.tolist()} loss dense {float(ld):.7f} dense again {float(ld2):.7f} ragged {float(lr):.7f} | worst grad {worst[0]} {worst[1]:.1e} (dense vs dense: {noise[0]} {noise[1]:.1e}) {'ok' if ok else 'FAIL'}")
+print("failures:", bad)
+sys.exit(1 if bad else 0)

