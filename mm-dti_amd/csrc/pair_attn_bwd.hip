@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void pair_attn_bwd_kernel(const bf16_t* __rest
 // RAG: see the forward kernel.  Skipped key tiles contribute nothing (P = 0, G = 0) and their G is NOT written: the caller
 // hands in a zero-initialised G when the batch is ragged.
 template <int NT, bool TILED, bool FULL, int NW, bool RAG, typename ST, typename GT>
-__global__ __launch_bounds__(64 * NW, NT > 9 ? 1 : 3) void pair_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const ST* __restrict__ s_in,
+__global__ __launch_bounds__(64 * NW, NT > 9 ? ((NT >= 16 && NW == 3) ? 2 : 1) : 3) void pair_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const ST* __restrict__ s_in,
                                                                  const bf16_t* __restrict__ dO, const GT* __restrict__ gin, GT* __restrict__ gout,
                                                                  bf16_t* __restrict__ dqkv, int N, int H, int ld, float scale,
                                                                  int g_in_zero, uint32_t thresh, float dscale, uint64_t seed,
@@ -454,7 +454,9 @@ extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, 
   hipStream_t st = (hipStream_t)stream;
   if (ld % 4 == 0 && aligned16(s) && aligned16(g) && N <= 16 * PA_MAX_NT) {
     const int nqb = (N + 15) / 16;
-    dim3 blk(nqb % 3 == 0 ? 192 : (nqb < 4 ? 64 * nqb : 256));
+    // (16 and 17 tiles: three waves and a register cap for two workgroups per CU -- with four waves the per-wave dK / dV accumulators
+    //  leave LDS for one workgroup, and 251 + 12 registers for one wave per SIMD: N = 250 / 258 took 4.2 / 3.9 ms against 2.15 at N = 240)
+    dim3 blk((nqb % 3 == 0 || nqb >= 16) ? 192 : (nqb < 4 ? 64 * nqb : 256));
 #define PA_MB(NT, TL, FL, NWV, RG, ST, GT)                                                                                     \
   hipLaunchKernelGGL((pair_attn_bwd_mfma_kernel<NT, TL, FL, NWV, RG, ST, GT>), grid, blk, 0, st, (const bf16_t*)qkv_bf16,      \
                      (const ST*)s, (const bf16_t*)do_bf16, (const GT*)g, (GT*)g, (bf16_t*)dqkv_bf16, N, H, ld, scale,           \
@@ -472,8 +474,8 @@ extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, 
     // (compact planes with fp32 gradients -- the hot path -- have one instantiation per tile count: see the forward)
 #define PA_MBC(NT)                                                                                                    \
   case NT:                                                                                                            \
-    if (key_tiles) PA_MB(NT, true, true, (NT % 3 == 0 ? 3 : 4), true, _Float16, float);                               \
-    else PA_MB(NT, true, true, (NT % 3 == 0 ? 3 : 4), false, _Float16, float);                                        \
+    if (key_tiles) PA_MB(NT, true, true, ((NT % 3 == 0 || NT >= 16) ? 3 : 4), true, _Float16, float);                               \
+    else PA_MB(NT, true, true, ((NT % 3 == 0 || NT >= 16) ? 3 : 4), false, _Float16, float);                                        \
     break
     if (compact && !g16) {
       switch (nqb) {
