@@ -456,7 +456,7 @@ extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, 
     const int nqb = (N + 15) / 16;
     // (16 and 17 tiles: three waves and a register cap for two workgroups per CU -- with four waves the per-wave dK / dV accumulators
     //  leave LDS for one workgroup, and 251 + 12 registers for one wave per SIMD: N = 250 / 258 took 4.2 / 3.9 ms against 2.15 at N = 240)
-    dim3 blk((nqb % 3 == 0 || nqb >= 16) ? 192 : (nqb < 4 ? 64 * nqb : 256));
+    dim3 blk((nqb % 3 == 0 || nqb >= 16 || nqb == 5) ? 192 : (nqb < 4 ? 64 * nqb : 256));   // (5 blocks: 2,2,1 on three waves beats 2,1,1,1 on four)
 #define PA_MB(NT, TL, FL, NWV, RG, ST, GT)                                                                                     \
   hipLaunchKernelGGL((pair_attn_bwd_mfma_kernel<NT, TL, FL, NWV, RG, ST, GT>), grid, blk, 0, st, (const bf16_t*)qkv_bf16,      \
                      (const ST*)s, (const bf16_t*)do_bf16, (const GT*)g, (GT*)g, (bf16_t*)dqkv_bf16, N, H, ld, scale,           \
@@ -474,8 +474,8 @@ extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, 
     // (compact planes with fp32 gradients -- the hot path -- have one instantiation per tile count: see the forward)
 #define PA_MBC(NT)                                                                                                    \
   case NT:                                                                                                            \
-    if (key_tiles) PA_MB(NT, true, true, ((NT % 3 == 0 || NT >= 16) ? 3 : 4), true, _Float16, float);                               \
-    else PA_MB(NT, true, true, ((NT % 3 == 0 || NT >= 16) ? 3 : 4), false, _Float16, float);                                        \
+    if (key_tiles) PA_MB(NT, true, true, ((NT % 3 == 0 || NT >= 16 || NT == 5) ? 3 : 4), true, _Float16, float);                               \
+    else PA_MB(NT, true, true, ((NT % 3 == 0 || NT >= 16 || NT == 5) ? 3 : 4), false, _Float16, float);                                        \
     break
     if (compact && !g16) {
       switch (nqb) {
