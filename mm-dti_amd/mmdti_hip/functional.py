@@ -251,6 +251,9 @@ class PairEncoderFn(torch.autograd.Function):
             ctx.st, ctx.mod = st, mod
         x_last = x.view(B, N, D)
         ctx.mark_non_differentiable(s_prev, x_last)
+        # (otherwise autograd hands the backward a freshly ZEROED tensor for each output nobody differentiates -- for S_last that is
+        #  a 0.55 GB fill per step, found with scratch/fill_diag.py)
+        ctx.set_materialize_grads(False)
         return out.view(B, N, D), s_prev, x_last
 
     @staticmethod
@@ -258,6 +261,8 @@ class PairEncoderFn(torch.autograd.Function):
         st, mod = ctx.st, ctx.mod
         B, N, D, H, ld, M, seed = st.B, st.N, st.D, st.H, st.ld, st.M, st.seed
         scale = (D // H) ** -0.5
+        if dout is None:                       # (nothing downstream used the encoder output)
+            dout = torch.zeros(M, D, device=st.emb.device, dtype=F32)
         dout = dout.contiguous().view(M, D)
         if mod.final_layer_norm is not None:
             fl = mod.final_layer_norm
