@@ -152,3 +152,26 @@ def test_worker_side_collate_yields_the_batches_of_the_in_process_collate():
         assert list(gb) == [k for k in rb if k != "src_coord"] + ["atom_counts"]
         assert torch.equal(gl, rl) and gb["src_edge_type"].dtype == torch.int16
         assert all(torch.equal(gb[k].long() if k == "src_edge_type" else gb[k], rb[k]) for k in gb if k != "atom_counts")
+
+
+def test_ragged_key_tile_counts_and_pair_bias_prefixes_host_logic():
+    """Host arithmetic of the ragged path (no GPU): the key-tile count a molecule's sweeps cover is the next SUPPORTED count (every
+    count up to 9 tiles, every 2nd up to 13, every 4th beyond, and the full count), and the pair-bias kernels' tile prefixes follow
+    from it -- forward: 4 x 4 pair blocks of the covered key tiles over ALL 4 * nt row blocks; backward: blocks of real pairs only."""
+    import torch
+    from mmdti_hip import ops
+    for nt in range(1, 18):
+        step = 1 if nt <= 9 else (2 if nt <= 13 else 4)
+        got = [ops.pair_key_tiles_effective(k, nt) for k in range(0, nt + 3)]
+        assert got[0] == got[1] and got[-1] == got[-2] == nt                       # clamped below and above
+        for k in range(1, nt + 1):
+            ke = ops.pair_key_tiles_effective(k, nt)
+            assert k <= ke <= nt and (ke == nt or ke % step == 0) and ke - k < step  # the smallest supported count >= k
+        assert sorted(set(got)) == sorted(set([k for k in range(step, nt, step)] + [nt]))
+    N = 130                                                                        # nt = 9, nb = 33
+    kt = torch.tensor([9, 3, 4, 1])
+    f, b = ops.gbf_tile_prefixes(kt, N, "cpu")
+    assert f.dtype == b.dtype == torch.int32 and f.tolist() == [0] + torch.cumsum(4 * kt * 36, 0).tolist()
+    assert b.tolist() == [0] + torch.cumsum(33 * torch.clamp(4 * kt, max=33), 0).tolist()
+    f2, _ = ops.gbf_tile_prefixes(torch.tensor([1, 11, 15]), 258, "cpu")           # nt = 17: counts round up to 4, 12, 16
+    assert (f2[1:] - f2[:-1]).tolist() == [4 * 4 * 68, 4 * 12 * 68, 4 * 16 * 68]
