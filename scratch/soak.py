@@ -1,11 +1,16 @@
-import sys, time, torch
+import os, sys, time, torch
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/mm-dti_amd')
 import bench
 from mmdti_hip.trainer import FineTuner
 model,_=bench.build_model(); model=model.cuda().train()
 tuner=FineTuner(model,"classification",total_steps=400,learning_rate=1e-4)
-_,batch,label=bench.synth(256,128,256,seed=1234)
+RAG=os.environ.get('SOAK_RAGGED')=='1'
+_,batch,label=bench.synth(256,128,256,seed=1234,ragged=RAG)
+if RAG:
+    from mmdti_hip.collate import atom_counts
+    counts=atom_counts(batch['src_tokens'],0)
 batch={k:v.cuda() for k,v in batch.items()}; label=label.cuda()
+if RAG: batch['atom_counts']=counts
 ts=[]; losses=[]
 for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 300):
     torch.cuda.synchronize(); t0=time.perf_counter()
