@@ -172,8 +172,6 @@ def main():
     model = model.to(dev).train()
     if os.environ.get("MMDTI_NO_OVERLAP") == "1":      # A/B switch: run the two towers back to back on one stream
         model.overlap_towers = False
-    if os.environ.get("MMDTI_SPLIT_TOWER1"):           # A/B switch: tower 1 as n sub-batches on n streams
-        model.split_tower1 = int(os.environ["MMDTI_SPLIT_TOWER1"])
     tuner = FineTuner(model, "classification", total_steps=10_000, distributed=(world > 1 or os.environ.get("MMDTI_FORCE_DDP") == "1"))
     _, batch, label = synth(args.batch, args.atoms, args.tokens, seed=1234 + rank, ragged=args.ragged)
     counts = None

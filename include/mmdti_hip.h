@@ -215,13 +215,23 @@ int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, const void*
                         sweeps are built for: every count up to 9 tiles, every 2nd up to 13, every 4th beyond) are all padding:
                         they are not loaded, not computed, and not stored unless rag_store != 0 (then written as -inf: pass it for the
                         last layer, whose S goes back to the caller).  Pad QUERY rows are computed as ever. */,
-                        int rag_store);
+                        int rag_store,
+                        const int* row_off /* nullable, with key_tiles only: PACKED token rows.  [B+1] int32 on the device: molecule b owns
+                        rows [row_off[b], row_off[b+1]) of qkv, o_bf16 and key_pad (then indexed by packed row) -- its n_b real tokens
+                        followed by at most ONE representative pad row -- instead of rows [b*N, (b+1)*N).  Why one row is enough: the
+                        reference zeroes padded rows before the first layer (transformers.py:114-118) and pads src_distance with 0 and
+                        src_edge_type with the pad index (mm_model.py:657-661), so at dropout 0 every pad row of a molecule has the same
+                        input, the same bias row and the same keys in every layer; the unmasked InfoNCE mean (infonce.py:32-33) then
+                        weights the one row by the number of pad positions (mmdti_seq_mean_packed_fwd).  Pair planes (bias_in, s_out) stay
+                        indexed by POSITION: query position i of molecule b is packed row row_off[b] + i; query rows past the
+                        representative one are neither computed nor stored. */);
 /* g (in/out, same layout as s; fp32, or bf16 for layout 7): on entry dL/dS_l from the layers above (ignored if g_in_zero), on
  * exit dL/dS_l total = dL/d(bias_in).  dqkv: [B,N,3*H*8] bf16.  key_tiles: as in the forward; the skipped tiles of g are neither
  * read nor written (hand in a zero-initialised g for a ragged batch). */
 int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, const void* s, const void* do_bf16, void* g,
                         void* dqkv_bf16, int B, int N, int H, int ld, float scale, int g_in_zero, float drop_p,
-                        unsigned long long seed, unsigned int site, int layout, const int* key_tiles);
+                        unsigned long long seed, unsigned int site, int layout, const int* key_tiles,
+                        const int* row_off /* nullable: packed token rows of qkv / do_bf16 / dqkv_bf16, as in the forward */);
 
 /* ---- Row softmax over materialised scores (HF eager_attention_forward :158-183; BertCoAttention
  * mm_module.py:497-514) ------------------------------------------------------------------------
@@ -243,13 +253,22 @@ int mmdti_softmax_bwd(mmdti_stream_t stream, const void* p_bf16, const float* dp
  * to the caller.  head_dim 32 or 64; Lq, Lk <= 256. */
 int mmdti_attn_fwd(mmdti_stream_t stream, const void* q_bf16, const void* k_bf16, const void* v_bf16,
                    const float* key_add, void* ctx_bf16, float* stats, int B, int heads, int Lq, int Lk, int head_dim,
-                   int ldq, int ldk, int ldo, float scale, float drop_p, unsigned long long seed, unsigned int site);
+                   int ldq, int ldk, int ldo, float scale, float drop_p, unsigned long long seed, unsigned int site,
+                   const int* q_off, const int* k_off, const int* k_cnt, int q_rows /* all nullable / 0 together: PACKED sequences
+                   (right-padded batches, mm_model.py:645-682 / HF tokenizer padding=True).  q_off, k_off: [B+1] int32 on the device,
+                   sequence b owns rows [off[b], off[b+1]) of the query-side (q, ctx) / key-side (k, v) row arrays -- its real tokens,
+                   then at most one representative pad row; k_cnt: [B] int32, REAL keys of sequence b (its first k_cnt[b] key-side
+                   rows).  Padded keys get probability exactly 0 in the reference (finfo.min / -10000 additive masks underflow), so
+                   leaving them out of the key range is the same arithmetic; key_add must be null.  Lq, Lk: the longest sequence
+                   (rows) of each side, <= 256.  stats (and drow in the backward) are then [heads, q_rows] with q_rows = q_off[B]. */);
 /* dq/dk/dv (bf16, strides lddq / lddk / lddk) from dctx (stride ldo); drow: [B,heads,Lq] fp32 scratch that receives
  * sum_j dP'_ij p_ij.  Same (seed, site) as the forward call regenerates the dropout mask. */
 int mmdti_attn_bwd(mmdti_stream_t stream, const void* q_bf16, const void* k_bf16, const void* v_bf16,
                    const float* key_add, const void* dctx_bf16, const float* stats, float* drow, void* dq_bf16,
                    void* dk_bf16, void* dv_bf16, int B, int heads, int Lq, int Lk, int head_dim, int ldq, int ldk, int ldo,
-                   int lddq, int lddk, float scale, float drop_p, unsigned long long seed, unsigned int site);
+                   int lddq, int lddk, float scale, float drop_p, unsigned long long seed, unsigned int site,
+                   const int* q_off, const int* k_off, const int* k_cnt, int q_rows /* packed sequences, as in the forward; the
+                   key-side rows past k_cnt[b] (the representative pad row) receive dk = dv = 0 */);
 
 /* ---- GELU on bf16 (kept for un-fused call sites) ------------------------------------------- */
 int mmdti_gelu_fwd_bf16(mmdti_stream_t stream, const void* u_bf16, void* y_bf16, long long n);
@@ -262,6 +281,16 @@ int mmdti_seq_mean_fwd(mmdti_stream_t stream, const void* x_bf16, int B, int S, 
  * backward of "pool the GELU outputs, then project" (mean_t(W2 h_t + b2) = W2 mean_t(h_t) + b2, infonce.py:28-33) */
 int mmdti_seq_mean_bwd(mmdti_stream_t stream, const float* dout, int B, int S, int D, int ld, void* dx_bf16, const void* aux_bf16,
                        int ld_aux, int aux_mode);
+/* The same unmasked mean over a PACKED token layout (mmdti_pair_attn_fwd, row_off): sequence b owns rows [row_off[b], row_off[b+1])
+ * of x -- n_real[b] real tokens, then (if n_real[b] < S) ONE representative pad row that stands for all S - n_real[b] padded
+ * positions:  out[b] = (sum_real x + (S - n_real[b]) * x_pad) / S   -- infonce.py:32-33 over the padded [B,S,*] tensor, whose pad rows
+ * are identical at dropout 0.  x: [rows, ld] bf16, D % 8 == 0, ld % 8 == 0. */
+int mmdti_seq_mean_packed_fwd(mmdti_stream_t stream, const void* x_bf16, int B, int S, int D, int ld, const int* row_off,
+                              const int* n_real, float* out);
+/* dx[r] = bf16(dout[b(r)] * w(r) / S * f(aux[r])), w = 1 for a real row, S - n_real[b] for the representative pad row; row_seq:
+ * [rows] int32, the sequence each packed row belongs to; f / aux_mode as in mmdti_seq_mean_bwd. */
+int mmdti_seq_mean_packed_bwd(mmdti_stream_t stream, const float* dout, int rows, int S, int D, int ld, const int* row_off,
+                              const int* n_real, const int* row_seq, void* dx_bf16, const void* aux_bf16, int ld_aux, int aux_mode);
 /* F.normalize(x, dim=-1) (infonce.py:104-105; contrastive.py:22-23) */
 int mmdti_l2norm_fwd(mmdti_stream_t stream, const float* x, int B, int D, int ldx, float* xhat, float* inv_norm);
 int mmdti_l2norm_bwd(mmdti_stream_t stream, const float* dxhat, const float* xhat, const float* inv_norm, int B,
@@ -311,6 +340,16 @@ int mmdti_masked_pool_fwd(mmdti_stream_t stream, const float* a, const float* t,
                           const unsigned char* mask_t, int B, int Na, int Nt, int D, float* pooled);
 int mmdti_masked_pool_bwd(mmdti_stream_t stream, const float* dpooled, const unsigned char* mask_a,
                           const unsigned char* mask_t, int B, int Na, int Nt, int D, float* da, float* dt);
+
+/* The same pooling over PACKED token layouts: a: [rows_a, D], t: [rows_t, D] fp32; sequence b owns rows [a_off[b], a_off[b+1]) of a,
+ * the first a_cnt[b] of them real (likewise t): pooled[b] = (sum of its real rows of a and t) / (a_cnt[b] + t_cnt[b]).  The
+ * representative pad rows do not enter (mm_model.py:572-573 zeroes padded rows before the sum) and get a zero gradient.
+ * a_seq / t_seq: [rows] int32, the sequence of each packed row (backward only). */
+int mmdti_masked_pool_packed_fwd(mmdti_stream_t stream, const float* a, const float* t, const int* a_off, const int* a_cnt,
+                                 const int* t_off, const int* t_cnt, int B, int D, float* pooled);
+int mmdti_masked_pool_packed_bwd(mmdti_stream_t stream, const float* dpooled, const int* a_off, const int* a_cnt, const int* a_seq,
+                                 int rows_a, const int* t_off, const int* t_cnt, const int* t_seq, int rows_t, int D, float* da,
+                                 float* dt);
 
 /* ---- small fp32 linear for the classification head (mm_model.py:44-84) ---------------------- */
 /* y = act(x.W^T + b); act: 0 none, 3 tanh */

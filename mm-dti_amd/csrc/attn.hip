@@ -61,6 +61,39 @@ __device__ __forceinline__ uint32_t attn_keep4(uint32_t key, uint32_t quad, uint
 constexpr float ATTN_LOG2E = 1.4426950408889634f;
 __device__ __forceinline__ float attn_mask2(float ka) { return fmaxf(ka * ATTN_LOG2E, -3.4028234663852886e38f); }
 
+// Variable-length (packed) sequences.  q_off / k_off: [B+1] int32 row offsets of every sequence in the query-side / key-side row
+// arrays (sequence b owns rows [off[b], off[b+1]) -- its real tokens, then at most one representative pad row); k_cnt: [B]
+// int32, the REAL keys of sequence b (the representative pad row of the key side is no key: the reference masks padded keys,
+// additively, to a probability of exactly 0).  Every row of the query side is a query.  Null pointers: the dense layout
+// (sequence b = rows [b*L, (b+1)*L), masked keys through key_add).  q_rows: total rows of the query side (stats / drow are
+// then [heads, q_rows] instead of [B, heads, Lq]).
+struct AttnVarlen {
+  const int* q_off;
+  const int* k_off;
+  const int* k_cnt;
+  int q_rows;
+};
+struct AttnSeq {
+  int q0, lq, k0, lk, krows;
+};
+__device__ __forceinline__ AttnSeq attn_seq(const AttnVarlen& vl, int b, int Lq, int Lk) {
+  AttnSeq s;
+  if (vl.q_off) {
+    s.q0 = __builtin_amdgcn_readfirstlane(vl.q_off[b]);
+    s.lq = __builtin_amdgcn_readfirstlane(vl.q_off[b + 1]) - s.q0;
+    s.k0 = __builtin_amdgcn_readfirstlane(vl.k_off[b]);
+    s.krows = __builtin_amdgcn_readfirstlane(vl.k_off[b + 1]) - s.k0;
+    s.lk = __builtin_amdgcn_readfirstlane(vl.k_cnt[b]);
+  } else {
+    s.q0 = b * Lq; s.lq = Lq; s.k0 = b * Lk; s.lk = Lk; s.krows = Lk;
+  }
+  return s;
+}
+// index of query row qi of (sequence b, head h) in stats / drow
+__device__ __forceinline__ long long attn_stat_row(const AttnVarlen& vl, const AttnSeq& sq, int bh, int h, int Lq, int qi) {
+  return vl.q_off ? (long long)h * vl.q_rows + sq.q0 + qi : (long long)bh * Lq + qi;
+}
+
 template <int HD>
 __device__ __forceinline__ void attn_fill_rows(bf16_t* lds, const bf16_t* g, int L, int rows, int ld, int tid, int nthreads) {
   constexpr int CPR = HD / 8, STR = AttnShape<HD>::STR;
@@ -112,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
                                                        const bf16_t* __restrict__ v, const float* __restrict__ key_add,
                                                        bf16_t* __restrict__ ctx, float* __restrict__ stats, int heads, int Lq,
                                                        int Lk, int ldq, int ldk, int ldo, float scale, uint32_t thresh16,
-                                                       float dscale, uint64_t seed, uint32_t site) {
+                                                       float dscale, uint64_t seed, uint32_t site, AttnVarlen vl) {
   extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
   constexpr int STR = AttnShape<HD>::STR, KC = AttnShape<HD>::KC, NB = AttnShape<HD>::NB, NP = NT * 16;
   bf16_t* sK = reinterpret_cast<bf16_t*>(attn_smem);
@@ -120,18 +153,19 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
   float* sKA = reinterpret_cast<float*>(sV + NP * STR);
   const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  attn_fill_rows<HD>(sK, k + (long long)b * Lk * ldk + h * HD, Lk, NP, ldk, tid, blockDim.x);
-  attn_fill_rows<HD>(sV, v + (long long)b * Lk * ldk + h * HD, Lk, NP, ldk, tid, blockDim.x);
-  for (int t = tid; t < NP; t += blockDim.x) sKA[t] = t < Lk ? (key_add ? attn_mask2(key_add[(long long)b * Lk + t]) : 0.f) : -INFINITY;
+  const AttnSeq sq = attn_seq(vl, b, Lq, Lk);
+  attn_fill_rows<HD>(sK, k + (long long)sq.k0 * ldk + h * HD, sq.lk, NP, ldk, tid, blockDim.x);
+  attn_fill_rows<HD>(sV, v + (long long)sq.k0 * ldk + h * HD, sq.lk, NP, ldk, tid, blockDim.x);
+  for (int t = tid; t < NP; t += blockDim.x) sKA[t] = t < sq.lk ? (key_add ? attn_mask2(key_add[(long long)b * Lk + t]) : 0.f) : -INFINITY;
   __syncthreads();
   const uint32_t rkey = attn_rng_key(seed, site, (uint32_t)bh);
   const float scale2 = scale * ATTN_LOG2E;
   const int g = lane >> 4, i = lane & 15;
-  const int nqt = (Lq + 15) >> 4;
+  const int nqt = (sq.lq + 15) >> 4;
   for (int qt = wave; qt < nqt; qt += nw) {
     const int qi = qt * 16 + i;
-    const bool qv = qi < Lq;
-    const bf16_t* qrow = q + ((long long)b * Lq + (qv ? qi : 0)) * ldq + h * HD;
+    const bool qv = qi < sq.lq;
+    const bf16_t* qrow = q + ((long long)sq.q0 + (qv ? qi : 0)) * ldq + h * HD;
     bf16x8 qf[KC];
 #pragma unroll
     for (int c = 0; c < KC; ++c) qf[c] = attn_frag_global<HD>(qrow, qv, c, lane);
@@ -163,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
     lsum += __shfl_xor(lsum, 16, 64);
     lsum += __shfl_xor(lsum, 32, 64);
     const float inv = 1.0f / lsum;
-    if (g == 0 && qv) *reinterpret_cast<float2*>(stats + ((long long)bh * Lq + qi) * 2) = make_float2(m, inv);
+    if (g == 0 && qv) *reinterpret_cast<float2*>(stats + attn_stat_row(vl, sq, bh, h, Lq, qi) * 2) = make_float2(m, inv);
     f32x4 o[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) o[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -186,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
       __builtin_amdgcn_sched_barrier(0);
     }
     if (qv) {
-      bf16_t* dst = ctx + ((long long)b * Lq + qi) * ldo + h * HD + 4 * g;
+      bf16_t* dst = ctx + ((long long)sq.q0 + qi) * ldo + h * HD + 4 * g;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) attn_store4(dst + nb * 16, o[nb]);
     }
@@ -200,7 +234,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const bf16_t* __restric
                                                          const bf16_t* __restrict__ dout, const float* __restrict__ stats,
                                                          bf16_t* __restrict__ dq, float* __restrict__ drow, int heads, int Lq,
                                                          int Lk, int ldq, int ldk, int ldo, int lddq, float scale,
-                                                         uint32_t thresh16, float dscale, uint64_t seed, uint32_t site) {
+                                                         uint32_t thresh16, float dscale, uint64_t seed, uint32_t site, AttnVarlen vl) {
   extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
   constexpr int STR = AttnShape<HD>::STR, KC = AttnShape<HD>::KC, NB = AttnShape<HD>::NB, NP = NT * 16;
   bf16_t* sK = reinterpret_cast<bf16_t*>(attn_smem);
@@ -208,19 +242,20 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const bf16_t* __restric
   float* sKA = reinterpret_cast<float*>(sV + NP * STR);
   const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  attn_fill_rows<HD>(sK, k + (long long)b * Lk * ldk + h * HD, Lk, NP, ldk, tid, blockDim.x);
-  attn_fill_rows<HD>(sV, v + (long long)b * Lk * ldk + h * HD, Lk, NP, ldk, tid, blockDim.x);
-  for (int t = tid; t < NP; t += blockDim.x) sKA[t] = t < Lk ? (key_add ? attn_mask2(key_add[(long long)b * Lk + t]) : 0.f) : -INFINITY;
+  const AttnSeq sq = attn_seq(vl, b, Lq, Lk);
+  attn_fill_rows<HD>(sK, k + (long long)sq.k0 * ldk + h * HD, sq.lk, NP, ldk, tid, blockDim.x);
+  attn_fill_rows<HD>(sV, v + (long long)sq.k0 * ldk + h * HD, sq.lk, NP, ldk, tid, blockDim.x);
+  for (int t = tid; t < NP; t += blockDim.x) sKA[t] = t < sq.lk ? (key_add ? attn_mask2(key_add[(long long)b * Lk + t]) : 0.f) : -INFINITY;
   __syncthreads();
   const uint32_t rkey = attn_rng_key(seed, site, (uint32_t)bh);
   const float scale2 = scale * ATTN_LOG2E;
   const int g = lane >> 4, i = lane & 15;
-  const int nqt = (Lq + 15) >> 4;
+  const int nqt = (sq.lq + 15) >> 4;
   for (int qt = wave; qt < nqt; qt += nw) {
     const int qi = qt * 16 + i;
-    const bool qv = qi < Lq;
-    const bf16_t* qrow = q + ((long long)b * Lq + (qv ? qi : 0)) * ldq + h * HD;
-    const bf16_t* orow = dout + ((long long)b * Lq + (qv ? qi : 0)) * ldo + h * HD;
+    const bool qv = qi < sq.lq;
+    const bf16_t* qrow = q + ((long long)sq.q0 + (qv ? qi : 0)) * ldq + h * HD;
+    const bf16_t* orow = dout + ((long long)sq.q0 + (qv ? qi : 0)) * ldo + h * HD;
     bf16x8 qf[KC], dof[KC];
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
@@ -228,7 +263,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const bf16_t* __restric
       dof[c] = attn_frag_global<HD>(orow, qv, c, lane);
     }
     float2 st = make_float2(0.f, 0.f);
-    if (qv) st = *reinterpret_cast<const float2*>(stats + ((long long)bh * Lq + qi) * 2);
+    if (qv) st = *reinterpret_cast<const float2*>(stats + attn_stat_row(vl, sq, bh, h, Lq, qi) * 2);
     // sweep 1: probabilities (kept in registers, sign bit = "dropped") and the row term D = sum_j dP'_ij p_ij
     f32x4 P[NT];
     float dsum = 0.f;
@@ -255,7 +290,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const bf16_t* __restric
     dsum *= dscale;
     dsum += __shfl_xor(dsum, 16, 64);
     dsum += __shfl_xor(dsum, 32, 64);
-    if (g == 0 && qv) drow[(long long)bh * Lq + qi] = dsum;
+    if (g == 0 && qv) drow[attn_stat_row(vl, sq, bh, h, Lq, qi)] = dsum;
     // sweep 2: dP again (two MFMAs per tile are cheaper than 64 more live registers), dS, dQ^T += K^T.dS^T
     f32x4 da[NB];
 #pragma unroll
@@ -280,7 +315,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const bf16_t* __restric
       __builtin_amdgcn_sched_barrier(0);
     }
     if (qv) {
-      bf16_t* dst = dq + ((long long)b * Lq + qi) * lddq + h * HD + 4 * g;
+      bf16_t* dst = dq + ((long long)sq.q0 + qi) * lddq + h * HD + 4 * g;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) attn_store4(dst + nb * 16, da[nb]);
     }
@@ -295,25 +330,27 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv_kernel(const bf16_t* __res
                                                           const float* __restrict__ drow, bf16_t* __restrict__ dk,
                                                           bf16_t* __restrict__ dv, int heads, int Lq, int Lk, int ldq, int ldk,
                                                           int ldo, int lddk, float scale, uint32_t thresh16, float dscale,
-                                                          uint64_t seed, uint32_t site, int key_stride) {
+                                                          uint64_t seed, uint32_t site, int key_stride, AttnVarlen vl) {
   extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
   constexpr int STR = AttnShape<HD>::STR, KC = AttnShape<HD>::KC, NB = AttnShape<HD>::NB;
-  const int LQP = ((Lq + 31) >> 5) << 5;
+  const int LQP_MAX = ((Lq + 31) >> 5) << 5;       // (the images are sized for the longest sequence of the launch)
   bf16_t* sQ = reinterpret_cast<bf16_t*>(attn_smem);
-  bf16_t* sO = sQ + LQP * STR;
-  float* sM = reinterpret_cast<float*>(sO + LQP * STR);
-  float* sI = sM + LQP;
-  float* sD = sI + LQP;
+  bf16_t* sO = sQ + LQP_MAX * STR;
+  float* sM = reinterpret_cast<float*>(sO + LQP_MAX * STR);
+  float* sI = sM + LQP_MAX;
+  float* sD = sI + LQP_MAX;
   const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  attn_fill_rows<HD>(sQ, q + (long long)b * Lq * ldq + h * HD, Lq, LQP, ldq, tid, blockDim.x);
-  attn_fill_rows<HD>(sO, dout + (long long)b * Lq * ldo + h * HD, Lq, LQP, ldo, tid, blockDim.x);
+  const AttnSeq sq = attn_seq(vl, b, Lq, Lk);
+  const int LQP = ((sq.lq + 31) >> 5) << 5;        // this sequence's queries, in 32-row steps
+  attn_fill_rows<HD>(sQ, q + (long long)sq.q0 * ldq + h * HD, sq.lq, LQP, ldq, tid, blockDim.x);
+  attn_fill_rows<HD>(sO, dout + (long long)sq.q0 * ldo + h * HD, sq.lq, LQP, ldo, tid, blockDim.x);
   for (int t = tid; t < LQP; t += blockDim.x) {
     float2 st = make_float2(0.f, 0.f);
     float d = 0.f;
-    if (t < Lq) {
-      st = *reinterpret_cast<const float2*>(stats + ((long long)bh * Lq + t) * 2);
-      d = drow[(long long)bh * Lq + t];
+    if (t < sq.lq) {
+      st = *reinterpret_cast<const float2*>(stats + attn_stat_row(vl, sq, bh, h, Lq, t) * 2);
+      d = drow[attn_stat_row(vl, sq, bh, h, Lq, t)];
     }
     sM[t] = st.x;
     sI[t] = st.y;
@@ -322,12 +359,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv_kernel(const bf16_t* __res
   __syncthreads();
   const uint32_t rkey = attn_rng_key(seed, site, (uint32_t)bh);
   const int g = lane >> 4, i = lane & 15;
-  const int nkt = (Lk + 15) >> 4;
+  // (packed rows: the representative pad row of the key side is visited too -- as a masked key, so that its dk / dv rows are
+  //  WRITTEN, as zeros)
+  const int nkt = (sq.krows + 15) >> 4;
   for (int kt = wave; kt < nkt; kt += nw) {
     const int key = kt * 16 + i;
-    const bool kv = key < Lk;
-    const bf16_t* krow = k + ((long long)b * Lk + (kv ? key : 0)) * ldk + h * HD;
-    const bf16_t* vrow = v + ((long long)b * Lk + (kv ? key : 0)) * ldk + h * HD;
+    const bool kv = key < sq.lk, kstore = key < sq.krows;
+    const bf16_t* krow = k + ((long long)sq.k0 + (kv ? key : 0)) * ldk + h * HD;
+    const bf16_t* vrow = v + ((long long)sq.k0 + (kv ? key : 0)) * ldk + h * HD;
     bf16x8 kf[KC], vf[KC];
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
@@ -384,9 +423,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv_kernel(const bf16_t* __res
         dka[nb] = ATTN_MFMA(attn_frag_tr<HD>(sQ, up * 32, up * 32 + 16, nb * 16, lane), sf, dka[nb]);
       }
     }
-    if (kv) {
-      bf16_t* dkd = dk + ((long long)b * Lk + key) * lddk + h * HD + 4 * g;
-      bf16_t* dvd = dv + ((long long)b * Lk + key) * lddk + h * HD + 4 * g;
+    if (kstore) {
+      bf16_t* dkd = dk + ((long long)sq.k0 + key) * lddk + h * HD + 4 * g;
+      bf16_t* dvd = dv + ((long long)sq.k0 + key) * lddk + h * HD + 4 * g;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         attn_store4(dkd + nb * 16, dka[nb]);
@@ -422,6 +461,13 @@ static int attn_check(const char* name, const void* q, const void* k, const void
   return MMDTI_OK;
 }
 
+static int attn_check_varlen(const char* name, const float* key_add, const int* q_off, const int* k_off, const int* k_cnt, int q_rows) {
+  const int n = (q_off ? 1 : 0) + (k_off ? 1 : 0) + (k_cnt ? 1 : 0);
+  MMDTI_REQUIRE(n == 0 || n == 3, "%s: q_off, k_off and k_cnt come together (packed sequences) or not at all", name);
+  MMDTI_REQUIRE(n == 0 || (q_rows > 0 && !key_add), "%s: packed sequences need q_rows > 0 and take no key_add (masked keys are left out of k_cnt)", name);
+  return MMDTI_OK;
+}
+
 }  // namespace mmdti
 MMDTI_DEFINE_SALT_PULL(attn)
 using namespace mmdti;
@@ -429,8 +475,10 @@ using namespace mmdti;
 extern "C" int mmdti_attn_fwd(mmdti_stream_t stream, const void* q_bf16, const void* k_bf16, const void* v_bf16,
                               const float* key_add, void* ctx_bf16, float* stats, int B, int heads, int Lq, int Lk,
                               int head_dim, int ldq, int ldk, int ldo, float scale, float drop_p, unsigned long long seed,
-                              unsigned int site) {
+                              unsigned int site, const int* q_off, const int* k_off, const int* k_cnt, int q_rows) {
   if (int e = attn_check("attn_fwd", q_bf16, k_bf16, v_bf16, B, heads, Lq, Lk, head_dim, ldq, ldk, drop_p)) return e;
+  if (int e = attn_check_varlen("attn_fwd", key_add, q_off, k_off, k_cnt, q_rows)) return e;
+  const AttnVarlen vl = {q_off, k_off, k_cnt, q_rows};
   MMDTI_REQUIRE(ctx_bf16 && stats && ldo >= heads * head_dim && ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(ctx_bf16) & 7) == 0 &&
                     (reinterpret_cast<uintptr_t>(stats) & 7) == 0, "attn_fwd: bad output arguments");
   const uint32_t th = thresh16_of(drop_p);
@@ -443,7 +491,7 @@ extern "C" int mmdti_attn_fwd(mmdti_stream_t stream, const void* q_bf16, const v
     if (!attr_done) { if (int e = attn_set_smem(attn_fwd_kernel<HD, NT>, smem_max)) return e; attr_done = true; }        \
     hipLaunchKernelGGL((attn_fwd_kernel<HD, NT>), dim3(B * heads), dim3(512), smem, (hipStream_t)stream,                 \
                        (const bf16_t*)q_bf16, (const bf16_t*)k_bf16, (const bf16_t*)v_bf16, key_add, (bf16_t*)ctx_bf16,  \
-                       stats, heads, Lq, Lk, ldq, ldk, ldo, scale, th, sc, (uint64_t)seed, (uint32_t)site);              \
+                       stats, heads, Lq, Lk, ldq, ldk, ldo, scale, th, sc, (uint64_t)seed, (uint32_t)site, vl);          \
   } while (0)
   if (head_dim == 64) { if (nt == 10) ATTN_F(64, 10); else ATTN_F(64, 16); }
   else                { if (nt == 10) ATTN_F(32, 10); else ATTN_F(32, 16); }
@@ -456,8 +504,10 @@ extern "C" int mmdti_attn_bwd(mmdti_stream_t stream, const void* q_bf16, const v
                               const float* key_add, const void* dctx_bf16, const float* stats, float* drow, void* dq_bf16,
                               void* dk_bf16, void* dv_bf16, int B, int heads, int Lq, int Lk, int head_dim, int ldq, int ldk,
                               int ldo, int lddq, int lddk, float scale, float drop_p, unsigned long long seed,
-                              unsigned int site) {
+                              unsigned int site, const int* q_off, const int* k_off, const int* k_cnt, int q_rows) {
   if (int e = attn_check("attn_bwd", q_bf16, k_bf16, v_bf16, B, heads, Lq, Lk, head_dim, ldq, ldk, drop_p)) return e;
+  if (int e = attn_check_varlen("attn_bwd", key_add, q_off, k_off, k_cnt, q_rows)) return e;
+  const AttnVarlen vl = {q_off, k_off, k_cnt, q_rows};
   MMDTI_REQUIRE(dctx_bf16 && stats && drow && dq_bf16 && dk_bf16 && dv_bf16, "attn_bwd: null argument");
   MMDTI_REQUIRE(ldo >= heads * head_dim && ldo % 8 == 0 && aligned16(dctx_bf16), "attn_bwd: dctx stride/alignment");
   MMDTI_REQUIRE(lddq >= heads * head_dim && lddk >= heads * head_dim && lddq % 4 == 0 && lddk % 4 == 0 &&
@@ -477,7 +527,7 @@ extern "C" int mmdti_attn_bwd(mmdti_stream_t stream, const void* q_bf16, const v
     hipLaunchKernelGGL((attn_bwd_q_kernel<HD, NT>), dim3(B * heads), dim3(256), smem_q, (hipStream_t)stream,               \
                        (const bf16_t*)q_bf16, (const bf16_t*)k_bf16, (const bf16_t*)v_bf16, key_add,                       \
                        (const bf16_t*)dctx_bf16, stats, (bf16_t*)dq_bf16, drow, heads, Lq, Lk, ldq, ldk, ldo, lddq, scale, \
-                       th, sc, (uint64_t)seed, (uint32_t)site);                                                            \
+                       th, sc, (uint64_t)seed, (uint32_t)site, vl);                                                        \
   } while (0)
 #define ATTN_BKV(HD)                                                                                                       \
   do {                                                                                                                     \
@@ -486,7 +536,7 @@ extern "C" int mmdti_attn_bwd(mmdti_stream_t stream, const void* q_bf16, const v
     hipLaunchKernelGGL((attn_bwd_kv_kernel<HD>), dim3(B * heads), dim3(512), smem_kv, (hipStream_t)stream,                 \
                        (const bf16_t*)q_bf16, (const bf16_t*)k_bf16, (const bf16_t*)v_bf16, key_add,                       \
                        (const bf16_t*)dctx_bf16, stats, drow, (bf16_t*)dk_bf16, (bf16_t*)dv_bf16, heads, Lq, Lk, ldq, ldk, \
-                       ldo, lddk, scale, th, sc, (uint64_t)seed, (uint32_t)site, nt * 16);                                 \
+                       ldo, lddk, scale, th, sc, (uint64_t)seed, (uint32_t)site, nt * 16, vl);                             \
   } while (0)
   if (head_dim == 64) { if (nt == 10) ATTN_BQ(64, 10); else ATTN_BQ(64, 16); }
   else                { if (nt == 10) ATTN_BQ(32, 10); else ATTN_BQ(32, 16); }

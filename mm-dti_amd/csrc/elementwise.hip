@@ -386,6 +386,59 @@ __global__ __launch_bounds__(256) void masked_pool_bwd_kernel(const float* __res
   }
 }
 
+// Packed token rows (see mmdti_masked_pool_packed_fwd): only a sequence's real rows enter; no masks to read.
+__global__ __launch_bounds__(256) void masked_pool_packed_fwd_kernel(const float* __restrict__ a, const float* __restrict__ t,
+                                                                     const int* __restrict__ a_off, const int* __restrict__ a_cnt,
+                                                                     const int* __restrict__ t_off, const int* __restrict__ t_cnt, int D,
+                                                                     float* __restrict__ pooled) {
+  const int b = blockIdx.x;
+  __shared__ float4 red[16][16];
+  const int na = a_cnt[b], nt = t_cnt[b];
+  const float* pa = a + (long long)a_off[b] * D;
+  const float* pt = t + (long long)t_off[b] * D;
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int col = blockIdx.y * 64 + cl * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col < D) {
+    for (int i = rg; i < na + nt; i += 16) {
+      const float* src = i < na ? pa + (long long)i * D : pt + (long long)(i - na) * D;
+      const float4 v = *reinterpret_cast<const float4*>(src + col);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  red[rg][cl] = s;
+  __syncthreads();
+  if (rg == 0 && col < D) {
+#pragma unroll
+    for (int r = 1; r < 16; ++r) {
+      const float4 v = red[r][cl];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const float inv = 1.0f / (float)(na + nt);
+    *reinterpret_cast<float4*>(pooled + (long long)b * D + col) = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+  }
+}
+// one float4 per thread: rows of da (first rows_a rows of the index space), then rows of dt
+__global__ __launch_bounds__(256) void masked_pool_packed_bwd_kernel(const float* __restrict__ dp, const int* __restrict__ a_off,
+                                                                     const int* __restrict__ a_cnt, const int* __restrict__ a_seq, int rows_a,
+                                                                     const int* __restrict__ t_off, const int* __restrict__ t_cnt,
+                                                                     const int* __restrict__ t_seq, int rows_t, int D, float* __restrict__ da,
+                                                                     float* __restrict__ dt) {
+  const int nv = D >> 2;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long row = idx / nv;
+  if (row >= (long long)rows_a + rows_t) return;
+  const int c = (int)(idx - row * nv) * 4;
+  const bool in_a = row < rows_a;
+  const int r = in_a ? (int)row : (int)(row - rows_a);
+  const int b = in_a ? a_seq[r] : t_seq[r];
+  const bool on = in_a ? (r - a_off[b] < a_cnt[b]) : (r - t_off[b] < t_cnt[b]);
+  const float inv = on ? 1.0f / (float)(a_cnt[b] + t_cnt[b]) : 0.f;
+  const float4 g = *reinterpret_cast<const float4*>(dp + (long long)b * D + c);
+  float* dst = (in_a ? da : dt) + (long long)r * D + c;
+  *reinterpret_cast<float4*>(dst) = make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv);
+}
+
 // ---------------------------------------------------------------- sum of squares / Adam
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, float* __restrict__ out) {
   float s = 0.f;
@@ -629,6 +682,28 @@ extern "C" int mmdti_masked_pool_bwd(mmdti_stream_t stream, const float* dpooled
   MMDTI_REQUIRE(dpooled && mask_a && mask_t && da && dt && B > 0 && Na > 0 && Nt > 0 && D > 0, "masked_pool_bwd: bad arguments");
   MMDTI_REQUIRE(D % 4 == 0 && aligned16(dpooled) && aligned16(da) && aligned16(dt), "masked_pool_bwd: D%%4 and 16-byte alignment required");
   hipLaunchKernelGGL(masked_pool_bwd_kernel, dim3(B, 8), dim3(256), 0, (hipStream_t)stream, dpooled, mask_a, mask_t, Na, Nt, D, da, dt);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_masked_pool_packed_fwd(mmdti_stream_t stream, const float* a, const float* t, const int* a_off, const int* a_cnt,
+                                            const int* t_off, const int* t_cnt, int B, int D, float* pooled) {
+  MMDTI_REQUIRE(a && t && a_off && a_cnt && t_off && t_cnt && pooled && B > 0 && D > 0, "masked_pool_packed_fwd: bad arguments");
+  MMDTI_REQUIRE(D % 4 == 0 && aligned16(a) && aligned16(t) && aligned16(pooled), "masked_pool_packed_fwd: D%%4 and 16-byte alignment required");
+  hipLaunchKernelGGL(masked_pool_packed_fwd_kernel, dim3(B, cdiv(D, 64)), dim3(256), 0, (hipStream_t)stream, a, t, a_off, a_cnt, t_off, t_cnt, D, pooled);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_masked_pool_packed_bwd(mmdti_stream_t stream, const float* dpooled, const int* a_off, const int* a_cnt, const int* a_seq,
+                                            int rows_a, const int* t_off, const int* t_cnt, const int* t_seq, int rows_t, int D, float* da,
+                                            float* dt) {
+  MMDTI_REQUIRE(dpooled && a_off && a_cnt && a_seq && t_off && t_cnt && t_seq && da && dt && rows_a > 0 && rows_t > 0 && D > 0,
+                "masked_pool_packed_bwd: bad arguments");
+  MMDTI_REQUIRE(D % 4 == 0 && aligned16(dpooled) && aligned16(da) && aligned16(dt), "masked_pool_packed_bwd: D%%4 and 16-byte alignment required");
+  const long long n = ((long long)rows_a + rows_t) * (D / 4);
+  hipLaunchKernelGGL(masked_pool_packed_bwd_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dpooled, a_off, a_cnt, a_seq,
+                     rows_a, t_off, t_cnt, t_seq, rows_t, D, da, dt);
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }

@@ -94,6 +94,69 @@ __global__ __launch_bounds__(256) void seq_mean_bwd_vec_kernel(const float* __re
   *reinterpret_cast<uint4*>(dx + row * ld + c8) = o;
 }
 
+// Packed token rows (see mmdti_seq_mean_packed_fwd): 32 rows per workgroup, the representative pad row weighted by the number of
+// padded positions it stands for.
+__global__ __launch_bounds__(256) void seq_mean_packed_fwd_kernel(const bf16_t* __restrict__ x, int S, int D, int ld, const int* __restrict__ row_off,
+                                                                  const int* __restrict__ n_real, float* __restrict__ out) {
+  extern __shared__ float red[];                // [4][D]
+  const int b = blockIdx.x, s0 = blockIdx.y * 32;
+  const int r0 = row_off[b], rows = row_off[b + 1] - r0, nr = n_real[b];
+  if (s0 >= rows) return;
+  const float wpad = (float)(S - nr);
+  const int cpr = D >> 3;
+  for (int c = threadIdx.x; c < cpr * 4; c += 256) {
+    const int piece = c % cpr, phase = c / cpr;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r = phase; r < 32 && s0 + r < rows; r += 4) {
+      const uint4 u = *reinterpret_cast<const uint4*>(x + ((long long)r0 + s0 + r) * ld + piece * 8);
+      const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
+      const float w = (s0 + r < nr) ? 1.f : wpad;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[2 * e] += w * __uint_as_float(w4[e] << 16);
+        acc[2 * e + 1] += w * __uint_as_float(w4[e] & 0xffff0000u);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[phase * D + piece * 8 + e] = acc[e];
+  }
+  __syncthreads();
+  const float inv = 1.0f / (float)S;
+  for (int d = threadIdx.x; d < D; d += 256)
+    atomicAdd(out + (long long)b * D + d, (red[d] + red[D + d] + red[2 * D + d] + red[3 * D + d]) * inv);
+}
+__global__ __launch_bounds__(256) void seq_mean_packed_bwd_kernel(const float* __restrict__ dout, int S, int D, int ld, const int* __restrict__ row_off,
+                                                                  const int* __restrict__ n_real, const int* __restrict__ row_seq,
+                                                                  const bf16_t* __restrict__ aux, int ld_aux, int aux_mode, bf16_t* __restrict__ dx,
+                                                                  long long rows) {
+  const int cpr = ld >> 3;
+  const long long chunk = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long row = chunk / cpr;
+  if (row >= rows) return;
+  const int c8 = (int)(chunk - row * cpr) * 8;
+  const int b = row_seq[row];
+  const int nr = n_real[b];
+  const float w = ((int)row - row_off[b] < nr ? 1.f : (float)(S - nr)) / (float)S;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (c8 + e < D) ? dout[(long long)b * D + c8 + e] * w : 0.f;
+  if (aux_mode) {
+    const uint4 u = *reinterpret_cast<const uint4*>(aux + row * ld_aux + c8);
+    const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float a = __uint_as_float((e & 1) ? (w4[e >> 1] & 0xffff0000u) : (w4[e >> 1] << 16));
+      v[e] *= aux_mode == 1 ? a : gelu_erf_grad(a);
+    }
+  }
+  uint4 o;
+  o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+  o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+  o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+  *reinterpret_cast<uint4*>(dx + row * ld + c8) = o;
+}
+
 // ---------------------------------------------------------------- F.normalize (eps 1e-12)
 __global__ __launch_bounds__(64) void l2norm_fwd_kernel(const float* __restrict__ x, int D, int ldx, float* __restrict__ xh, float* __restrict__ invn) {
   const int b = blockIdx.x, lane = threadIdx.x;
@@ -680,6 +743,32 @@ extern "C" int mmdti_seq_mean_bwd(mmdti_stream_t stream, const float* dout, int 
     MMDTI_REQUIRE(aux_mode == 0, "seq_mean_bwd: the aux factor needs 8-column aligned rows");
     hipLaunchKernelGGL(seq_mean_bwd_kernel, dim3(B * S), dim3(256), 0, (hipStream_t)stream, dout, S, D, ld, (bf16_t*)dx_bf16);
   }
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+extern "C" int mmdti_seq_mean_packed_fwd(mmdti_stream_t stream, const void* x_bf16, int B, int S, int D, int ld, const int* row_off,
+                                         const int* n_real, float* out) {
+  MMDTI_REQUIRE(x_bf16 && out && row_off && n_real && B > 0 && S > 0 && D > 0 && ld >= D, "seq_mean_packed_fwd: bad arguments");
+  MMDTI_REQUIRE(D % 8 == 0 && ld % 8 == 0 && D <= 4096 && aligned16(x_bf16), "seq_mean_packed_fwd: D %% 8, ld %% 8, D <= 4096 and 16-byte alignment required");
+  if (hipMemsetAsync(out, 0, (size_t)B * D * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+    set_error("seq_mean_packed_fwd: hipMemsetAsync failed");
+    return MMDTI_ERR_LAUNCH;
+  }
+  // (a sequence has at most S rows: S - 1 real tokens + the representative pad row, or S real tokens)
+  hipLaunchKernelGGL(seq_mean_packed_fwd_kernel, dim3(B, cdiv(S, 32)), dim3(256), 4 * (size_t)D * sizeof(float), (hipStream_t)stream,
+                     (const bf16_t*)x_bf16, S, D, ld, row_off, n_real, out);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+extern "C" int mmdti_seq_mean_packed_bwd(mmdti_stream_t stream, const float* dout, int rows, int S, int D, int ld, const int* row_off,
+                                         const int* n_real, const int* row_seq, void* dx_bf16, const void* aux_bf16, int ld_aux, int aux_mode) {
+  MMDTI_REQUIRE(dout && dx_bf16 && row_off && n_real && row_seq && rows > 0 && S > 0 && D > 0 && ld >= D, "seq_mean_packed_bwd: bad arguments");
+  MMDTI_REQUIRE(aux_mode >= 0 && aux_mode <= 2 && (aux_mode == 0 || aux_bf16), "seq_mean_packed_bwd: aux_mode %d needs aux", aux_mode);
+  MMDTI_REQUIRE(ld % 8 == 0 && aligned16(dx_bf16) && (aux_mode == 0 || (ld_aux % 8 == 0 && ld_aux >= ld && aligned16(aux_bf16))),
+                "seq_mean_packed_bwd: 8-column aligned rows required");
+  const long long chunks = (long long)rows * (ld / 8);
+  hipLaunchKernelGGL(seq_mean_packed_bwd_kernel, dim3((unsigned)cdiv(chunks, 256)), dim3(256), 0, (hipStream_t)stream, dout, S, D, ld, row_off,
+                     n_real, row_seq, (const bf16_t*)aux_bf16, ld_aux, aux_mode, (bf16_t*)dx_bf16, (long long)rows);
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }

@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256, NT > 9 ? 2 : 4) void pair_attn_fwd_mfma_kernel
                                                                  ST* __restrict__ s_out, bf16_t* __restrict__ o,
                                                                  const unsigned char* __restrict__ key_pad, int N, int H, int ld,
                                                                  float scale, uint32_t thresh, float dscale, uint64_t seed,
-                                                                 uint32_t site, const int* __restrict__ key_tiles, int rag_store) {
+                                                                 uint32_t site, const int* __restrict__ key_tiles, int rag_store,
+                                                                 const int* __restrict__ row_off) {
   static_assert(TILED || sizeof(ST) == 4, "compact pair tensors exist in the tiled layout only");
   static_assert(!RAG || sizeof(ST) == 2, "key-tile skipping is built for the compact layout only");
   constexpr int NP = NT * 16;
@@ -139,15 +140,21 @@ __global__ __launch_bounds__(256, NT > 9 ? 2 : 4) void pair_attn_fwd_mfma_kernel
   const int nKB = (N + 15) >> 4;
   // (wave-uniform: one molecule per workgroup; rounded up to a count the sweeps are unrolled for)
   const int kt = RAG ? pa_kt_effective(min(__builtin_amdgcn_readfirstlane(key_tiles[b]), nKB), NT) : NT;
-  const bf16_t* base = qkv + (long long)b * N * D3 + h * HD;
+  // PACKED token rows (RAG only, row_off != null): molecule b owns rows [row_off[b], row_off[b+1]) of qkv / o / key_pad -- its real
+  // tokens followed by at most ONE representative pad row (every pad row of a molecule is the same row at dropout 0: zeroed
+  // input, constant bias row, same keys) -- instead of rows [b*N, (b+1)*N).  Pair planes stay indexed by position.
+  const bool packed = RAG && row_off != nullptr;
+  const int row0 = packed ? __builtin_amdgcn_readfirstlane(row_off[b]) : b * N;
+  const int rows = packed ? __builtin_amdgcn_readfirstlane(row_off[b + 1]) - row0 : N;
+  const bf16_t* base = qkv + (long long)row0 * D3 + h * HD;
   for (int t = tid; t < NP; t += blockDim.x) {
     uint4 q = make_uint4(0u, 0u, 0u, 0u), kk = q, vv = q;
     float msk = 1.f;
-    if (t < N) {
+    if (t < rows) {
       q = *reinterpret_cast<const uint4*>(base + (long long)t * D3);
       kk = *reinterpret_cast<const uint4*>(base + (long long)t * D3 + D);
       vv = *reinterpret_cast<const uint4*>(base + (long long)t * D3 + 2 * D);
-      msk = (key_pad && key_pad[b * N + t]) ? 1.f : 0.f;
+      msk = (key_pad && key_pad[row0 + t]) ? 1.f : 0.f;
     }
     *reinterpret_cast<uint4*>(sQ + t * 8) = q;
     *reinterpret_cast<uint4*>(sK + t * 8) = kk;
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(256, NT > 9 ? 2 : 4) void pair_attn_fwd_mfma_kernel
     constexpr bool EDGE = decltype(edge_c)::value;
     constexpr int KT = decltype(kt_c)::value;   // key tiles this molecule's sweeps cover (NT unless RAG)
     const int qi = qb * 16 + c16;
-    const bool qvalid = EDGE ? qi < N : true;
+    const bool qvalid = EDGE ? qi < rows : true;
     const long long rowoff = ((long long)bh * N + (qvalid ? qi : 0)) * ld;   // (also the dropout counter base)
     const pa_s16x4 zero4 = {0, 0, 0, 0};
     // B of S^T = K.Q^T : Q[query c16][d = 4g..4g+3] (k = d: lane groups 2, 3 carry zeros)
@@ -284,14 +291,15 @@ __global__ __launch_bounds__(256, NT > 9 ? 2 : 4) void pair_attn_fwd_mfma_kernel
       uint2 pk;
       pk.x = (uint32_t)f2bf(oacc[0]) | ((uint32_t)f2bf(oacc[1]) << 16);
       pk.y = (uint32_t)f2bf(oacc[2]) | ((uint32_t)f2bf(oacc[3]) << 16);
-      *reinterpret_cast<uint2*>(o + ((long long)b * N + qi) * D + h * HD + 4 * g) = pk;
+      *reinterpret_cast<uint2*>(o + ((long long)row0 + qi) * D + h * HD + 4 * g) = pk;
     }
 #undef PA_PRED
 #undef PA_FAST
   };
+  const int nQB = packed ? (rows + 15) >> 4 : nKB;   // (packed: the pad rows past the representative one are not computed)
   auto run = [&](auto kt_c) {
-    for (int qb = wave; qb < nKB; qb += nwaves) {
-      if (TILED && qb * 16 + 16 <= N) body(qb, std::false_type{}, kt_c);
+    for (int qb = wave; qb < nQB; qb += nwaves) {
+      if (TILED && qb * 16 + 16 <= rows) body(qb, std::false_type{}, kt_c);
       else body(qb, std::true_type{}, kt_c);
     }
   };
@@ -320,11 +328,12 @@ using namespace mmdti;
 extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, const void* bias_in, void* s_out,
                                    void* o_bf16, const unsigned char* key_pad, int B, int N, int H, int ld,
                                    float scale, float drop_p, unsigned long long seed, unsigned int site, int layout,
-                                   const int* key_tiles, int rag_store) {
+                                   const int* key_tiles, int rag_store, const int* row_off) {
   const int tiled = layout & 1, compact = (layout >> 1) & 1;   // bit 0: tiled planes; bit 1: compact planes (S fp16; tiled only)
   if (int e = check_common("pair_attn_fwd", B, N, H, ld)) return e;
   MMDTI_REQUIRE((layout & ~3) == 0 && (!compact || tiled), "pair_attn_fwd: layout must be 0 (row-major fp32), 1 (tiled fp32) or 3 (tiled, fp16 logits)");
   MMDTI_REQUIRE(!key_tiles || compact, "pair_attn_fwd: key_tiles (ragged batches) needs the compact tiled pair layout (layout 3)");
+  MMDTI_REQUIRE(!row_off || key_tiles, "pair_attn_fwd: packed token rows (row_off) need key_tiles");
   MMDTI_REQUIRE(!tiled || (ld % 4 == 0 && N <= 16 * PA_MAX_NT), "pair_attn_fwd: the tiled pair layout needs ld %% 4 == 0 and N <= 272");
   MMDTI_REQUIRE(qkv_bf16 && bias_in && s_out && o_bf16, "pair_attn_fwd: null pointer");
   MMDTI_REQUIRE(aligned16(qkv_bf16), "pair_attn_fwd: qkv must be 16-byte aligned");
@@ -340,7 +349,7 @@ extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, 
     dim3 blk(nqb % 3 == 0 ? 192 : (nqb < 4 ? 64 * nqb : 256));
 #define PA_M(NT, TL, FL, RG, ST)                                                                                                     \
   hipLaunchKernelGGL((pair_attn_fwd_mfma_kernel<NT, TL, FL, RG, ST>), grid, blk, 0, s, (const bf16_t*)qkv_bf16, (const ST*)bias_in, \
-                     (ST*)s_out, (bf16_t*)o_bf16, key_pad, N, H, ld, scale, th, sc, (uint64_t)seed, (uint32_t)site, key_tiles, rag_store)
+                     (ST*)s_out, (bf16_t*)o_bf16, key_pad, N, H, ld, scale, th, sc, (uint64_t)seed, (uint32_t)site, key_tiles, rag_store, row_off)
 #define PA_MT(NT)                                                                           \
   do {                                                                                      \
     if (!tiled) PA_M(NT, false, false, false, float);                                       \

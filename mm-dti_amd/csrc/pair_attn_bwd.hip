@@ -154,7 +154,8 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? ((NT >= 16 && NW == 3) ? 2 : 1) :
                                                                  const bf16_t* __restrict__ dO, const GT* __restrict__ gin, GT* __restrict__ gout,
                                                                  bf16_t* __restrict__ dqkv, int N, int H, int ld, float scale,
                                                                  int g_in_zero, uint32_t thresh, float dscale, uint64_t seed,
-                                                                 uint32_t site, const int* __restrict__ key_tiles) {
+                                                                 uint32_t site, const int* __restrict__ key_tiles,
+                                                                 const int* __restrict__ row_off) {
   static_assert(TILED || (sizeof(ST) == 4 && sizeof(GT) == 4), "compact pair tensors exist in the tiled layout only");
   static_assert(!RAG || sizeof(ST) == 2, "key-tile skipping is built for the compact layout only");
   constexpr int NP = NT * 16;
@@ -179,14 +180,18 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? ((NT >= 16 && NW == 3) ? 2 : 1) :
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int nKB = (N + 15) >> 4;
   const int kt = RAG ? pa_kt_effective(min(__builtin_amdgcn_readfirstlane(key_tiles[b]), nKB), NT) : NT;   // (see the forward kernel)
-  const bf16_t* base = qkv + (long long)b * N * D3 + h * HD;
+  // (packed token rows: see the forward kernel)
+  const bool packed = RAG && row_off != nullptr;
+  const int row0 = packed ? __builtin_amdgcn_readfirstlane(row_off[b]) : b * N;
+  const int rows = packed ? __builtin_amdgcn_readfirstlane(row_off[b + 1]) - row0 : N;
+  const bf16_t* base = qkv + (long long)row0 * D3 + h * HD;
   for (int t = tid; t < NP + 2; t += blockDim.x) {
     uint4 q = make_uint4(0u, 0u, 0u, 0u), kk = q, vv = q, dd = q;
-    if (t < N) {
+    if (t < rows) {
       q = *reinterpret_cast<const uint4*>(base + (long long)t * D3);
       kk = *reinterpret_cast<const uint4*>(base + (long long)t * D3 + D);
       vv = *reinterpret_cast<const uint4*>(base + (long long)t * D3 + 2 * D);
-      dd = *reinterpret_cast<const uint4*>(dO + ((long long)b * N + t) * D + h * HD);
+      dd = *reinterpret_cast<const uint4*>(dO + ((long long)row0 + t) * D + h * HD);
     }
     *reinterpret_cast<uint4*>(sQ + t * 8) = q;      // (t = NP, NP + 1: the zeroed tails)
     *reinterpret_cast<uint4*>(sD + t * 8) = dd;
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? ((NT >= 16 && NW == 3) ? 2 : 1) :
     constexpr bool EDGE = decltype(edge_c)::value;
     constexpr int KT = decltype(kt_c)::value;   // key tiles this molecule's sweeps cover (NT unless RAG)
     const int qi = qb * 16 + c16;
-    const bool qvalid = EDGE ? qi < N : true;
+    const bool qvalid = EDGE ? qi < rows : true;
     const long long rowoff = ((long long)bh * N + (qvalid ? qi : 0)) * ld;   // (also the dropout counter base)
     const long long tbase = ((long long)bh * nKB + qb) * nKB * 256 + lane * 4;
     const ST* sin_p = s_in + (TILED ? tbase : rowoff);     // (predicate-off lanes read the row's first 16 bytes: in bounds)
@@ -397,21 +402,22 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? ((NT >= 16 && NW == 3) ? 2 : 1) :
       uint2 pk;
       pk.x = (uint32_t)f2bf(dq[0] * scale) | ((uint32_t)f2bf(dq[1] * scale) << 16);
       pk.y = (uint32_t)f2bf(dq[2] * scale) | ((uint32_t)f2bf(dq[3] * scale) << 16);
-      *reinterpret_cast<uint2*>(dqkv + ((long long)b * N + qi) * D3 + h * HD + 4 * g) = pk;
+      *reinterpret_cast<uint2*>(dqkv + ((long long)row0 + qi) * D3 + h * HD + 4 * g) = pk;
     }
 #undef PA_PRED
 #undef PA_FAST
   };
+  const int nQB = packed ? (rows + 15) >> 4 : nKB;
   auto run = [&](auto kt_c) {
-    for (int qb = wave; qb < nKB; qb += nwaves) {
-      if (TILED && qb * 16 + 16 <= N) body(qb, std::false_type{}, kt_c);
+    for (int qb = wave; qb < nQB; qb += nwaves) {
+      if (TILED && qb * 16 + 16 <= rows) body(qb, std::false_type{}, kt_c);
       else body(qb, std::true_type{}, kt_c);
     }
   };
   if constexpr (RAG) pa_dispatch_kt<NT, NT>(kt, run);
   else run(std::integral_constant<int, NT>{});
   __syncthreads();
-  for (int key = tid; key < N; key += blockDim.x) {
+  for (int key = tid; key < rows; key += blockDim.x) {   // (packed: the representative pad row is no key -- its sums are the zeros they started as)
     const int t = key >> 4, kg = (key & 15) >> 2, r = key & 3;
     float a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int w = 0; w < nwaves; ++w) {
@@ -424,7 +430,7 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? ((NT >= 16 && NW == 3) ? 2 : 1) :
     }
 #pragma unroll
     for (int d = 0; d < 8; ++d) a[d] *= scale;     // dK = scale * G^T.Q  (Q sits unscaled in LDS)
-    bf16_t* dst = dqkv + ((long long)b * N + key) * D3 + h * HD;
+    bf16_t* dst = dqkv + ((long long)row0 + key) * D3 + h * HD;
     store8_bf16(dst + D, a);
     store8_bf16(dst + 2 * D, c2);
   }
@@ -437,13 +443,14 @@ using namespace mmdti;
 extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, const void* s, const void* do_bf16,
                                    void* g, void* dqkv_bf16, int B, int N, int H, int ld, float scale,
                                    int g_in_zero, float drop_p, unsigned long long seed, unsigned int site, int layout,
-                                   const int* key_tiles) {
+                                   const int* key_tiles, const int* row_off) {
   // bit 0: tiled planes; bit 1: compact planes (s is fp16; tiled only); bit 2: g is bf16 (with bit 1 only; no ragged form)
   const int tiled = layout & 1, compact = (layout >> 1) & 1, g16 = (layout >> 2) & 1;
   if (int e = check_common("pair_attn_bwd", B, N, H, ld)) return e;
   MMDTI_REQUIRE((layout & ~7) == 0 && (!compact || tiled) && (!g16 || compact),
                 "pair_attn_bwd: layout must be 0 (row-major fp32), 1 (tiled fp32), 3 (tiled, fp16 logits) or 7 (tiled, fp16 logits, bf16 gradients)");
   MMDTI_REQUIRE(!key_tiles || (compact && !g16), "pair_attn_bwd: key_tiles (ragged batches) needs layout 3 (tiled, fp16 logits, fp32 gradients)");
+  MMDTI_REQUIRE(!row_off || key_tiles, "pair_attn_bwd: packed token rows (row_off) need key_tiles");
   MMDTI_REQUIRE(!tiled || (ld % 4 == 0 && N <= 16 * PA_MAX_NT), "pair_attn_bwd: the tiled pair layout needs ld %% 4 == 0 and N <= 272");
   MMDTI_REQUIRE(qkv_bf16 && s && do_bf16 && g && dqkv_bf16, "pair_attn_bwd: null pointer");
   MMDTI_REQUIRE(aligned16(qkv_bf16) && aligned16(do_bf16) && aligned16(dqkv_bf16), "pair_attn_bwd: alignment");
@@ -460,7 +467,7 @@ extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, 
 #define PA_MB(NT, TL, FL, NWV, RG, ST, GT)                                                                                     \
   hipLaunchKernelGGL((pair_attn_bwd_mfma_kernel<NT, TL, FL, NWV, RG, ST, GT>), grid, blk, 0, st, (const bf16_t*)qkv_bf16,      \
                      (const ST*)s, (const bf16_t*)do_bf16, (const GT*)g, (GT*)g, (bf16_t*)dqkv_bf16, N, H, ld, scale,           \
-                     g_in_zero, th, sc, (uint64_t)seed, (uint32_t)site, key_tiles)
+                     g_in_zero, th, sc, (uint64_t)seed, (uint32_t)site, key_tiles, row_off)
 #define PA_MBW(NT, TL, FL, RG, ST, GT)                                                      \
   do {                                                                                      \
     if (blk.x == 192) PA_MB(NT, TL, FL, 3, RG, ST, GT); else PA_MB(NT, TL, FL, 4, RG, ST, GT); \

@@ -83,7 +83,8 @@ def collate_batch(samples, padding_idx, tokenizer):
 
 # -------------------------------------------------------------------------------------------------- device payload (8f-3)
 NEVER_CONSUMED = ('src_coord',)     # collated by the reference, swallowed by **kwargs in MM_Model.forward (mm_model.py:540)
-HOST_FIELDS = ('atom_counts',)      # stay on the host: MM_Model reads them to pick kernels without a device sync
+# stay on the host: MM_Model reads them to pick kernels and layouts without a device sync
+HOST_FIELDS = ('atom_counts', 'token_counts', 'token_pad_id', 'packable')
 INT16_MAX = 32767
 
 
@@ -117,7 +118,31 @@ def device_payload(net_input, n_edge_types=None, pad_idx=0):
     st = out.get('src_tokens')
     if st is not None and st.device.type == 'cpu' and 'atom_counts' not in out:
         out['atom_counts'] = atom_counts(st, pad_idx)
+    out.update(packing_fields(out, pad_idx))
     return out
+
+
+def packing_fields(batch, pad_idx=0):
+    """Host-side facts that let MM_Model run a ragged batch on PACKED token rows (packing.py): ``token_counts`` ([B] int32 SMILES
+    lengths), ``token_pad_id`` (the one id every masked SMILES slot holds, -1 when nothing is masked) and ``packable`` -- True iff
+    both sides are right-padded as the reference collates them (mm_model.py:645-682, HF ``padding=True``): atom tokens without a
+    pad hole, attention masks that are non-empty prefixes of ones, one id in all masked slots.  {} when it cannot be decided here
+    (device tensors, fields missing)."""
+    from .packing import right_padded_lengths
+    st, ids, am = batch.get('src_tokens'), batch.get('input_ids'), batch.get('attention_mask')
+    if any(t is None or not torch.is_tensor(t) or t.device.type != 'cpu' for t in (st, ids, am)) or 'token_counts' in batch:
+        return {}
+    atoms = right_padded_lengths(st.ne(pad_idx))
+    toks = right_padded_lengths(am.ne(0))
+    if atoms is None or toks is None:
+        return {'packable': False}
+    masked = ids[am.eq(0)]
+    pad_id = -1
+    if masked.numel():
+        pad_id = int(masked[0])
+        if not bool((masked == pad_id).all()):
+            return {'packable': False}
+    return {'token_counts': toks.to(torch.int32), 'token_pad_id': pad_id, 'packable': True}
 
 
 class HostCollate:

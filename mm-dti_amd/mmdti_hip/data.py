@@ -10,7 +10,7 @@ from __future__ import annotations
 
 from typing import Iterator, List, Sequence
 
-HOST_FIELDS = ('atom_counts',)      # (collate.HOST_FIELDS; repeated here so that this module keeps importing without torch)
+HOST_FIELDS = ('atom_counts', 'token_counts', 'token_pad_id', 'packable')      # (collate.HOST_FIELDS; repeated here so that this module keeps importing without torch)
 
 import numpy as np
 

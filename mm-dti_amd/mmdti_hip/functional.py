@@ -184,16 +184,27 @@ class PairEncoderFn(torch.autograd.Function):
              compact fp16 planes PairBiasFn produces on the hot path), padding_mask [B,N] bool|None
     outputs: x [B,N,D] fp32, S_last in the layout and dtype of bias (pre-softmax logits of the last layer, -inf at padded keys),
              x_pre [B,N,D] fp32 (stream before the final LN; only the discarded x_norm aux output reads it)
+    pack (packing.PackedRows, compact tiled bias + key_tiles only): PACKED token rows -- emb / padding_mask / x / x_pre are
+             [pack.M, D] / [pack.M]: every molecule's real tokens plus one representative pad row (all pad rows of a molecule
+             are the same row at dropout 0); S_last then lacks the query rows past the representative one.
     """
 
     @staticmethod
-    def forward(ctx, emb, bias, padding_mask, mod, training, key_tiles=None):
-        B, N, D = emb.shape
+    def forward(ctx, emb, bias, padding_mask, mod, training, key_tiles=None, pack=None):
+        if pack is not None:
+            B, N, D = pack.B, pack.S, emb.shape[-1]
+            if emb.dim() != 2 or emb.shape[0] != pack.M:
+                raise ops.MMDTIError("PairEncoderFn: packed rows expect emb [pack.M, D]")
+        else:
+            B, N, D = emb.shape
         H = mod.attention_heads
         tiled = ops.pair_is_tiled(bias)        # [B,H,nt,nt,256] tile layout (see ops.pair_tile) or row-major [B,H,N,ld]
         compact = tiled and bias.dtype == torch.float16     # logits chain as fp16 (ops.PAIR_COMPACT, PairBiasFn)
         if not compact or ops.PAIR_G_BF16:
             key_tiles = None                   # (only the compact tiled kernels with fp32 gradients have a ragged form)
+        if pack is not None and key_tiles is None:
+            raise ops.MMDTIError("PairEncoderFn: packed rows need the compact tiled pair layout and key_tiles")
+        row_off = None if pack is None else pack.off
         # The gradient of a compact (fp16) bias is NOT an fp16 tensor (fp32, or bf16 on request), and autograd casts whatever a
         # backward returns to the dtype of the input.  PairBiasFn therefore hangs a slot on the bias it produces; the backward
         # below leaves the real gradient chain there and hands autograd a zero-storage placeholder.
@@ -201,13 +212,14 @@ class PairEncoderFn(torch.autograd.Function):
         if compact and slot is None and bias.requires_grad:
             raise ops.MMDTIError("PairEncoderFn: an fp16 pair bias that needs a gradient must come from PairBiasFn")
         ld = ops.pair_ld(N) if tiled else bias.shape[-1]
-        M = B * N
+        M = B * N if pack is None else pack.M
         p_emb = mod.emb_dropout if training else 0.0
         p_res = mod.dropout if training else 0.0
         p_att = mod.attention_dropout if training else 0.0
         seed = dropout_state.next_seed()
         sites = _Sites()
-        st = SimpleNamespace(B=B, N=N, D=D, H=H, ld=ld, M=M, seed=seed, p_emb=p_emb, p_res=p_res, p_att=p_att, layers=[], kt=key_tiles, slot=slot)
+        st = SimpleNamespace(B=B, N=N, D=D, H=H, ld=ld, M=M, seed=seed, p_emb=p_emb, p_res=p_res, p_att=p_att, layers=[], kt=key_tiles, slot=slot,
+                             row_off=row_off, packed=pack is not None)
         keep = any(ctx.needs_input_grad)      # inference (torch.no_grad / frozen inputs): nothing is kept for a backward --
                                               # the 15 per-layer logit tensors are freed as the stack advances
         emb = emb.contiguous()
@@ -230,7 +242,7 @@ class PairEncoderFn(torch.autograd.Function):
             L.site_att = sites.next()
             # (ragged batches: all-padding key tiles are skipped; the last layer writes them as -inf because its S is returned)
             L.s, L.o = ops.pair_attn_fwd(L.qkv, s_prev, padding_mask if li == 0 else None, B, N, H, ld, scale, p_att, seed, L.site_att,
-                                         key_tiles=key_tiles, rag_store=li == len(mod.layers) - 1)
+                                         key_tiles=key_tiles, rag_store=(li == len(mod.layers) - 1) and pack is None, row_off=row_off)
             s_prev = L.s
             L.site_o = sites.next()
             L.x1 = ops.linear_fwd(L.o, wbf16(att.out_proj.weight), att.out_proj.bias, residual=x, out_dtype=F32, drop_p=p_res, seed=seed, site=L.site_o)
@@ -249,12 +261,12 @@ class PairEncoderFn(torch.autograd.Function):
             out = x
         if keep:
             ctx.st, ctx.mod = st, mod
-        x_last = x.view(B, N, D)
+        x_last = x.view(B, N, D) if pack is None else x
         ctx.mark_non_differentiable(s_prev, x_last)
         # (otherwise autograd hands the backward a freshly ZEROED tensor for each output nobody differentiates -- for S_last that is
         #  a 0.55 GB fill per step, found with scratch/fill_diag.py)
         ctx.set_materialize_grads(False)
-        return out.view(B, N, D), s_prev, x_last
+        return (out.view(B, N, D) if pack is None else out), s_prev, x_last
 
     @staticmethod
     def backward(ctx, dout, _ds_unused, _dx_unused):
@@ -299,7 +311,7 @@ class PairEncoderFn(torch.autograd.Function):
             if g_zero:
                 # (fp32, or bf16 under MMDTI_PAIR_G_BF16; skipped key tiles of G are never written)
                 G = (torch.empty if st.kt is None else torch.zeros)(L.s.shape, device=L.s.device, dtype=ops.pair_grad_dtype(L.s))
-            dqkv = ops.pair_attn_bwd(L.qkv, L.s, do, G, B, N, H, ld, scale, g_zero, st.p_att, seed, L.site_att, key_tiles=st.kt)
+            dqkv = ops.pair_attn_bwd(L.qkv, L.s, do, G, B, N, H, ld, scale, g_zero, st.p_att, seed, L.site_att, key_tiles=st.kt, row_off=st.row_off)
             _wgrad(dqkv, L.h1, att.in_proj.weight, att.in_proj.bias)
             dh1 = ops.linear_bwd_input(dqkv, wbf16(att.in_proj.weight))
             if li > 0:
@@ -330,7 +342,7 @@ class PairEncoderFn(torch.autograd.Function):
         _launch_deferred_wgrads(deferred, deferred_layers)
         _join_side_wgrads()
         _join_stream_after_backward()
-        return demb.view(B, N, D), G, None, None, None, None
+        return (demb if st.packed else demb.view(B, N, D)), G, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------- Gaussian pair bias
@@ -427,6 +439,32 @@ class PairBiasFn(torch.autograd.Function):
         return None, None, None, None, None, None, None
 
 
+class PairCompactFn(torch.autograd.Function):
+    """Row-major fp32 pair bias [B,H,N,ld] -> the compact tiled planes (fp16, -inf in every pad slot, gradient slot attached) that
+    the ragged / packed pair-attention kernels stream.  Layout glue (plain indexing) for configurations the fused pair-bias kernel
+    is not built for (head / basis counts other than 64 / 128): the hot path gets this layout straight from PairBiasFn."""
+
+    @staticmethod
+    def forward(ctx, bias, N):
+        out = ops.pair_tile(bias[..., :N].float().clamp(max=65504.0), N).to(torch.float16)
+        ctx.N, ctx.ld = N, bias.shape[-1]
+        ctx.slot = out._mmdti_grad_slot = SimpleNamespace(g=None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        chain, ctx.slot.g = ctx.slot.g, None
+        real = any(sd != 0 for sd in g.stride())
+        if chain is None:
+            chain = g.float()
+        elif real:
+            chain = chain.float() + g.float()
+        d = ops.pair_untile(chain.float(), ctx.N)
+        if ctx.ld != ctx.N:
+            d = torch.nn.functional.pad(d, (0, ctx.ld - ctx.N))
+        return d, None
+
+
 class EmbeddingFn(torch.autograd.Function):
     """nn.Embedding with padding_idx (mm_model.py:439-441,552)."""
 
@@ -448,8 +486,11 @@ class EmbeddingFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------- BERT-style layer
 def _bert_layer_fwd(st, s1_32, s1_16, s2_16, key_add, W, heads, p_hid, p_att, eps, seed, sites, self_attn):
     """Post-LN BERT layer with query from s1 and key/value from s2 (HF RobertaLayer; BertCrossAttentionLayer
-    mm_module.py:615-626).  s1_32: [B*Lq,D] fp32; s1_16/s2_16 bf16; key_add [B,Lk] fp32.  Returns (out32, out16)."""
+    mm_module.py:615-626).  s1_32: [B*Lq,D] fp32; s1_16/s2_16 bf16; key_add [B,Lk] fp32.  Returns (out32, out16).
+    Packed sequences (st.vl, an ops.AttnVarlen): the row arrays hold st.Mq / st.Mk packed rows instead of B*Lq / B*Lk, the keys of
+    a sequence are its real rows only (key_add is None), Lq / Lk are the longest sequences."""
     B, Lq, Lk, D = st.B, st.Lq, st.Lk, st.D
+    Mq, vl = st.Mq, st.vl
     hd = D // heads
     ld = (Lk + 7) // 8 * 8
     L = SimpleNamespace(s1_16=s1_16, s2_16=s2_16, ld=ld, heads=heads, self_attn=self_attn, W=W, eps=eps)
@@ -477,8 +518,10 @@ def _bert_layer_fwd(st, s1_32, s1_16, s2_16, key_add, W, heads, p_hid, p_att, ep
         L.v = ops.linear_fwd(s2_16, wbf16(W.v_w), W.v_b)
     if L.fused:
         # scores, softmax, dropout and context in one kernel: the [B,heads,Lq,Lk] tensor never reaches HBM
-        L.ctx, L.stats = ops.attn_fwd(L.q, L.k, L.v, key_add, B, heads, Lq, Lk, 1.0 / math.sqrt(hd), p_att, seed, L.site_att)
+        L.ctx, L.stats = ops.attn_fwd(L.q, L.k, L.v, key_add, B, heads, Lq, Lk, 1.0 / math.sqrt(hd), p_att, seed, L.site_att, vl=vl)
     else:
+        if vl is not None:
+            raise ops.MMDTIError("packed sequences need the fused attention kernels (head_dim 32 / 64, at most 256 tokens)")
         S = torch.empty(B, heads, Lq, ld, device=s1_32.device, dtype=F32)
         ops.gemm(L.q, L.k, M=Lq, N=Lk, K=hd, lda=D, ldb=D, out=S, ldc=ld, batch=(B, heads), sA=(Lq * D, hd), sB=(Lk * D, hd),
                  sC=(heads * Lq * ld, Lq * ld), alpha=1.0 / math.sqrt(hd))
@@ -490,7 +533,7 @@ def _bert_layer_fwd(st, s1_32, s1_16, s2_16, key_add, W, heads, p_hid, p_att, ep
     L.site_o = sites.next()
     L.y = ops.linear_fwd(L.ctx, wbf16(W.o_w), W.o_b, residual=s1_32, out_dtype=F32, drop_p=p_hid, seed=seed, site=L.site_o)
     L.a32, L.a16, L.am, L.ar = ops.layernorm_fwd(L.y, W.ln1_w, W.ln1_b, eps, want_f32=True, want_bf16=True)
-    L.u = torch.empty(B * Lq, W.i_w.shape[0], device=s1_32.device, dtype=BF16)
+    L.u = torch.empty(Mq, W.i_w.shape[0], device=s1_32.device, dtype=BF16)
     L.i = ops.linear_fwd(L.a16, wbf16(W.i_w), W.i_b, act=ops.ACT_GELU_FWD, aux_out=L.u)
     L.site_f = sites.next()
     L.z = ops.linear_fwd(L.i, wbf16(W.o2_w), W.o2_b, residual=L.a32, out_dtype=F32, drop_p=p_hid, seed=seed, site=L.site_f)
@@ -502,6 +545,7 @@ def _bert_layer_fwd(st, s1_32, s1_16, s2_16, key_add, W, heads, p_hid, p_att, ep
 def _bert_layer_bwd(st, L, dout, seed):
     """-> (ds1 fp32 [B*Lq,D], ds2 fp32 [B*Lk,D] or None when self_attn (then ds1 holds the sum))."""
     B, Lq, Lk, D = st.B, st.Lq, st.Lk, st.D
+    Mq, Mk, vl = st.Mq, st.Mk, st.vl
     W, heads, ld = L.W, L.heads, L.ld
     hd = D // heads
     pend, raw = [], []                     # the layer's weight gradients leave as one grouped launch (see _lin_bwd_params_many)
@@ -523,22 +567,22 @@ def _bert_layer_bwd(st, L, dout, seed):
         if L.self_attn:
             outv = (dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:])
         else:
-            outv = (torch.empty(B * Lq, D, device=dev, dtype=BF16), dqkv[:, :D], dqkv[:, D:])
+            outv = (torch.empty(Mq, D, device=dev, dtype=BF16), dqkv[:, :D], dqkv[:, D:])
         dq, dk, dv = ops.attn_bwd(L.q, L.k, L.v, L.key_add, dctx, L.stats, B, heads, Lq, Lk, 1.0 / math.sqrt(hd), L.p_att, seed, L.site_att,
-                                  out=outv)
+                                  out=outv, vl=vl)
         raw.append((dqkv, L.s1_16 if L.self_attn else L.s2_16, L.fw[2], L.fb[2].view(-1), None))
         ds1 = dy
         if L.self_attn:
-            ops.gemm(dqkv, L.fw[0], M=B * Lq, N=D, K=3 * D, lda=3 * D, ldb=D, transB=True, out=ds1, ldc=D, beta=1.0)
+            ops.gemm(dqkv, L.fw[0], M=Mq, N=D, K=3 * D, lda=3 * D, ldb=D, transB=True, out=ds1, ldc=D, beta=1.0)
             _lin_bwd_params_many(pend, raw)
             return ds1, None
         pend.append(((dq, L.s1_16, W.q_w, W.q_b), {}))
-        ops.gemm(dq, wbf16(W.q_w), M=B * Lq, N=D, K=D, lda=D, ldb=D, transB=True, out=ds1, ldc=D, beta=1.0)
-        ds2 = ops.gemm(dqkv, L.fw[0], M=B * Lk, N=D, K=2 * D, lda=2 * D, ldb=D, transB=True, out_dtype=F32)
+        ops.gemm(dq, wbf16(W.q_w), M=Mq, N=D, K=D, lda=D, ldb=D, transB=True, out=ds1, ldc=D, beta=1.0)
+        ds2 = ops.gemm(dqkv, L.fw[0], M=Mk, N=D, K=2 * D, lda=2 * D, ldb=D, transB=True, out_dtype=F32)
         _lin_bwd_params_many(pend, raw)
         return ds1, ds2
     if L.fused:
-        dq, dk, dv = ops.attn_bwd(L.q, L.k, L.v, L.key_add, dctx, L.stats, B, heads, Lq, Lk, 1.0 / math.sqrt(hd), L.p_att, seed, L.site_att)
+        dq, dk, dv = ops.attn_bwd(L.q, L.k, L.v, L.key_add, dctx, L.stats, B, heads, Lq, Lk, 1.0 / math.sqrt(hd), L.p_att, seed, L.site_att, vl=vl)
     else:
         dP = torch.empty(B, heads, Lq, ld, device=dev, dtype=F32)
         ops.gemm(dctx, L.v, M=Lq, N=Lk, K=hd, lda=D, ldb=D, out=dP, ldc=ld, batch=(B, heads), sA=(Lq * D, hd), sB=(Lk * D, hd),
@@ -560,13 +604,13 @@ def _bert_layer_bwd(st, L, dout, seed):
     _lin_bwd_params_many(pend, raw)
     # ds1 = dy (residual) + dq.Wq ; ds2 = dk.Wk + dv.Wv     (fp32, accumulated by the GEMM's beta=1 epilogue)
     ds1 = dy
-    ops.gemm(dq, wbf16(W.q_w), M=B * Lq, N=D, K=D, lda=D, ldb=D, transB=True, out=ds1, ldc=D, beta=1.0)
+    ops.gemm(dq, wbf16(W.q_w), M=Mq, N=D, K=D, lda=D, ldb=D, transB=True, out=ds1, ldc=D, beta=1.0)
     if L.self_attn:
-        ops.gemm(dk, wbf16(W.k_w), M=B * Lk, N=D, K=D, lda=D, ldb=D, transB=True, out=ds1, ldc=D, beta=1.0)
-        ops.gemm(dv, wbf16(W.v_w), M=B * Lk, N=D, K=D, lda=D, ldb=D, transB=True, out=ds1, ldc=D, beta=1.0)
+        ops.gemm(dk, wbf16(W.k_w), M=Mk, N=D, K=D, lda=D, ldb=D, transB=True, out=ds1, ldc=D, beta=1.0)
+        ops.gemm(dv, wbf16(W.v_w), M=Mk, N=D, K=D, lda=D, ldb=D, transB=True, out=ds1, ldc=D, beta=1.0)
         return ds1, None
-    ds2 = ops.gemm(dk, wbf16(W.k_w), M=B * Lk, N=D, K=D, lda=D, ldb=D, transB=True, out_dtype=F32)
-    ops.gemm(dv, wbf16(W.v_w), M=B * Lk, N=D, K=D, lda=D, ldb=D, transB=True, out=ds2, ldc=D, beta=1.0)
+    ds2 = ops.gemm(dk, wbf16(W.k_w), M=Mk, N=D, K=D, lda=D, ldb=D, transB=True, out_dtype=F32)
+    ops.gemm(dv, wbf16(W.v_w), M=Mk, N=D, K=D, lda=D, ldb=D, transB=True, out=ds2, ldc=D, beta=1.0)
     return ds1, ds2
 
 
@@ -585,7 +629,10 @@ class RobertaEncoderFn(torch.autograd.Function):
     `mod` exposes: word/position/token_type embedding weights, emb LayerNorm, layers, cfg (heads, eps, dropouts, pad)."""
 
     @staticmethod
-    def forward(ctx, anchor, input_ids, attention_mask, mod, training):
+    def forward(ctx, anchor, input_ids, attention_mask, mod, training, pack=None):
+        """pack (packing.PackedRows over the right-padded input_ids): the tower runs on the packed rows -- every sequence's real
+        tokens plus ONE representative pad row (pad word embedding + position padding_idx: all masked slots are that row) -- and
+        returns [pack.M, D]; masked keys are left out of the attention instead of being added finfo.min (probability 0 either way)."""
         B, Lq = input_ids.shape
         cfg = mod.cfg
         D = mod.word.shape[1]
@@ -595,32 +642,36 @@ class RobertaEncoderFn(torch.autograd.Function):
         p_att = cfg.attn_dropout if training else 0.0
         ids = input_ids.contiguous()
         pos = ops.roberta_position_ids(ids, cfg.pad_idx)
+        vl, Mq = None, B * Lq
+        if pack is not None:
+            ids, pos = ids.view(-1)[pack.gather], pos.view(-1)[pack.gather]      # (integer plumbing: the packed rows' ids)
+            vl, Mq, Lq = ops.AttnVarlen(pack, pack), pack.M, pack.max_rows
         e = ops.embedding_fwd3(ids, mod.word, pos, mod.position, mod.token_type)      # word + position + token type 0, one pass
         zeros = None
-        st = SimpleNamespace(B=B, Lq=Lq, Lk=Lq, D=D, seed=seed, ids=ids, pos=pos, zeros=zeros, e=e, layers=[], p_hid=p_hid)
+        st = SimpleNamespace(B=B, Lq=Lq, Lk=Lq if vl is None else vl.Lk, D=D, seed=seed, ids=ids, pos=pos, zeros=zeros, e=e, layers=[], p_hid=p_hid, Mq=Mq, Mk=Mq, vl=vl)
         keep = any(ctx.needs_input_grad)      # inference: no per-layer activations are kept
         st.site_emb = sites.next()
-        x32, x16, st.em, st.er = ops.layernorm_fwd(e.view(B * Lq, D), mod.emb_ln_w, mod.emb_ln_b, cfg.ln_eps, want_f32=True, want_bf16=True,
+        x32, x16, st.em, st.er = ops.layernorm_fwd(e.view(Mq, D), mod.emb_ln_w, mod.emb_ln_b, cfg.ln_eps, want_f32=True, want_bf16=True,
                                                    drop_p=p_hid, seed=seed, site=st.site_emb)
-        key_add = ((1.0 - attention_mask.to(F32)) * torch.finfo(torch.float32).min).contiguous()
+        key_add = ((1.0 - attention_mask.to(F32)) * torch.finfo(torch.float32).min).contiguous() if vl is None else None
         for layer in mod.layers:
             L, x32, x16 = _bert_layer_fwd(st, x32, x16, x16, key_add, bert_weights(layer), cfg.heads, p_hid, p_att, cfg.ln_eps, seed, sites, True)
             if keep:
                 st.layers.append(L)
         if keep:
             ctx.st, ctx.mod = st, mod
-        return x32.view(B, Lq, D)
+        return x32.view(B, Lq, D) if vl is None else x32
 
     @staticmethod
     def backward(ctx, dout):
         st, mod = ctx.st, ctx.mod
         B, Lq, D = st.B, st.Lq, st.D
-        dx = dout.contiguous().view(B * Lq, D)
+        dx = dout.contiguous().view(st.Mq, D)
         for layer, L in zip(reversed(list(mod.layers)), reversed(st.layers)):
             dx, _ = _bert_layer_bwd(st, L, dx, st.seed)
             L.__dict__.clear()
             notify_grads_ready(layer.parameters())
-        de = ops.layernorm_bwd(dx, st.e.view(B * Lq, D), mod.emb_ln_w, st.em, st.er, gbuf(mod.emb_ln_w), gbuf(mod.emb_ln_b),
+        de = ops.layernorm_bwd(dx, st.e.view(st.Mq, D), mod.emb_ln_w, st.em, st.er, gbuf(mod.emb_ln_w), gbuf(mod.emb_ln_b),
                                drop_p=st.p_hid, seed=st.seed, site=st.site_emb)
         cfg = mod.cfg
         de16 = ops.cast_bf16(de)
@@ -632,37 +683,45 @@ class RobertaEncoderFn(torch.autograd.Function):
                 ops.embedding_bwd_gemm(ids, de16, g, pad)
         notify_grads_ready(mod.embeddings.parameters())
         _join_stream_after_backward()   # (MM_Model runs this tower on a side stream)
-        return None, None, None, None, None
+        return None, None, None, None, None, None
 
 
 class CrossLayerFn(torch.autograd.Function):
     """One BertCrossEncoder layer (mm_module.py:663-677, :615-626): s1 attends to s2 under an additive key mask."""
 
     @staticmethod
-    def forward(ctx, s1, s2, key_add, layer, cfg, training):
-        B, Lq, D = s1.shape
-        Lk = s2.shape[1]
+    def forward(ctx, s1, s2, key_add, layer, cfg, training, packs=None):
+        """packs = (PackedRows of s1, PackedRows of s2): s1 [M1, D] / s2 [M2, D] are packed rows, key_add is None -- the keys of a
+        sequence are the REAL rows of s2 (the reference adds -10000 to padded keys, mm_model.py:392-393: probability exactly 0)."""
         seed = dropout_state.next_seed()
         sites = _Sites()
         p_hid = cfg.hidden_dropout if training else 0.0
         p_att = cfg.attn_dropout if training else 0.0
-        st = SimpleNamespace(B=B, Lq=Lq, Lk=Lk, D=D, seed=seed)
-        s1c = s1.contiguous().view(B * Lq, D)
+        if packs is not None:
+            vl = ops.AttnVarlen(packs[0], packs[1])
+            D = s1.shape[-1]
+            st = SimpleNamespace(B=packs[0].B, Lq=vl.Lq, Lk=vl.Lk, D=D, seed=seed, Mq=vl.q_rows, Mk=vl.k_rows, vl=vl)
+        else:
+            B, Lq, D = s1.shape
+            Lk = s2.shape[1]
+            st = SimpleNamespace(B=B, Lq=Lq, Lk=Lk, D=D, seed=seed, Mq=B * Lq, Mk=B * Lk, vl=None)
+        s1c = s1.contiguous().view(st.Mq, D)
         s1_16 = ops.cast_bf16(s1c)
-        s2_16 = ops.cast_bf16(s2.contiguous().view(B * Lk, D))
-        L, out32, _ = _bert_layer_fwd(st, s1c, s1_16, s2_16, key_add.contiguous(), bert_weights(layer), cfg.heads, p_hid, p_att, cfg.ln_eps,
-                                      seed, sites, False)
+        s2_16 = ops.cast_bf16(s2.contiguous().view(st.Mk, D))
+        L, out32, _ = _bert_layer_fwd(st, s1c, s1_16, s2_16, None if key_add is None else key_add.contiguous(), bert_weights(layer), cfg.heads,
+                                      p_hid, p_att, cfg.ln_eps, seed, sites, False)
         if any(ctx.needs_input_grad):
             ctx.st, ctx.L, ctx.layer = st, L, layer
-        return out32.view(B, Lq, D)
+        ctx.shapes = (s1.shape, s2.shape)
+        return out32.view(s1.shape)
 
     @staticmethod
     def backward(ctx, dout):
         st, L = ctx.st, ctx.L
-        ds1, ds2 = _bert_layer_bwd(st, L, dout.contiguous().view(st.B * st.Lq, st.D), st.seed)
+        ds1, ds2 = _bert_layer_bwd(st, L, dout.contiguous().view(st.Mq, st.D), st.seed)
         L.__dict__.clear()
         notify_grads_ready(ctx.layer.parameters())
-        return ds1.view(st.B, st.Lq, st.D), ds2.view(st.B, st.Lk, st.D), None, None, None, None
+        return ds1.view(ctx.shapes[0]), ds2.view(ctx.shapes[1]), None, None, None, None, None
 
 
 class DropoutFn(torch.autograd.Function):
@@ -696,9 +755,17 @@ class InfoNCEFn(torch.autograd.Function):
     returned is this rank's share of the global loss (the sum over ranks equals the single-process loss)."""
 
     @staticmethod
-    def forward(ctx, query, positive, mod, training, gather, reduce_scatter, row0):
-        B, Nq, D = query.shape
-        Np = positive.shape[1]
+    def forward(ctx, query, positive, mod, training, gather, reduce_scatter, row0, packs=None):
+        """packs = (PackedRows of query, PackedRows of positive): [M, D] packed rows; the unmasked mean over the padded positions
+        (infonce.py:32-33) weights each representative pad row by the number of padded positions it stands for."""
+        if packs is not None:
+            B, D = packs[0].B, query.shape[-1]
+            Nq, Np = packs[0].M, packs[1].M           # (rows of the whole side, not per sequence)
+            if not (POOL_THEN_PROJECT and mod.info_proj_query[0].weight.shape[0] % 8 == 0 and mod.info_proj_positive[0].weight.shape[0] % 8 == 0):
+                raise ops.MMDTIError("InfoNCEFn: packed rows need the pool-then-project form (hidden width % 8 == 0)")
+        else:
+            B, Nq, D = query.shape
+            Np = positive.shape[1]
         d = mod.d_l
         ldp = _pad8(d)
         seed = dropout_state.next_seed()
@@ -706,12 +773,18 @@ class InfoNCEFn(torch.autograd.Function):
         st = SimpleNamespace(B=B, Nq=Nq, Np=Np, D=D, d=d, ldp=ldp, seed=seed, p=p)
         dev = query.device
 
-        def proj(x, seq, n, dropout_p, site):
+        def proj(x, seq, n, dropout_p, site, pack=None):
             L = SimpleNamespace()
-            L.x16 = ops.cast_bf16(x.contiguous().view(B * n, D), dropout_p, seed, site)
-            L.u = torch.empty(B * n, seq[0].weight.shape[0], device=dev, dtype=BF16)
+            rows = B * n if pack is None else pack.M
+            L.x16 = ops.cast_bf16(x.contiguous().view(rows, D), dropout_p, seed, site)
+            L.u = torch.empty(rows, seq[0].weight.shape[0], device=dev, dtype=BF16)
             h = ops.linear_fwd(L.x16, wbf16(seq[0].weight), seq[0].bias, act=ops.ACT_GELU_FWD, aux_out=L.u)
             Hd = h.shape[1]
+            if pack is not None:
+                L.hbar = ops.seq_mean_packed_fwd(h, pack, Hd, Hd)
+                L.mean = ops.linear_f32_fwd(L.hbar, seq[2].weight.detach(), seq[2].bias.detach())
+                L.h = None
+                return L
             if POOL_THEN_PROJECT and Hd % 8 == 0:
                 # mean_t(W2 h_t + b2) == W2 mean_t(h_t) + b2: pool the GELU outputs (fp32), then ONE [B, Hd] x [d, Hd] fp32 linear
                 # -- instead of a 50-wide bf16 GEMM over every token, its three backward GEMMs and a bf16 round of the
@@ -727,8 +800,9 @@ class InfoNCEFn(torch.autograd.Function):
             L.mean = ops.seq_mean_fwd(pr, B, n, d, ldp)
             return L
 
-        st.Lq = proj(query, mod.info_proj_query, Nq, p, 1)
-        st.Lp = proj(positive, mod.info_proj_positive, Np, 0.0, 2)
+        st.packs = packs
+        st.Lq = proj(query, mod.info_proj_query, Nq, p, 1, None if packs is None else packs[0])
+        st.Lp = proj(positive, mod.info_proj_positive, Np, 0.0, 2, None if packs is None else packs[1])
         both = torch.cat((st.Lq.mean, st.Lp.mean), dim=1)            # [B, 2d] (tiny; one message under DDP)
         both_all = gather(both) if gather is not None else both
         Bg = both_all.shape[0]
@@ -754,12 +828,15 @@ class InfoNCEFn(torch.autograd.Function):
             dboth = ctx.rs(dboth)                                   # sum over ranks, keep own rows
         dboth = (dboth * dloss).contiguous()
 
-        def proj_bwd(L, dmean, seq, n, dropout_p, site, want_dx):
+        def proj_bwd(L, dmean, seq, n, dropout_p, site, want_dx, pack=None):
             if L.h is None:                                                                  # pooled first (see forward)
                 gw, gb = gbuf(seq[2].weight), gbuf(seq[2].bias)
                 dhbar = ops.linear_f32_bwd(L.hbar, seq[2].weight.detach(), None, dmean.contiguous(), gw, gb)
                 Hd = L.hbar.shape[1]
-                du = ops.seq_mean_bwd(dhbar, B, n, Hd, Hd, aux=L.u, aux_mode=1 if ops.GELU_SAVE_GRAD else 2)
+                if pack is not None:
+                    du = ops.seq_mean_packed_bwd(dhbar, pack, Hd, Hd, aux=L.u, aux_mode=1 if ops.GELU_SAVE_GRAD else 2)
+                else:
+                    du = ops.seq_mean_bwd(dhbar, B, n, Hd, Hd, aux=L.u, aux_mode=1 if ops.GELU_SAVE_GRAD else 2)
                 _lin_bwd_params(du, L.x16, seq[0].weight, seq[0].bias)
                 if not want_dx:
                     return None
@@ -784,10 +861,13 @@ class InfoNCEFn(torch.autograd.Function):
                 dx = ops.dropout_f32(dx, dropout_p, st.seed, site)
             return dx
 
-        dxq = proj_bwd(st.Lq, dboth[:, :d], mod.info_proj_query, st.Nq, st.p, 1, ctx.needs_input_grad[0])
-        dxp = proj_bwd(st.Lp, dboth[:, d:], mod.info_proj_positive, st.Np, 0.0, 2, ctx.needs_input_grad[1])
+        pk = st.packs
+        dxq = proj_bwd(st.Lq, dboth[:, :d], mod.info_proj_query, st.Nq, st.p, 1, ctx.needs_input_grad[0], None if pk is None else pk[0])
+        dxp = proj_bwd(st.Lp, dboth[:, d:], mod.info_proj_positive, st.Np, 0.0, 2, ctx.needs_input_grad[1], None if pk is None else pk[1])
         notify_grads_ready(mod.parameters())
-        return (None if dxq is None else dxq.view(B, st.Nq, st.D), None if dxp is None else dxp.view(B, st.Np, st.D), None, None, None, None, None)
+        if pk is not None:
+            return dxq, dxp, None, None, None, None, None, None
+        return (None if dxq is None else dxq.view(B, st.Nq, st.D), None if dxp is None else dxp.view(B, st.Np, st.D), None, None, None, None, None, None)
 
 
 class InfoNCELossFn(torch.autograd.Function):
@@ -851,16 +931,23 @@ class MaskedPoolFn(torch.autograd.Function):
     """mm_model.py:572-576: zero padded rows, concat, sum / (#atom tokens + #SMILES tokens)."""
 
     @staticmethod
-    def forward(ctx, a, t, mask_a, mask_t):
+    def forward(ctx, a, t, mask_a, mask_t, packs=None):
+        if packs is not None:          # packed rows: a [M1, D], t [M2, D]; the masks are implied by the packings
+            ctx.packs = packs
+            return ops.masked_pool_packed_fwd(a.contiguous(), t.contiguous(), packs[0], packs[1])
+        ctx.packs = None
         ma, mt = ops._u8(mask_a), ops._u8(mask_t)
         ctx.sv = (ma, mt, a.shape[1], t.shape[1])
         return ops.masked_pool_fwd(a.contiguous(), t.contiguous(), ma, mt)
 
     @staticmethod
     def backward(ctx, dp):
+        if ctx.packs is not None:
+            da, dt = ops.masked_pool_packed_bwd(dp.contiguous(), ctx.packs[0], ctx.packs[1])
+            return da, dt, None, None, None
         ma, mt, Na, Nt = ctx.sv
         da, dt = ops.masked_pool_bwd(dp.contiguous(), ma, mt, Na, Nt)
-        return da, dt, None, None
+        return da, dt, None, None, None
 
 
 class LinearF32Fn(torch.autograd.Function):

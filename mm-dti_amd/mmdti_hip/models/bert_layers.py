@@ -61,12 +61,17 @@ class BertCrossEncoder(nn.Module):
         self.layer = nn.ModuleList([BertLayerParams(config.hidden_size, config.intermediate_size, config.layer_norm_eps)
                                     for _ in range(layer_num)])
 
-    def forward(self, s1_hidden_states, s2_hidden_states, s2_attention_mask, output_all_encoded_layers=True):
-        B, Lk = s2_hidden_states.shape[0], s2_hidden_states.shape[1]
-        key_add = s2_attention_mask.reshape(B, Lk).float()
+    def forward(self, s1_hidden_states, s2_hidden_states, s2_attention_mask, output_all_encoded_layers=True, packs=None):
+        """packs = (PackedRows of s1, PackedRows of s2): both inputs are packed rows [M, D] and the mask is implied (the keys of
+        a sequence are the real rows of s2) -- see packing.py."""
+        if packs is None:
+            B, Lk = s2_hidden_states.shape[0], s2_hidden_states.shape[1]
+            key_add = s2_attention_mask.reshape(B, Lk).float()
+        else:
+            key_add = None
         outs = []
         for layer in self.layer:
-            s1_hidden_states = CrossLayerFn.apply(s1_hidden_states.float(), s2_hidden_states.float(), key_add, layer, self.cfg, self.training)
+            s1_hidden_states = CrossLayerFn.apply(s1_hidden_states.float(), s2_hidden_states.float(), key_add, layer, self.cfg, self.training, packs)
             if output_all_encoded_layers:
                 outs.append(s1_hidden_states)
         if not output_all_encoded_layers:
@@ -135,12 +140,14 @@ class RobertaTower(nn.Module):
     def layers(self):
         return self.encoder.layer
 
-    def forward(self, input_ids, attention_mask=None, return_dict=True, **kwargs):
+    def forward(self, input_ids, attention_mask=None, return_dict=True, pack=None, **kwargs):
+        """pack (packing.PackedRows of the right-padded input_ids, lengths = attention_mask.sum(1), masked slots holding the pad
+        id): the last hidden state comes back as packed rows [pack.M, D] instead of [B, L, D]."""
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
         if input_ids.shape[1] + self.cfg.pad_idx + 1 > self.cfg.max_pos:
             raise ValueError(f"sequence length {input_ids.shape[1]} exceeds max_position_embeddings {self.cfg.max_pos}")
-        out = RobertaEncoderFn.apply(self.word, input_ids, attention_mask, self, self.training)
+        out = RobertaEncoderFn.apply(self.word, input_ids, attention_mask, self, self.training, pack)
         return (out,)
 
     @classmethod

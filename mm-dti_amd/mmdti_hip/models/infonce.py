@@ -35,7 +35,13 @@ class InfoNCE(nn.Module):
     def set_global_negatives(self, gather, reduce_scatter, row0):
         self._gather, self._reduce_scatter, self._row0 = gather, reduce_scatter, int(row0)
 
-    def forward(self, query, positive_key, negative_keys=None):
+    def forward(self, query, positive_key, negative_keys=None, packs=None):
+        """packs = (PackedRows of query, PackedRows of positive_key): the inputs are packed rows [M, D] (packing.py); the
+        unmasked mean of infonce.py:32-33 weights each representative pad row by the padded positions it stands for."""
+        if packs is not None:
+            if negative_keys is not None or self.reduction != 'mean' or query.dim() != 2 or positive_key.dim() != 2 or packs[0].B != packs[1].B:
+                raise ValueError('packed rows: <query> / <positive_key> must be [rows, dim] with one packing each, implicit negatives.')
+            return InfoNCEFn.apply(query.float(), positive_key.float(), self, self.training, self._gather, self._reduce_scatter, self._row0, packs)
         if negative_keys is not None:
             raise ValueError("explicit negative_keys are unreachable in the reference (infonce.py:98 raises); not supported")
         if self.reduction != 'mean':

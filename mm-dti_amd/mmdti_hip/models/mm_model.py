@@ -27,9 +27,10 @@ import torch
 import torch.nn as nn
 
 from ..unicore_compat import Dictionary, init_bert_params, get_activation_fn
-from ..functional import PairBiasFn, EmbeddingFn, DropoutFn, MaskedPoolFn, LinearF32Fn
+from ..functional import PairBiasFn, PairCompactFn, EmbeddingFn, DropoutFn, MaskedPoolFn, LinearF32Fn
 from .. import ops
 from ..collate import right_pad, collate_batch
+from ..packing import PackedRows
 
 PAIR_RAGGED = os.environ.get("MMDTI_PAIR_RAGGED", "1") != "0"
 from .transformers import TransformerEncoderWithPair
@@ -135,9 +136,30 @@ class CrossAttentionModel(nn.Module):
         self.two_streams = os.environ.get("MMDTI_CROSS_TWO_STREAMS", "1") != "0"
         self._stream = None
 
-    def forward(self, text_embeddings, graph_embeddings, text_mask, graph_mask):
+    def forward(self, text_embeddings, graph_embeddings, text_mask, graph_mask, packs=None):
+        """packs = (PackedRows of text_embeddings, PackedRows of graph_embeddings): both inputs (and both outputs) are packed rows
+        [M, D]; the additive -10000 key masks are then implied -- a sequence's keys are its real rows (packing.py)."""
         text_embeddings = DropoutFn.apply(text_embeddings, self.dropout.p, self.training)
         graph_embeddings = DropoutFn.apply(graph_embeddings, self.dropout.p, self.training)
+        if packs is not None:
+            rev = (packs[1], packs[0])
+            if self.two_streams and text_embeddings.is_cuda:
+                main = torch.cuda.current_stream()
+                if self._stream is None:
+                    self._stream = torch.cuda.Stream()
+                st = self._stream
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    text_to_graph = self.text_attention(text_embeddings, graph_embeddings, None, packs=packs)[-1]
+                for t in (text_embeddings, graph_embeddings):
+                    t.record_stream(st)
+                graph_to_text = self.graph_attention(graph_embeddings, text_embeddings, None, packs=rev)[-1]
+                main.wait_stream(st)
+                text_to_graph.record_stream(main)
+                return text_to_graph, graph_to_text
+            graph_to_text = self.graph_attention(graph_embeddings, text_embeddings, None, packs=rev)[-1]
+            text_to_graph = self.text_attention(text_embeddings, graph_embeddings, None, packs=packs)[-1]
+            return text_to_graph, graph_to_text
         extended_txt_mask = (1.0 - text_mask.unsqueeze(1).unsqueeze(2).to(dtype=torch.float32)) * -10000.0
         extended_img_mask = (1.0 - graph_mask.unsqueeze(1).unsqueeze(2).to(dtype=torch.float32)) * -10000.0
         if self.two_streams and text_embeddings.is_cuda:
@@ -243,9 +265,14 @@ class MM_Model(nn.Module):
                            sigma=self.fds_cfg.sigma, momentum=self.fds_cfg.momentum)
         self.overlap_towers = bool(params.get('overlap_towers', True))
         self.infonce_on_side_stream = bool(params.get('infonce_on_side_stream', os.environ.get("MMDTI_INFONCE_SIDE", "1") != "0"))
-        self.split_tower1 = int(params.get('split_tower1', 1))
+        # strict_reference=True: every padded row is computed, as the reference does (with dropout ON its padded rows draw
+        # independent masks).  False (default): ragged batches run on PACKED token rows -- real tokens plus one representative pad
+        # row per sequence, weighted by the padded positions it stands for in the unmasked InfoNCE mean (packing.py): identical
+        # results at dropout 0, equal in expectation under dropout.
+        self.strict_reference = bool(params.get('strict_reference', os.environ.get("MMDTI_STRICT_REFERENCE", "0") == "1"))
+        self.last_layout = "padded"          # what the last forward ran on ("padded" | "packed"): read by bench.py / tests
         self._side = None
-        self._third = None
+        self._pack_cache = None
 
     # ------------------------------------------------------------------ construction helpers
     @classmethod
@@ -268,13 +295,6 @@ class MM_Model(nn.Module):
             raise RuntimeError(f"Uni-Mol checkpoint {path} lacks {len(missing)} tower-1 parameters, e.g. {missing[:5]}")
         self.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
 
-    def _extra_stream(self, i):
-        if self._third is None:
-            self._third = {}
-        if i not in self._third:
-            self._third[i] = torch.cuda.Stream()
-        return self._third[i]
-
     def _side_stream(self):
         if self._side is None:
             self._side = torch.cuda.Stream()
@@ -287,27 +307,63 @@ class MM_Model(nn.Module):
         N = src_distance.shape[-1]
         return PairBiasFn.apply(self.gbf.means.weight, src_distance.float(), src_edge_type, self.gbf, self.gbf_proj, ops.pair_ld(N), key_tiles_host)
 
+    def _packings(self, src_tokens, input_ids, atom_counts, token_counts, token_pad_id, packable):
+        """-> (PackedRows of tower 1, PackedRows of tower 2) when this batch can and should run on packed token rows, else None.
+        Decided on the HOST (the counts come from collate.device_payload): no device sync."""
+        if self.strict_reference or not packable or atom_counts is None or token_counts is None or not src_tokens.is_cuda or not PAIR_RAGGED:
+            return None
+        if token_pad_id is not None and int(token_pad_id) not in (-1, int(self.bert.cfg.pad_idx)):
+            return None                                   # masked SMILES slots do not hold the pad id: their rows are not one row
+        (B, N), L = src_tokens.shape, input_ids.shape[1]
+        if not (ops.PAIR_COMPACT and not ops.PAIR_G_BF16 and ops.pair_tiled_ok(N)):
+            return None                                   # (the packed pair kernels exist for the compact tiled planes)
+        c = self._pack_cache
+        if c is not None and c[0] is atom_counts and c[1] is token_counts and c[2] == (B, N, L, src_tokens.device):
+            return c[3]
+        ac, tc = torch.as_tensor(atom_counts, device="cpu"), torch.as_tensor(token_counts, device="cpu")
+        if ac.numel() != B or tc.numel() != B or int(ac.max()) > N or int(tc.max()) > L or int(ac.min()) < 1 or int(tc.min()) < 1:
+            return None
+        packs = None
+        if int(ac.min()) < N or int(tc.min()) < L:         # (nothing padded: the padded layout IS the packed one)
+            pk1, pk2 = PackedRows(ac, N), PackedRows(tc, L)
+            D2, D1 = self.bert.cfg.dim, self.args.encoder_embed_dim
+            hd_ok = all(ops.attn_eligible(pk1.max_rows, pk2.max_rows, D // h, D) for D, h in
+                        ((D2, self.bert.cfg.heads), (self.cross_cfg.hidden_size, self.cross_cfg.num_attention_heads)))
+            if hd_ok and max(pk1.max_rows, pk2.max_rows) <= 256 and D1 == self.cross_cfg.hidden_size:
+                packs = (pk1.to(src_tokens.device), pk2.to(src_tokens.device))
+        self._pack_cache = (atom_counts, token_counts, (B, N, L, src_tokens.device), packs)
+        return packs
+
     def forward(self, src_tokens, src_distance, src_edge_type, input_ids, attention_mask, weights=None,
                 return_infonce_loss=False, return_ct_loss=False, return_feature=False, net_target=None, use_weight=None,
-                epoch=0, atom_counts=None, **kwargs):
+                epoch=0, atom_counts=None, token_counts=None, token_pad_id=None, packable=False, **kwargs):
         padding_mask = src_tokens.eq(self.padding_idx)
         # Ragged batches.  atom_counts ([B] ints ON THE HOST: position of each molecule's last real token + 1, attached by
         # collate.device_payload) tells, without a device sync, whether some molecule is shorter than the padded length; then the
         # pair-attention kernels skip the all-padding key tiles (a third to a half of the pair traffic on a drug-like batch).
+        # With token_counts / packable as well (both sides verified right-padded on the host) the whole step runs on PACKED token
+        # rows: padded query rows are not computed either (packing.py).
+        packs = self._packings(src_tokens, input_ids, atom_counts, token_counts, token_pad_id, packable)
+        self.last_layout = "padded" if packs is None else "packed"
         key_tiles = kt_host = None
         if atom_counts is not None and PAIR_RAGGED and src_tokens.is_cuda:
             kt = (torch.as_tensor(atom_counts, device="cpu").to(torch.int64) + 15) // 16
             nt = (src_tokens.shape[1] + 15) // 16
-            if int(kt.min()) < nt:
+            if int(kt.min()) < nt or packs is not None:
                 kt = kt.clamp_(min=1, max=nt)
-                covered = sum(ops.pair_key_tiles_effective(int(k), nt) for k in kt.tolist())     # (what the kernels cover: ops.pair_key_tiles_effective)
-                ops.set_pair_kept(covered / (kt.numel() * nt))
+                eff = [ops.pair_key_tiles_effective(int(k), nt) for k in kt.tolist()]     # (what the kernels cover)
+                if packs is None:
+                    ops.set_pair_kept(sum(eff) / (kt.numel() * nt))
+                else:      # packed rows: only the query blocks up to the representative pad row are walked
+                    qb = ((packs[0].rows_host + 15) // 16).tolist()
+                    ops.set_pair_kept(sum(q * e for q, e in zip(qb, eff)) / (kt.numel() * nt * nt))
                 kt_host = kt
                 key_tiles = kt.to(torch.int32).to(src_tokens.device, non_blocking=True)
         img_mask = ~padding_mask
         attention_mask = attention_mask.bool().to(src_tokens.device)
         # NOTE: the reference sets padding_mask=None when nothing is padded (:548-549), which costs a host sync
         # (`.any()`); the kernels treat an all-false mask identically, so no branch is needed here.
+        pk1, pk2 = packs if packs is not None else (None, None)
 
         # The two towers are independent until InfoNCE: tower 2 runs on a side HIP stream so its kernels fill the CUs that
         # tower 1's tile tails and latency-bound pair kernels leave idle (autograd replays each backward on the stream of
@@ -317,38 +373,27 @@ class MM_Model(nn.Module):
             main = torch.cuda.current_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                out_bert = self.bert(input_ids, attention_mask, return_dict=True)[0]
+                out_bert = self.bert(input_ids, attention_mask, return_dict=True, pack=pk2)[0]
 
-        def tower1(sl):
-            xs = EmbeddingFn.apply(self.embed_tokens.weight, src_tokens[sl], self.padding_idx)
-            bias_s = self.pair_bias(src_distance[sl], src_edge_type[sl], None if kt_host is None else kt_host[sl])
-            return self.encoder.encode(xs, bias_s, padding_mask[sl], None if key_tiles is None else key_tiles[sl])[0]
-
-        Bm = src_tokens.shape[0]
-        parts = int(self.split_tower1)
-        if side is not None and parts > 1 and Bm % parts == 0 and Bm >= 2 * parts:
-            # Tower 1 in `parts` sub-batches on as many streams: the HBM-bound pair kernels of one overlap the MFMA-bound
-            # GEMMs of another (molecules are independent until InfoNCE, so the arithmetic is unchanged).
-            step = Bm // parts
-            reps = []
-            for i in range(1, parts):
-                st_i = self._extra_stream(i)
-                st_i.wait_stream(main)
-                with torch.cuda.stream(st_i):
-                    reps.append((tower1(slice(i * step, (i + 1) * step)), st_i))
-            rep0 = tower1(slice(0, step))
-            for r, st_i in reps:
-                main.wait_stream(st_i)
-                r.record_stream(main)
-            encoder_rep = torch.cat([rep0] + [r for r, _ in reps], 0)
+        if pk1 is None:
+            xs = EmbeddingFn.apply(self.embed_tokens.weight, src_tokens, self.padding_idx)
+            bias_s = self.pair_bias(src_distance, src_edge_type, kt_host)
+            encoder_rep = self.encoder.encode(xs, bias_s, padding_mask, key_tiles)[0]
         else:
-            encoder_rep = tower1(slice(0, Bm))
+            # packed rows of tower 1: [M1] token ids / pad flags (integer plumbing; the representative pad row is the first padded
+            # slot of its molecule, so it gathers the pad id), the pair bias stays positional
+            ids1, pad1 = src_tokens.reshape(-1)[pk1.gather], padding_mask.reshape(-1)[pk1.gather]
+            xs = EmbeddingFn.apply(self.embed_tokens.weight, ids1, self.padding_idx)
+            bias_s = self.pair_bias(src_distance, src_edge_type, kt_host)
+            if bias_s.dtype != torch.float16:         # (head / basis counts the fused pair-bias kernel is not built for: re-lay out)
+                bias_s = PairCompactFn.apply(bias_s, src_tokens.shape[1])
+            encoder_rep = self.encoder.encode(xs, bias_s, pad1, key_tiles, pack=pk1)[0]
 
         if side is not None:
             main.wait_stream(side)
             out_bert.record_stream(main)
         else:
-            out_bert = self.bert(input_ids, attention_mask, return_dict=True)[0]
+            out_bert = self.bert(input_ids, attention_mask, return_dict=True, pack=pk2)[0]
 
         infonce_side = False
         if return_infonce_loss:
@@ -358,16 +403,16 @@ class MM_Model(nn.Module):
             if side is not None and self.infonce_on_side_stream:
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    ct_loss = self.infonce(encoder_rep, out_bert)
+                    ct_loss = self.infonce(encoder_rep, out_bert, packs=packs)
                 encoder_rep.record_stream(side)
                 out_bert.record_stream(side)
                 infonce_side = True
             else:
-                ct_loss = self.infonce(encoder_rep, out_bert)
+                ct_loss = self.infonce(encoder_rep, out_bert, packs=packs)
 
-        cross_txt_output_layer, cross_output_layer = self.cross_modal_module(encoder_rep, out_bert, img_mask, attention_mask)
+        cross_txt_output_layer, cross_output_layer = self.cross_modal_module(encoder_rep, out_bert, img_mask, attention_mask, packs=packs)
         # mm_model.py:572-576 (zero padded rows, concat, masked mean) in one kernel
-        classification_feats_pooled = MaskedPoolFn.apply(cross_txt_output_layer, cross_output_layer, img_mask, attention_mask)
+        classification_feats_pooled = MaskedPoolFn.apply(cross_txt_output_layer, cross_output_layer, img_mask, attention_mask, packs)
 
         smoothed_features = classification_feats_pooled
         if self.training and epoch >= self.fds_cfg.start_smooth and self.use_fds and self.task == 'regression':

@@ -62,11 +62,14 @@ class TransformerEncoderWithPair(nn.Module):
             ]
         )
 
-    def encode(self, emb: torch.Tensor, pair_bias: torch.Tensor, padding_mask: Optional[torch.Tensor], key_tiles: Optional[torch.Tensor] = None):
+    def encode(self, emb: torch.Tensor, pair_bias: torch.Tensor, padding_mask: Optional[torch.Tensor], key_tiles: Optional[torch.Tensor] = None,
+               pack=None):
         """Fast path used by MM_Model: pair_bias is [B,H,N,ld] fp32 (internal layout).  -> (x [B,N,D], S_last, x_pre).
         key_tiles ([B] int32 on the device, tiled layout only): 16-key tiles of each molecule that hold a real key -- the pair
-        attention kernels skip the all-padding key tiles past it (ragged batches)."""
-        return PairEncoderFn.apply(emb, pair_bias, padding_mask, self, self.training, key_tiles)
+        attention kernels skip the all-padding key tiles past it (ragged batches).
+        pack (packing.PackedRows, with key_tiles): emb / padding_mask / x are packed rows [pack.M, ...] -- real tokens plus one
+        representative pad row per molecule (see packing.py)."""
+        return PairEncoderFn.apply(emb, pair_bias, padding_mask, self, self.training, key_tiles, pack)
 
     def forward(
         self,

@@ -533,25 +533,40 @@ def set_pair_kept(frac):
     _pair_kept = float(frac)
 
 
-def pair_attn_fwd(qkv, bias_in, key_pad, B, N, H, ld, scale, drop_p=0.0, seed=0, site=0, key_tiles=None, rag_store=False):
+def pair_attn_fwd(qkv, bias_in, key_pad, B, N, H, ld, scale, drop_p=0.0, seed=0, site=0, key_tiles=None, rag_store=False, row_off=None):
+    """row_off ([B+1] int32 on the device, with key_tiles): packed token rows -- qkv / o / key_pad hold molecule b's real tokens +
+    at most one representative pad row at rows [row_off[b], row_off[b+1]) (packing.PackedRows); the pair planes stay positional."""
     _chk(qkv, BF16, "pair_attn.qkv")
     layout = _pair_layout_s(bias_in, "pair_attn.bias")
     tiled = pair_is_tiled(bias_in)
+    rows = qkv.shape[0] if row_off is not None else B * N
+    if row_off is not None:
+        _chk(row_off, torch.int32, "pair_attn.row_off")
+        if row_off.numel() != B + 1 or key_tiles is None:
+            raise MMDTIError("pair_attn_fwd: row_off must be [B+1] and come with key_tiles")
+        if key_pad is not None and key_pad.numel() != rows:
+            raise MMDTIError("pair_attn_fwd: with packed rows key_pad is indexed by packed row")
+    elif qkv.shape[0] != B * N:
+        raise MMDTIError(f"pair_attn_fwd: qkv has {qkv.shape[0]} rows, expected B*N = {B * N}")
     s_out = torch.empty_like(bias_in) if tiled else torch.empty(B, H, N, ld, device=qkv.device, dtype=F32)
-    o = torch.empty(B * N, H * 8, device=qkv.device, dtype=BF16)
+    o = torch.empty(rows, H * 8, device=qkv.device, dtype=BF16)
     kp = _u8(key_pad)
     t0 = kernel_timer.begin("pair_attn_fwd")
     if key_tiles is not None:
         _chk(key_tiles, torch.int32, "pair_attn.key_tiles")
     lib().mmdti_pair_attn_fwd(_stream(), qkv.data_ptr(), bias_in.data_ptr(), s_out.data_ptr(), o.data_ptr(), _p(kp), B, N, H, ld,
-                              float(scale), float(drop_p), int(seed), int(site), layout, _p(key_tiles), int(rag_store))
+                              float(scale), float(drop_p), int(seed), int(site), layout, _p(key_tiles), int(rag_store), _p(row_off))
     # per (pair, head): read the bias / previous logits, write S (4 B each; compact 2 B); per (token, head): q|k|v in (48 B), o out (16 B)
     kept, es = _pair_kept if key_tiles is not None else 1.0, float(s_out.element_size())
-    kernel_timer.end("pair_attn_fwd", t0, float(B) * H * (N * N * (es * kept + es * (1.0 if rag_store else kept)) + N * 64.0))
+    kernel_timer.end("pair_attn_fwd", t0, float(H) * (B * N * N * (es * kept + es * (1.0 if rag_store else kept)) + rows * 64.0))
     return s_out, o
 
 
-def pair_attn_bwd(qkv, s, do, g, B, N, H, ld, scale, g_in_zero, drop_p=0.0, seed=0, site=0, key_tiles=None):
+def pair_attn_bwd(qkv, s, do, g, B, N, H, ld, scale, g_in_zero, drop_p=0.0, seed=0, site=0, key_tiles=None, row_off=None):
+    if (row_off is None and qkv.shape[0] != B * N) or do.shape[0] != qkv.shape[0]:
+        raise MMDTIError("pair_attn_bwd: qkv / do row counts do not match the layout")
+    if row_off is not None:
+        _chk(row_off, torch.int32, "pair_attn.row_off")
     dqkv = torch.empty_like(qkv)
     tiled = pair_is_tiled(s)
     layout = _pair_layout_s(s, "pair_attn_bwd.s")
@@ -563,10 +578,10 @@ def pair_attn_bwd(qkv, s, do, g, B, N, H, ld, scale, g_in_zero, drop_p=0.0, seed
         layout |= 4
     t0 = kernel_timer.begin("pair_attn_bwd")
     lib().mmdti_pair_attn_bwd(_stream(), qkv.data_ptr(), s.data_ptr(), do.data_ptr(), g.data_ptr(), dqkv.data_ptr(), B, N, H, ld,
-                              float(scale), int(g_in_zero), float(drop_p), int(seed), int(site), layout, _p(key_tiles))
+                              float(scale), int(g_in_zero), float(drop_p), int(seed), int(site), layout, _p(key_tiles), _p(row_off))
     # per (pair, head): read S, read + write G (4 B each, compact 2 B; the first layer reads no G); per (token, head): 7 x 16 B rows
     kept = _pair_kept if key_tiles is not None else 1.0
-    kernel_timer.end("pair_attn_bwd", t0, float(B) * H * (N * N * kept * (s.element_size() + g.element_size() * (1 if g_in_zero else 2)) + N * 112.0))
+    kernel_timer.end("pair_attn_bwd", t0, float(H) * (B * N * N * kept * (s.element_size() + g.element_size() * (1 if g_in_zero else 2)) + qkv.shape[0] * 112.0))
     return dqkv
 
 
@@ -595,42 +610,67 @@ def attn_eligible(Lq, Lk, hd, D):
     return FUSED_ATTN and hd in (32, 64) and Lq <= 256 and Lk <= 256 and D % 8 == 0
 
 
-def attn_fwd(q, k, v, key_add, B, heads, Lq, Lk, scale, drop_p=0.0, seed=0, site=0):
-    """q [B*Lq, D], k/v [B*Lk, D] bf16 -> (ctx [B*Lq, D] bf16, stats [B,heads,Lq,2] fp32)."""
+class AttnVarlen:
+    """Packed sequences for the fused attention kernels (include/mmdti_hip.h, mmdti_attn_fwd): q_off / k_off [B+1] int32 row
+    offsets of the query / key side, k_cnt [B] int32 real keys per sequence (device tensors); q_rows / k_rows total rows;
+    pairs: sum_b q_rows_b * k_cnt_b (work accounting)."""
+
+    def __init__(self, q_pack, k_pack):
+        self.q_off, self.k_off, self.k_cnt = q_pack.off, k_pack.off, k_pack.n_real
+        self.q_rows, self.k_rows = q_pack.M, k_pack.M
+        self.Lq, self.Lk = q_pack.max_rows, int(k_pack.counts_host.max())
+        self.pairs = float((q_pack.rows_host * k_pack.counts_host).sum())
+
+    def args(self):
+        return (self.q_off.data_ptr(), self.k_off.data_ptr(), self.k_cnt.data_ptr(), self.q_rows)
+
+
+_NO_VARLEN = (0, 0, 0, 0)
+
+
+def attn_fwd(q, k, v, key_add, B, heads, Lq, Lk, scale, drop_p=0.0, seed=0, site=0, vl=None):
+    """q [B*Lq, D], k/v [B*Lk, D] bf16 -> (ctx [B*Lq, D] bf16, stats [B,heads,Lq,2] fp32).  vl (AttnVarlen): packed sequences --
+    q [vl.q_rows, D], k/v [vl.k_rows, D], Lq / Lk the longest sequence of each side; stats is [heads, q_rows, 2]."""
     for t_, n_ in ((q, "attn.q"), (k, "attn.k"), (v, "attn.v")):
         _chk(t_, BF16, n_, contiguous=False)
         if t_.stride(1) != 1:
             raise MMDTIError(f"{n_}: unit column stride required")
     D = q.shape[1]
     hd = D // heads
-    ctx = torch.empty(B * Lq, D, device=q.device, dtype=BF16)
-    stats = torch.empty(B, heads, Lq, 2, device=q.device, dtype=F32)
+    rows_q = B * Lq if vl is None else vl.q_rows
+    if q.shape[0] != rows_q or k.shape[0] != (B * Lk if vl is None else vl.k_rows) or (vl is not None and key_add is not None):
+        raise MMDTIError("attn_fwd: row counts do not match the layout (packed sequences take no key_add)")
+    ctx = torch.empty(rows_q, D, device=q.device, dtype=BF16)
+    stats = torch.empty((B, heads, Lq, 2) if vl is None else (heads, rows_q, 2), device=q.device, dtype=F32)
     t0 = kernel_timer.begin("attn_fwd")
     lib().mmdti_attn_fwd(_stream(), q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(key_add), ctx.data_ptr(), stats.data_ptr(), B, heads, Lq, Lk,
-                         hd, q.stride(0), k.stride(0), D, float(scale), float(drop_p), int(seed), int(site))
-    kernel_timer.end("attn_fwd", t0, 4.0 * B * heads * Lq * Lk * hd)          # flops: q.k^T and p.v
+                         hd, q.stride(0), k.stride(0), D, float(scale), float(drop_p), int(seed), int(site), *(_NO_VARLEN if vl is None else vl.args()))
+    kernel_timer.end("attn_fwd", t0, 4.0 * heads * hd * (B * Lq * Lk if vl is None else vl.pairs))          # flops: q.k^T and p.v
     return ctx, stats
 
 
-def attn_bwd(q, k, v, key_add, dctx, stats, B, heads, Lq, Lk, scale, drop_p=0.0, seed=0, site=0, out=None):
+def attn_bwd(q, k, v, key_add, dctx, stats, B, heads, Lq, Lk, scale, drop_p=0.0, seed=0, site=0, out=None, vl=None):
     """out: optional (dq, dk, dv) destination views (unit column stride; dk and dv share one row stride)."""
     _chk(dctx, BF16, "attn.dctx")
     D = q.shape[1]
     hd = D // heads
+    rows_q, rows_k = (B * Lq, B * Lk) if vl is None else (vl.q_rows, vl.k_rows)
+    if q.shape[0] != rows_q or k.shape[0] != rows_k or dctx.shape[0] != rows_q:
+        raise MMDTIError("attn_bwd: row counts do not match the layout")
     if out is not None:
         dq, dk, dv = out
-        if dk.stride(0) != dv.stride(0) or any(t.stride(1) != 1 or t.dtype != BF16 for t in out):
+        if dk.stride(0) != dv.stride(0) or any(t.stride(1) != 1 or t.dtype != BF16 for t in out) or dq.shape[0] != rows_q or dk.shape[0] != rows_k:
             raise MMDTIError("attn_bwd: bad output views")
     else:
-        dq = torch.empty(B * Lq, D, device=q.device, dtype=BF16)
-        dk = torch.empty(B * Lk, D, device=q.device, dtype=BF16)
-        dv = torch.empty(B * Lk, D, device=q.device, dtype=BF16)
-    drow = torch.empty(B, heads, Lq, device=q.device, dtype=F32)
+        dq = torch.empty(rows_q, D, device=q.device, dtype=BF16)
+        dk = torch.empty(rows_k, D, device=q.device, dtype=BF16)
+        dv = torch.empty(rows_k, D, device=q.device, dtype=BF16)
+    drow = torch.empty((B, heads, Lq) if vl is None else (heads, rows_q), device=q.device, dtype=F32)
     t0 = kernel_timer.begin("attn_bwd")
     lib().mmdti_attn_bwd(_stream(), q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(key_add), dctx.data_ptr(), stats.data_ptr(), drow.data_ptr(),
                          dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, heads, Lq, Lk, hd, q.stride(0), k.stride(0), dctx.stride(0), dq.stride(0), dk.stride(0),
-                         float(scale), float(drop_p), int(seed), int(site))
-    kernel_timer.end("attn_bwd", t0, 10.0 * B * heads * Lq * Lk * hd)         # flops of the five products an attention backward needs (scores once)
+                         float(scale), float(drop_p), int(seed), int(site), *(_NO_VARLEN if vl is None else vl.args()))
+    kernel_timer.end("attn_bwd", t0, 10.0 * heads * hd * (B * Lq * Lk if vl is None else vl.pairs))         # flops of the five products an attention backward needs (scores once)
     return dq, dk, dv
 
 
@@ -645,6 +685,24 @@ def seq_mean_bwd(dout, B, S, D, ld, aux=None, aux_mode=0):
     """dx[b*S+s] = dout[b] / S (bf16), optionally times aux (aux_mode 1) or gelu'(aux) (2) elementwise."""
     dx = torch.empty(B * S, ld, device=dout.device, dtype=BF16)
     lib().mmdti_seq_mean_bwd(_stream(), dout.data_ptr(), B, S, D, ld, dx.data_ptr(), _p(aux), 0 if aux is None else aux.stride(0), int(aux_mode))
+    return dx
+
+
+def seq_mean_packed_fwd(x, pack, D, ld):
+    """x [pack.M, ld] bf16 -> [B, D] fp32: the unmasked mean over the S padded positions, the representative pad row weighted by
+    the number of padded positions it stands for (mmdti_seq_mean_packed_fwd)."""
+    _chk(x, BF16, "seq_mean_packed.x", contiguous=False)
+    if x.shape[0] != pack.M:
+        raise MMDTIError("seq_mean_packed_fwd: x does not have the packed row count")
+    out = torch.empty(pack.B, D, device=x.device, dtype=F32)
+    lib().mmdti_seq_mean_packed_fwd(_stream(), x.data_ptr(), pack.B, pack.S, D, ld, pack.off.data_ptr(), pack.n_real.data_ptr(), out.data_ptr())
+    return out
+
+
+def seq_mean_packed_bwd(dout, pack, D, ld, aux=None, aux_mode=0):
+    dx = torch.empty(pack.M, ld, device=dout.device, dtype=BF16)
+    lib().mmdti_seq_mean_packed_bwd(_stream(), dout.data_ptr(), pack.M, pack.S, D, ld, pack.off.data_ptr(), pack.n_real.data_ptr(),
+                                    pack.row_seq.data_ptr(), dx.data_ptr(), _p(aux), 0 if aux is None else aux.stride(0), int(aux_mode))
     return dx
 
 
@@ -736,6 +794,27 @@ def masked_pool_bwd(dp, mask_a, mask_t, Na, Nt):
     da = torch.empty(B, Na, D, device=dp.device, dtype=F32)
     dt = torch.empty(B, Nt, D, device=dp.device, dtype=F32)
     lib().mmdti_masked_pool_bwd(_stream(), dp.data_ptr(), mask_a.data_ptr(), mask_t.data_ptr(), B, Na, Nt, D, da.data_ptr(), dt.data_ptr())
+    return da, dt
+
+
+def masked_pool_packed_fwd(a, t, pa, pt):
+    """a [pa.M, D], t [pt.M, D] fp32 packed rows -> pooled [B, D]: sum of every sequence's REAL rows of both / (n_a + n_t)."""
+    _chk(a, F32, "masked_pool_packed.a"); _chk(t, F32, "masked_pool_packed.t")
+    if a.shape[0] != pa.M or t.shape[0] != pt.M or pa.B != pt.B:
+        raise MMDTIError("masked_pool_packed_fwd: row counts do not match the packings")
+    D = a.shape[1]
+    out = torch.empty(pa.B, D, device=a.device, dtype=F32)
+    lib().mmdti_masked_pool_packed_fwd(_stream(), a.data_ptr(), t.data_ptr(), pa.off.data_ptr(), pa.n_real.data_ptr(), pt.off.data_ptr(),
+                                       pt.n_real.data_ptr(), pa.B, D, out.data_ptr())
+    return out
+
+
+def masked_pool_packed_bwd(dp, pa, pt):
+    B, D = dp.shape
+    da = torch.empty(pa.M, D, device=dp.device, dtype=F32)
+    dt = torch.empty(pt.M, D, device=dp.device, dtype=F32)
+    lib().mmdti_masked_pool_packed_bwd(_stream(), dp.data_ptr(), pa.off.data_ptr(), pa.n_real.data_ptr(), pa.row_seq.data_ptr(), pa.M,
+                                       pt.off.data_ptr(), pt.n_real.data_ptr(), pt.row_seq.data_ptr(), pt.M, D, da.data_ptr(), dt.data_ptr())
     return da, dt
 
 

@@ -251,4 +251,4 @@ def shard_batch(batch: dict, label, rank: int, world: int):
     assert B % world == 0, "global batch must divide evenly (drop_last on the global sampler)"
     b = B // world
     sl = slice(rank * b, (rank + 1) * b)
-    return {k: v[sl] for k, v in batch.items()}, label[sl]
+    return {k: (v[sl] if torch.is_tensor(v) else v) for k, v in batch.items()}, label[sl]      # (host scalars -- token_pad_id, packable -- describe every shard)

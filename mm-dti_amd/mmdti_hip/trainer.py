@@ -78,9 +78,8 @@ class FineTuner:
                 dropout_state.reseed(dropout_state.base + 0x9E37 * (self.negs.rank + 1))
             self.reducer = ArenaReducer(self.arena, bucket_bytes)
             self._b_loc = None
-            # gradient buckets leave during backward (MMDTI_NO_REDUCE_OVERLAP=1: all of them after it); sub-batched
-            # tower 1 accumulates into the same gradients several times per step, so it keeps the after-backward form
-            if os.environ.get("MMDTI_NO_REDUCE_OVERLAP") != "1" and getattr(model, "split_tower1", 1) == 1:
+            # gradient buckets leave during backward (MMDTI_NO_REDUCE_OVERLAP=1: all of them after it)
+            if os.environ.get("MMDTI_NO_REDUCE_OVERLAP") != "1":
                 add_grad_ready_hook(self, self.reducer.on_grads_ready)
         if task == "regression":
             self.task_loss = lambda lg, y: MSELossFn.apply(lg, y.float())
@@ -149,6 +148,11 @@ class FineTuner:
         read them before the next call.  Not available under data parallelism (collectives are left out of graphs here)."""
         if self.reducer is not None:
             raise RuntimeError("graphed_step: not supported with distributed=True (use step())")
+        # Host-side batch descriptors (atom_counts, token_counts, ...) select kernels and tile counts on the HOST at capture time;
+        # a replay with another batch of the same padded shape would run with the captured batch's lengths.  The graph therefore
+        # runs the padded layout: correct for any batch of the shape.
+        from .collate import HOST_FIELDS
+        net_input = {k: v for k, v in net_input.items() if k not in HOST_FIELDS}
         key = (epoch >= getattr(getattr(self.model, "fds_cfg", None), "start_smooth", 1 << 30), bool(use_weight), tuple(sorted(kw.items())),
                tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(net_input.items())), tuple(net_target.shape), net_target.dtype)
         ent = self._graphs.get(key)

@@ -94,3 +94,11 @@ def cosine(a, b):
     a = a.detach().double().cpu().flatten() if torch.is_tensor(a) else T(a).double().flatten()
     b = b.detach().double().cpu().flatten() if torch.is_tensor(b) else T(b).double().flatten()
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+def host_fields(batch_cpu, pad_idx=0):
+    """The host-side descriptors collate.device_payload attaches to a collated batch (atom / token counts, packable): with them
+    MM_Model runs a ragged batch on packed token rows (mmdti_hip/packing.py)."""
+    from mmdti_hip.collate import device_payload, HOST_FIELDS
+    full = device_payload({k: v for k, v in batch_cpu.items()}, pad_idx=pad_idx)
+    return {k: full[k] for k in HOST_FIELDS if k in full}

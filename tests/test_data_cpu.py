@@ -122,7 +122,10 @@ def test_device_payload_drops_unread_fields_and_narrows_edge_types_without_chang
     out = device_payload(batch, n_edge_types=31 * 31)
     assert "src_coord" not in out and out["src_edge_type"].dtype == torch.int16
     assert torch.equal(out["src_edge_type"].long(), batch["src_edge_type"])
-    assert all(out[k] is batch[k] for k in out if k not in ("src_edge_type", "atom_counts"))
+    from mmdti_hip.collate import HOST_FIELDS
+    assert all(out[k] is batch[k] for k in out if k not in ("src_edge_type",) + HOST_FIELDS)
+    # host-side descriptors of the packed token layout: SMILES lengths, the id of the masked slots, right-padded on both sides
+    assert out["packable"] is True and out["token_pad_id"] == 1 and torch.equal(out["token_counts"], batch["attention_mask"].sum(1).to(torch.int32))
     # host-side lengths for the ragged pair kernels: last non-pad position + 1 of every molecule
     st = batch["src_tokens"]
     want = torch.tensor([max(j + 1 for j in range(st.shape[1]) if int(st[b, j]) != 0) for b in range(st.shape[0])], dtype=torch.int32)
@@ -149,9 +152,11 @@ def test_worker_side_collate_yields_the_batches_of_the_in_process_collate():
     got = list(DataLoader(data, batch_size=4, shuffle=False, collate_fn=hc, num_workers=2))
     assert len(ref) == len(got) == 6
     for (rb, rl), (gb, gl) in zip(ref, got):
-        assert list(gb) == [k for k in rb if k != "src_coord"] + ["atom_counts"]
+        from mmdti_hip.collate import HOST_FIELDS
+        assert list(gb) == [k for k in rb if k != "src_coord"] + list(HOST_FIELDS)
         assert torch.equal(gl, rl) and gb["src_edge_type"].dtype == torch.int16
-        assert all(torch.equal(gb[k].long() if k == "src_edge_type" else gb[k], rb[k]) for k in gb if k != "atom_counts")
+        assert all(torch.equal(gb[k].long() if k == "src_edge_type" else gb[k], rb[k]) for k in gb if k not in HOST_FIELDS)
+        assert gb["packable"] is True and torch.equal(gb["token_counts"].long(), rb["attention_mask"].sum(1))
 
 
 def test_ragged_key_tile_counts_and_pair_bias_prefixes_host_logic():

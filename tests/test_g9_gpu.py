@@ -16,7 +16,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import mmdti_oracle as O
-from g9util import (T, samples_from, tiny_cfg, refarch_cfg, tokenizer_from, product_model, load_fixture_weights, rel_l2, cosine)
+from g9util import (T, samples_from, tiny_cfg, refarch_cfg, tokenizer_from, product_model, load_fixture_weights, rel_l2, cosine, host_fields)
 
 ZERO_GRADS = ("pooler", "key.bias", "gbf_proj.linear2.bias")     # analytically zero (softmax shift invariance): rounding noise on both sides
 REPORT = {}
@@ -87,13 +87,27 @@ def _capture_towers(model):
     return store
 
 
+def _padded_towers(model, store):
+    """(encoder_rep [B,N,D], out_bert [B,L,D]) of the last forward; a packed run's rows are expanded to the padded tensors (every
+    padded slot = its sequence's representative pad row) for comparison with the reference's padded outputs."""
+    enc, bert = store["enc"], store["bert"]
+    if model.last_layout == "packed":
+        pk1, pk2 = model._pack_cache[3]
+        enc, bert = pk1.unpack(enc), pk2.unpack(bert)
+    return enc, bert
+
+
 def _task_loss(task, logits, tgt):
     from mmdti_hip.functional import CELossFn, MSELossFn
     return MSELossFn.apply(logits, tgt) if task == "regression" else CELossFn.apply(logits, tgt)
 
 
+@pytest.mark.parametrize("layout", ["padded", "packed"])
 @pytest.mark.parametrize("tag", ["cls", "reg_fds"])
-def test_g9_model_tiny_hip(golden, tag):
+def test_g9_model_tiny_hip(golden, tag, layout):
+    """layout: the padded rows the reference computes on, or the packed token rows (real tokens + one representative pad row per
+    sequence, mmdti_hip/packing.py) -- the fixtures' batches are ragged, so the packed run is compared with the reference's own
+    run on padded tensors."""
     g = golden("g9_model_tiny_" + tag)
     task = str(g["task"])
     sd = {k[2:]: T(v) for k, v in g.items() if k.startswith("w_")}
@@ -104,6 +118,9 @@ def test_g9_model_tiny_hip(golden, tag):
     load_fixture_weights(model, sd)
     store = _capture_towers(model)
     batch = {k[2:]: T(v).cuda() for k, v in g.items() if k.startswith("b_") and k != "b_label"}
+    if layout == "packed":
+        batch.update(host_fields({k[2:]: T(v) for k, v in g.items() if k.startswith("b_") and k != "b_label"}))
+        assert batch["packable"]
     label = T(g["b_label"]).cuda()
     tgt = label.float() if task == "regression" else label.long()
     model.train()                                          # every dropout probability is 0: value parity in train mode
@@ -132,13 +149,15 @@ def test_g9_model_tiny_hip(golden, tag):
         model.FDS.load_state_dict({k[len("fds_ep2_"):]: T(v) for k, v in g.items() if k.startswith("fds_ep2_")}, strict=False)
         epoch = 2
     logits, infonce, ct = model(**batch, return_infonce_loss=True, return_ct_loss=True, net_target=tgt, use_weight=False, epoch=epoch)
-    r = dict(enc=rel_l2(store["enc"], g["o_enc"]), bert=rel_l2(store["bert"], g["o_bert"]), logits=rel_l2(logits, g["o_logits"]),
+    assert model.last_layout == layout
+    enc, bert = _padded_towers(model, store)
+    r = dict(enc=rel_l2(enc, g["o_enc"]), bert=rel_l2(bert, g["o_bert"]), logits=rel_l2(logits, g["o_logits"]),
              infonce=abs(float(infonce) - float(g["o_infonce"])) / abs(float(g["o_infonce"])),
              ct=abs(float(ct) - float(g["o_ct"])) / max(abs(float(g["o_ct"])), 1e-6))
     tl = _task_loss(task, logits, tgt)
     loss = 1.0 * tl + 0.1 * infonce + 0.1 * ct
     r["loss"] = abs(float(loss) - float(g["o_loss"])) / abs(float(g["o_loss"]))
-    _report("g9_model_tiny_" + tag, **r)
+    _report("g9_model_tiny_" + tag + ("" if layout == "padded" else "_packed"), **r)
     assert r["enc"] < 1e-2 and r["bert"] < 1e-2 and r["logits"] < 2e-2, r
     assert r["infonce"] < 1e-3 and r["loss"] < 1e-3, r                              # north star: losses within 1e-3 relative
     assert r["ct"] < 5e-3 or abs(float(ct) - float(g["o_ct"])) < 2e-4, r            # B=6 ConR/SupCon over exp(x/0.07): amplifies feature rounding
@@ -177,8 +196,9 @@ def test_g9_model_tiny_hip(golden, tag):
     assert abs(float(r5[3]) - float(g["r5_ct"])) < 5e-3 * abs(float(g["r5_ct"])) + 2e-4
 
 
+@pytest.mark.parametrize("layout", ["padded", "packed"])
 @pytest.mark.parametrize("tag", ["cls", "reg"])
-def test_g9_model_refarch_hip(golden, tag):
+def test_g9_model_refarch_hip(golden, tag, layout):
     """The reference architecture -- 15 x 512 / 64 heads / 128 Gaussians, 6-layer RoBERTa, 16-head fusion -- against the
     reference's own fp32 run of models/mm_model.py: embeddings, logits, losses and gradients at full depth."""
     g = golden("g9_model_refarch_" + tag)
@@ -191,12 +211,16 @@ def test_g9_model_refarch_hip(golden, tag):
     store = _capture_towers(model)
     model.train()
     batch = {k[2:]: T(v).cuda() for k, v in g.items() if k.startswith("b_") and k != "b_label"}
+    if layout == "packed":
+        batch.update(host_fields({k[2:]: T(v) for k, v in g.items() if k.startswith("b_") and k != "b_label"}))
     label = T(g["b_label"]).cuda()
     tgt = label.float() if task == "regression" else label.long()
     logits, infonce, ct = model(**batch, return_infonce_loss=True, return_ct_loss=True, net_target=tgt, use_weight=False, epoch=0)
+    assert model.last_layout == layout
     tl = _task_loss(task, logits, tgt)
     loss = 1.0 * tl + 0.1 * infonce + 0.1 * ct
-    r = dict(enc=rel_l2(store["enc"], g["o_enc"]), bert=rel_l2(store["bert"], g["o_bert"]), logits=rel_l2(logits, g["o_logits"]),
+    enc, bert = _padded_towers(model, store)
+    r = dict(enc=rel_l2(enc, g["o_enc"]), bert=rel_l2(bert, g["o_bert"]), logits=rel_l2(logits, g["o_logits"]),
              infonce=abs(float(infonce) - float(g["o_infonce"])) / abs(float(g["o_infonce"])),
              ct=abs(float(ct) - float(g["o_ct"])) / max(abs(float(g["o_ct"])), 1e-6),
              task_loss=abs(float(tl) - float(g["o_task_loss"])) / abs(float(g["o_task_loss"])),
@@ -214,7 +238,7 @@ def test_g9_model_refarch_hip(golden, tag):
     full = {k[2:]: (rel_l2(grads[k[2:]].grad, g[k]), cosine(grads[k[2:]].grad, g[k])) for k in g if k.startswith("g_")}
     worst_full = max(full.items(), key=lambda t: t[1][0])
     r.update(worst_grad_norm_err=worst_gn[1], worst_grad_rel_l2=worst_full[1][0], min_grad_cos=min(v[1] for v in full.values()))
-    _report("g9_model_refarch_" + tag, **r, worst_grad_norm_param=worst_gn[0], worst_grad_param=worst_full[0])
+    _report("g9_model_refarch_" + tag + ("" if layout == "padded" else "_packed"), **r, worst_grad_norm_param=worst_gn[0], worst_grad_param=worst_full[0])
     # embeddings after 15 pre-LN layers / 6 post-LN layers with bf16 GEMM operands (bound measured)
     assert r["enc"] < 2e-2 and r["bert"] < 1e-2 and r["logits"] < 3e-2, r
     # the step loss (what the trainer optimises) within the north star's 1e-3; InfoNCE alone at B = 4 sits at 1.2-1.4e-3 -- the
@@ -226,10 +250,13 @@ def test_g9_model_refarch_hip(golden, tag):
 
 
 # ------------------------------------------------------------------------------------------------ trainer (a18)
+@pytest.mark.parametrize("layout", ["padded", "packed"])
 @pytest.mark.parametrize("tag", ["reg_fds", "cls"])
-def test_g10_trainer_hip(golden, tag, tmp_path):
+def test_g10_trainer_hip(golden, tag, tmp_path, layout):
     """The Trainer drop-in (mmdti_hip.tasks.Trainer) against the reference's own ``Trainer.fit_predict`` run: 4 epochs x 5
-    steps of batch 4 (+ FDS passes, validation, best-checkpoint reload) on the same samples with the same torch seed."""
+    steps of batch 4 (+ FDS passes, validation, best-checkpoint reload) on the same samples with the same torch seed.
+    layout: strict_reference=True computes every padded row; the default runs each ragged batch on packed token rows (the
+    Trainer's collate attaches the host-side lengths) -- both against the same reference run."""
     from mmdti_hip.tasks import Trainer
     g = golden("g10_trainer_" + tag)
     task = str(g["task"])
@@ -238,9 +265,11 @@ def test_g10_trainer_hip(golden, tag, tmp_path):
     tok = tokenizer_from(str(g["tok_json"]), 38)
     ocfg = tiny_cfg(task, sd["bert.embeddings.word_embeddings.weight"].shape[0])
     kw = dict(fds=True, fds_num=6, _fds_raw_values=g["fds_raw"], use_scaler=False) if task == "regression" else {}
-    model = product_model(ocfg, tok, **kw)
+    model = product_model(ocfg, tok, strict_reference=layout == "padded", **kw)
     load_fixture_weights(model, sd)
     train, valid = samples_from(g, "train_"), samples_from(g, "valid_")
+    layouts = set()
+    model.register_forward_hook(lambda m, i, o: layouts.add(m.last_layout))
     ids = {id(s[0]): i for i, s in enumerate(train)}
     ids.update({id(s[0]): 100 + i for i, s in enumerate(valid)})
     orders = []
@@ -261,6 +290,7 @@ def test_g10_trainer_hip(golden, tag, tmp_path):
                                  use_weight=False)
     # exact: every loader pass (training shuffles, FDS passes, validation) saw the reference's batches in its order
     assert np.array_equal(np.array(orders), g["batch_order"])
+    assert layout in layouts and (layout == "packed" or layouts == {"padded"}), layouts
     steps = np.concatenate([h["steps"] for h in trainer.history])            # [20, 4] = loss, task, infonce, ct
     err = dict(task=float(np.max(np.abs(steps[:, 1] - g["step_task_loss"]) / (np.abs(g["step_task_loss"]) + 1e-2))),
                infonce=float(np.max(np.abs(steps[:, 2] - g["step_infonce"]) / np.abs(g["step_infonce"]))),
@@ -272,7 +302,7 @@ def test_g10_trainer_hip(golden, tag, tmp_path):
     per = [rel_l2(ck[k], g["ck_" + k]) for k in ck if ck[k].is_floating_point() and float(np.abs(g["ck_" + k]).max()) > 0
            and not k.startswith("FDS.")]
     err["ckpt"], err["ckpt_median"] = max(per), float(np.median(per))
-    _report("g10_trainer_" + tag, **err)
+    _report("g10_trainer_" + tag + ("" if layout == "padded" else "_packed"), **err)
     # 20 optimizer steps at lr 5e-4 with bf16 GEMMs vs the reference's fp32 CPU run: drift accumulates with training
     assert err["first_step_task"] < 2e-3 and err["task"] < 5e-2 and err["infonce"] < 1e-2 and err["ct"] < 5e-2, err
     # (worst checkpoint tensor: a zero-initialised bias after 20 sign-like Adam steps; varies run to run with atomics order)
