@@ -250,7 +250,7 @@ int mmdti_softmax_bwd(mmdti_stream_t stream, const void* p_bf16, const float* dp
  * [B,heads,Lq,Lk] scores.  q: rows b*Lq+i, head h at columns [h*head_dim, (h+1)*head_dim), row stride ldq (elements);
  * k, v: rows b*Lk+j, stride ldk; ctx: [B*Lq, ldo] bf16; key_add: [B,Lk] fp32 additive mask or null.
  * stats: [B,heads,Lq,2] fp32 (row max of the logits in base-2 units, i.e. times log2 e; 1/row sum) saved for the backward -- opaque
- * to the caller.  head_dim 32 or 64; Lq, Lk <= 256. */
+ * to the caller.  head_dim 16, 32 or 64; Lq, Lk <= 256. */
 int mmdti_attn_fwd(mmdti_stream_t stream, const void* q_bf16, const void* k_bf16, const void* v_bf16,
                    const float* key_add, void* ctx_bf16, float* stats, int B, int heads, int Lq, int Lk, int head_dim,
                    int ldq, int ldk, int ldo, float scale, float drop_p, unsigned long long seed, unsigned int site,

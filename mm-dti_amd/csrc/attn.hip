@@ -1,4 +1,4 @@
-// Fused BERT-style multi-head attention for gfx950 (head_dim 32 or 64, up to 256 queries x 256 keys per head).
+// Fused BERT-style multi-head attention for gfx950 (head_dim 16, 32 or 64, up to 256 queries x 256 keys per head).
 //
 // Replaces, for the ChemBERTa tower (HF eager_attention_forward, modeling_roberta.py:158-183, called through
 // mm_model.py:562) and the cross-modal layers (BertCoAttention, mm_module.py:470-514), the chain
@@ -37,7 +37,7 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 template <int HD>
 struct AttnShape {
   static constexpr int STR = HD + 8;
-  static constexpr int KC = HD / 32;  // 32-wide k chunks of a head_dim contraction
+  static constexpr int KC = HD < 32 ? 1 : HD / 32;  // 32-wide k chunks of a head_dim contraction (head_dim 16: one chunk, upper half zero)
   static constexpr int NB = HD / 16;  // 16-wide head_dim blocks of an output
 };
 
@@ -107,6 +107,7 @@ __device__ __forceinline__ void attn_fill_rows(bf16_t* lds, const bf16_t* g, int
 // rows row0..row0+15 as an MFMA operand (lane = row, 8 consecutive k): one ds_read_b128
 template <int HD>
 __device__ __forceinline__ bf16x8 attn_frag_rm(const bf16_t* lds, int row0, int c, int lane) {
+  if (HD < 32 && 8 * (lane >> 4) >= HD) return bf16x8{0, 0, 0, 0, 0, 0, 0, 0};   // k-slots past a 16-wide head: zeros
   return *reinterpret_cast<const bf16x8*>(lds + (row0 + (lane & 15)) * AttnShape<HD>::STR + 32 * c + 8 * (lane >> 4));
 }
 // columns n0..n0+15 as an MFMA operand (lane = column) whose k-slots 8g+j are rows r0+4g+j (j<4) and r1+4g+(j-4)
@@ -122,7 +123,7 @@ __device__ __forceinline__ bf16x8 attn_frag_tr(const bf16_t* lds, int r0, int r1
 template <int HD>
 __device__ __forceinline__ bf16x8 attn_frag_global(const bf16_t* base, bool valid, int c, int lane) {
   bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (valid) z = *reinterpret_cast<const bf16x8*>(base + 32 * c + 8 * (lane >> 4));
+  if (valid && (HD >= 32 || 8 * (lane >> 4) < HD)) z = *reinterpret_cast<const bf16x8*>(base + 32 * c + 8 * (lane >> 4));
   return z;
 }
 __device__ __forceinline__ bf16x8 attn_pack(const f32x4& a, const f32x4& b) {
@@ -453,7 +454,7 @@ static int attn_set_smem(K kern, size_t smem) {
 static int attn_check(const char* name, const void* q, const void* k, const void* v, int B, int heads, int Lq, int Lk, int hd,
                       int ldq, int ldk, float drop_p) {
   MMDTI_REQUIRE(q && k && v && B > 0 && heads > 0 && Lq > 0 && Lk > 0, "%s: bad arguments", name);
-  MMDTI_REQUIRE(hd == 32 || hd == 64, "%s: head_dim must be 32 or 64 (got %d)", name, hd);
+  MMDTI_REQUIRE(hd == 16 || hd == 32 || hd == 64, "%s: head_dim must be 16, 32 or 64 (got %d)", name, hd);
   MMDTI_REQUIRE(Lq <= 256 && Lk <= 256, "%s: at most 256 queries / keys per head (got %d / %d)", name, Lq, Lk);
   MMDTI_REQUIRE(ldq >= heads * hd && ldk >= heads * hd && ldq % 8 == 0 && ldk % 8 == 0, "%s: row strides must cover heads*head_dim and be multiples of 8", name);
   MMDTI_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v), "%s: 16-byte alignment required", name);
@@ -493,8 +494,9 @@ extern "C" int mmdti_attn_fwd(mmdti_stream_t stream, const void* q_bf16, const v
                        (const bf16_t*)q_bf16, (const bf16_t*)k_bf16, (const bf16_t*)v_bf16, key_add, (bf16_t*)ctx_bf16,  \
                        stats, heads, Lq, Lk, ldq, ldk, ldo, scale, th, sc, (uint64_t)seed, (uint32_t)site, vl);          \
   } while (0)
-  if (head_dim == 64) { if (nt == 10) ATTN_F(64, 10); else ATTN_F(64, 16); }
-  else                { if (nt == 10) ATTN_F(32, 10); else ATTN_F(32, 16); }
+  if (head_dim == 64)      { if (nt == 10) ATTN_F(64, 10); else ATTN_F(64, 16); }
+  else if (head_dim == 32) { if (nt == 10) ATTN_F(32, 10); else ATTN_F(32, 16); }
+  else                     { if (nt == 10) ATTN_F(16, 10); else ATTN_F(16, 16); }
 #undef ATTN_F
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
@@ -538,10 +540,11 @@ extern "C" int mmdti_attn_bwd(mmdti_stream_t stream, const void* q_bf16, const v
                        (const bf16_t*)dctx_bf16, stats, drow, (bf16_t*)dk_bf16, (bf16_t*)dv_bf16, heads, Lq, Lk, ldq, ldk, \
                        ldo, lddk, scale, th, sc, (uint64_t)seed, (uint32_t)site, nt * 16, vl);                             \
   } while (0)
-  if (head_dim == 64) { if (nt == 10) ATTN_BQ(64, 10); else ATTN_BQ(64, 16); }
-  else                { if (nt == 10) ATTN_BQ(32, 10); else ATTN_BQ(32, 16); }
+  if (head_dim == 64)      { if (nt == 10) ATTN_BQ(64, 10); else ATTN_BQ(64, 16); }
+  else if (head_dim == 32) { if (nt == 10) ATTN_BQ(32, 10); else ATTN_BQ(32, 16); }
+  else                     { if (nt == 10) ATTN_BQ(16, 10); else ATTN_BQ(16, 16); }
   MMDTI_LAUNCH_CHECK();
-  if (head_dim == 64) ATTN_BKV(64); else ATTN_BKV(32);
+  if (head_dim == 64) ATTN_BKV(64); else if (head_dim == 32) ATTN_BKV(32); else ATTN_BKV(16);
 #undef ATTN_BQ
 #undef ATTN_BKV
   MMDTI_LAUNCH_CHECK();

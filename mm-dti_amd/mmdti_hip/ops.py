@@ -607,7 +607,7 @@ FUSED_ATTN = True      # tests flip this to exercise the materialised-scores pat
 
 
 def attn_eligible(Lq, Lk, hd, D):
-    return FUSED_ATTN and hd in (32, 64) and Lq <= 256 and Lk <= 256 and D % 8 == 0
+    return FUSED_ATTN and hd in (16, 32, 64) and Lq <= 256 and Lk <= 256 and D % 8 == 0
 
 
 class AttnVarlen:

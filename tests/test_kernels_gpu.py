@@ -1204,7 +1204,7 @@ def _attn_ref(q, k, v, add, heads, scale, keep=None, p_drop=0.0):
 
 
 @pytest.mark.parametrize("B,heads,Lq,Lk,hd", [(2, 8, 256, 256, 64), (2, 3, 37, 50, 64), (3, 16, 130, 256, 32), (2, 16, 256, 130, 32),
-                                              (1, 2, 1, 1, 32), (2, 4, 161, 161, 64), (1, 2, 16, 160, 32)])
+                                              (1, 2, 1, 1, 32), (2, 4, 161, 161, 64), (1, 2, 16, 160, 32), (2, 4, 37, 50, 16), (1, 4, 200, 256, 16)])
 def test_attn_fused_matches_reference(ops, B, heads, Lq, Lk, hd):
     D = heads * hd
     scale = 1.0 / math.sqrt(hd)
@@ -1231,7 +1231,7 @@ def test_attn_fused_matches_reference(ops, B, heads, Lq, Lk, hd):
         assert (dk.view(B, Lk, D)[0, Lk - Lk // 3:] == 0).all() and (dv.view(B, Lk, D)[0, Lk - Lk // 3:] == 0).all()
 
 
-@pytest.mark.parametrize("Lq,Lk,hd", [(70, 96, 64), (130, 256, 32)])
+@pytest.mark.parametrize("Lq,Lk,hd", [(70, 96, 64), (130, 256, 32), (40, 48, 16)])
 def test_attn_fused_dropout_mask_consistent(ops, Lq, Lk, hd):
     """The keep mask is recovered from the forward itself (indicator V columns); with that mask plugged into the torch
     reference, forward and all three gradients must agree -- i.e. the three kernels regenerate the SAME mask."""
