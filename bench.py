@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--no-rooflines", action="store_true", help="skip the extra (untimed) steps that time every kernel family")
     ap.add_argument("--graph", action="store_true", help="replay the step from one captured HIP graph (FineTuner.graphed_step; single GPU)")
     ap.add_argument("--ragged", action="store_true", help="molecules of mixed length padded to the batch maximum (not the headline workload)")
+    ap.add_argument("--no-ragged-workload", action="store_true", help="skip the second (mixed-length) workload record of the default run")
     args = ap.parse_args()
 
     from mmdti_hip import parallel, ops
@@ -173,15 +174,18 @@ def main():
     if os.environ.get("MMDTI_NO_OVERLAP") == "1":      # A/B switch: run the two towers back to back on one stream
         model.overlap_towers = False
     tuner = FineTuner(model, "classification", total_steps=10_000, distributed=(world > 1 or os.environ.get("MMDTI_FORCE_DDP") == "1"))
-    _, batch, label = synth(args.batch, args.atoms, args.tokens, seed=1234 + rank, ragged=args.ragged)
-    counts = None
-    if args.ragged:
-        from mmdti_hip.collate import atom_counts
-        counts = atom_counts(batch["src_tokens"], 0)        # host-side lengths: the pair kernels skip all-padding key tiles
-    batch = {k: v.to(dev) for k, v in batch.items()}
-    if counts is not None:
-        batch["atom_counts"] = counts
-    label = label.to(dev)
+    from mmdti_hip.collate import packing_fields, atom_counts
+
+    def resident(seed, ragged):
+        """a synthetic collated batch resident in HBM in the reference's format (int64 edge types), plus -- for a ragged batch --
+        the host-side lengths collate.device_payload attaches (the kernels then skip padding: packed token rows)"""
+        _, b, y = synth(args.batch, args.atoms, args.tokens, seed=seed, ragged=ragged)
+        host = dict(packing_fields(b), atom_counts=atom_counts(b["src_tokens"], 0)) if ragged else {}
+        b = {k: v.to(dev) for k, v in b.items()}
+        b.update(host)
+        return b, y.to(dev)
+
+    batch, label = resident(1234 + rank, args.ragged)
 
     def barrier():
         torch.cuda.synchronize()
@@ -208,6 +212,44 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
     losses = {"loss": float(out.loss), "task": float(out.task_loss), "infonce": float(out.infonce_loss), "ct": float(out.ct_loss)}
+    headline_layout = model.last_layout
+
+    # Second workload, timed in the same process (not the headline): SURVEY 8d's C-main length distribution -- atoms ~ N(48, 20^2)
+    # clamped to [8, 128], SMILES 0.8 x atoms, padded to the batch maximum as the reference collates.  Timed on the packed token
+    # rows (the default for a ragged batch) and, for the A/B, on the reference's padded rows (strict_reference).
+    workloads = {}
+    if not args.ragged and not args.no_ragged_workload:
+        rb, rl = resident(4321 + rank, True)
+        rec = {}
+        for tag, strict in (("packed", False), ("padded", True)):
+            model.strict_reference = strict
+            for _ in range(max(2, args.warmup)):
+                tuner.step(rb, rl, epoch=0)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                ro = tuner.step(rb, rl, epoch=0)
+            barrier()
+            d1 = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([d1], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                d1 = float(t)
+            rec[tag] = {"ms_per_step": round(d1 / args.steps * 1e3, 3), "value": round(args.batch * world * args.steps / d1, 2), "layout_ran": model.last_layout,
+                        "loss_last_step": float(ro.loss)}
+        model.strict_reference = False
+        pk = model._pack_cache[3] if model._pack_cache is not None else None
+        Nr, Lr = int(rb["src_tokens"].shape[1]), int(rb["input_ids"].shape[1])
+        workloads["ragged"] = {
+            "workload": f"same step, {args.batch} molecules/GPU of mixed length (atoms ~ N(48, 20^2) clamped to [8, {args.atoms}], SMILES 0.8 x atoms) "
+                        f"right-padded to the batch maximum N = {Nr}, L = {Lr}",
+            "unit": "molecules/s", "steps": args.steps, "value": rec["packed"]["value"], "ms_per_step": rec["packed"]["ms_per_step"],
+            "layout": rec["packed"]["layout_ran"], "strict_reference": False,
+            "token_rows": None if pk is None else {"tower1_packed": pk[0].M, "tower1_padded": args.batch * Nr, "tower2_packed": pk[1].M, "tower2_padded": args.batch * Lr},
+            "padded_rows_for_comparison": {"ms_per_step": rec["padded"]["ms_per_step"], "value": rec["padded"]["value"], "layout": rec["padded"]["layout_ran"],
+                                           "strict_reference": True},
+            "note": "packed token rows: every sequence's real tokens + ONE representative pad row weighted by the padded positions it stands for in the "
+                    "unmasked InfoNCE mean (identical to the padded computation at dropout 0, equal in expectation under dropout; DESIGN.md section 3)"}
 
     # every kernel family in two extra modes (every rank runs them: the step holds collectives):
     #   "overlapped": streams as in the timed region (a launch's event time includes sharing the chip with the other tower);
@@ -262,10 +304,11 @@ def main():
             "config": {"workload": f"BBBP-like classification + SupCon + InfoNCE fine-tune step, {args.batch} molecules/GPU x {args.atoms} atoms x "
                                    f"{args.tokens} SMILES tokens ({shape}), fwd+bwd+allreduce+clip+Adam, dropout on",
                        "global_batch": args.batch * world, "atoms": args.atoms, "tokens": args.tokens, "padded_N": N, "parallelism": f"dp{world}",
-                       "launch": "one HIP graph per step" if (args.graph and world == 1) else "eager (one launch per kernel)", "unimol": "15L/512/64h", "chemberta_assumed": "6L/512/8h/ffn2048/vocab600", "infonce_negatives": "global",
+                       "launch": "one HIP graph per step" if (args.graph and world == 1) else "eager (one launch per kernel)",
+                       "token_layout": headline_layout, "strict_reference": bool(model.strict_reference), "unimol": "15L/512/64h", "chemberta_assumed": "6L/512/8h/ffn2048/vocab600", "infonce_negatives": "global",
                        "grad_buckets_reduced_during_backward": None if tuner.reducer is None or not tuner.reducer.active
                        else f"{tuner.reducer.overlapped}/{len(tuner.reducer.buckets)}"},
-            "losses_last_step": losses, "roofline": roofline, "rooflines": rooflines, "cpu_baseline": cpu,
+            "losses_last_step": losses, "roofline": roofline, "rooflines": rooflines, "cpu_baseline": cpu, "workloads": workloads,
         }
         print(json.dumps(line))
     if torch.distributed.is_initialized():
