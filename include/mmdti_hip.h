@@ -362,6 +362,9 @@ int mmdti_linear_f32_bwd(mmdti_stream_t stream, const float* x, const float* W, 
 int mmdti_mse_loss(mmdti_stream_t stream, const float* pred, const float* target, int n, float* loss, float* dpred);
 int mmdti_ce_loss(mmdti_stream_t stream, const float* logits, const long long* target, int B, int C, float* loss,
                   float* dlogits);
+/* nn.BCEWithLogitsLoss() -- the 'bce' entry of the multilabel_classification loss table (models/nnmodel.py:28-29) -- over n = B * C
+ * logits against 0 / 1 targets given as fp32: mean-reduced loss + dlogits in one pass. */
+int mmdti_bce_logits_loss(mmdti_stream_t stream, const float* logits, const float* target, int n, float* loss, float* dlogits);
 
 /* ---- optimizer step on the flat arenas (tasks/trainer.py:160,270-282) ---------------------- */
 /* sum of squares of g into out[0] (atomic; zero first) */

@@ -696,6 +696,21 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ p, c
   s = block_sum(s, red);
   if (threadIdx.x == 0) *loss = s / (float)n;
 }
+// nn.BCEWithLogitsLoss(), mean over all B x C elements: max(x, 0) - x t + log1p(exp(-|x|)); d/dx = sigmoid(x) - t
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ x, const float* __restrict__ t, int n, float* __restrict__ loss,
+                                                         float* __restrict__ dx) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float xi = x[i], ti = t[i];
+    const float e = expf(-fabsf(xi));
+    s += fmaxf(xi, 0.f) - xi * ti + log1pf(e);
+    const float sig = xi >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    dx[i] = (sig - ti) / (float)n;
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) *loss = s / (float)n;
+}
 __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ lg, const long long* __restrict__ tg, int B, int C, float* __restrict__ loss,
                                                  float* __restrict__ dl) {
   __shared__ float red[4];
@@ -890,6 +905,12 @@ extern "C" int mmdti_linear_f32_bwd(mmdti_stream_t stream, const float* x, const
 extern "C" int mmdti_mse_loss(mmdti_stream_t stream, const float* pred, const float* target, int n, float* loss, float* dpred) {
   MMDTI_REQUIRE(pred && target && loss && dpred && n > 0, "mse_loss: bad arguments");
   hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, target, n, loss, dpred);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+extern "C" int mmdti_bce_logits_loss(mmdti_stream_t stream, const float* logits, const float* target, int n, float* loss, float* dlogits) {
+  MMDTI_REQUIRE(logits && target && loss && dlogits && n > 0, "bce_logits_loss: bad arguments");
+  hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, target, n, loss, dlogits);
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }

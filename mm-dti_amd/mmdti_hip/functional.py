@@ -190,7 +190,10 @@ class PairEncoderFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, emb, bias, padding_mask, mod, training, key_tiles=None, pack=None):
+    def forward(ctx, emb, bias, padding_mask, mod, training, key_tiles=None, pack=None, aux_grads=False):
+        """aux_grads: S_last and x_pre are differentiable outputs (the reference's auxiliary returns -- attn, delta_pair_repr, x_norm,
+        delta_pair_repr_norm, models/transformers.py:141-181 -- are functions of them); fp32 pair planes only.  MM_Model discards those
+        returns (mm_model.py:559), so the hot path leaves it off and autograd never materialises a gradient for them."""
         if pack is not None:
             B, N, D = pack.B, pack.S, emb.shape[-1]
             if emb.dim() != 2 or emb.shape[0] != pack.M:
@@ -204,6 +207,8 @@ class PairEncoderFn(torch.autograd.Function):
             key_tiles = None                   # (only the compact tiled kernels with fp32 gradients have a ragged form)
         if pack is not None and key_tiles is None:
             raise ops.MMDTIError("PairEncoderFn: packed rows need the compact tiled pair layout and key_tiles")
+        if aux_grads and (compact or pack is not None):
+            raise ops.MMDTIError("PairEncoderFn: differentiable auxiliary outputs need fp32 pair planes on padded rows")
         row_off = None if pack is None else pack.off
         # The gradient of a compact (fp16) bias is NOT an fp16 tensor (fp32, or bf16 on request), and autograd casts whatever a
         # backward returns to the dtype of the input.  PairBiasFn therefore hangs a slot on the bias it produces; the backward
@@ -262,28 +267,40 @@ class PairEncoderFn(torch.autograd.Function):
         if keep:
             ctx.st, ctx.mod = st, mod
         x_last = x.view(B, N, D) if pack is None else x
-        ctx.mark_non_differentiable(s_prev, x_last)
+        if not aux_grads:
+            ctx.mark_non_differentiable(s_prev, x_last)
         # (otherwise autograd hands the backward a freshly ZEROED tensor for each output nobody differentiates -- for S_last that is
         #  a 0.55 GB fill per step, found with scratch/fill_diag.py)
         ctx.set_materialize_grads(False)
         return (out.view(B, N, D) if pack is None else out), s_prev, x_last
 
     @staticmethod
-    def backward(ctx, dout, _ds_unused, _dx_unused):
+    def backward(ctx, dout, ds_last, dx_pre):
+        # ds_last / dx_pre: gradients of the auxiliary outputs (aux_grads; None otherwise -- gradients are not materialised)
         st, mod = ctx.st, ctx.mod
         B, N, D, H, ld, M, seed = st.B, st.N, st.D, st.H, st.ld, st.M, st.seed
         scale = (D // H) ** -0.5
         if dout is None:                       # (nothing downstream used the encoder output)
             dout = torch.zeros(M, D, device=st.emb.device, dtype=F32)
         dout = dout.contiguous().view(M, D)
+        if dx_pre is not None:
+            dx_pre = dx_pre.contiguous().view(M, D).float()
         if mod.final_layer_norm is not None:
             fl = mod.final_layer_norm
             nxt = (st.p_res, st.layers[-1].site_f, gbuf(mod.layers[-1].fc2.bias)) if st.layers else None
-            dx = ops.layernorm_bwd(dout, st.x_last, fl.weight, st.f_mean, st.f_rstd, gbuf(fl.weight), gbuf(fl.bias), bf16_copy=nxt)
+            dx = ops.layernorm_bwd(dout, st.x_last, fl.weight, st.f_mean, st.f_rstd, gbuf(fl.weight), gbuf(fl.bias), dres=dx_pre, bf16_copy=nxt)
             dx, dx16 = dx if nxt is not None else (dx, None)
         else:
-            dx, dx16 = dout, None
+            dx, dx16 = (dout if dx_pre is None else dout + dx_pre), None
         G = None
+        if ds_last is not None:
+            # the chain starts from the gradient of the returned logits; padded keys carry none (the reference fills them in place,
+            # transformers.py:122-135: no gradient passes a filled entry)
+            G = ds_last.to(F32).contiguous().clone()
+            if st.pad is not None and not ops.pair_is_tiled(G):
+                G.masked_fill_(st.pad.view(B, 1, 1, N), 0.0)
+            if G.shape[-1] > N and not ops.pair_is_tiled(G):
+                G[..., N:] = 0.0
         below = [Lb.site_f for Lb in st.layers[:-1]]      # site of the FFN dropout of the layer UNDER each layer
         deferred, deferred_layers = [], []
         n_defer = DEFER_WGRAD_LAYERS if dout.is_cuda else 0
@@ -342,7 +359,7 @@ class PairEncoderFn(torch.autograd.Function):
         _launch_deferred_wgrads(deferred, deferred_layers)
         _join_side_wgrads()
         _join_stream_after_backward()
-        return (demb if st.packed else demb.view(B, N, D)), G, None, None, None, None, None
+        return (demb if st.packed else demb.view(B, N, D)), G, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------- Gaussian pair bias
@@ -988,6 +1005,21 @@ class CELossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target):
         loss, d = ops.ce_loss(logits.contiguous(), target.contiguous().view(-1).long())
+        ctx.d = d
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dl):
+        return ctx.d * dl, None
+
+
+class BCELogitsLossFn(torch.autograd.Function):
+    """nn.BCEWithLogitsLoss() on [B, C] logits (models/nnmodel.py:28-29, multilabel_classification 'bce'); the reference hands the
+    targets over as int64 (tasks/trainer.py:119), the kernel reads them as fp32."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        loss, d = ops.bce_logits_loss(logits.contiguous(), target.contiguous().to(F32))
         ctx.d = d
         return loss.view(())
 

@@ -77,34 +77,37 @@ class TransformerEncoderWithPair(nn.Module):
         attn_mask: Optional[torch.Tensor] = None,
         padding_mask: Optional[torch.Tensor] = None,
     ):
-        """Reference signature and 5-tuple (models/transformers.py:96-183).  The four auxiliary outputs are discarded by
-        MM_Model (mm_model.py:559); they are produced here with plain tensor glue for API completeness only."""
+        """Reference signature and 5-tuple (models/transformers.py:96-183).  All five returns are differentiable, as in the
+        reference: the encoder output through the kernels' own backward; the four auxiliary ones (discarded by MM_Model,
+        mm_model.py:559) as plain tensor glue on the encoder's last logits and its pre-final-LN stream, whose gradients enter the
+        same kernel backward (``PairEncoderFn(aux_grads=True)``)."""
         assert attn_mask is not None
         bsz, seq_len = emb.size(0), emb.size(1)
         H = self.attention_heads
         bias = attn_mask.view(bsz, H, seq_len, seq_len)
+        pad = None
         if padding_mask is not None:
             # the reference merges the key-padding mask into the CALLER's tensor in place (:122-135)
-            bias.masked_fill_(padding_mask.unsqueeze(1).unsqueeze(2).to(torch.bool), float("-inf"))
-        x, s_last, x_pre = self.encode(emb.float(), bias.float(), padding_mask)
-        with torch.no_grad():
-            token_mask = 1.0 - padding_mask.float() if padding_mask is not None else torch.ones(bsz, seq_len, device=emb.device)
-            delta = s_last - bias
-            if padding_mask is not None:
-                delta.masked_fill_(padding_mask.unsqueeze(1).unsqueeze(2).to(torch.bool), 0.0)
-            attn = s_last.permute(0, 2, 3, 1).contiguous()
-            delta = delta.permute(0, 2, 3, 1).contiguous()
+            pad = padding_mask.unsqueeze(1).unsqueeze(2).to(torch.bool)
+            bias.masked_fill_(pad, float("-inf"))
+        x, s_last, x_pre = PairEncoderFn.apply(emb.float(), bias.float(), padding_mask, self, self.training, None, None, True)
+        token_mask = 1.0 - padding_mask.float() if padding_mask is not None else torch.ones(bsz, seq_len, device=emb.device)
+        delta = s_last - bias.float()                  # (-inf - -inf at padded keys: filled next, as :163-164 does)
+        if pad is not None:
+            delta = delta.masked_fill(pad, 0.0)
+        attn = s_last.permute(0, 2, 3, 1).contiguous()
+        delta = delta.permute(0, 2, 3, 1).contiguous()
 
-            def norm_loss(t, eps=1e-10, tolerance=1.0):
-                max_norm = t.shape[-1] ** 0.5
-                norm = torch.sqrt(torch.sum(t.float() ** 2, dim=-1) + eps)
-                return torch.nn.functional.relu((norm - max_norm).abs() - tolerance)
+        def norm_loss(t, eps=1e-10, tolerance=1.0):
+            max_norm = t.shape[-1] ** 0.5
+            norm = torch.sqrt(torch.sum(t.float() ** 2, dim=-1) + eps)
+            return torch.nn.functional.relu((norm - max_norm).abs() - tolerance)
 
-            pair_mask = token_mask[..., None] * token_mask[..., None, :]
-            dn = norm_loss(delta)
-            delta_norm = (torch.sum(pair_mask * dn, dim=(-1, -2)) / (1e-10 + torch.sum(pair_mask, dim=(-1, -2)))).mean()
-            xn = norm_loss(x_pre)
-            x_norm = (torch.sum(token_mask * xn, dim=-1) / (1e-10 + torch.sum(token_mask, dim=-1))).mean()
+        pair_mask = token_mask[..., None] * token_mask[..., None, :]
+        dn = norm_loss(delta)
+        delta_norm = (torch.sum(pair_mask * dn, dim=(-1, -2)) / (1e-10 + torch.sum(pair_mask, dim=(-1, -2)))).mean()
+        xn = norm_loss(x_pre)
+        x_norm = (torch.sum(token_mask * xn, dim=-1) / (1e-10 + torch.sum(token_mask, dim=-1))).mean()
         if self.final_head_layer_norm is not None:
             delta = self.final_head_layer_norm(delta)
         return x, attn, delta, x_norm, delta_norm

@@ -849,6 +849,16 @@ def ce_loss(logits, target):
     return loss, d
 
 
+def bce_logits_loss(logits, target):
+    _chk(logits, F32, "bce_logits.logits"); _chk(target, F32, "bce_logits.target")
+    if target.shape != logits.shape:
+        raise MMDTIError(f"bce_logits_loss: target shape {tuple(target.shape)} != logits shape {tuple(logits.shape)}")
+    loss = torch.empty(1, device=logits.device, dtype=F32)
+    d = torch.empty_like(logits)
+    lib().mmdti_bce_logits_loss(_stream(), logits.data_ptr(), target.data_ptr(), logits.numel(), loss.data_ptr(), d.data_ptr())
+    return loss, d
+
+
 def sumsq(g, out):
     lib().mmdti_sumsq_f32(_stream(), g.data_ptr(), g.numel(), out.data_ptr())
     return out

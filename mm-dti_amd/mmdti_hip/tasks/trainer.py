@@ -57,16 +57,79 @@ def _auc(y, p):
     return float((ranks[y == 1].sum() - npos * (npos + 1) / 2.0) / (npos * nneg))
 
 
+def _log_loss(y, p):
+    """binary log loss of P(class 1), probabilities clipped to [eps, 1 - eps] (sklearn.metrics.log_loss)"""
+    y, p = np.asarray(y).ravel().astype(np.float64), np.asarray(p).ravel().astype(np.float64)
+    eps = np.finfo(np.float64).eps
+    p = np.clip(p, eps, 1.0 - eps)
+    return float(-np.mean(y * np.log(p) + (1.0 - y) * np.log(1.0 - p)))
+
+
+def _auprc(y, p):
+    """average precision: sum over the distinct score thresholds (descending) of (recall step) x precision"""
+    y, p = np.asarray(y).ravel().astype(int), np.asarray(p).ravel().astype(np.float64)
+    if y.sum() == 0:
+        raise ValueError("average precision needs a positive in the validation set")
+    order = np.argsort(-p, kind="mergesort")
+    ys, ps = y[order], p[order]
+    last = np.r_[np.nonzero(np.diff(ps))[0], len(ps) - 1]          # last index of every group of tied scores
+    tp = np.cumsum(ys)[last]
+    precision, recall = tp / (last + 1.0), tp / float(y.sum())
+    return float(np.sum(np.diff(np.r_[0.0, recall]) * precision))
+
+
+def _confusion(y, p):
+    y, q = np.asarray(y).ravel().astype(int), (np.asarray(p).ravel() > 0.5).astype(int)
+    return float(((q == 1) & (y == 1)).sum()), float(((q == 1) & (y == 0)).sum()), float(((q == 0) & (y == 1)).sum()), float(((q == 0) & (y == 0)).sum())
+
+
+def _f1(y, p):
+    tp, fp, fn, _ = _confusion(y, p)
+    return 0.0 if tp == 0 else float(2 * tp / (2 * tp + fp + fn))
+
+
+def _mcc(y, p):
+    tp, fp, fn, tn = _confusion(y, p)
+    den = np.sqrt((tp + fp) * (tp + fn) * (tn + fp) * (tn + fn))
+    return 0.0 if den == 0 else float((tp * tn - fp * fn) / den)
+
+
+def _pearson(y, p):
+    y, p = np.asarray(y).ravel().astype(np.float64), np.asarray(p).ravel().astype(np.float64)
+    return float(np.corrcoef(y, p)[0, 1])
+
+
+def _midranks(v):
+    order = np.argsort(v, kind="mergesort")
+    r = np.empty(len(v))
+    sv, i = v[order], 0
+    while i < len(sv):
+        j = i
+        while j + 1 < len(sv) and sv[j + 1] == sv[i]:
+            j += 1
+        r[order[i:j + 1]] = 0.5 * (i + j) + 1.0
+        i = j + 1
+    return r
+
+
 _METRIC_TABLE = {      # name -> (function(y_true, y_pred), larger_is_better)   (directions as utils/metrics.py:72-112)
     "mse": (lambda y, p: float(np.mean((y - p) ** 2)), False),
     "rmse": (lambda y, p: float(np.sqrt(np.mean((y - p) ** 2))), False),
     "mae": (lambda y, p: float(np.mean(np.abs(y - p))), False),
     "r2": (lambda y, p: float(1.0 - np.sum((y - p) ** 2) / np.sum((y - np.mean(y)) ** 2)), True),
+    "pearsonr": (_pearson, True),
+    "spearmanr": (lambda y, p: _pearson(_midranks(np.asarray(y).ravel().astype(np.float64)), _midranks(np.asarray(p).ravel().astype(np.float64))), True),
     "auc": (_auc, True),
     "auroc": (_auc, True),
+    "auprc": (_auprc, True),
+    "log_loss": (_log_loss, False),
     "acc": (lambda y, p: float(np.mean((np.asarray(p) > 0.5).astype(int) == np.asarray(y).astype(int))), True),
+    "f1_score": (_f1, True),
+    "mcc": (_mcc, True),
 }
-_DEFAULT_METRIC = {"regression": "mse", "classification": "auc"}
+# the FIRST default metric of every task is the reference's (utils/metrics.py:114-120 DEFAULT_METRICS): it is the one logged and, with
+# metrics other than 'loss' / 'none' / '', the one that drives early stopping
+_DEFAULT_METRIC = {"regression": "mse", "classification": "log_loss", "multilabel_classification": "log_loss", "multilabel_regression": "mse"}
 
 
 class EpochMetric:
@@ -318,9 +381,11 @@ class Trainer(object):
 
 
 def _builtin_loss(task):
-    from ..functional import CELossFn, MSELossFn
+    from ..functional import CELossFn, MSELossFn, BCELogitsLossFn
     if task == "regression":
         return lambda o, t: MSELossFn.apply(o, t.float())
+    if task == "multilabel_classification":
+        return lambda o, t: BCELogitsLossFn.apply(o, t)
     return lambda o, t: CELossFn.apply(o, t)
 
 
@@ -328,11 +393,18 @@ def _is_builtin_loss(loss_func, task):
     """True when ``loss_func`` is the reference's task loss for this task (models/nnmodel.py:24-34: ``nn.MSELoss()`` /
     ``myCrossEntropyLoss``) -- those run in the mse / cross-entropy kernels; any other callable is applied as given."""
     if loss_func is None:
-        return True
+        return task in ("regression", "classification", "multiclass", "multilabel_classification")
     if task == "regression":
         return isinstance(loss_func, torch.nn.MSELoss) and loss_func.reduction == "mean"
     if task in ("classification", "multiclass"):
-        return getattr(loss_func, "__name__", "") == "myCrossEntropyLoss" or isinstance(loss_func, torch.nn.CrossEntropyLoss)
+        if getattr(loss_func, "__name__", "") == "myCrossEntropyLoss":
+            return True
+        # a configured nn.CrossEntropyLoss (class weights, label smoothing, another ignore_index / reduction) is NOT the plain kernel
+        return (isinstance(loss_func, torch.nn.CrossEntropyLoss) and loss_func.weight is None and loss_func.label_smoothing == 0.0
+                and loss_func.ignore_index == -100 and loss_func.reduction == "mean")
+    if task == "multilabel_classification":      # the table's 'bce' entry; 'focal' / 'ghm' are applied as given
+        return (isinstance(loss_func, torch.nn.BCEWithLogitsLoss) and loss_func.weight is None and loss_func.pos_weight is None
+                and loss_func.reduction == "mean")
     return False
 
 

@@ -19,7 +19,7 @@ from typing import Optional
 
 import torch
 
-from .functional import CELossFn, MSELossFn
+from .functional import CELossFn, MSELossFn, BCELogitsLossFn
 from .parallel import ArenaReducer, GlobalNegatives, gather_features
 from .runtime import ParamArena, add_grad_ready_hook, remove_grad_ready_hook, dropout_state
 
@@ -81,12 +81,16 @@ class FineTuner:
             # gradient buckets leave during backward (MMDTI_NO_REDUCE_OVERLAP=1: all of them after it)
             if os.environ.get("MMDTI_NO_REDUCE_OVERLAP") != "1":
                 add_grad_ready_hook(self, self.reducer.on_grads_ready)
+        # built-in task-loss kernels (models/nnmodel.py:24-34): MSE, cross-entropy, and BCE-with-logits for the multilabel table's
+        # 'bce' entry; every other task / loss (focal, GHM, MAE-with-NaN ...) runs as the callable the caller passes as `loss_func`
         if task == "regression":
             self.task_loss = lambda lg, y: MSELossFn.apply(lg, y.float())
         elif task in ("classification", "multiclass"):
             self.task_loss = lambda lg, y: CELossFn.apply(lg, y)
+        elif task == "multilabel_classification":
+            self.task_loss = lambda lg, y: BCELogitsLossFn.apply(lg, y)
         else:
-            raise NotImplementedError(f"task loss for {task!r} is outside the hot path of this build (models/nnmodel.py:24-34)")
+            self.task_loss = None
 
     # ------------------------------------------------------------------
     def _bind_global_negatives(self, b_loc: int):
@@ -116,7 +120,11 @@ class FineTuner:
         logits = out[0]
         infonce = out[1] if return_infonce_loss else None
         ct = out[-1] if (return_ct_loss and len(out) > (2 if return_infonce_loss else 1)) else None
-        tl = (loss_func or self.task_loss)(logits, net_target)
+        lf = loss_func or self.task_loss
+        if lf is None:
+            raise ValueError(f"FineTuner: task {self.task!r} has no built-in loss kernel -- pass the task loss as `loss_func` "
+                             "(any callable on (logits, target), e.g. the reference's LOSS_RREGISTER entry, models/nnmodel.py:24-34)")
+        tl = lf(logits, net_target)
         loss = self.alpha * tl
         if infonce is not None:
             # under DDP `infonce` is this rank's share of the GLOBAL loss: x world so that the rank-mean of gradients is exact

@@ -749,6 +749,8 @@ def task_loss(logits, target, task):
     """models/nnmodel.py:24-34, models/loss.py:278-289."""
     if task == "regression":
         return F.mse_loss(logits, target.float())
+    if task == "multilabel_classification":          # LOSS_RREGISTER['multilabel_classification']['bce'] = nn.BCEWithLogitsLoss()
+        return F.binary_cross_entropy_with_logits(logits, target.float())
     return F.cross_entropy(logits, target.flatten().long())
 
 

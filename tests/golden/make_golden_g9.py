@@ -75,14 +75,23 @@ def g9_encoder(T):
         x, attn, delta, x_norm, delta_norm = enc(emb_l, attn_mask=attn_mask, padding_mask=padding_mask)
         gx = torch.randn(x.shape, generator=g)
         params = list(enc.parameters())
-        gs = torch.autograd.grad((x * gx).sum(), [emb_l, bias_l] + params, allow_unused=True)
+        gs = torch.autograd.grad((x * gx).sum(), [emb_l, bias_l] + params, allow_unused=True, retain_graph=True)
+        # the AUXILIARY outputs are differentiable in the reference (:141-181): gradients of x_norm, delta_pair_repr_norm and
+        # delta_pair_repr (and of attn at its finite entries) with respect to the inputs and the parameters
+        gd = torch.randn(delta.shape, generator=g)
+        ga = torch.randn(attn.shape, generator=g)
+        fin = torch.isfinite(attn)
+        aux = 0.7 * x_norm + 1.3 * delta_norm + (delta * gd).sum() + (torch.where(fin, attn, torch.zeros_like(attn)) * ga).sum()
+        gaux = torch.autograd.grad(aux, [emb_l, bias_l] + params, allow_unused=True)
         arrays = dict(emb=emb, bias0=bias0, padding_mask=pad, has_padding=np.array(padding_mask is not None), heads=H,
                       attn_mask_after=attn_mask, x=x, attn=attn, delta=delta, x_norm=x_norm, delta_norm=delta_norm, gx=gx,
-                      d_emb=gs[0], d_bias=gs[1])
-        for (n, p), gp in zip(enc.named_parameters(), gs[2:]):
+                      d_emb=gs[0], d_bias=gs[1], g_delta=gd, g_attn=ga, d_emb_aux=gaux[0], d_bias_aux=gaux[1])
+        for (n, p), gp, gq in zip(enc.named_parameters(), gs[2:], gaux[2:]):
             arrays["w_" + n] = p
             arrays["g_" + n] = torch.zeros_like(p) if gp is None else gp
             arrays["hasgrad_" + n] = np.array(gp is not None)
+            arrays["gaux_" + n] = torch.zeros_like(p) if gq is None else gq
+            arrays["hasgaux_" + n] = np.array(gq is not None)
         npz("g9_encoder_" + tag, **arrays)
 
 
@@ -304,6 +313,41 @@ def g9_model(MM, tok_json, vocab_rob):
         npz("g9_model_refarch_" + ("cls" if task == "classification" else "reg"), **arrays)
 
 
+def g9_model_b32(MM, tok_json, vocab_rob):
+    """The reference architecture at B = 32: a B x B InfoNCE softmax large enough that the mean over rows
+    averages the per-row amplification of embedding rounding (at B = 4 the fixture above sits at 1.1-1.4e-3).  Tower outputs are
+    stored for the first 8 molecules only (fixture size); losses, logits and gradient norms for the whole batch."""
+    for task in ("classification", "regression"):
+        with tempfile.TemporaryDirectory() as tmp:
+            model = build_reference_model(MM, REFARCH, task, tmp, tok_json, vocab_rob)
+        ocfg = oracle_cfg(REFARCH, task, vocab_rob, model.output_dim)
+        P = O.init_params(ocfg, seed=92, std=0.02)
+        load_oracle_params(model, P)
+        hooks = attach_hooks(model)
+        model.train()
+        samples = synth_samples(32, 20, tok_json, seed=94, task=task)
+        b, y = model.batch_collate_fn(samples)
+        out = run_step(model, b, y, task, 0, hooks)
+        arrays = dict(task=np.array(task), seed=92, std=0.02, vocab_rob=vocab_rob, b_label=y,
+                      w_check=np.array([float(P["encoder.layers.7.fc1.weight"][5, 7]), float(P["bert.encoder.layer.3.output.dense.weight"][1, 2])]))
+        for k, v in b.items():
+            if k != "src_coord":                      # (never consumed: mm_model.py:540)
+                arrays["b_" + k] = v
+        for k, v in out.items():
+            arrays["o_" + k] = v[:8] if k in ("enc", "bert") else v
+        names, norms = [], []
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                names.append(n)
+                norms.append(float(p.grad.norm()))
+        arrays["gn_names"], arrays["gn"] = np.array(names), np.array(norms)
+        for n in ("classification_head.out_proj.weight", "encoder.layers.0.fc1.bias", "encoder.layers.14.self_attn.in_proj.bias",
+                  "gbf.means.weight", "gbf.stds.weight", "encoder.emb_layer_norm.weight", "bert.embeddings.LayerNorm.weight",
+                  "infonce.info_proj_query.2.weight", "gbf_proj.linear2.weight"):
+            arrays["g_" + n] = dict(model.named_parameters())[n].grad
+        npz("g9_model_refarch_b32_" + ("cls" if task == "classification" else "reg"), **arrays)
+
+
 # ------------------------------------------------------------------------------------------------ G9c: collate
 def g9_collate(MM, tok_json, vocab_rob):
     with tempfile.TemporaryDirectory() as tmp:
@@ -410,11 +454,13 @@ if __name__ == "__main__":
     MM = importlib.import_module("models.mm_model")
     TR = importlib.import_module("tasks.trainer")
     tok_json, vocab_rob = S.make_tokenizer_json()
-    which = sys.argv[1:] or ["encoder", "model", "collate", "trainer"]
+    which = sys.argv[1:] or ["encoder", "model", "model_b32", "collate", "trainer"]
     if "encoder" in which:
         g9_encoder(T)
     if "model" in which:
         g9_model(MM, tok_json, vocab_rob)
+    if "model_b32" in which:
+        g9_model_b32(MM, tok_json, vocab_rob)
     if "collate" in which:
         g9_collate(MM, tok_json, vocab_rob)
     if "trainer" in which:

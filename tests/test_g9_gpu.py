@@ -69,6 +69,29 @@ def test_g9_encoder_hip(golden, tag):
         else:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
     assert worst < 5e-2, worst
+    # ---- the auxiliary outputs are differentiable too (models/transformers.py:141-181): gradients of
+    #      0.7 x_norm + 1.3 delta_norm + <delta, g_delta> + <attn (finite entries), g_attn>  vs the reference's autograd
+    enc.zero_grad(set_to_none=True)
+    emb2 = T(g["emb"]).cuda().requires_grad_()
+    leaf2 = T(g["bias0"]).cuda().requires_grad_()
+    x2, attn2, delta2, xn2, dn2 = enc(emb2, attn_mask=leaf2 * 1.0, padding_mask=pm)
+    assert all(t.requires_grad for t in (x2, attn2, delta2, xn2, dn2))
+    finm = torch.isfinite(attn2)
+    aux = 0.7 * xn2 + 1.3 * dn2 + (delta2 * T(g["g_delta"]).cuda()).sum() + (torch.where(finm, attn2, torch.zeros_like(attn2)) * T(g["g_attn"]).cuda()).sum()
+    aux.backward()
+    ra = dict(d_emb=rel_l2(emb2.grad, g["d_emb_aux"]), cos_emb=cosine(emb2.grad, g["d_emb_aux"]))
+    gb2, rb2 = leaf2.grad.cpu().view(B, H, N, N), T(g["d_bias_aux"]).view(B, H, N, N)
+    ra["d_bias"] = rel_l2(gb2[keep], rb2[keep])
+    assert float(gb2[~keep].abs().max()) == 0.0 if pm is not None else True          # no gradient passes a filled (-inf) entry
+    worst_aux = ("", 0.0)
+    for n, p in enc.named_parameters():
+        if bool(g["hasgaux_" + n]) and float(np.abs(g["gaux_" + n]).max()) > 1e-7 and not n.endswith("in_proj.bias"):
+            assert p.grad is not None, n
+            worst_aux = max(worst_aux, (n, rel_l2(p.grad, g["gaux_" + n])), key=lambda t: t[1])
+    ra["worst_param"] = worst_aux[1]
+    _report("g9_encoder_aux_" + tag, **ra, worst_param_name=worst_aux[0])
+    # bf16 GEMM operands / bf16-stored activation gradients, two layers: the same bands as the main output's gradients above
+    assert ra["d_emb"] < 4e-2 and ra["cos_emb"] > 0.999 and ra["d_bias"] < 4e-2 and worst_aux[1] < 6e-2, ra
 
 
 # ------------------------------------------------------------------------------------------------ MM_Model wiring (a1-a19)
@@ -240,13 +263,58 @@ def test_g9_model_refarch_hip(golden, tag, layout):
     r.update(worst_grad_norm_err=worst_gn[1], worst_grad_rel_l2=worst_full[1][0], min_grad_cos=min(v[1] for v in full.values()))
     _report("g9_model_refarch_" + tag + ("" if layout == "padded" else "_packed"), **r, worst_grad_norm_param=worst_gn[0], worst_grad_param=worst_full[0])
     # embeddings after 15 pre-LN layers / 6 post-LN layers with bf16 GEMM operands (bound measured)
-    assert r["enc"] < 2e-2 and r["bert"] < 1e-2 and r["logits"] < 3e-2, r
+    assert r["enc"] < 6.5e-3 and r["bert"] < 3e-3 and r["logits"] < 4.5e-3, r      # (measured 4.7e-3 / 2.1e-3 / 2.3-3.0e-3, x 1.3)
     # the step loss (what the trainer optimises) within the north star's 1e-3; InfoNCE alone at B = 4 sits at 1.2-1.4e-3 -- the
     # CPU emulation of the bf16 contract gives the same 1.2e-3 on this shape (profiles/r02_rounding_sites_cpu.json): operand
     # rounding of weights and activations, amplified by 1/temperature = 10, not a kernel property
-    assert r["infonce"] < 2.5e-3 and r["task_loss"] < 2e-3 and r["loss"] < 1e-3, r
+    # (the B = 32 fixture below holds InfoNCE to 1e-3; this 4 x 4 case stays as the amplification witness: measured 1.14-1.36e-3, x 1.3)
+    assert r["infonce"] < 1.8e-3 and r["task_loss"] < 2e-3 and r["loss"] < 1e-3, r
     assert r["ct"] < 1e-2 or abs(float(ct) - float(g["o_ct"])) < 5e-4, r           # B=4 contrastive term (exp(x/0.07) of bf16-computed features)
     assert worst_gn[1] < 0.1 and worst_full[1][0] < 0.12 and r["min_grad_cos"] > 0.99, (worst_gn, worst_full, r["min_grad_cos"])
+
+
+@pytest.mark.parametrize("layout", ["padded", "packed"])
+@pytest.mark.parametrize("tag", ["cls", "reg"])
+def test_g9_model_refarch_b32_hip(golden, tag, layout):
+    """The reference architecture at B = 32 against the reference's own fp32 run: with 32 rows in the
+    InfoNCE softmax the north star's 1e-3 on every loss holds (the B = 4 fixture above is the amplification witness: 1.1-1.4e-3)."""
+    g = golden("g9_model_refarch_b32_" + tag)
+    task = str(g["task"])
+    ocfg = refarch_cfg(task, int(g["vocab_rob"]))
+    P = O.init_params(ocfg, seed=int(g["seed"]), std=float(g["std"]))
+    assert float(P["encoder.layers.7.fc1.weight"][5, 7]) == float(g["w_check"][0])
+    model = product_model(ocfg).cuda()
+    load_fixture_weights(model, P)
+    store = _capture_towers(model)
+    model.train()
+    cpu = {k[2:]: T(v) for k, v in g.items() if k.startswith("b_") and k != "b_label"}
+    batch = {k: v.cuda() for k, v in cpu.items()}
+    if layout == "packed":
+        batch.update(host_fields(cpu))
+    label = T(g["b_label"]).cuda()
+    tgt = label.float() if task == "regression" else label.long()
+    logits, infonce, ct = model(**batch, return_infonce_loss=True, return_ct_loss=True, net_target=tgt, use_weight=False, epoch=0)
+    assert model.last_layout == layout
+    tl = _task_loss(task, logits, tgt)
+    loss = 1.0 * tl + 0.1 * infonce + 0.1 * ct
+    enc, bert = _padded_towers(model, store)
+    r = dict(enc=rel_l2(enc[:8], g["o_enc"]), bert=rel_l2(bert[:8], g["o_bert"]), logits=rel_l2(logits, g["o_logits"]),
+             infonce=abs(float(infonce) - float(g["o_infonce"])) / abs(float(g["o_infonce"])),
+             ct=abs(float(ct) - float(g["o_ct"])) / max(abs(float(g["o_ct"])), 1e-6),
+             task_loss=abs(float(tl) - float(g["o_task_loss"])) / abs(float(g["o_task_loss"])),
+             loss=abs(float(loss) - float(g["o_loss"])) / abs(float(g["o_loss"])))
+    loss.backward()
+    grads = dict(model.named_parameters())
+    full = {k[2:]: (rel_l2(grads[k[2:]].grad, g[k]), cosine(grads[k[2:]].grad, g[k])) for k in g if k.startswith("g_")}
+    worst_full = max(full.items(), key=lambda t: t[1][0])
+    r.update(worst_grad_rel_l2=worst_full[1][0], min_grad_cos=min(v[1] for v in full.values()))
+    _report("g9_model_refarch_b32_" + tag + ("" if layout == "padded" else "_packed"), **r, worst_grad_param=worst_full[0])
+    # north star: losses within 1e-3 relative -- InfoNCE included at this batch size
+    assert r["infonce"] < 1e-3 and r["loss"] < 1e-3 and r["task_loss"] < 2e-3, r
+    assert r["ct"] < 1e-2 or abs(float(ct) - float(g["o_ct"])) < 5e-4, r
+    # embeddings: measured 4.7e-3 / 2.1e-3 / 2.3-3.0e-3 (the cost of bf16 GEMM operands over 15 / 6 layers, DESIGN.md section 2) x 1.3
+    assert r["enc"] < 6.5e-3 and r["bert"] < 3e-3 and r["logits"] < 4.5e-3, r
+    assert worst_full[1][0] < 0.12 and r["min_grad_cos"] > 0.99, (worst_full, r["min_grad_cos"])
 
 
 # ------------------------------------------------------------------------------------------------ trainer (a18)
@@ -395,5 +463,5 @@ def test_embedding_parity_at_reference_depth_vs_fp32():
     for name in ("encoder_rep", "out_bert", "logits"):
         r = rep[name]
         assert r["hip_vs_fp32"] <= 1.5 * r["emulation_vs_fp32"] + 1e-3 and r["hip_vs_emulation"] < 4.5e-3, (name, r)   # (two realisations of the same rounding points differ by ~sqrt(2) x their distance to fp32 / 2)
-    assert rep["encoder_rep"]["hip_vs_fp32"] < 8e-3 and rep["out_bert"]["hip_vs_fp32"] < 4e-3, rep
+    assert rep["encoder_rep"]["hip_vs_fp32"] < 6e-3 and rep["out_bert"]["hip_vs_fp32"] < 3e-3, rep      # (measured 4.6e-3 / 2.1e-3, x 1.3)
     assert rep["infonce"]["hip_vs_fp32"] < 2e-3 and rep["ct"]["hip_vs_fp32"] < 2e-3, rep

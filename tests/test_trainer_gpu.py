@@ -415,3 +415,84 @@ def test_graphed_step_matches_eager_and_redraws_dropout():
             assert torch.equal(a, m3(**dev))
     finally:
         ops.seed_salt_reset()
+
+
+def test_multilabel_classification_trains_with_ct_multi_and_bce(tmp_path):
+    """the reference constructs ``multilabel_classification`` (models/mm_model.py:481-486: CT_Multi) with the
+    BCE / GHM / focal loss table (models/nnmodel.py:24-34).  A 12-label toy: the step (BCE-with-logits kernel + CT_Multi + InfoNCE)
+    against the oracle, FineTuner with the built-in kernel and with the loss passed as a callable, a task without a built-in
+    kernel, and a short ``tasks.Trainer.fit_predict`` run with ``nn.BCEWithLogitsLoss()``."""
+    from mmdti_hip.trainer import FineTuner
+    from mmdti_hip.functional import BCELogitsLossFn
+    from mmdti_hip.tasks import Trainer
+    task, C = "multilabel_classification", 12
+    ocfg = _ocfg(task, C)
+    P = {k: v.requires_grad_() for k, v in O.init_params(ocfg, seed=4, std=0.08).items()}
+    batch, label = O.synth_batch(8, 10, 14, ocfg, seed=9, ragged=True, n_labels=C)
+    assert label.shape == (8, C) and label.dtype == torch.int64
+    dev = {k: v.cuda() for k, v in batch.items()}
+    y = label.cuda()
+    model = _model(task, C).eval()
+    model.load_state_dict({k: v.detach() for k, v in P.items()}, strict=False)
+    logits, infonce, ct = model(**dev, return_infonce_loss=True, return_ct_loss=True, net_target=y)
+    tl = BCELogitsLossFn.apply(logits, y)
+    loss = tl + 0.1 * infonce + 0.1 * ct
+    out = O.mm_forward(batch, P, ocfg, net_target=label, bf16=True)
+    ref, ref_tl = O.step_loss(out, label, task)
+    assert abs(float(tl) - float(ref_tl)) <= 1e-3 * abs(float(ref_tl)) and abs(float(ct) - float(out["ct"])) <= 2e-3 * abs(float(out["ct"])) + 1e-5
+    assert abs(float(loss) - float(ref)) <= 1e-3 * abs(float(ref))
+    # the kernel against torch's own BCE-with-logits on the same logits, value and gradient
+    lg = logits.detach().clone().requires_grad_()
+    t_ref = torch.nn.functional.binary_cross_entropy_with_logits(lg, y.float())
+    t_ref.backward()
+    lk = logits.detach().clone().requires_grad_()
+    BCELogitsLossFn.apply(lk, y).backward()
+    assert abs(float(t_ref) - float(tl)) < 1e-6 and float((lk.grad - lg.grad).abs().max()) < 1e-7
+    loss.backward()
+    ref.backward()
+    g = model.classification_head.out_proj.weight.grad
+    rg = P["classification_head.out_proj.weight"].grad
+    assert float((g.cpu() - rg).norm() / rg.norm()) < 3e-2
+    # FineTuner: built-in kernel == the same loss passed as a callable; a task without a kernel needs the callable
+    m1, m2 = _model(task, C).eval(), _model(task, C).eval()
+    m2.load_state_dict(m1.state_dict())
+    o1 = FineTuner(m1, task, total_steps=10).step(dev, y)
+    o2 = FineTuner(m2, task, total_steps=10).step(dev, y, loss_func=lambda lg_, t_: torch.nn.functional.binary_cross_entropy_with_logits(lg_, t_.float()))
+    assert abs(float(o1.task_loss) - float(o2.task_loss)) < 1e-6 and abs(float(o1.loss) - float(o2.loss)) < 1e-5
+    m3 = _model("regression", C).eval()
+    t3 = FineTuner(m3, "multilabel_regression", total_steps=10)
+    with pytest.raises(ValueError):
+        t3.step(dev, y.float(), return_ct_loss=False)
+    o3 = t3.step(dev, y.float(), return_ct_loss=False, loss_func=lambda lg_, t_: (lg_ - t_).abs().mean())
+    assert np.isfinite(float(o3.loss))
+    # through the Trainer drop-in: loss goes down over a few epochs on a learnable multilabel target
+    rng = np.random.default_rng(3)
+    samples = []
+    for _ in range(48):
+        na = int(rng.integers(4, 10))
+        atoms = rng.choice(np.arange(4, 30), size=na)
+        d = O.coords2unimol(atoms, rng.normal(0, 3.0, size=(na, 3)), 31)
+        d["smile"] = "C" * int(rng.integers(3, 10))
+        samples.append((d, np.array([int((atoms == 4 + c).any()) for c in range(C)], dtype=np.int64)))
+
+    class _Tok:
+        pad_token_id = 1
+
+        def __call__(self, smiles, padding=True, truncation=True, return_tensors="pt"):
+            L = max(len(s) for s in smiles) + 2
+            ids = torch.ones(len(smiles), L, dtype=torch.long)
+            att = torch.zeros(len(smiles), L, dtype=torch.long)
+            for r, s in enumerate(smiles):
+                ids[r, :len(s) + 2] = torch.tensor([0] + [5 + (ord(c) % 7) for c in s] + [2])
+                att[r, :len(s) + 2] = 1
+            return {"input_ids": ids, "attention_mask": att}
+
+    model = _model(task, C, _tokenizer=_Tok())
+    trainer = Trainer(save_path=str(tmp_path), task=task, metrics="none", learning_rate=1e-3, batch_size=8, epochs=4, warmup_ratio=0.1, patience=20,
+                      max_norm=5.0, use_cuda=True, use_amp=True, alpha=1, beta=0.1, seed=1)
+    y_pred = trainer.fit_predict(model, samples[:40], samples[40:], torch.nn.BCEWithLogitsLoss(), torch.sigmoid, str(tmp_path), 0, None,
+                                 return_infonce_loss=True, return_ct_loss=True, use_weight=False)
+    assert y_pred.shape == (8, C) and np.isfinite(y_pred).all() and (y_pred >= 0).all() and (y_pred <= 1).all()
+    first, last = trainer.history[0]["steps"][:, 1].mean(), trainer.history[-1]["steps"][:, 1].mean()
+    assert last < first, (first, last)
+    assert trainer.history[0]["metric"] == "log_loss"                  # the reference's first default metric for the task
