@@ -118,6 +118,9 @@ ALL_SITES = frozenset({"w", "x", "qkv", "qkv2", "p", "proj", "s16"})
 # layer's softmax runs on the rounded value -- the HIP path's compact pair planes, and what the reference's AMP path does
 # (autocast makes attn_weights fp16).  Cost at the reference depth: profiles/r02_s16_budget_cpu.json.
 BF16_SITES = set(ALL_SITES)
+# storage type the sites round to: bfloat16 (the HIP path's contract) or float16 (what the reference's own AMP run uses,
+# tasks/trainer.py:181-182 -- scratch/rounding_sites_fp16.py measures what that would buy; values saturate at 65504)
+ROUND_DTYPE = torch.bfloat16
 
 
 class _RoundF16(torch.autograd.Function):
@@ -136,7 +139,11 @@ class _RoundF16(torch.autograd.Function):
 
 def _r(x: Tensor, on: bool, site: str = "x") -> Tensor:
     """bf16 round-trip used by the ``emulate_bf16`` contract."""
-    return x.to(torch.bfloat16).to(torch.float32) if (on and site in BF16_SITES) else x
+    if not (on and site in BF16_SITES):
+        return x
+    if ROUND_DTYPE is torch.float16:
+        return torch.clamp(x, min=-65504.0, max=65504.0).to(torch.float16).to(torch.float32)
+    return x.to(ROUND_DTYPE).to(torch.float32)
 
 
 def linear(x: Tensor, w: Tensor, b: Optional[Tensor], bf16: bool = False) -> Tensor:
