@@ -201,6 +201,34 @@ class ArenaReducer:
         self._pending = []
 
 
+_HOST_GROUP = None
+
+
+def host_group():
+    """A gloo process group for HOST-side exchanges (a few integers per step, decisions of the epoch loop): a collective on host
+    memory costs no device synchronisation -- an RCCL all-reduce of two lengths followed by ``int(t[0])`` stalls the host until the
+    GPU queue has drained.  The default group itself when it is gloo (CPU runs).  Created on first use: every rank must reach that
+    first use together (they do: it sits in the per-step / per-epoch control flow)."""
+    global _HOST_GROUP
+    if _HOST_GROUP is None:
+        _HOST_GROUP = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+    return _HOST_GROUP
+
+
+def host_all_reduce_max(values, group=None):
+    """element-wise MAX over ranks of a short list of Python ints, through host memory"""
+    t = torch.tensor(list(values), dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group if group is not None else host_group())
+    return [int(v) for v in t]
+
+
+def host_broadcast_ints(values, src=0, group=None):
+    """rank ``src``'s list of Python ints on every rank, through host memory"""
+    t = torch.tensor(list(values), dtype=torch.int64)
+    dist.broadcast(t, src=src, group=group if group is not None else host_group())
+    return [int(v) for v in t]
+
+
 PAD_VALUES = {"src_tokens": 0, "src_edge_type": 0, "src_distance": 0.0, "src_coord": 0.0, "input_ids": 1, "attention_mask": 0}
 
 
@@ -209,15 +237,15 @@ def pad_to_global_lengths(batch: dict, group=None, pad_values: Optional[dict] = 
     all-reduce).  The reference's InfoNCE head averages its per-token projections over ALL positions including padding
     (infonce.py:32-33), so the loss depends on the padded length: with rank-local collation every rank must use the global
     lengths for N ranks to reproduce the single-process value on the union batch.  pad_values: per-key fill (defaults to the
-    reference's: dictionary pad 0 for tokens / edge types, 0.0 for distances, RoBERTa pad 1 for input_ids, 0 for the mask)."""
-    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+    reference's: dictionary pad 0 for tokens / edge types, 0.0 for distances, RoBERTa pad 1 for input_ids, 0 for the mask).
+    The two lengths are tensor SHAPES -- host integers -- and are exchanged as such (host_group: gloo): no device->host
+    synchronisation enters the step.  group: a HOST-capable (gloo) group, default host_group()."""
+    if not (dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("MMDTI_FORCE_DDP") == "1")):
         return batch
     pv = dict(PAD_VALUES, **(pad_values or {}))
     n_loc = batch["src_tokens"].shape[1]
     l_loc = batch["input_ids"].shape[1] if "input_ids" in batch else 0
-    lens = torch.tensor([n_loc, l_loc], device=batch["src_tokens"].device, dtype=torch.int64)
-    dist.all_reduce(lens, op=dist.ReduceOp.MAX, group=group)
-    n_glob, l_glob = int(lens[0]), int(lens[1])
+    n_glob, l_glob = host_all_reduce_max([n_loc, l_loc], group)
     out = {}
     for k, v in batch.items():
         if k in ("src_tokens",):

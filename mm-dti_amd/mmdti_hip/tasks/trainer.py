@@ -247,20 +247,27 @@ class Trainer(object):
                                "(the reference's use_cuda=False plumbing run is the reference's own PyTorch-CPU code)")
 
     # -------------------------------------------------------------- fit
+    def _ddp(self):
+        """more than one rank behind this trainer"""
+        return self.distributed and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+
+    def train_loader(self, model, train_dataset, feature_name=None):
+        """-> (loader, sampler | None).  Data parallel: each rank draws a disjoint, equally sized shard of every epoch's permutation
+        (``DistributedSampler(drop_last=True)``; batch_size is per rank), so every rank takes the same number of steps -- a rank
+        with one batch more would wait forever in that step's collectives.  Device-independent (covered by the 2-rank gloo tests)."""
+        if self._ddp():
+            from torch.utils.data.distributed import DistributedSampler
+            sampler = DistributedSampler(train_dataset, shuffle=True, seed=self.seed, drop_last=True)
+            return TorchDataLoader(dataset=train_dataset, batch_size=self.batch_size, sampler=sampler, collate_fn=self._collate_for(model),
+                                   drop_last=True, **self._loader_kwargs()), sampler
+        return NNDataLoader(feature_name=feature_name, dataset=train_dataset, batch_size=self.batch_size, shuffle=True,
+                            collate_fn=self._collate_for(model), drop_last=True, **self._loader_kwargs()), None
+
     def fit_predict(self, model, train_dataset, valid_dataset, loss_func, activation_fn, dump_dir, fold, target_scaler, feature_name=None,
                     return_infonce_loss=False, return_ct_loss=False, use_weight=False):
         self._require_device()
         model = model.to(self.device)
-        sampler = None
-        if self.distributed and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            # data parallel: each rank draws a disjoint, equally sized shard of every epoch's permutation (batch_size is per rank)
-            from torch.utils.data.distributed import DistributedSampler
-            sampler = DistributedSampler(train_dataset, shuffle=True, seed=self.seed, drop_last=True)
-            train_dataloader = TorchDataLoader(dataset=train_dataset, batch_size=self.batch_size, sampler=sampler,
-                                               collate_fn=self._collate_for(model), drop_last=True, **self._loader_kwargs())
-        else:
-            train_dataloader = NNDataLoader(feature_name=feature_name, dataset=train_dataset, batch_size=self.batch_size, shuffle=True,
-                                            collate_fn=self._collate_for(model), drop_last=True, **self._loader_kwargs())
+        train_dataloader, sampler = self.train_loader(model, train_dataset, feature_name)
         min_val_loss, max_score, wait = float("inf"), float("-inf"), 0
         num_training_steps = len(train_dataloader) * self.max_epochs
         engine = FineTuner(model, self.task, learning_rate=self.learning_rate, adam_eps=1e-6, warmup_ratio=0.0,
@@ -300,16 +307,36 @@ class Trainer(object):
                 wait, total_val_loss, min_val_loss, metric_score, max_score, model, dump_dir, fold, self.patience, epoch)
             if is_early_stop:
                 break
+        self._checkpoint_barrier()          # rank 0's last write is complete before any rank reads the file
         y_preds, _, _ = self.predict(model, valid_dataset, loss_func, activation_fn, dump_dir, fold, target_scaler, epoch, load_model=True,
                                      feature_name=feature_name)
         return y_preds
 
     # -------------------------------------------------------------- early stopping / checkpoint (:330-385, utils/metrics.py:220-258)
     def _save(self, model, dump_dir, fold):
+        """rank 0 only; written to a temporary name and renamed, so a reader never sees a half-written archive (torch.save is
+        not atomic)"""
         if self.rank != 0:
             return
         os.makedirs(dump_dir, exist_ok=True)
-        torch.save({'model_state_dict': model.state_dict()}, os.path.join(dump_dir, f'model_{fold}.pth'))
+        path = os.path.join(dump_dir, f'model_{fold}.pth')
+        tmp = path + f'.tmp{os.getpid()}'
+        torch.save({'model_state_dict': model.state_dict()}, tmp)
+        os.replace(tmp, path)
+
+    def _checkpoint_barrier(self):
+        if self._ddp():
+            from ..parallel import host_group
+            torch.distributed.barrier(group=host_group())
+
+    def _agree(self, flag: bool) -> bool:
+        """Data parallel: every rank follows RANK 0's reading of a per-epoch decision.  Each rank validates on its own device and the
+        loss kernels add with atomics, so two ranks can differ in the last bit of a validation scalar; at a near-tie one rank
+        would leave the epoch loop while the others enter the next step's collectives and wait forever."""
+        if not self._ddp():
+            return flag
+        from ..parallel import host_broadcast_ints
+        return bool(host_broadcast_ints([int(flag)], src=0)[0])
 
     def _early_stop_choice(self, wait, loss, min_loss, metric_score, max_score, model, dump_dir, fold, patience, epoch):
         by_loss = not isinstance(self.metrics_str, str) or self.metrics_str in ['loss', 'none', '']
@@ -319,7 +346,7 @@ class Trainer(object):
             name, value = next(iter(metric_score.items()))
             increase = _is_increase(self.metrics, self.task, name)
             best = max_score if increase else min_loss
-        improved = value >= best if increase else value <= best
+        improved = self._agree(value >= best if increase else value <= best)
         stop = False
         if improved:
             best, wait = value, 0

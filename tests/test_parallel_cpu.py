@@ -288,7 +288,94 @@ def _worker_unequal_local_batches_raise(rank, world, initfile, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("worker", [_worker_global_negatives, _worker_reducer, _worker_reducer_hook, _worker_step_equivalence,
+def _worker_trainer_ddp_plumbing(rank, world, initfile, out):
+    """The device-independent parts of ``tasks.Trainer(distributed=True)`` on 2 gloo ranks: the
+    sampler deals disjoint shards with EQUAL step counts; ``decorate_torch_batch`` pads every rank's batch to the global lengths
+    with host-side integers; the checkpoint is written by rank 0 only, atomically, and visible to every rank after the barrier;
+    the early-stop / improved decision of every rank is rank 0's (a near-tie must not split the ranks)."""
+    _init(rank, world, initfile)
+    import numpy as np
+    from mmdti_hip.tasks import Trainer
+    from mmdti_hip.collate import collate_batch
+    from oracle import mmdti_oracle as O
+    td = os.path.dirname(out)
+    trainer = Trainer(save_path=td, task="regression", metrics="none", batch_size=3, epochs=2, use_cuda=False, distributed=True, seed=11,
+                      narrow_inputs=True)
+    assert trainer._ddp() and trainer.rank == rank
+
+    class _Tok:
+        def __call__(self, smiles, padding=True, truncation=True, return_tensors="pt"):
+            L = max(len(s) for s in smiles) + 2
+            ids = torch.ones(len(smiles), L, dtype=torch.long)
+            att = torch.zeros(len(smiles), L, dtype=torch.long)
+            for r, s in enumerate(smiles):
+                ids[r, :len(s) + 2] = torch.tensor([0] + [5 + (ord(c) % 7) for c in s] + [2])
+                att[r, :len(s) + 2] = 1
+            return {"input_ids": ids, "attention_mask": att}
+
+    class _Model(torch.nn.Module):          # what the trainer touches outside the step: collate, padding index, dictionary, state dict
+        padding_idx, dictionary, tokenizer = 0, list(range(31)), _Tok()
+
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.full((3,), float(rank)))      # ranks hold DIFFERENT values: only rank 0's may be saved
+
+        def batch_collate_fn(self, samples):
+            return collate_batch(samples, 0, self.tokenizer)
+
+    rng = np.random.default_rng(1)
+    data = []
+    for i in range(17):                                                    # 17 samples, 2 ranks, batch 3: shards of 8 -> 2 steps each
+        na = int(rng.integers(2, 12))
+        d = O.coords2unimol(rng.integers(4, 30, size=na), rng.normal(0, 3, size=(na, 3)), 31)
+        d["smile"] = "C" * int(rng.integers(2, 15))
+        data.append((d, np.array([float(i)], dtype=np.float32)))
+    model = _Model()
+    loader, sampler = trainer.train_loader(model, data)
+    assert sampler is not None
+    sampler.set_epoch(0)
+    seen, shapes = [], []
+    for batch in loader:
+        net_input, target = trainer.decorate_torch_batch(batch)
+        seen += [int(v) for v in target.flatten().tolist()]
+        shapes.append((net_input["src_tokens"].shape[1], net_input["input_ids"].shape[1]))
+        assert net_input["src_edge_type"].dtype == torch.int16 and net_input["packable"] and len(net_input["atom_counts"]) == 3
+        assert net_input["src_distance"].shape[1:] == (shapes[-1][0],) * 2
+    steps = torch.tensor([len(shapes)])
+    all_steps = [torch.zeros_like(steps) for _ in range(world)]
+    dist.all_gather(all_steps, steps)
+    assert all(int(t) == len(shapes) == 2 for t in all_steps)              # equal step counts
+    mine = torch.tensor(seen + [-1] * (8 - len(seen)))
+    both = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    a, b = (set(int(v) for v in t.tolist() if v >= 0) for t in both)
+    assert not (a & b) and len(a) == len(b) == 6                           # disjoint shards
+    sh = torch.tensor(shapes)
+    both_sh = [torch.zeros_like(sh) for _ in range(world)]
+    dist.all_gather(both_sh, sh)
+    assert torch.equal(both_sh[0], both_sh[1])                              # every step: ONE padded length on all ranks
+    # decisions: rank 1 sees a (slightly) worse value than its best, rank 0 a better one -> both follow rank 0 and rank 0 saves
+    value = 1.0 - 1e-7 if rank == 0 else 1.0 + 1e-7
+    stop, best, wait, _ = trainer._early_stop_choice(0, value, 1.0, {"mse": value}, float("-inf"), model, td, 0, patience=1, epoch=0)
+    assert not stop and wait == 0 and best == value
+    trainer._checkpoint_barrier()
+    path = os.path.join(td, "model_0.pth")
+    ck = torch.load(path, weights_only=True)["model_state_dict"]
+    assert torch.equal(ck["w"], torch.zeros(3)) and not [f for f in os.listdir(td) if ".tmp" in f]
+    # ... and the other way round: rank 0 sees no improvement, rank 1 would have -> nobody saves, both count a wait and stop together
+    trainer._checkpoint_barrier()               # (every rank has read the file)
+    os.remove(path) if rank == 0 else None
+    trainer._checkpoint_barrier()
+    value = 2.0 if rank == 0 else 0.5
+    stop, best, wait, _ = trainer._early_stop_choice(0, value, 1.0, {"mse": value}, float("-inf"), model, td, 0, patience=1, epoch=0)
+    trainer._checkpoint_barrier()
+    assert stop and wait == 1 and best == 1.0 and not os.path.exists(path)
+    if rank == 0:
+        torch.save({"ok": True}, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("worker", [_worker_trainer_ddp_plumbing, _worker_global_negatives, _worker_reducer, _worker_reducer_hook, _worker_step_equivalence,
                                     _worker_fds_stats_identical, _worker_bucket_sampler_global_infonce, _worker_unequal_local_batches_raise])
 def test_two_ranks_gloo(worker):
     with tempfile.TemporaryDirectory() as td:

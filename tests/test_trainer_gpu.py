@@ -296,27 +296,56 @@ def test_gradient_buckets_leave_during_backward_single_rank_group(monkeypatch):
     torch.testing.assert_close(g1, plain.arena.grad, rtol=1e-3, atol=1e-5)
 
 
+@pytest.mark.parametrize("mode", ["padded", "packed", "ddp"])
 @pytest.mark.parametrize("task,odim", [("classification", 2), ("regression", 1)])
-def test_step_has_no_host_synchronisation(task, odim):
+def test_step_has_no_host_synchronisation(task, odim, mode, monkeypatch):
     """The whole step -- forward, three losses, backward, clip, Adam -- enqueues without the host ever waiting for the
     device (the reference does four float(t.data) reads per step, tasks/trainer.py:195-197,238).  torch's sync debug mode
     raises on .item(), pageable host<->device copies and the like; the default host tensor([1]) weight of CT_Single
-    (models/contrastive.py:62) used to cost two of them."""
+    (models/contrastive.py:62) used to cost two of them.
+    packed: with the host-side lengths of collate.device_payload the step runs on packed token rows -- the layout is decided and
+    its index arrays are built on the host.  ddp: a 1-rank RCCL group (MMDTI_FORCE_DDP=1) with ``pad_to_global_lengths`` inside
+    the loop: the global padded lengths travel as host integers (gloo side group), the all-gather / bucketed all-reduce are
+    enqueued -- still no device->host synchronisation."""
+    import torch.distributed as dist
     from mmdti_hip.trainer import FineTuner
+    from mmdti_hip.collate import device_payload, to_device
+    from mmdti_hip.parallel import init_from_env, pad_to_global_lengths
     ocfg = _ocfg(task, odim)
     batch, label = O.synth_batch(8, 10, 14, ocfg, seed=7, ragged=True)
-    dev = {k: v.cuda() for k, v in batch.items()}
     lab = label.cuda()
-    tuner = FineTuner(_model(task, odim).train(), task)
-    for _ in range(2):
-        tuner.step(dev, lab)
-    torch.cuda.synchronize()
-    torch.cuda.set_sync_debug_mode("error")
+    if mode == "ddp":
+        monkeypatch.setenv("MMDTI_FORCE_DDP", "1")
+        monkeypatch.setenv("MASTER_PORT", "29573")
+        for k, v in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")):
+            monkeypatch.setenv(k, v)
+        init_from_env(force=True)
     try:
-        out = tuner.step(dev, lab)
+        wide = mode != "padded"                   # (the packed layout needs the fused attention kernels' head sizes)
+        tuner = FineTuner(_model(task, odim, wide).train(), task, distributed=mode == "ddp")
+
+        def resident():
+            if mode == "padded":
+                return {k: v.cuda() for k, v in batch.items()}
+            d = to_device(device_payload(batch), "cuda")
+            return pad_to_global_lengths(d) if mode == "ddp" else d
+
+        for _ in range(2):
+            tuner.step(resident(), lab)
+        torch.cuda.synchronize()
+        dev = resident() if mode == "padded" else None
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            out = tuner.step(dev if dev is not None else resident(), lab)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        assert torch.isfinite(out.loss).item()
+        assert tuner.model.last_layout == ("padded" if mode == "padded" else "packed")
     finally:
-        torch.cuda.set_sync_debug_mode("default")
-    assert torch.isfinite(out.loss).item()
+        if mode == "ddp":
+            import mmdti_hip.parallel as par
+            par._HOST_GROUP = None
+            dist.destroy_process_group()
 
 
 def test_device_prefetcher_feeds_the_step():
