@@ -363,14 +363,17 @@ def test_device_prefetcher_feeds_the_step():
     for (bi, li), (bo, lo) in zip(host, DevicePrefetcher(host, "cuda")):
         assert "src_coord" not in bo and bo["src_edge_type"].dtype == torch.int16
         assert torch.equal(bo["src_edge_type"].cpu().long(), bi["src_edge_type"])
-        assert all(torch.equal(bo[k].cpu(), bi[k]) for k in bo if k not in ("src_edge_type", "atom_counts"))
+        from mmdti_hip.collate import HOST_FIELDS
+        assert all(torch.equal(bo[k].cpu(), bi[k]) for k in bo if k not in ("src_edge_type",) + HOST_FIELDS)
+        assert bo["packable"] is True and bo["token_counts"].device.type == "cpu"
         assert bo["atom_counts"].device.type == "cpu" and bo["atom_counts"].dtype == torch.int32            # host-side lengths
     m1, m2 = _model("classification", 2).eval(), _model("classification", 2).eval()
     m2.load_state_dict(m1.state_dict())
     t1, t2 = FineTuner(m1, "classification"), FineTuner(m2, "classification")
     for (b1, l1), (bh, lh) in zip(DevicePrefetcher(host, "cuda"), host):
         o1 = t1.step(b1, l1)
-        o2 = t2.step({k: v.cuda() for k, v in bh.items()}, lh.cuda())
+        from mmdti_hip.collate import device_payload, to_device
+        o2 = t2.step(to_device(device_payload(bh), "cuda"), lh.cuda())      # (same host-side descriptors: both steps take the packed layout)
         assert abs(float(o1.loss) - float(o2.loss)) <= 1e-5 * abs(float(o2.loss)) + 1e-7
 
 
