@@ -258,16 +258,16 @@ def main():
     extra = 0 if args.no_rooflines else 2
     if extra:
         from mmdti_hip import functional as Fn
-        was = (model.overlap_towers, model.infonce_on_side_stream, model.cross_modal_module.two_streams, Fn.DEFER_WGRAD_LAYERS, Fn.WGRAD_SIDE)
+        was = (model.overlap_towers, model.infonce_on_side_stream, model.cross_modal_module.two_streams, Fn.DEFER_WGRAD_LAYERS)
         for mode, ov in (("overlapped", True), ("alone", False)):
             if not ov:
-                model.overlap_towers, model.infonce_on_side_stream, model.cross_modal_module.two_streams, Fn.DEFER_WGRAD_LAYERS, Fn.WGRAD_SIDE = False, False, False, 0, False
+                model.overlap_towers, model.infonce_on_side_stream, model.cross_modal_module.two_streams, Fn.DEFER_WGRAD_LAYERS = False, False, False, 0
             ops.kernel_timer.enable(tuple(FAMILIES))
             for _ in range(extra):
                 tuner.step(batch, label, epoch=0)
             fam[mode] = ops.kernel_timer.summary()
             ops.kernel_timer.disable()
-        model.overlap_towers, model.infonce_on_side_stream, model.cross_modal_module.two_streams, Fn.DEFER_WGRAD_LAYERS, Fn.WGRAD_SIDE = was
+        model.overlap_towers, model.infonce_on_side_stream, model.cross_modal_module.two_streams, Fn.DEFER_WGRAD_LAYERS = was
     barrier()
 
     if rank == 0:

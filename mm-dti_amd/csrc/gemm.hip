@@ -1135,149 +1135,6 @@ __global__ __launch_bounds__(256) void grouped_reduce_kernel(GroupArgs g) {
   }
 }
 
-
-// =====================================================================================================================
-// Ring kernel: 256 x 128 output tiles, FOUR waves (2 x 2; 128 x 64 each = 8 x 4 accumulator tiles, the per-wave shape of
-// gemm_big_kernel: 12 operand fragments feed 32 MFMAs, 0.375 LDS reads per MFMA against 0.5 for the 64 x 64 wave tiles of
-// the 128 x 128 kernels, whose reads alone ask for the whole 128 B/clk of the CU at MFMA peak), K in steps of 32 through a
-// THREE-stage LDS-DMA ring of 24 KB stages (A0 | A1 | B pieces of 128 rows x 32 k).  72 KB -> TWO workgroups per CU:
-//   * two stages (48 KB) of DMA in flight per workgroup across ONE barrier per K-step -- 96 KB per CU, what the ~1.5 us
-//     L2 / MALL latency asks for at ~1.2 PF/s and 85 flop/B (the 128 x 128 kernels hold ~32 KB x 4 only while they wait,
-//     the 256 x 256 one 64 KB x 1);
-//   * the second workgroup's K loop runs under the first one's epilogue (the 256 x 256 kernel has nobody to do that), and
-//     twice as many tiles as 256 x 256 for the same register budget (256 VGPRs at two waves per SIMD).
-// Iteration t:  s_waitcnt vmcnt(6) (own pieces of stage t landed; stage t+1's six stay in flight) -> s_barrier (stage t
-// visible to all; every wave is past the reads of stage t-1) -> DMA of stage t+2 into the buffer of stage t-1 -> 12
-// fragment reads + 32 MFMAs on stage t.
-constexpr int RBK = 32;
-constexpr int RBM = 256, RBN = 128;
-constexpr int RPIECE = 128 * RBK;            // elements of one 8 KB piece
-constexpr int RSTAGE = 3 * RPIECE;           // A0 | A1 | B
-
-// byte offset (relative to the operand's K-step origin) of chunk c (0..511) of a 128-row x 32-k piece whose first row is row0
-template <bool TR>
-__device__ __forceinline__ uint32_t ring_offset1(int c, int ld, int row0, int rows) {
-  if (!TR) {   // [row][k] image, 64-byte rows: 16-byte chunk XOR (row >> 2) & 3 -> conflict-free ds_read_b128 fragments
-    const int rl = c >> 2, kc = (c & 3) ^ ((rl >> 2) & 3);
-    const int row = min(row0 + rl, rows - 1);
-    return (uint32_t)(((long long)row * ld + kc * 8) * 2);
-  } else {     // [k][row] image: as the BK = 64 kernels (tr_swz), 32 k rows
-    const int k = c >> 4, rs = (c & 15) ^ (tr_swz(k) >> 3);
-    const int row = min(row0 + rs * 8, rows - 8);
-    return (uint32_t)(((long long)k * ld + row) * 2);
-  }
-}
-__device__ __forceinline__ void ring_issue(const bf16_t* kbase, uint32_t o0, uint32_t o1, bf16_t* piece, int wave) {
-  typedef __attribute__((address_space(1))) const void gptr_t;
-  typedef __attribute__((address_space(3))) void lptr_t;
-  const char* b = reinterpret_cast<const char*>(kbase);
-  bf16_t* d = piece + wave * 512;          // wave-instruction j covers chunks j*256 + wave*64 + lane
-  __builtin_amdgcn_global_load_lds((gptr_t*)(b + o0), (lptr_t*)(d), 16, 0, 0);
-  __builtin_amdgcn_global_load_lds((gptr_t*)(b + o1), (lptr_t*)(d + 2048), 16, 0, 0);
-}
-template <bool TR>
-__device__ __forceinline__ bf16x8 ring_frag(const bf16_t* img, int row0, int lane) {
-  if (!TR) {
-    const int row = row0 + (lane & 15);
-    return *reinterpret_cast<const bf16x8*>(img + row * RBK + (((lane >> 4) ^ ((row >> 2) & 3)) * 8));
-  } else {
-    return load_frag<true>(img, row0, 0, lane);
-  }
-}
-
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int tiles_n = (a.N + RBN - 1) / RBN, tiles_m = (a.M + RBM - 1) / RBM;
-  const int wg = xcd_remap(blockIdx.x, tiles_n * tiles_m);
-  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
-  const int m0 = tm * RBM, n0 = tn * RBN;
-  const int nt = a.K / RBK;
-  const bf16_t* __restrict__ A = a.A;
-  const bf16_t* __restrict__ B = a.B;
-  const long long kstepA = TA ? (long long)RBK * a.lda : RBK, kstepB = TB ? (long long)RBK * a.ldb : RBK;
-  const uint32_t oA00 = ring_offset1<TA>(tid, a.lda, m0, a.M), oA01 = ring_offset1<TA>(tid + 256, a.lda, m0, a.M);
-  const uint32_t oA10 = ring_offset1<TA>(tid, a.lda, m0 + 128, a.M), oA11 = ring_offset1<TA>(tid + 256, a.lda, m0 + 128, a.M);
-  const uint32_t oB0 = ring_offset1<TB>(tid, a.ldb, n0, a.N), oB1 = ring_offset1<TB>(tid + 256, a.ldb, n0, a.N);
-  f32x4 acc[8][4] = {};
-#define RING_ISSUE(T, BUF)                                                      \
-  {                                                                             \
-    const int tt = min((T), nt - 1);                                            \
-    const bf16_t* ak = A + tt * kstepA;                                         \
-    const bf16_t* bk = B + tt * kstepB;                                         \
-    bf16_t* sb = smem + (BUF) * RSTAGE;                                         \
-    ring_issue(ak, oA00, oA01, sb, wave);                                       \
-    ring_issue(bk, oB0, oB1, sb + 2 * RPIECE, wave);                            \
-    ring_issue(ak, oA10, oA11, sb + RPIECE, wave);                              \
-  }
-  RING_ISSUE(0, 0);
-  RING_ISSUE(1, 1);
-  int cur = 0;
-  for (int t = 0; t < nt; ++t) {
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    const int nb = cur >= 1 ? cur - 1 : 2;          // (t + 2) % 3
-    RING_ISSUE(t + 2, nb);
-    const bf16_t* img = smem + cur * RSTAGE;
-    const bf16x8 fb0 = ring_frag<TB>(img + 2 * RPIECE, wc * 64 + 0, lane), fb1 = ring_frag<TB>(img + 2 * RPIECE, wc * 64 + 16, lane),
-                 fb2 = ring_frag<TB>(img + 2 * RPIECE, wc * 64 + 32, lane), fb3 = ring_frag<TB>(img + 2 * RPIECE, wc * 64 + 48, lane);
-    const bf16x8 fa0 = ring_frag<TA>(img, wr * 64 + 0, lane), fa1 = ring_frag<TA>(img, wr * 64 + 16, lane),
-                 fa2 = ring_frag<TA>(img, wr * 64 + 32, lane), fa3 = ring_frag<TA>(img, wr * 64 + 48, lane);
-    const bf16x8 fa4 = ring_frag<TA>(img + RPIECE, wr * 64 + 0, lane), fa5 = ring_frag<TA>(img + RPIECE, wr * 64 + 16, lane),
-                 fa6 = ring_frag<TA>(img + RPIECE, wr * 64 + 32, lane), fa7 = ring_frag<TA>(img + RPIECE, wr * 64 + 48, lane);
-    __builtin_amdgcn_s_setprio(1);
-#define RMF(R, C) acc[R][C] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb##C, fa##R, acc[R][C], 0, 0, 0)
-#define RMF_ROW(R) RMF(R, 0); RMF(R, 1); RMF(R, 2); RMF(R, 3)
-    RMF_ROW(0); RMF_ROW(1); RMF_ROW(2); RMF_ROW(3); RMF_ROW(4); RMF_ROW(5); RMF_ROW(6); RMF_ROW(7);
-#undef RMF_ROW
-#undef RMF
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    cur = cur == 2 ? 0 : cur + 1;
-  }
-#undef RING_ISSUE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();   // no DMA in flight, every read retired: LDS is free for the epilogue
-  // accumulator (R = H*4 + i, C): row m0 + H*128 + wr*64 + i*16 + (lane & 15), columns n0 + wc*64 + C*16 + 4*(lane >> 4) + {0..3}
-  const int l15 = lane & 15, g4 = (lane >> 4) * 4;
-  if (a.dbg & 1) {   // loop-only timing: keep the accumulators live, store nothing in practice
-    float keep = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) keep += acc[i][0][0] + acc[i][1][1] + acc[i][2][2] + acc[i][3][3];
-    if (keep == 1.2345e-30f) reinterpret_cast<float*>(a.C)[0] = keep;
-    return;
-  }
-  float* sC = reinterpret_cast<float*>(smem);
-  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#define RSTG(R, L, C) *reinterpret_cast<f32x4*>(sC + ((L) * 16 + l15) * LDC_S + wc * 64 + (C) * 16 + g4) = acc[R][C]
-#define RSTG_ROW(R, L) RSTG(R, L, 0); RSTG(R, L, 1); RSTG(R, L, 2); RSTG(R, L, 3)
-  // four passes of 64 rows through the [64][132] fp32 image; 256 threads then run the fused epilogue on 8 contiguous columns each
-#define RING_PASS(P)                                                                                                  \
-  if (wr == ((P) & 1)) { RSTG_ROW(((P) >> 1) * 4 + 0, 0); RSTG_ROW(((P) >> 1) * 4 + 1, 1); RSTG_ROW(((P) >> 1) * 4 + 2, 2); RSTG_ROW(((P) >> 1) * 4 + 3, 3); } \
-  __syncthreads();                                                                                                    \
-  for (int it = 0; it < 4; ++it) {                                                                                    \
-    const int chunk = tid + it * 256;                                                                                 \
-    const int rr = chunk >> 4, cc = (chunk & 15) * 8;                                                                 \
-    const int row = m0 + ((P) >> 1) * 128 + ((P) & 1) * 64 + rr, col = n0 + cc;                                       \
-    if (row < a.M && col < a.N) epilogue_oct(a, sC + rr * LDC_S + cc, row, col, true, 0, a.colsum ? cs : nullptr, ebias.b0, ebias.b1); \
-  }
-  const EpiBias ebias = epi_bias(a, n0 + (tid & 15) * 8, true);
-  RING_PASS(0)
-  __syncthreads();
-  RING_PASS(1)
-  __syncthreads();
-  RING_PASS(2)
-  __syncthreads();
-  RING_PASS(3)
-  if (a.colsum) epilogue_colsum(a, sC, cs, tid, n0);
-#undef RING_PASS
-#undef RSTG_ROW
-#undef RSTG
-}
-
 }  // namespace mmdti
 
 MMDTI_DEFINE_SALT_PULL(gemm)
@@ -1294,14 +1151,12 @@ static const void* zero_page() {
   }
   return page;
 }
-static int g_gemm_ring = getenv("MMDTI_GEMM_RING") ? atoi(getenv("MMDTI_GEMM_RING")) : 1;
 static int g_gemm_dbg = 0;     // measurement only: 1 = gemm_big_kernel returns after its K loop (no epilogue, no slab pass)
 
 extern "C" int mmdti_set_option(const char* name, int value) {
   MMDTI_REQUIRE(name != nullptr, "set_option: null name");
   if (strcmp(name, "gemm_big") == 0) { g_gemm_big = value; return MMDTI_OK; }
   if (strcmp(name, "gemm_dbg") == 0) { g_gemm_dbg = value; return MMDTI_OK; }
-  if (strcmp(name, "gemm_ring") == 0) { g_gemm_ring = value; return MMDTI_OK; }
   set_error("set_option: unknown option '%s'", name);
   return MMDTI_ERR_INVALID;
 }
@@ -1419,31 +1274,6 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
   const bool dbuf_path = fast && use_glds && ((splitk > 1 && (tiles >= 48 || (arowsum_out && transA))) || use_glds == 3);
   // 256 x 256 tiles with the DMA in flight across barriers (gemm_big_kernel): MMDTI_GEMM_BIG=0 off, 1 (default) where
   // the shape fills the chip, 2 every eligible shape
-  // 256 x 128 ring kernel (gemm_ring_kernel): MMDTI_GEMM_RING=0 off, 1 (default) on the tall activation GEMMs, 2 every eligible shape
-  const bool ring_ok = fast && g_gemm_ring && K % RBK == 0 && batch_outer * batch_inner == 1 && splitk == 1 && a.vec_ok &&
-                       c_dtype != MMDTI_DT_F32_ATOMIC && !arowsum_out && N >= 64 && M >= 256;
-  // Measured (scratch/gemm_ring_test.py, profiles/r02_gemm_ring_ab.json): 990-1110 TF/s in the K loop on square-ish problems
-  // (x1.08 at 16384 x 4096 x 4096, x1.19 at 8192^3 over the 128 x 128 kernels), but x0.5...0.95 on the fine-tune step's own
-  // shapes -- 512-wide outputs cap every kernel here near 900 TF/s (four column tiles share an A tile), K = 512 leaves 16
-  // K-steps per tile, and 33 280 rows are 130 row tiles (520 tiles on 512 slots).  So by default it takes long-K, wide problems only.
-  if (ring_ok && (g_gemm_ring == 2 || (K >= 4096 && N >= 1024 && (long long)cdiv(M, RBM) * cdiv(N, RBN) >= 1024))) {
-    typedef void (*rkern_t)(GemmArgs);
-    static const rkern_t rkerns[2][2] = {{gemm_ring_kernel<false, false>, gemm_ring_kernel<false, true>},
-                                         {gemm_ring_kernel<true, false>, gemm_ring_kernel<true, true>}};
-    const size_t smem_r = (size_t)3 * RSTAGE * sizeof(bf16_t);
-    static bool ring_attr = false;
-    if (!ring_attr) {
-      for (int i = 0; i < 4; ++i)
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(rkerns[i >> 1][i & 1]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_r) != hipSuccess) {
-          set_error("gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", smem_r);
-          return MMDTI_ERR_LAUNCH;
-        }
-      ring_attr = true;
-    }
-    hipLaunchKernelGGL(rkerns[transA ? 1 : 0][transB ? 1 : 0], dim3(cdiv(M, RBM) * cdiv(N, RBN)), dim3(256), smem_r, s, a);
-    MMDTI_LAUNCH_CHECK();
-    return MMDTI_OK;
-  }
   const int use_big = g_gemm_big;
   const bool big_ok = fast && use_big && batch_outer * batch_inner == 1 && !colsum_out && M >= 256 && N >= 256 &&
                       (c_dtype == MMDTI_DT_F32_ATOMIC || a.vec_ok) && M % 256 == 0 && N % 256 == 0;

@@ -63,18 +63,7 @@ def _lin_bwd_params_many(calls, raw_items=()):
         ops.colsum(dy, gb, cols=cols)
 
 
-EPILOGUE_COLSUM = os.environ.get("MMDTI_EPILOGUE_COLSUM", "0") == "1"
 POOL_THEN_PROJECT = os.environ.get("MMDTI_INFONCE_POOL_FIRST", "1") != "0"      # InfoNCE head: pool the GELU outputs, then project
-
-
-def _epilogue_colsum(bias):
-    """Gradient buffer of `bias` if the GEMM epilogue should accumulate column sums into it (vector epilogue: width % 8
-    == 0).  Off by default: with 4160 output tiles adding into 2048 addresses the epilogue's atomics cost more (+60 us on
-    the GELU'-dX GEMM of the bench) than letting the bias gradient ride on the weight-gradient GEMM (+5 us), which is what
-    _lin_bwd_params does when this returns None.  MMDTI_EPILOGUE_COLSUM=1 restores the epilogue form."""
-    if not EPILOGUE_COLSUM or bias is None or bias.numel() % 8 != 0:
-        return None
-    return gbuf(bias)
 
 
 def _join_stream_after_backward():
@@ -121,47 +110,11 @@ def _launch_deferred_wgrads(deferred, layers):
     torch.autograd.Variable._execution_engine.queue_callback(_join)
 
 
-# Option (default off, MMDTI_WGRAD_SIDE=1): weight gradients of the pair encoder on their OWN stream, layer by layer.  They
-# are leaves of the backward graph (only the optimizer reads them) and MFMA-bound, and the next thing on the main stream is the
-# layer below's pair-attention backward -- HBM-bound, matrix pipes idle -- so the grouped launch of layer l could run
-# underneath it.  Measured (same box, r02): 57.4 vs 57.5 ms/step, nothing: a workgroup of the grouped kernel holds 128 KB of
-# a CU's 160 KB of LDS and a pair-attention workgroup needs 40 KB, so the two kernels take turns on a CU instead of sharing it.
-# Operands stay referenced until the launch's event has completed (or the streams are joined at the end of backward).
-WGRAD_SIDE = os.environ.get("MMDTI_WGRAD_SIDE", "0") == "1"
-_wgrad_inflight = []
-
-
 def _wgrad_stream():
     global _wgrad_stream_obj
     if _wgrad_stream_obj is None:
         _wgrad_stream_obj = torch.cuda.Stream()
     return _wgrad_stream_obj
-
-
-def _launch_side_wgrads(pending, layer):
-    main = torch.cuda.current_stream()
-    ws = _wgrad_stream()
-    ws.wait_stream(main)                         # every operand of `pending` has been produced on `main` by now
-    with torch.cuda.stream(ws):
-        _lin_bwd_params_many(pending)
-        notify_grads_ready(layer.parameters())     # (recorded on this stream: the reducer's event sits behind the GEMMs)
-        ev = torch.cuda.Event()
-        ev.record(ws)
-    _wgrad_inflight.append((ev, pending))
-    while _wgrad_inflight and _wgrad_inflight[0][0].query():
-        _wgrad_inflight.pop(0)                     # that launch is done: its operands may be recycled
-
-
-def _join_side_wgrads():
-    """queue (once per backward) the join of the weight-gradient stream into whatever stream ends the backward pass"""
-    if not _wgrad_inflight:
-        return
-
-    def _join(stream=_wgrad_stream()):
-        torch.cuda.current_stream().wait_stream(stream)
-        _wgrad_inflight.clear()
-
-    torch.autograd.Variable._execution_engine.queue_callback(_join)
 
 
 class _Sites:
@@ -315,9 +268,8 @@ class PairEncoderFn(torch.autograd.Function):
             # (dx16 = bf16 dropout-backward copy of dx, written by the LayerNorm backward that produced dx)
             dy2 = dx16 if dx16 is not None else ops.cast_bf16(dx, st.p_res, seed, L.site_f)
             _wgrad(dy2, L.a, layer.fc2.weight, layer.fc2.bias, bias_done=dx16 is not None)
-            cs = _epilogue_colsum(layer.fc1.bias)          # fc1.bias gradient = column sums of du: taken in the GEMM's epilogue
-            du = ops.linear_bwd_input(dy2, wbf16(layer.fc2.weight), act=ops.ACT_GELU_DX, aux_in=L.u, colsum=cs)
-            _wgrad(du, L.h2, layer.fc1.weight, layer.fc1.bias, bias_done=cs is not None)
+            du = ops.linear_bwd_input(dy2, wbf16(layer.fc2.weight), act=ops.ACT_GELU_DX, aux_in=L.u)
+            _wgrad(du, L.h2, layer.fc1.weight, layer.fc1.bias)      # (the bias gradient rides on the weight-gradient GEMM)
             dh2 = ops.linear_bwd_input(du, wbf16(layer.fc1.weight))
             dx, dy1 = ops.layernorm_bwd(dh2, L.x1, ln2.weight, L.m2, L.r2, gbuf(ln2.weight), gbuf(ln2.bias), dres=dx,
                                         bf16_copy=(st.p_res, L.site_o, gbuf(att.out_proj.bias)))
@@ -336,16 +288,13 @@ class PairEncoderFn(torch.autograd.Function):
                                              bf16_copy=(st.p_res, below[li - 1], gbuf(mod.layers[li - 1].fc2.bias)))
             else:
                 dx, dx16 = ops.layernorm_bwd(dh1, L.x, ln1.weight, L.m1, L.r1, gbuf(ln1.weight), gbuf(ln1.bias), dres=dx), None
-            side = WGRAD_SIDE and dout.is_cuda and not hold
             if hold:
                 deferred.append(pending)
                 deferred_layers.append(layer)
-            elif side:
-                _launch_side_wgrads(pending, layer)
             else:
                 _lin_bwd_params_many(pending)
             L.__dict__.clear()       # release this layer's activations (S_l is ~1 GB at the bench shape)
-            if not hold and not side:
+            if not hold:
                 notify_grads_ready(layer.parameters())
         eln = mod.emb_layer_norm
         demb = ops.layernorm_bwd(dx, st.emb.view(M, D), eln.weight, st.emb_mean, st.emb_rstd, gbuf(eln.weight), gbuf(eln.bias),
@@ -357,7 +306,6 @@ class PairEncoderFn(torch.autograd.Function):
             st.slot.g = G                                                            # -> PairBiasFn.backward (see forward)
             G = torch.zeros((), device=G.device, dtype=torch.float16).expand(G.shape)
         _launch_deferred_wgrads(deferred, deferred_layers)
-        _join_side_wgrads()
         _join_stream_after_backward()
         return (demb if st.packed else demb.view(B, N, D)), G, None, None, None, None, None, None
 
@@ -568,9 +516,8 @@ def _bert_layer_bwd(st, L, dout, seed):
     pend, raw = [], []                     # the layer's weight gradients leave as one grouped launch (see _lin_bwd_params_many)
     dz, dzb = ops.layernorm_bwd(dout, L.z, W.ln2_w, L.zm, L.zr, gbuf(W.ln2_w), gbuf(W.ln2_b), bf16_copy=(L.p_hid, L.site_f, gbuf(W.o2_b)))
     pend.append(((dzb, L.i, W.o2_w, W.o2_b), dict(bias_done=True)))
-    cs = _epilogue_colsum(W.i_b)
-    du = ops.linear_bwd_input(dzb, wbf16(W.o2_w), act=ops.ACT_GELU_DX, aux_in=L.u, colsum=cs)
-    pend.append(((du, L.a16, W.i_w, W.i_b), dict(bias_done=cs is not None)))
+    du = ops.linear_bwd_input(dzb, wbf16(W.o2_w), act=ops.ACT_GELU_DX, aux_in=L.u)
+    pend.append(((du, L.a16, W.i_w, W.i_b), {}))
     da = ops.linear_bwd_input(du, wbf16(W.i_w))
     # a32 = LN1(y) feeds the FFN AND the residual add of z: both gradients go through LN1's backward
     dy, dyb = ops.layernorm_bwd(da, L.y, W.ln1_w, L.am, L.ar, gbuf(W.ln1_w), gbuf(W.ln1_b), dy_add=dz, bf16_copy=(L.p_hid, L.site_o, gbuf(W.o_b)))
