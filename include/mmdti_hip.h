@@ -78,6 +78,18 @@ int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void* B, void* C
                     unsigned long long seed, unsigned int site, float* colsum_out, float* arowsum_out, void* workspace,
                     long long workspace_bytes);
 
+/* ---- Linear + residual + LayerNorm in one kernel ------------------------------------------------
+ * The Linear that closes a residual branch and the LayerNorm that follows it: unicore out_proj -> final_layer_norm and fc2 -> the
+ * next layer's self_attn_layer_norm / the encoder's final_layer_norm (pre-LN, models/transformers.py:137-139,160-161); HF / BertCross
+ * attention.output.dense -> LayerNorm and output.dense -> LayerNorm (post-LN, mm_model.py:562, mm_module.py:523-534,561-587):
+ *   x_out[M,N] (fp32) = residual + dropout(A.W^T + bias);   h = (x - mean) * rstd * gamma + beta  -> ln_f32 and / or ln_bf16
+ * (either may be null); mean, rstd: [M] fp32 (row mean and 1/sqrt(biased var + eps), what mmdti_layernorm_bwd takes).
+ * A: [M,K] bf16 (lda), W: [N,K] bf16 (ldb); N == 512 (a workgroup owns whole rows), K % 64 == 0.  Dropout counters are those of
+ * mmdti_gemm_bf16's epilogue (element row*N + col), so the fused and the unfused path draw the same mask. */
+int mmdti_gemm_ln_bf16(mmdti_stream_t stream, const void* A_bf16, const void* W_bf16, const float* bias, const float* residual, int M,
+                       int N, int K, int lda, int ldb, int ldr, float drop_p, unsigned long long seed, unsigned int site, float* x_out,
+                       const float* gamma, const float* beta, float eps, float* ln_f32, void* ln_bf16, float* mean, float* rstd);
+
 /* ---- Grouped weight gradients of one transformer layer -----------------------------------------
  * The weight half of nn.Linear's backward for up to 8 Linears that saw the SAME token rows (unicore in_proj / out_proj /
  * fc1 / fc2 of one encoder layer, models/transformers.py:137-139; query|key|value / dense / intermediate / output of one

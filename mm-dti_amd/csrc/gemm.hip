@@ -1135,6 +1135,188 @@ __global__ __launch_bounds__(256) void grouped_reduce_kernel(GroupArgs g) {
   }
 }
 
+
+// =====================================================================================================================
+// GEMM + LayerNorm: the Linear that closes a residual branch and the LayerNorm that follows it, in ONE kernel.
+//     x = residual + dropout(A.W^T + bias)          (fp32, stored: the residual stream, and the LayerNorm backward's input)
+//     h = LN(x) * gamma + beta                      (bf16 for the next GEMM and / or fp32; row mean and 1/std saved)
+// Pre-LN tower 1 (unicore TransformerEncoderLayer reached from models/transformers.py:137-139): out_proj -> final_layer_norm,
+// fc2 -> the NEXT layer's self_attn_layer_norm (or the encoder's final_layer_norm, :160-161); post-LN BERT layers (HF RobertaLayer,
+// mm_module.py:615-626): attention.output.dense -> LayerNorm, output.dense -> LayerNorm.  The separate LayerNorm kernel re-read
+// the 4-byte stream the GEMM had just written (68 MB per launch at 33 280 tokens) and cost a launch per LayerNorm.
+// A workgroup owns WHOLE rows (N == 512 columns: one wave per 64-column slab, 16 * R rows), so the row statistics stay on chip:
+// 8 waves x (16R x 64) accumulators, the same LDS-DMA fetch -> barrier -> multiply -> barrier K loop as gemm_glds_kernel with a
+// (16R | 512) x 64 tile pair (8 R + 64 KB; two workgroups per CU overlap each other).  Epilogue per 16-row slice: park the
+// slice in LDS, 32 threads per row (two 8-column pieces each) form x, reduce mean and the centred second moment inside their
+// half-wave (two passes, as layernorm.hip), write x, h, mean, rstd.  The dropout counters are those of the plain GEMM epilogue
+// (element row * N + col), so the fused and the unfused path draw the same mask.
+constexpr int LN_BN = 512;
+constexpr int LDC_LN = LN_BN + 4;
+
+struct GemmLnArgs {
+  const bf16_t* A;
+  const bf16_t* W;
+  const float* bias;
+  const float* residual;
+  const float* gamma;
+  const float* beta;
+  float* x_out;
+  float* ln_f32;
+  bf16_t* ln_bf16;
+  float* mean;
+  float* rstd;
+  int M, K, lda, ldb, ldr;
+  float eps;
+  uint32_t drop_thresh;
+  float drop_scale;
+  uint64_t seed;
+  uint32_t site;
+};
+
+template <int R>
+__global__ __launch_bounds__(512, 4) void gemm_ln_kernel(GemmLnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+  constexpr int ROWS = 16 * R;
+  bf16_t* imgA = smem;
+  bf16_t* imgB = smem + ROWS * LDT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * ROWS;
+  // A tile: ROWS x 8 chunks of 16 B (<= 640: the second DMA on the first waves only); W tile: 512 x 8 = 4096 chunks, 8 per thread
+  uint32_t oA[2], oB[8];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = j * 512 + tid;
+    const int rl = min(c >> 3, ROWS - 1), kc = (c & 7) ^ (rl & 7);
+    const int row = min(m0 + rl, a.M - 1);
+    oA[j] = (uint32_t)(((long long)row * a.lda + kc * 8) * 2);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = j * 512 + tid;
+    const int rl = c >> 3, kc = (c & 7) ^ (rl & 7);
+    oB[j] = (uint32_t)(((long long)rl * a.ldb + kc * 8) * 2);
+  }
+  typedef __attribute__((address_space(1))) const void gptr_t;
+  typedef __attribute__((address_space(3))) void lptr_t;
+  f32x4 acc[R][4] = {};
+  const int ktiles = a.K / BK;
+  constexpr int A_CHUNKS = ROWS * 8;
+#define LMF(I, J) acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb##J, fa, acc[I][J], 0, 0, 0)
+#define LN_KK(KK)                                                                                       \
+  {                                                                                                     \
+    const bf16x8 fb0 = load_frag<false>(imgB, wave * 64 + 0, KK, lane), fb1 = load_frag<false>(imgB, wave * 64 + 16, KK, lane), \
+                 fb2 = load_frag<false>(imgB, wave * 64 + 32, KK, lane), fb3 = load_frag<false>(imgB, wave * 64 + 48, KK, lane); \
+    _Pragma("unroll") for (int I = 0; I < R; ++I) {                                                     \
+      const bf16x8 fa = load_frag<false>(imgA, I * 16, KK, lane);                                       \
+      LMF(I, 0); LMF(I, 1); LMF(I, 2); LMF(I, 3);                                                       \
+    }                                                                                                   \
+  }
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const char* ab = reinterpret_cast<const char*>(a.A + (long long)kt * BK);
+    const char* bb = reinterpret_cast<const char*>(a.W + (long long)kt * BK);
+    __builtin_amdgcn_global_load_lds((gptr_t*)(ab + oA[0]), (lptr_t*)(imgA + wave * 512), 16, 0, 0);
+    if (A_CHUNKS > 512 && wave * 64 + 512 < A_CHUNKS)
+      __builtin_amdgcn_global_load_lds((gptr_t*)(ab + oA[1]), (lptr_t*)(imgA + 4096 + wave * 512), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t*)(bb + oB[j]), (lptr_t*)(imgB + j * 4096 + wave * 512), 16, 0, 0);
+    __syncthreads();
+    LN_KK(0);
+    LN_KK(1);
+    __syncthreads();
+  }
+#undef LN_KK
+#undef LMF
+  // ---- epilogue, 16 rows at a time through a [16][516] fp32 image (the operand tiles are dead)
+  float* sC = reinterpret_cast<float*>(smem);
+  const int g4 = (lane >> 4) * 4, l15 = lane & 15;
+  const int er = tid >> 5, ec = (tid & 31) * 8;            // this thread's row of the slice, its two 8-column pieces: ec, ec + 256
+  // bias / gamma / beta rows sit in LDS behind the staging image (48 registers otherwise, beside the live accumulators)
+  float* sBias = sC + 16 * LDC_LN;
+  float* sGam = sBias + LN_BN;
+  float* sBet = sGam + LN_BN;
+  sBias[tid] = a.bias ? a.bias[tid] : 0.f;
+  sGam[tid] = a.gamma[tid];
+  sBet[tid] = a.beta[tid];
+#pragma unroll
+  for (int I = 0; I < R; ++I) {
+#pragma unroll
+    for (int J = 0; J < 4; ++J) *reinterpret_cast<f32x4*>(sC + l15 * LDC_LN + wave * 64 + J * 16 + g4) = acc[I][J];
+    __syncthreads();
+    const int row = m0 + I * 16 + er;
+    const bool ok = row < a.M;
+    float v[16];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float4 lo = *reinterpret_cast<const float4*>(sC + er * LDC_LN + ec + 256 * h);
+      const float4 hi = *reinterpret_cast<const float4*>(sC + er * LDC_LN + ec + 256 * h + 4);
+      float* w = v + 8 * h;
+      const float4 b0 = *reinterpret_cast<const float4*>(sBias + ec + 256 * h), b1 = *reinterpret_cast<const float4*>(sBias + ec + 256 * h + 4);
+      w[0] = lo.x + b0.x; w[1] = lo.y + b0.y; w[2] = lo.z + b0.z; w[3] = lo.w + b0.w;
+      w[4] = hi.x + b1.x; w[5] = hi.y + b1.y; w[6] = hi.z + b1.z; w[7] = hi.w + b1.w;
+      if (a.drop_thresh) {
+        const uint64_t idx = (uint64_t)(ok ? row : 0) * (uint64_t)LN_BN + (uint64_t)(ec + 256 * h);
+        const Rand4 r0 = philox4(a.seed, a.site, idx >> 2), r1 = philox4(a.seed, a.site, (idx >> 2) + 1);
+        const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = rw[e] >= a.drop_thresh ? w[e] * a.drop_scale : 0.f;
+      }
+      if (a.residual && ok) {
+        const float* rp = a.residual + (long long)row * a.ldr + ec + 256 * h;
+        const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+        w[0] += r0.x; w[1] += r0.y; w[2] += r0.z; w[3] += r0.w; w[4] += r1.x; w[5] += r1.y; w[6] += r1.z; w[7] += r1.w;
+      }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s += v[e];
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s * (1.0f / (float)LN_BN);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) q += (v[e] - mean) * (v[e] - mean);
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) q += __shfl_xor(q, off, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / (float)LN_BN) + a.eps);
+    if (ok) {
+      if ((tid & 31) == 0) {
+        a.mean[row] = mean;
+        a.rstd[row] = rstd;
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int col = ec + 256 * h;
+        const float* w = v + 8 * h;
+        float* xp = a.x_out + (long long)row * LN_BN + col;
+        *reinterpret_cast<float4*>(xp) = make_float4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<float4*>(xp + 4) = make_float4(w[4], w[5], w[6], w[7]);
+        float o[8];
+        const float4 g0 = *reinterpret_cast<const float4*>(sGam + col), g1 = *reinterpret_cast<const float4*>(sGam + col + 4);
+        const float4 e0 = *reinterpret_cast<const float4*>(sBet + col), e1 = *reinterpret_cast<const float4*>(sBet + col + 4);
+        o[0] = (w[0] - mean) * rstd * g0.x + e0.x; o[1] = (w[1] - mean) * rstd * g0.y + e0.y;
+        o[2] = (w[2] - mean) * rstd * g0.z + e0.z; o[3] = (w[3] - mean) * rstd * g0.w + e0.w;
+        o[4] = (w[4] - mean) * rstd * g1.x + e1.x; o[5] = (w[5] - mean) * rstd * g1.y + e1.y;
+        o[6] = (w[6] - mean) * rstd * g1.z + e1.z; o[7] = (w[7] - mean) * rstd * g1.w + e1.w;
+        if (a.ln_f32) {
+          float* lp = a.ln_f32 + (long long)row * LN_BN + col;
+          *reinterpret_cast<float4*>(lp) = make_float4(o[0], o[1], o[2], o[3]);
+          *reinterpret_cast<float4*>(lp + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        }
+        if (a.ln_bf16) {
+          uint4 u;
+          u.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+          u.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+          u.z = (uint32_t)f2bf(o[4]) | ((uint32_t)f2bf(o[5]) << 16);
+          u.w = (uint32_t)f2bf(o[6]) | ((uint32_t)f2bf(o[7]) << 16);
+          *reinterpret_cast<uint4*>(a.ln_bf16 + (long long)row * LN_BN + col) = u;
+        }
+      }
+    }
+    __syncthreads();   // the next slice overwrites the image
+  }
+}
+
 }  // namespace mmdti
 
 MMDTI_DEFINE_SALT_PULL(gemm)
@@ -1352,6 +1534,45 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
   }
   else
     hipLaunchKernelGGL(kerns[transA ? 1 : 0][transB ? 1 : 0][fast ? 1 : 0], grid, block, smem, s, a);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+
+extern "C" int mmdti_gemm_ln_bf16(mmdti_stream_t stream, const void* A_bf16, const void* W_bf16, const float* bias, const float* residual,
+                                  int M, int N, int K, int lda, int ldb, int ldr, float drop_p, unsigned long long seed, unsigned int site,
+                                  float* x_out, const float* gamma, const float* beta, float eps, float* ln_f32, void* ln_bf16,
+                                  float* mean, float* rstd) {
+  MMDTI_REQUIRE(A_bf16 && W_bf16 && x_out && gamma && beta && mean && rstd && (ln_f32 || ln_bf16), "gemm_ln: null argument");
+  MMDTI_REQUIRE(M > 0 && N == LN_BN && K > 0 && K % BK == 0, "gemm_ln: N must be %d and K a multiple of %d (got M=%d N=%d K=%d)", LN_BN, BK, M, N, K);
+  MMDTI_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K && aligned16(A_bf16) && aligned16(W_bf16), "gemm_ln: operand strides / alignment");
+  MMDTI_REQUIRE(aligned16(x_out) && aligned16(gamma) && aligned16(beta) && (!bias || aligned16(bias)) && (!ln_f32 || aligned16(ln_f32)) &&
+                    (!ln_bf16 || aligned16(ln_bf16)) && (!residual || (aligned16(residual) && ldr % 4 == 0 && ldr >= N)),
+                "gemm_ln: 16-byte alignment required");
+  MMDTI_REQUIRE((long long)M * lda * 2 < 0x7fffffffLL && (long long)N * ldb * 2 < 0x7fffffffLL, "gemm_ln: operand too large for 32-bit offsets");
+  MMDTI_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "gemm_ln: dropout p out of range");
+  GemmLnArgs a;
+  a.A = (const bf16_t*)A_bf16; a.W = (const bf16_t*)W_bf16; a.bias = bias; a.residual = residual; a.gamma = gamma; a.beta = beta;
+  a.x_out = x_out; a.ln_f32 = ln_f32; a.ln_bf16 = (bf16_t*)ln_bf16; a.mean = mean; a.rstd = rstd;
+  a.M = M; a.K = K; a.lda = lda; a.ldb = ldb; a.ldr = ldr; a.eps = eps;
+  a.drop_thresh = dropout_thresh(drop_p); a.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  a.seed = seed; a.site = site;
+  // rows per tile: 64 or 80 -- whichever needs less (rounds of the 512 resident workgroups) x (rows per tile)
+  static const int force_r = getenv("MMDTI_GEMM_LN_ROWS") ? atoi(getenv("MMDTI_GEMM_LN_ROWS")) : 0;
+  const long long cost4 = (long long)cdiv(cdiv(M, 64), 512) * 4, cost5 = (long long)cdiv(cdiv(M, 80), 512) * 5;
+  const int R = force_r == 64 ? 4 : (force_r == 80 ? 5 : (cost5 < cost4 ? 5 : 4));
+  const size_t smem = max((size_t)(16 * R + LN_BN) * LDT * sizeof(bf16_t), (size_t)(16 * LDC_LN + 3 * LN_BN) * sizeof(float));
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ln_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ln_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) {
+      set_error("gemm_ln: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+      return MMDTI_ERR_LAUNCH;
+    }
+    attr = true;
+  }
+  if (R == 5) hipLaunchKernelGGL(gemm_ln_kernel<5>, dim3(cdiv(M, 80)), dim3(512), smem, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(gemm_ln_kernel<4>, dim3(cdiv(M, 64)), dim3(512), smem, (hipStream_t)stream, a);
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }

@@ -191,32 +191,52 @@ class PairEncoderFn(torch.autograd.Function):
         scale = (D // H) ** -0.5
         s_prev = bias.contiguous()
         st.bias0 = s_prev if not mod.layers else None     # only needed to shape a zero gradient when there is no layer
+        # Every Linear that closes a residual branch runs fused with the LayerNorm that reads its output (ops.linear_ln_fwd): out_proj
+        # with this layer's final_layer_norm, fc2 with the NEXT layer's self_attn_layer_norm -- or, after the last layer, with the
+        # encoder's final_layer_norm.  `nxt` carries that next LayerNorm's output into the next iteration.
+        nlayers = len(mod.layers)
+        nxt = None
+        out = None
         for li, layer in enumerate(mod.layers):
             L = SimpleNamespace(x=x)
             ln1, ln2 = layer.self_attn_layer_norm, layer.final_layer_norm
             att = layer.self_attn
-            _, L.h1, L.m1, L.r1 = ops.layernorm_fwd(x, ln1.weight, ln1.bias, ln1.eps)
+            if nxt is None:
+                _, L.h1, L.m1, L.r1 = ops.layernorm_fwd(x, ln1.weight, ln1.bias, ln1.eps)
+            else:
+                L.h1, L.m1, L.r1 = nxt
             L.qkv = ops.linear_fwd(L.h1, wbf16(att.in_proj.weight), att.in_proj.bias)
             L.site_att = sites.next()
             # (ragged batches: all-padding key tiles are skipped; the last layer writes them as -inf because its S is returned)
             L.s, L.o = ops.pair_attn_fwd(L.qkv, s_prev, padding_mask if li == 0 else None, B, N, H, ld, scale, p_att, seed, L.site_att,
-                                         key_tiles=key_tiles, rag_store=(li == len(mod.layers) - 1) and pack is None, row_off=row_off)
+                                         key_tiles=key_tiles, rag_store=(li == nlayers - 1) and pack is None, row_off=row_off)
             s_prev = L.s
             L.site_o = sites.next()
-            L.x1 = ops.linear_fwd(L.o, wbf16(att.out_proj.weight), att.out_proj.bias, residual=x, out_dtype=F32, drop_p=p_res, seed=seed, site=L.site_o)
-            _, L.h2, L.m2, L.r2 = ops.layernorm_fwd(L.x1, ln2.weight, ln2.bias, ln2.eps)
+            L.x1, _, L.h2, L.m2, L.r2 = ops.linear_ln_fwd(L.o, wbf16(att.out_proj.weight), att.out_proj.bias, ln2.weight, ln2.bias, ln2.eps,
+                                                          residual=x, drop_p=p_res, seed=seed, site=L.site_o)
             L.u = torch.empty(M, layer.fc1.weight.shape[0], device=emb.device, dtype=BF16)
             L.a = ops.linear_fwd(L.h2, wbf16(layer.fc1.weight), layer.fc1.bias, act=ops.ACT_GELU_FWD, aux_out=L.u)
             L.site_f = sites.next()
-            x = ops.linear_fwd(L.a, wbf16(layer.fc2.weight), layer.fc2.bias, residual=L.x1, out_dtype=F32, drop_p=p_res, seed=seed, site=L.site_f)
+            if li + 1 < nlayers:
+                nl = mod.layers[li + 1].self_attn_layer_norm
+                x, _, h1n, m1n, r1n = ops.linear_ln_fwd(L.a, wbf16(layer.fc2.weight), layer.fc2.bias, nl.weight, nl.bias, nl.eps, residual=L.x1,
+                                                        drop_p=p_res, seed=seed, site=L.site_f)
+                nxt = (h1n, m1n, r1n)
+            elif mod.final_layer_norm is not None:
+                fl = mod.final_layer_norm
+                x, out, _, st.f_mean, st.f_rstd = ops.linear_ln_fwd(L.a, wbf16(layer.fc2.weight), layer.fc2.bias, fl.weight, fl.bias, fl.eps,
+                                                                    residual=L.x1, drop_p=p_res, seed=seed, site=L.site_f, want_f32=True, want_bf16=False)
+            else:
+                x = ops.linear_fwd(L.a, wbf16(layer.fc2.weight), layer.fc2.bias, residual=L.x1, out_dtype=F32, drop_p=p_res, seed=seed, site=L.site_f)
             if keep:
                 st.layers.append(L)
         st.x_last = x
-        if mod.final_layer_norm is not None:
-            fl = mod.final_layer_norm
-            out, _, st.f_mean, st.f_rstd = ops.layernorm_fwd(x, fl.weight, fl.bias, fl.eps, want_f32=True, want_bf16=False)
-        else:
-            out = x
+        if out is None:
+            if mod.final_layer_norm is not None:
+                fl = mod.final_layer_norm
+                out, _, st.f_mean, st.f_rstd = ops.layernorm_fwd(x, fl.weight, fl.bias, fl.eps, want_f32=True, want_bf16=False)
+            else:
+                out = x
         if keep:
             ctx.st, ctx.mod = st, mod
         x_last = x.view(B, N, D) if pack is None else x
@@ -496,13 +516,14 @@ def _bert_layer_fwd(st, s1_32, s1_16, s2_16, key_add, W, heads, p_hid, p_att, ep
         ops.gemm(L.pd, L.v, M=Lq, N=hd, K=Lk, lda=ld, ldb=D, transB=True, out=L.ctx, ldc=D, batch=(B, heads),
                  sA=(heads * Lq * ld, Lq * ld), sB=(Lk * D, hd), sC=(Lq * D, hd))
     L.site_o = sites.next()
-    L.y = ops.linear_fwd(L.ctx, wbf16(W.o_w), W.o_b, residual=s1_32, out_dtype=F32, drop_p=p_hid, seed=seed, site=L.site_o)
-    L.a32, L.a16, L.am, L.ar = ops.layernorm_fwd(L.y, W.ln1_w, W.ln1_b, eps, want_f32=True, want_bf16=True)
+    # (each closing Linear of a residual branch runs fused with the post-LN LayerNorm behind it: ops.linear_ln_fwd)
+    L.y, L.a32, L.a16, L.am, L.ar = ops.linear_ln_fwd(L.ctx, wbf16(W.o_w), W.o_b, W.ln1_w, W.ln1_b, eps, residual=s1_32, drop_p=p_hid, seed=seed,
+                                                      site=L.site_o, want_f32=True, want_bf16=True)
     L.u = torch.empty(Mq, W.i_w.shape[0], device=s1_32.device, dtype=BF16)
     L.i = ops.linear_fwd(L.a16, wbf16(W.i_w), W.i_b, act=ops.ACT_GELU_FWD, aux_out=L.u)
     L.site_f = sites.next()
-    L.z = ops.linear_fwd(L.i, wbf16(W.o2_w), W.o2_b, residual=L.a32, out_dtype=F32, drop_p=p_hid, seed=seed, site=L.site_f)
-    out32, out16, L.zm, L.zr = ops.layernorm_fwd(L.z, W.ln2_w, W.ln2_b, eps, want_f32=True, want_bf16=True)
+    L.z, out32, out16, L.zm, L.zr = ops.linear_ln_fwd(L.i, wbf16(W.o2_w), W.o2_b, W.ln2_w, W.ln2_b, eps, residual=L.a32, drop_p=p_hid, seed=seed,
+                                                      site=L.site_f, want_f32=True, want_bf16=True)
     L.p_hid, L.p_att = p_hid, p_att
     return L, out32, out16
 

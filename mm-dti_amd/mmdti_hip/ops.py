@@ -90,6 +90,40 @@ def linear_fwd(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=BF16, 
                 out_dtype=out_dtype, aux_out=aux_out, drop_p=drop_p, seed=seed, site=site)
 
 
+GEMM_LN = os.environ.get("MMDTI_GEMM_LN", "1") != "0"       # 0: the Linear and the LayerNorm that follows it as two kernels
+
+
+def linear_ln_eligible(x, w, residual=None):
+    return (GEMM_LN and w.shape[0] == 512 and x.shape[-1] % 64 == 0 and x.stride(-1) == 1 and x.stride(0) % 8 == 0 and w.stride(0) % 8 == 0
+            and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and x.shape[0] * x.stride(0) * 2 < 0x7fffffff
+            and (residual is None or (residual.stride(-1) == 1 and residual.stride(0) % 4 == 0 and residual.data_ptr() % 16 == 0)))
+
+
+def linear_ln_fwd(x, w, bias, gamma, beta, eps, *, residual=None, drop_p=0.0, seed=0, site=0, want_f32=False, want_bf16=True):
+    """The Linear that closes a residual branch + the LayerNorm behind it (mmdti_gemm_ln_bf16):
+    y = residual + dropout(x.w^T + bias) (fp32);  h = LN(y) -> (y, h32 | None, h16 | None, mean, rstd).  One kernel when the output
+    is 512 wide (the reference architecture's width), else the GEMM and the LayerNorm kernels back to back -- same results up to
+    the order of the row sums."""
+    if not linear_ln_eligible(x, w, residual):
+        y = linear_fwd(x, w, bias, residual=residual, out_dtype=F32, drop_p=drop_p, seed=seed, site=site)
+        h32, h16, mean, rstd = layernorm_fwd(y, gamma, beta, eps, want_f32=want_f32, want_bf16=want_bf16)
+        return y, h32, h16, mean, rstd
+    _chk(x, BF16, "linear_ln.x", contiguous=False); _chk(w, BF16, "linear_ln.w", contiguous=False)
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, device=x.device, dtype=F32)
+    h32 = torch.empty(M, N, device=x.device, dtype=F32) if want_f32 else None
+    h16 = torch.empty(M, N, device=x.device, dtype=BF16) if want_bf16 else None
+    mean = torch.empty(M, device=x.device, dtype=F32)
+    rstd = torch.empty(M, device=x.device, dtype=F32)
+    t0 = kernel_timer.begin("gemm")
+    lib().mmdti_gemm_ln_bf16(_stream(), x.data_ptr(), w.data_ptr(), _p(bias), _p(residual), M, N, K, x.stride(0), w.stride(0),
+                             N if residual is None else residual.stride(0), float(drop_p), int(seed), int(site), y.data_ptr(), gamma.data_ptr(),
+                             beta.data_ptr(), float(eps), _p(h32), _p(h16), mean.data_ptr(), rstd.data_ptr())
+    kernel_timer.end("gemm", t0, 2.0 * M * N * K, tag=(M, N, K, 0, 0, 1, 1, "ln", want_bf16, want_f32, residual is not None))
+    return y, h32, h16, mean, rstd
+
+
 def linear_bwd_input(dy, w, *, act=ACT_NONE, aux_in=None, out_dtype=BF16, K_valid=None, colsum=None):
     """dx[M,K] = dy[M,N] . w[N,K]  (optionally * gelu'(aux_in)).  colsum: [K] fp32 buffer that receives += column sums of dx
     (the bias gradient of the Linear that produced this layer's input, when dx is that Linear's output gradient)."""

@@ -1146,6 +1146,41 @@ def test_gemm_tall_tiles_match_square_tiles(ops, transB, monkeypatch):
     assert torch.isfinite(yb.float()).all()
 
 
+@pytest.mark.parametrize("M,K,R", [(1, 512, 0), (63, 512, 0), (64, 64, 0), (130, 2048, 0), (1000, 512, 80), (3333, 2048, 64), (33280, 512, 0), (12713, 2048, 0)])
+def test_gemm_ln_fused_matches_gemm_then_layernorm(ops, M, K, R, monkeypatch):
+    """mmdti_gemm_ln_bf16: the Linear that closes a residual branch and the LayerNorm behind it in one kernel (N = 512) against the
+    two kernels it replaces.  x = residual + dropout(A.W^T + b): bit-equal (same k order, same dropout counters); mean / rstd / h:
+    the row sums are taken in another order -- 1e-6 relative, bf16 outputs within one rounding step."""
+    if R:
+        monkeypatch.setenv("MMDTI_GEMM_LN_ROWS", str(R))       # (read once per process: the first parametrisation that sets it wins)
+    N = 512
+    g = G(M + K)
+    x = dev(bf(torch.randn(M, K, generator=g)))
+    w = dev(bf(torch.randn(N, K, generator=g) * 0.05))
+    b = dev(torch.randn(N, generator=g))
+    res = dev(torch.randn(M, N, generator=g) * 2.0 + 0.5)
+    gam, bet = dev(torch.randn(N, generator=g) * 0.2 + 1.0), dev(torch.randn(N, generator=g) * 0.1)
+    for kw in (dict(residual=res, drop_p=0.1, seed=7, site=3), dict(residual=None, drop_p=0.0), dict(residual=res, drop_p=0.0)):
+        for f32, b16 in ((False, True), (True, True), (True, False)):
+            y, h32, h16, mean, rstd = ops.linear_ln_fwd(x, w, b, gam, bet, 1e-5, want_f32=f32, want_bf16=b16, **kw)
+            y_ref = ops.linear_fwd(x, w, b, out_dtype=torch.float32, **kw)
+            r32, r16, rm, rr = ops.layernorm_fwd(y_ref, gam, bet, 1e-5, want_f32=True, want_bf16=True)
+            assert torch.equal(y, y_ref)
+            close(mean, rm, 1e-5, 1e-6); close(rstd, rr, 1e-5, 1e-6)
+            assert (h32 is None) == (not f32) and (h16 is None) == (not b16)
+            if f32:
+                close(h32, r32, 1e-5, 2e-6)
+            if b16:
+                d = (h16.float() - r16.float()).abs()
+                assert float(d.max()) <= 2.0 ** -7 * float(r16.float().abs().max()) and float((d > 0).float().mean()) < 0.01
+    assert ops.linear_ln_eligible(x, w, res)
+    # other widths take the two kernels (same results through the same wrapper)
+    w2 = dev(bf(torch.randn(256, K, generator=g) * 0.05))
+    assert not ops.linear_ln_eligible(x, w2)
+    y, _, h16, mean, rstd = ops.linear_ln_fwd(x, w2, None, gam[:256].contiguous(), bet[:256].contiguous(), 1e-5)
+    assert y.shape == (M, 256) and h16.shape == (M, 256)
+
+
 # ------------------------------------------------------------------------------------------- fused attention
 def _attn_ref(q, k, v, add, heads, scale, keep=None, p_drop=0.0):
     """fp32 torch restatement on bf16-rounded operands (oracle mha, mmdti_oracle.py:320-338, minus the Linears)."""
