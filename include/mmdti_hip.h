@@ -43,6 +43,11 @@ typedef void* mmdti_stream_t;
 #define MMDTI_DT_F32 0
 #define MMDTI_DT_BF16 1
 #define MMDTI_DT_F32_ATOMIC 2 /* atomicAdd into fp32 C (split-K / gradient accumulation) */
+/* fp16 forward-operand mode (opt-in; the reference's own AMP dtype, tasks/trainer.py:181-182 -- three more mantissa bits than bf16
+ * at the same matrix-pipe rate; profiles/r03_rounding_sites_fp16.json): */
+#define MMDTI_DT_F16 3        /* the 16-bit output is fp16 instead of bf16 */
+#define MMDTI_DT_AB_F16 16    /* OR-ed into mmdti_gemm_bf16's c_dtype: A and B hold fp16 (forward Linear shapes only: row-major A,
+                                 weight-layout B, no split-K, no batch) */
 
 #define MMDTI_CT_REGRESS 0
 #define MMDTI_CT_SINGLE 1
@@ -88,7 +93,8 @@ int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void* B, void* C
  * mmdti_gemm_bf16's epilogue (element row*N + col), so the fused and the unfused path draw the same mask. */
 int mmdti_gemm_ln_bf16(mmdti_stream_t stream, const void* A_bf16, const void* W_bf16, const float* bias, const float* residual, int M,
                        int N, int K, int lda, int ldb, int ldr, float drop_p, unsigned long long seed, unsigned int site, float* x_out,
-                       const float* gamma, const float* beta, float eps, float* ln_f32, void* ln_bf16, float* mean, float* rstd);
+                       const float* gamma, const float* beta, float eps, float* ln_f32, void* ln_bf16, float* mean, float* rstd,
+                       int f16 /* bit 0: A and W hold fp16; bit 1: ln_bf16 receives fp16 */);
 
 /* ---- Grouped weight gradients of one transformer layer -----------------------------------------
  * The weight half of nn.Linear's backward for up to 8 Linears that saw the SAME token rows (unicore in_proj / out_proj /
@@ -110,7 +116,8 @@ int mmdti_linear_dw_grouped_splits(int tiles, int rows);
  * (transformers.py:115-118).  Writes y_f32 and/or y_bf16 (either may be null). */
 int mmdti_layernorm_fwd(mmdti_stream_t stream, const float* x, const float* gamma, const float* beta, float eps,
                         int rows, int D, float* y_f32, void* y_bf16, float* mean, float* rstd,
-                        const unsigned char* row_zero, float drop_p, unsigned long long seed, unsigned int site);
+                        const unsigned char* row_zero, float drop_p, unsigned long long seed, unsigned int site,
+                        int y16_f16 /* != 0: y_bf16 receives fp16 (the fp16 forward-operand mode) */);
 /* dx = dres + LN'(dy + dy_add) ; dgamma/dbeta atomic accumulate.  dy is fp32 (dy_dtype=MMDTI_DT_F32) or bf16;
  * dy_add (fp32, nullable) is a second upstream gradient of the LN OUTPUT (post-LN residual: a = LN(y) feeds both the FFN
  * and the next residual add); dres (fp32, nullable) is a gradient of the LN INPUT that bypasses the LN (pre-LN residual). */
@@ -130,6 +137,11 @@ int mmdti_colsum_bf16(mmdti_stream_t stream, const void* x_bf16, int rows, int c
 int mmdti_cast_f32_bf16(mmdti_stream_t stream, const float* x, void* y_bf16, long long n, float drop_p,
                         unsigned long long seed, unsigned int site);
 int mmdti_cast_bf16_f32(mmdti_stream_t stream, const void* x_bf16, float* y, long long n);
+/* fp16 forward-operand mode: y = fp16(dropout(x)) (as mmdti_cast_f32_bf16), and fp16 -> bf16 (round to nearest even) for the
+ * backward GEMMs, which keep bf16 operands (gradients need bf16's range) */
+int mmdti_cast_f32_f16(mmdti_stream_t stream, const float* x, void* y_f16, long long n, float drop_p, unsigned long long seed,
+                       unsigned int site);
+int mmdti_cast_f16_bf16(mmdti_stream_t stream, const void* x_f16, int rows, int cols, int ldx, void* y_bf16);
 /* y = dropout(x) in fp32 (F.dropout on fp32 activations: infonce.py:24, mm_model.py:390-391,79,82) */
 int mmdti_dropout_f32(mmdti_stream_t stream, const float* x, float* y, long long n, float drop_p,
                       unsigned long long seed, unsigned int site);
@@ -236,7 +248,9 @@ int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, const void*
                         input, the same bias row and the same keys in every layer; the unmasked InfoNCE mean (infonce.py:32-33) then
                         weights the one row by the number of pad positions (mmdti_seq_mean_packed_fwd).  Pair planes (bias_in, s_out) stay
                         indexed by POSITION: query position i of molecule b is packed row row_off[b] + i; query rows past the
-                        representative one are neither computed nor stored. */);
+                        representative one are neither computed nor stored. */,
+                        int qkv_f16 /* != 0 (layout 3 only): qkv holds fp16 and o_bf16 receives fp16 -- the fp16 forward-operand
+                        mode (MMDTI_DT_AB_F16); the backward takes bf16 copies */);
 /* g (in/out, same layout as s; fp32, or bf16 for layout 7): on entry dL/dS_l from the layers above (ignored if g_in_zero), on
  * exit dL/dS_l total = dL/d(bias_in).  dqkv: [B,N,3*H*8] bf16.  key_tiles: as in the forward; the skipped tiles of g are neither
  * read nor written (hand in a zero-initialised g for a ragged batch). */
@@ -272,7 +286,8 @@ int mmdti_attn_fwd(mmdti_stream_t stream, const void* q_bf16, const void* k_bf16
                    then at most one representative pad row; k_cnt: [B] int32, REAL keys of sequence b (its first k_cnt[b] key-side
                    rows).  Padded keys get probability exactly 0 in the reference (finfo.min / -10000 additive masks underflow), so
                    leaving them out of the key range is the same arithmetic; key_add must be null.  Lq, Lk: the longest sequence
-                   (rows) of each side, <= 256.  stats (and drow in the backward) are then [heads, q_rows] with q_rows = q_off[B]. */);
+                   (rows) of each side, <= 256.  stats (and drow in the backward) are then [heads, q_rows] with q_rows = q_off[B]. */,
+                   int ctx_f16 /* != 0: ctx_bf16 receives fp16 (it feeds the output projection's GEMM: fp16 forward-operand mode) */);
 /* dq/dk/dv (bf16, strides lddq / lddk / lddk) from dctx (stride ldo); drow: [B,heads,Lq] fp32 scratch that receives
  * sum_j dP'_ij p_ij.  Same (seed, site) as the forward call regenerates the dropout mask. */
 int mmdti_attn_bwd(mmdti_stream_t stream, const void* q_bf16, const void* k_bf16, const void* v_bf16,

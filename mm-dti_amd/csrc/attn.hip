@@ -146,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
                                                        const bf16_t* __restrict__ v, const float* __restrict__ key_add,
                                                        bf16_t* __restrict__ ctx, float* __restrict__ stats, int heads, int Lq,
                                                        int Lk, int ldq, int ldk, int ldo, float scale, uint32_t thresh16,
-                                                       float dscale, uint64_t seed, uint32_t site, AttnVarlen vl) {
+                                                       float dscale, uint64_t seed, uint32_t site, AttnVarlen vl, int ctx_f16) {
   extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
   constexpr int STR = AttnShape<HD>::STR, KC = AttnShape<HD>::KC, NB = AttnShape<HD>::NB, NP = NT * 16;
   bf16_t* sK = reinterpret_cast<bf16_t*>(attn_smem);
@@ -223,7 +223,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
     if (qv) {
       bf16_t* dst = ctx + ((long long)sq.q0 + qi) * ldo + h * HD + 4 * g;
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) attn_store4(dst + nb * 16, o[nb]);
+      for (int nb = 0; nb < NB; ++nb) {
+        if (ctx_f16) {   // the context feeds the output projection's forward GEMM: fp16 in the fp16 forward-operand mode
+          uint2 pk;
+          pk.x = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)o[nb][0]) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)o[nb][1]) << 16);
+          pk.y = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)o[nb][2]) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)o[nb][3]) << 16);
+          *reinterpret_cast<uint2*>(dst + nb * 16) = pk;
+        } else {
+          attn_store4(dst + nb * 16, o[nb]);
+        }
+      }
     }
   }
 }
@@ -476,7 +485,7 @@ using namespace mmdti;
 extern "C" int mmdti_attn_fwd(mmdti_stream_t stream, const void* q_bf16, const void* k_bf16, const void* v_bf16,
                               const float* key_add, void* ctx_bf16, float* stats, int B, int heads, int Lq, int Lk,
                               int head_dim, int ldq, int ldk, int ldo, float scale, float drop_p, unsigned long long seed,
-                              unsigned int site, const int* q_off, const int* k_off, const int* k_cnt, int q_rows) {
+                              unsigned int site, const int* q_off, const int* k_off, const int* k_cnt, int q_rows, int ctx_f16) {
   if (int e = attn_check("attn_fwd", q_bf16, k_bf16, v_bf16, B, heads, Lq, Lk, head_dim, ldq, ldk, drop_p)) return e;
   if (int e = attn_check_varlen("attn_fwd", key_add, q_off, k_off, k_cnt, q_rows)) return e;
   const AttnVarlen vl = {q_off, k_off, k_cnt, q_rows};
@@ -492,7 +501,7 @@ extern "C" int mmdti_attn_fwd(mmdti_stream_t stream, const void* q_bf16, const v
     if (!attr_done) { if (int e = attn_set_smem(attn_fwd_kernel<HD, NT>, smem_max)) return e; attr_done = true; }        \
     hipLaunchKernelGGL((attn_fwd_kernel<HD, NT>), dim3(B * heads), dim3(512), smem, (hipStream_t)stream,                 \
                        (const bf16_t*)q_bf16, (const bf16_t*)k_bf16, (const bf16_t*)v_bf16, key_add, (bf16_t*)ctx_bf16,  \
-                       stats, heads, Lq, Lk, ldq, ldk, ldo, scale, th, sc, (uint64_t)seed, (uint32_t)site, vl);          \
+                       stats, heads, Lq, Lk, ldq, ldk, ldo, scale, th, sc, (uint64_t)seed, (uint32_t)site, vl, ctx_f16); \
   } while (0)
   if (head_dim == 64)      { if (nt == 10) ATTN_F(64, 10); else ATTN_F(64, 16); }
   else if (head_dim == 32) { if (nt == 10) ATTN_F(32, 10); else ATTN_F(32, 16); }

@@ -23,6 +23,10 @@ static inline int grid_for(long long n, int per_block) {
 }
 
 // ---------------------------------------------------------------- casts / dropout / axpy
+__device__ __forceinline__ bf16_t f2h16(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }
+
+// F16: the 16-bit output is fp16 (the fp16 forward-operand mode), else bf16
+template <bool F16>
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y,
                                                             long long n4, long long n, uint32_t thresh, float dscale,
                                                             uint64_t seed, uint32_t site) {
@@ -36,8 +40,13 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
       for (int e = 0; e < 4; ++e) o[e] = rw[e] >= thresh ? o[e] * dscale : 0.f;
     }
     uint2 pk;
-    pk.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
-    pk.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+    if (F16) {
+      pk.x = (uint32_t)f2h16(o[0]) | ((uint32_t)f2h16(o[1]) << 16);
+      pk.y = (uint32_t)f2h16(o[2]) | ((uint32_t)f2h16(o[3]) << 16);
+    } else {
+      pk.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+      pk.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+    }
     reinterpret_cast<uint2*>(y)[i] = pk;
   }
   // tail (n % 4)
@@ -45,7 +54,25 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
     long long i = (n & ~3LL) + threadIdx.x;
     float o = x[i];
     if (thresh) o = dropout_keep(seed, site, (uint64_t)i, thresh) ? o * dscale : 0.f;
-    y[i] = f2bf(o);
+    y[i] = F16 ? f2h16(o) : f2bf(o);
+  }
+}
+
+// fp16 -> bf16 (round to nearest even), rows of `cols` elements (cols % 8 == 0) with a source row stride: the backward GEMMs of
+// the fp16 forward-operand mode take the saved forward activations as bf16
+__global__ __launch_bounds__(256) void cast_f16_bf16_kernel(const bf16_t* __restrict__ x, int cols8, int ldx, bf16_t* __restrict__ y, long long n8) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const long long row = i / cols8;
+    const int c = (int)(i - row * cols8) * 8;
+    const uint4 u = *reinterpret_cast<const uint4*>(x + row * ldx + c);
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float lo = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[e] & 0xffffu)), hi = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[e] >> 16));
+      o[e] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    }
+    *reinterpret_cast<uint4*>(y + row * (long long)cols8 * 8 + c) = make_uint4(o[0], o[1], o[2], o[3]);
   }
 }
 
@@ -527,8 +554,29 @@ extern "C" int mmdti_cast_f32_bf16(mmdti_stream_t stream, const float* x, void* 
   MMDTI_REQUIRE(x && y_bf16 && n > 0, "cast_f32_bf16: bad arguments");
   MMDTI_REQUIRE(aligned16(x) && (reinterpret_cast<uintptr_t>(y_bf16) & 7) == 0, "cast_f32_bf16: alignment");
   DROP_SETUP("cast_f32_bf16");
-  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x,
+  hipLaunchKernelGGL(cast_f32_bf16_kernel<false>, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x,
                      (bf16_t*)y_bf16, n / 4, n, th, sc, (uint64_t)seed, (uint32_t)site);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_cast_f32_f16(mmdti_stream_t stream, const float* x, void* y_f16, long long n, float drop_p,
+                                  unsigned long long seed, unsigned int site) {
+  MMDTI_REQUIRE(x && y_f16 && n > 0, "cast_f32_f16: bad arguments");
+  MMDTI_REQUIRE(aligned16(x) && (reinterpret_cast<uintptr_t>(y_f16) & 7) == 0, "cast_f32_f16: alignment");
+  DROP_SETUP("cast_f32_f16");
+  hipLaunchKernelGGL(cast_f32_bf16_kernel<true>, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     (bf16_t*)y_f16, n / 4, n, th, sc, (uint64_t)seed, (uint32_t)site);
+  MMDTI_LAUNCH_CHECK();
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_cast_f16_bf16(mmdti_stream_t stream, const void* x_f16, int rows, int cols, int ldx, void* y_bf16) {
+  MMDTI_REQUIRE(x_f16 && y_bf16 && rows > 0 && cols > 0 && cols % 8 == 0 && ldx >= cols && ldx % 8 == 0, "cast_f16_bf16: bad arguments (cols %% 8, ldx %% 8)");
+  MMDTI_REQUIRE(aligned16(x_f16) && aligned16(y_bf16), "cast_f16_bf16: 16-byte alignment required");
+  const long long n8 = (long long)rows * (cols / 8);
+  hipLaunchKernelGGL(cast_f16_bf16_kernel, dim3(grid_for(n8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x_f16, cols / 8, ldx,
+                     (bf16_t*)y_bf16, n8);
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }

@@ -25,6 +25,23 @@ namespace mmdti {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// One v_mfma_f32_16x16x32 on raw 16-bit operand fragments: bf16 (the step's contract) or fp16 (F16: the opt-in forward-operand
+// mode -- the reference's own AMP dtype, tasks/trainer.py:181-182, three more mantissa bits at the same matrix-pipe rate).
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma32(const bf16x8& b, const bf16x8& a, const f32x4& c) {
+  if constexpr (F16) {
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, b), __builtin_bit_cast(f16x8, a), c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+// two fp32 -> one 32-bit word of bf16 (f16 == 0) or fp16 values
+__device__ __forceinline__ uint32_t pack16x2(int f16, float lo, float hi) {
+  return f16 ? ((uint32_t)f2h(lo) | ((uint32_t)f2h(hi) << 16)) : ((uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16));
+}
+
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int LDT = BK;      // [row][k] image: unpadded 128-B rows, 16-B chunks XOR-swizzled by (row & 7) -> conflict-free ds_read_b128
 constexpr int LDTR = BM;     // [k][row] image: unpadded 256-B rows, 8-B units XOR-swizzled by k -> conflict-free ds_read_b64_tr_b16
@@ -47,6 +64,7 @@ struct GemmArgs {
   bf16_t* aux_out;        // gelu: store pre-activation
   int ld_aux;
   int c_dtype;            // MMDTI_DT_F32 / MMDTI_DT_BF16 / MMDTI_DT_F32_ATOMIC
+  int c_f16;              // with MMDTI_DT_BF16: the 16-bit output is fp16 (MMDTI_DT_F16 at the C ABI)
   uint32_t drop_thresh;
   float drop_scale;
   uint64_t seed;
@@ -203,7 +221,7 @@ __device__ __forceinline__ void epi_elem(const GemmArgs& a, float accv, int row,
   if (a.residual && lead) v += a.residual[(long long)row * a.ldr + col];
   const long long ci = coff + (long long)row * a.ldc + col;
   if (a.c_dtype == MMDTI_DT_BF16) {
-    reinterpret_cast<bf16_t*>(a.C)[ci] = f2bf(v);
+    reinterpret_cast<bf16_t*>(a.C)[ci] = a.c_f16 ? f2h(v) : f2bf(v);
   } else if (a.c_dtype == MMDTI_DT_F32) {
     float* c = reinterpret_cast<float*>(a.C);
     c[ci] = (a.beta != 0.f) ? v + a.beta * c[ci] : v;
@@ -318,10 +336,10 @@ __device__ __forceinline__ void epilogue_oct(const GemmArgs& a, const float* src
   const long long ci = coff + (long long)row * a.ldc + col;
   if (a.c_dtype == MMDTI_DT_BF16) {
     uint4 u;
-    u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-    u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-    u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-    u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+    u.x = pack16x2(a.c_f16, v[0], v[1]);
+    u.y = pack16x2(a.c_f16, v[2], v[3]);
+    u.z = pack16x2(a.c_f16, v[4], v[5]);
+    u.w = pack16x2(a.c_f16, v[6], v[7]);
     if (a.stream_c) nt_store16(reinterpret_cast<bf16_t*>(a.C) + ci, u);
     else *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + ci) = u;
     if (cs) {   // column sums of the ROUNDED values: what a column-sum pass over C would add up
@@ -366,7 +384,7 @@ __device__ __forceinline__ void epilogue_colsum(const GemmArgs& a, float* lds, c
   }
 }
 
-template <bool TA, bool TB, bool FAST>
+template <bool TA, bool TB, bool FAST, bool F16 = false>
 __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(GemmArgs a) {
   // LDS image: [buf 0: A | B][buf 1: A | B]; addressed by integer offsets from ONE __shared__ base so that every access
   // stays a ds_* instruction (pointer arrays indexed at run time decay to flat loads + scratch).
@@ -430,7 +448,7 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(GemmArgs a) {
 // operands swapped (B fragment first): the accumulator then holds C^T tiles, i.e. lane = output ROW (lane&15) and the 4
   // registers = 4 consecutive output COLUMNS (4*(lane>>4)+r) -- the epilogue stores 8/16 contiguous bytes per lane
   // straight from registers, no LDS transpose.
-#define MF(I, J) acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb##J, fa##I, acc[I][J], 0, 0, 0)
+#define MF(I, J) acc[I][J] = mfma32<F16>(fb##J, fa##I, acc[I][J])
 #define GEMM_KK(IMGA, IMGB, KK)                                                                    \
   {                                                                                                \
     const bf16x8 fa0 = load_frag<TA>(IMGA, wr * 64 + 0, KK, lane), fa1 = load_frag<TA>(IMGA, wr * 64 + 16, KK, lane), \
@@ -555,7 +573,7 @@ __device__ __forceinline__ void glds_tile(const bf16_t* kbase, const Off4& off, 
 
 // DBUF: two (A|B) tile pairs in LDS, the DMA of tile kt+1 in flight while tile kt is multiplied (one barrier per K-step,
 // 64 KB -> 2 workgroups per CU): for the long-K split-K weight gradients, where depth of pipeline beats occupancy.
-template <bool TA, bool TB, bool DBUF>
+template <bool TA, bool TB, bool DBUF, bool F16 = false>
 __global__ __launch_bounds__(256, DBUF ? 2 : 4) void gemm_glds_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
   constexpr int TILE = BM * LDT;
@@ -580,7 +598,7 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 4) void gemm_glds_kernel(GemmArgs a
   f32x4 acc[4][4] = {};
   const Off4 offA = glds_offsets<TA>(a.lda, m0, a.M, tid), offB = glds_offsets<TB>(a.ldb, n0, a.N, tid);
   const long long kstepA = TA ? (long long)BK * a.lda : BK, kstepB = TB ? (long long)BK * a.ldb : BK;
-#define MF(I, J) acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb##J, fa##I, acc[I][J], 0, 0, 0)
+#define MF(I, J) acc[I][J] = mfma32<F16>(fb##J, fa##I, acc[I][J])
 #define GEMM_KK(IMGA, IMGB, KK)                                                                    \
   {                                                                                                \
     const bf16x8 fa0 = load_frag<TA>(IMGA, wr * 64 + 0, KK, lane), fa1 = load_frag<TA>(IMGA, wr * 64 + 16, KK, lane), \
@@ -684,7 +702,7 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 4) void gemm_glds_kernel(GemmArgs a
 constexpr int BMT = 144;
 constexpr int TALL_ROWS_PER_PASS = 48;
 
-template <bool TB>
+template <bool TB, bool F16 = false>
 __global__ __launch_bounds__(256, 4) void gemm_glds_tall_kernel(GemmArgs a, int mstep) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
   bf16_t* imgA = smem;
@@ -714,8 +732,8 @@ __global__ __launch_bounds__(256, 4) void gemm_glds_tall_kernel(GemmArgs a, int 
   f32x4 acc[9][2] = {};
   typedef __attribute__((address_space(1))) const void gptr_t;
   typedef __attribute__((address_space(3))) void lptr_t;
-#define TMF(I) acc[I][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0, fa##I, acc[I][0], 0, 0, 0); \
-               acc[I][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1, fa##I, acc[I][1], 0, 0, 0)
+#define TMF(I) acc[I][0] = mfma32<F16>(fb0, fa##I, acc[I][0]); \
+               acc[I][1] = mfma32<F16>(fb1, fa##I, acc[I][1])
 #define TALL_KK(KK)                                                                                   \
   {                                                                                                   \
     const bf16x8 fb0 = load_frag<TB>(imgB, wave * 32, KK, lane), fb1 = load_frag<TB>(imgB, wave * 32 + 16, KK, lane); \
@@ -1171,9 +1189,10 @@ struct GemmLnArgs {
   float drop_scale;
   uint64_t seed;
   uint32_t site;
+  int ln_f16;   // ln_bf16 receives fp16 values (the fp16 forward-operand mode)
 };
 
-template <int R>
+template <int R, bool F16 = false>
 __global__ __launch_bounds__(512, 4) void gemm_ln_kernel(GemmLnArgs a) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
   constexpr int ROWS = 16 * R;
@@ -1201,7 +1220,7 @@ __global__ __launch_bounds__(512, 4) void gemm_ln_kernel(GemmLnArgs a) {
   f32x4 acc[R][4] = {};
   const int ktiles = a.K / BK;
   constexpr int A_CHUNKS = ROWS * 8;
-#define LMF(I, J) acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb##J, fa, acc[I][J], 0, 0, 0)
+#define LMF(I, J) acc[I][J] = mfma32<F16>(fb##J, fa, acc[I][J])
 #define LN_KK(KK)                                                                                       \
   {                                                                                                     \
     const bf16x8 fb0 = load_frag<false>(imgB, wave * 64 + 0, KK, lane), fb1 = load_frag<false>(imgB, wave * 64 + 16, KK, lane), \
@@ -1305,10 +1324,10 @@ __global__ __launch_bounds__(512, 4) void gemm_ln_kernel(GemmLnArgs a) {
         }
         if (a.ln_bf16) {
           uint4 u;
-          u.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
-          u.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
-          u.z = (uint32_t)f2bf(o[4]) | ((uint32_t)f2bf(o[5]) << 16);
-          u.w = (uint32_t)f2bf(o[6]) | ((uint32_t)f2bf(o[7]) << 16);
+          u.x = pack16x2(a.ln_f16, o[0], o[1]);
+          u.y = pack16x2(a.ln_f16, o[2], o[3]);
+          u.z = pack16x2(a.ln_f16, o[4], o[5]);
+          u.w = pack16x2(a.ln_f16, o[6], o[7]);
           *reinterpret_cast<uint4*>(a.ln_bf16 + (long long)row * LN_BN + col) = u;
         }
       }
@@ -1370,7 +1389,14 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
   MMDTI_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "gemm: lda/ldb must be multiples of 8 elements (got %d,%d)", lda, ldb);
   MMDTI_REQUIRE(sAo % 8 == 0 && sAi % 8 == 0 && sBo % 8 == 0 && sBi % 8 == 0, "gemm: batch strides must be multiples of 8");
   MMDTI_REQUIRE(batch_outer >= 1 && batch_inner >= 1 && splitk >= 1, "gemm: batch/splitk must be >= 1");
+  const bool ab16 = (c_dtype & MMDTI_DT_AB_F16) != 0;       // A and B hold fp16 (forward shapes only)
+  c_dtype &= ~MMDTI_DT_AB_F16;
+  const int c_f16 = c_dtype == MMDTI_DT_F16;
+  if (c_f16) c_dtype = MMDTI_DT_BF16;
   MMDTI_REQUIRE(c_dtype == MMDTI_DT_F32 || c_dtype == MMDTI_DT_BF16 || c_dtype == MMDTI_DT_F32_ATOMIC, "gemm: bad c_dtype");
+  MMDTI_REQUIRE(!ab16 || (!transA && !transB && splitk == 1 && !arowsum_out && batch_outer * batch_inner == 1),
+                "gemm: fp16 operands are built for the forward Linear shapes (row-major A, weight-layout B, no split-K, no batch)");
+  MMDTI_REQUIRE(!c_f16 || !colsum_out, "gemm: colsum_out with an fp16 output is not supported");
   MMDTI_REQUIRE(splitk == 1 || c_dtype == MMDTI_DT_F32_ATOMIC, "gemm: splitk>1 needs the atomic fp32 output mode");
   MMDTI_REQUIRE(splitk == 1 || (act == MMDTI_ACT_NONE && drop_p == 0.f), "gemm: splitk>1 cannot fuse act/dropout");
   MMDTI_REQUIRE((act != MMDTI_ACT_GELU_BWD && act != MMDTI_ACT_MUL_AUX) || aux_in, "gemm: gelu_bwd / mul_aux need aux_in");
@@ -1386,7 +1412,7 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
   a.batch_inner = batch_inner;
   a.sAo = sAo; a.sAi = sAi; a.sBo = sBo; a.sBi = sBi; a.sCo = sCo; a.sCi = sCi;
   a.splitk = splitk; a.alpha = alpha; a.beta = beta; a.bias = bias; a.residual = residual; a.ldr = ldr;
-  a.act = act; a.aux_in = (const bf16_t*)aux_in; a.aux_out = (bf16_t*)aux_out; a.ld_aux = ld_aux; a.c_dtype = c_dtype;
+  a.act = act; a.aux_in = (const bf16_t*)aux_in; a.aux_out = (bf16_t*)aux_out; a.ld_aux = ld_aux; a.c_dtype = c_dtype; a.c_f16 = c_f16;
   a.drop_thresh = dropout_thresh(drop_p); a.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   a.seed = seed; a.site = site;
   a.colsum = colsum_out;
@@ -1457,7 +1483,7 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
   // 256 x 256 tiles with the DMA in flight across barriers (gemm_big_kernel): MMDTI_GEMM_BIG=0 off, 1 (default) where
   // the shape fills the chip, 2 every eligible shape
   const int use_big = g_gemm_big;
-  const bool big_ok = fast && use_big && batch_outer * batch_inner == 1 && !colsum_out && M >= 256 && N >= 256 &&
+  const bool big_ok = !ab16 && fast && use_big && batch_outer * batch_inner == 1 && !colsum_out && M >= 256 && N >= 256 &&
                       (c_dtype == MMDTI_DT_F32_ATOMIC || a.vec_ok) && M % 256 == 0 && N % 256 == 0;
   if (big_ok && (use_big == 2 || big_shape_pays(M, N, K, splitk, transA, transB, aux_in != nullptr))) {
     typedef void (*bkern_t)(GemmArgs);
@@ -1526,11 +1552,27 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
     if (mstep) {
       grid.x = cdiv(M, mstep) * cdiv(N, BN);
       const size_t smem_t = (size_t)(BMT + BN) * LDT * sizeof(bf16_t);
-      if (transB) hipLaunchKernelGGL(gemm_glds_tall_kernel<true>, grid, block, smem_t, s, a, mstep);
+      if (ab16) hipLaunchKernelGGL((gemm_glds_tall_kernel<false, true>), grid, block, smem_t, s, a, mstep);
+      else if (transB) hipLaunchKernelGGL(gemm_glds_tall_kernel<true>, grid, block, smem_t, s, a, mstep);
       else hipLaunchKernelGGL(gemm_glds_tall_kernel<false>, grid, block, smem_t, s, a, mstep);
+    } else if (ab16) {
+      hipLaunchKernelGGL((gemm_glds_kernel<false, false, false, true>), grid, block, smem, s, a);
     } else {
       hipLaunchKernelGGL(gkerns[transA ? 1 : 0][transB ? 1 : 0], grid, block, smem, s, a);
     }
+  }
+  else if (ab16) {
+    static bool attr16 = false;
+    if (!attr16) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<false, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+        set_error("gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", smem);
+        return MMDTI_ERR_LAUNCH;
+      }
+      attr16 = true;
+    }
+    if (fast) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true, true>), grid, block, smem, s, a);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<false, false, false, true>), grid, block, smem, s, a);
   }
   else
     hipLaunchKernelGGL(kerns[transA ? 1 : 0][transB ? 1 : 0][fast ? 1 : 0], grid, block, smem, s, a);
@@ -1542,7 +1584,7 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
 extern "C" int mmdti_gemm_ln_bf16(mmdti_stream_t stream, const void* A_bf16, const void* W_bf16, const float* bias, const float* residual,
                                   int M, int N, int K, int lda, int ldb, int ldr, float drop_p, unsigned long long seed, unsigned int site,
                                   float* x_out, const float* gamma, const float* beta, float eps, float* ln_f32, void* ln_bf16,
-                                  float* mean, float* rstd) {
+                                  float* mean, float* rstd, int f16) {
   MMDTI_REQUIRE(A_bf16 && W_bf16 && x_out && gamma && beta && mean && rstd && (ln_f32 || ln_bf16), "gemm_ln: null argument");
   MMDTI_REQUIRE(M > 0 && N == LN_BN && K > 0 && K % BK == 0, "gemm_ln: N must be %d and K a multiple of %d (got M=%d N=%d K=%d)", LN_BN, BK, M, N, K);
   MMDTI_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K && aligned16(A_bf16) && aligned16(W_bf16), "gemm_ln: operand strides / alignment");
@@ -1557,6 +1599,8 @@ extern "C" int mmdti_gemm_ln_bf16(mmdti_stream_t stream, const void* A_bf16, con
   a.M = M; a.K = K; a.lda = lda; a.ldb = ldb; a.ldr = ldr; a.eps = eps;
   a.drop_thresh = dropout_thresh(drop_p); a.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   a.seed = seed; a.site = site;
+  a.ln_f16 = (f16 >> 1) & 1;          // bit 0: A and W are fp16; bit 1: the 16-bit LayerNorm output is fp16
+  const bool ab16 = f16 & 1;
   // rows per tile: 64 or 80 -- whichever needs less (rounds of the 512 resident workgroups) x (rows per tile)
   static const int force_r = getenv("MMDTI_GEMM_LN_ROWS") ? atoi(getenv("MMDTI_GEMM_LN_ROWS")) : 0;
   const long long cost4 = (long long)cdiv(cdiv(M, 64), 512) * 4, cost5 = (long long)cdiv(cdiv(M, 80), 512) * 5;
@@ -1565,13 +1609,18 @@ extern "C" int mmdti_gemm_ln_bf16(mmdti_stream_t stream, const void* A_bf16, con
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ln_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ln_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ln_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ln_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ln_kernel<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) {
       set_error("gemm_ln: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
       return MMDTI_ERR_LAUNCH;
     }
     attr = true;
   }
-  if (R == 5) hipLaunchKernelGGL(gemm_ln_kernel<5>, dim3(cdiv(M, 80)), dim3(512), smem, (hipStream_t)stream, a);
+  if (ab16) {
+    if (R == 5) hipLaunchKernelGGL((gemm_ln_kernel<5, true>), dim3(cdiv(M, 80)), dim3(512), smem, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((gemm_ln_kernel<4, true>), dim3(cdiv(M, 64)), dim3(512), smem, (hipStream_t)stream, a);
+  } else if (R == 5) hipLaunchKernelGGL(gemm_ln_kernel<5>, dim3(cdiv(M, 80)), dim3(512), smem, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(gemm_ln_kernel<4>, dim3(cdiv(M, 64)), dim3(512), smem, (hipStream_t)stream, a);
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;

@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      float* __restrict__ y32, bf16_t* __restrict__ y16,
                                                      float* __restrict__ mean_o, float* __restrict__ rstd_o,
                                                      const unsigned char* __restrict__ row_zero, uint32_t thresh,
-                                                     float dscale, uint64_t seed, uint32_t site) {
+                                                     float dscale, uint64_t seed, uint32_t site, int y16_f16) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -61,8 +61,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     if (y32) reinterpret_cast<float4*>(y32 + (long long)row * D)[c] = make_float4(o[0], o[1], o[2], o[3]);
     if (y16) {
       uint2 pk;
-      pk.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
-      pk.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+      if (y16_f16) {   // fp16 forward-operand mode
+        pk.x = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)o[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)o[1]) << 16);
+        pk.y = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)o[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)o[3]) << 16);
+      } else {
+        pk.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+        pk.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+      }
       reinterpret_cast<uint2*>(y16 + (long long)row * D)[c] = pk;
     }
   }
@@ -228,7 +233,7 @@ static int ln_nv(int D) { return (D / 4 + 63) / 64; }
 extern "C" int mmdti_layernorm_fwd(mmdti_stream_t stream, const float* x, const float* gamma, const float* beta,
                                    float eps, int rows, int D, float* y_f32, void* y_bf16, float* mean, float* rstd,
                                    const unsigned char* row_zero, float drop_p, unsigned long long seed,
-                                   unsigned int site) {
+                                   unsigned int site, int y16_f16) {
   MMDTI_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 2048, "layernorm_fwd: need rows>0, D%%4==0, D<=2048 (D=%d)", D);
   MMDTI_REQUIRE(x && gamma && beta && (y_f32 || y_bf16), "layernorm_fwd: null pointer");
   MMDTI_REQUIRE(aligned16(x) && aligned16(gamma) && aligned16(beta), "layernorm_fwd: 16-byte alignment required");
@@ -239,7 +244,7 @@ extern "C" int mmdti_layernorm_fwd(mmdti_stream_t stream, const float* x, const 
   hipStream_t s = (hipStream_t)stream;
 #define LN_F(NV)                                                                                                    \
   hipLaunchKernelGGL((ln_fwd_kernel<NV>), grid, block, 0, s, x, gamma, beta, eps, rows, D, y_f32, (bf16_t*)y_bf16, \
-                     mean, rstd, row_zero, th, sc, (uint64_t)seed, (uint32_t)site)
+                     mean, rstd, row_zero, th, sc, (uint64_t)seed, (uint32_t)site, y16_f16)
   switch (ln_nv(D)) {
     case 1: LN_F(1); break;
     case 2: LN_F(2); break;

@@ -63,6 +63,30 @@ __device__ __forceinline__ void pa_split4(const f32x4& v, pa_s16x4& hi, pa_s16x4
   lo = pa_pack4(r);
 }
 #define PA_MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A, B, C, 0, 0, 0)
+// The forward kernel also exists for q | k | v stored as fp16 (F16: the opt-in fp16 forward-operand mode -- three more mantissa
+// bits in the operands of q.k^T and P.v; the raw 16-bit LDS images are the same, only the MFMA and the split of P change)
+typedef _Float16 pa_h16x4 __attribute__((ext_vector_type(4)));
+template <bool F16>
+__device__ __forceinline__ f32x4 pa_mfma16(const pa_s16x4& a, const pa_s16x4& b, const f32x4& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(pa_h16x4, a), __builtin_bit_cast(pa_h16x4, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+// x = hi + lo in the operand type of the product (bf16, or fp16 when F16: 22 mantissa bits kept of the fp32 factor)
+template <bool F16>
+__device__ __forceinline__ void pa_split4_t(const f32x4& v, pa_s16x4& hi, pa_s16x4& lo) {
+  if constexpr (F16) {
+    pa_h16x4 h, l;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      h[r] = (_Float16)v[r];
+      l[r] = (_Float16)(v[r] - (float)h[r]);
+    }
+    hi = __builtin_bit_cast(pa_s16x4, h);
+    lo = __builtin_bit_cast(pa_s16x4, l);
+  } else {
+    pa_split4(v, hi, lo);
+  }
+}
 #define PA_LOG2E 1.44269504088896340736f
 
 // Element types of the pair tensors.  Row-major planes and the round-1 tiled planes hold fp32.  The COMPACT tiled planes

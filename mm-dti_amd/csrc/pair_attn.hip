@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void pair_attn_fwd_kernel(const bf16_t* __rest
 // pa_kt_effective of it) are all padding -- -inf in every S of the chain, 0 in G -- so they are neither loaded nor computed nor
 // (rag_store == 0) stored; pad QUERY rows are still computed (the reference's unmasked InfoNCE mean reads the encoder output at
 // padded positions).  rag_store != 0: the skipped tiles are written as -inf (the last layer, whose S is returned to the caller).
-template <int NT, bool TILED, bool FULL, bool RAG, typename ST>
+template <int NT, bool TILED, bool FULL, bool RAG, typename ST, bool F16 = false>
 __global__ __launch_bounds__(256, NT > 9 ? 2 : 4) void pair_attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, const ST* __restrict__ bias_in,
                                                                  ST* __restrict__ s_out, bf16_t* __restrict__ o,
                                                                  const unsigned char* __restrict__ key_pad, int N, int H, int ld,
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, NT > 9 ? 2 : 4) void pair_attn_fwd_mfma_kernel
         f32x4 c = S[t];
         const pa_s16x4 ka = g < 2 ? *reinterpret_cast<const pa_s16x4*>(sK + (t * 16 + c16) * 8 + 4 * g) : zero4;
         f32x4 qk = {0.f, 0.f, 0.f, 0.f};
-        qk = PA_MFMA16(ka, qv, qk);   // exact bf16 products, fp32 accumulation
+        qk = pa_mfma16<F16>(ka, qv, qk);   // exact products of the 16-bit operands, fp32 accumulation
 #pragma unroll
         for (int r = 0; r < 4; ++r) c[r] += scale * qk[r];
         if (!TILED || key_pad) {   // (tiled tensors carry -inf in their pad keys already: only a real padding mask is left)
@@ -281,16 +281,21 @@ __global__ __launch_bounds__(256, NT > 9 ? 2 : 4) void pair_attn_fwd_mfma_kernel
         // O^T += V^T . P^T : A = V[keys 16t + 4g..4g+3][d = c16 & 7] (rows d >= 8 of the result are never stored), B = P^T as it sits
         const pa_s16x4 va = *reinterpret_cast<const pa_s16x4*>(sVT + (c16 & 7) * KSTR + t * 16 + 4 * g);
         pa_s16x4 ph, pl;
-        pa_split4(p, ph, pl);
-        oacc = PA_MFMA16(va, ph, oacc);
-        oacc = PA_MFMA16(va, pl, oacc);
+        pa_split4_t<F16>(p, ph, pl);
+        oacc = pa_mfma16<F16>(va, ph, oacc);
+        oacc = pa_mfma16<F16>(va, pl, oacc);
       }
     }
     // O^T accumulator: column = query, rows d = 4g + r (valid for g < 2)
     if (qvalid && g < 2) {
       uint2 pk;
-      pk.x = (uint32_t)f2bf(oacc[0]) | ((uint32_t)f2bf(oacc[1]) << 16);
-      pk.y = (uint32_t)f2bf(oacc[2]) | ((uint32_t)f2bf(oacc[3]) << 16);
+      if constexpr (F16) {   // (o feeds out_proj's forward GEMM: fp16 like every forward GEMM operand of this mode)
+        pk.x = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)oacc[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)oacc[1]) << 16);
+        pk.y = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)oacc[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)oacc[3]) << 16);
+      } else {
+        pk.x = (uint32_t)f2bf(oacc[0]) | ((uint32_t)f2bf(oacc[1]) << 16);
+        pk.y = (uint32_t)f2bf(oacc[2]) | ((uint32_t)f2bf(oacc[3]) << 16);
+      }
       *reinterpret_cast<uint2*>(o + ((long long)row0 + qi) * D + h * HD + 4 * g) = pk;
     }
 #undef PA_PRED
@@ -328,12 +333,13 @@ using namespace mmdti;
 extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, const void* bias_in, void* s_out,
                                    void* o_bf16, const unsigned char* key_pad, int B, int N, int H, int ld,
                                    float scale, float drop_p, unsigned long long seed, unsigned int site, int layout,
-                                   const int* key_tiles, int rag_store, const int* row_off) {
+                                   const int* key_tiles, int rag_store, const int* row_off, int qkv_f16) {
   const int tiled = layout & 1, compact = (layout >> 1) & 1;   // bit 0: tiled planes; bit 1: compact planes (S fp16; tiled only)
   if (int e = check_common("pair_attn_fwd", B, N, H, ld)) return e;
   MMDTI_REQUIRE((layout & ~3) == 0 && (!compact || tiled), "pair_attn_fwd: layout must be 0 (row-major fp32), 1 (tiled fp32) or 3 (tiled, fp16 logits)");
   MMDTI_REQUIRE(!key_tiles || compact, "pair_attn_fwd: key_tiles (ragged batches) needs the compact tiled pair layout (layout 3)");
   MMDTI_REQUIRE(!row_off || key_tiles, "pair_attn_fwd: packed token rows (row_off) need key_tiles");
+  MMDTI_REQUIRE(!qkv_f16 || compact, "pair_attn_fwd: fp16 q | k | v (the fp16 forward-operand mode) is built for the compact tiled pair layout (layout 3)");
   MMDTI_REQUIRE(!tiled || (ld % 4 == 0 && N <= 16 * PA_MAX_NT), "pair_attn_fwd: the tiled pair layout needs ld %% 4 == 0 and N <= 272");
   MMDTI_REQUIRE(qkv_bf16 && bias_in && s_out && o_bf16, "pair_attn_fwd: null pointer");
   MMDTI_REQUIRE(aligned16(qkv_bf16), "pair_attn_fwd: qkv must be 16-byte aligned");
@@ -358,7 +364,12 @@ extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, 
     // The hot path (compact planes) has an instantiation for EVERY tile count: all its tiles exist, the interior ones run
     // without predicates (FULL).  In a kernel instantiated for more tiles than N has, the surplus tiles are predicated off but
     // still walked and no tile takes the fast path -- 25-45 % more time per real tile (N = 96 / 113 / 128 on the 9-tile kernel).
-#define PA_MC(NT) case NT: if (key_tiles) PA_M(NT, true, true, true, _Float16); else PA_M(NT, true, true, false, _Float16); break
+#define PA_MH(NT, RG)                                                                                                                  \
+  hipLaunchKernelGGL((pair_attn_fwd_mfma_kernel<NT, true, true, RG, _Float16, true>), grid, blk, 0, s, (const bf16_t*)qkv_bf16,       \
+                     (const _Float16*)bias_in, (_Float16*)s_out, (bf16_t*)o_bf16, key_pad, N, H, ld, scale, th, sc, (uint64_t)seed,   \
+                     (uint32_t)site, key_tiles, rag_store, row_off)
+#define PA_MC(NT) case NT: if (qkv_f16) { if (key_tiles) PA_MH(NT, true); else PA_MH(NT, false); } \
+                           else if (key_tiles) PA_M(NT, true, true, true, _Float16); else PA_M(NT, true, true, false, _Float16); break
     if (compact) {
       switch (nqb) {
         PA_MC(1); PA_MC(2); PA_MC(3); PA_MC(4); PA_MC(5); PA_MC(6); PA_MC(7); PA_MC(8); PA_MC(9); PA_MC(10); PA_MC(11); PA_MC(12);
@@ -366,6 +377,7 @@ extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, 
       }
     } else if (nqb <= 5) PA_MT(5); else if (nqb <= 9) PA_MT(9); else if (nqb <= 13) PA_MT(13); else PA_MT(17);
 #undef PA_MC
+#undef PA_MH
 #undef PA_MT
 #undef PA_M
     MMDTI_LAUNCH_CHECK();

@@ -21,7 +21,7 @@ import torch
 
 from . import ops
 from .ops import BF16, F32
-from .runtime import fused_views, wbf16, gbuf, dropout_state, notify_grads_ready
+from .runtime import fused_views, wbf16, wfwd, gbuf, dropout_state, notify_grads_ready
 
 
 # ------------------------------------------------------------------------------------------------- helpers
@@ -205,29 +205,29 @@ class PairEncoderFn(torch.autograd.Function):
                 _, L.h1, L.m1, L.r1 = ops.layernorm_fwd(x, ln1.weight, ln1.bias, ln1.eps)
             else:
                 L.h1, L.m1, L.r1 = nxt
-            L.qkv = ops.linear_fwd(L.h1, wbf16(att.in_proj.weight), att.in_proj.bias)
+            L.qkv = ops.linear_fwd(L.h1, wfwd(att.in_proj.weight), att.in_proj.bias)
             L.site_att = sites.next()
             # (ragged batches: all-padding key tiles are skipped; the last layer writes them as -inf because its S is returned)
             L.s, L.o = ops.pair_attn_fwd(L.qkv, s_prev, padding_mask if li == 0 else None, B, N, H, ld, scale, p_att, seed, L.site_att,
                                          key_tiles=key_tiles, rag_store=(li == nlayers - 1) and pack is None, row_off=row_off)
             s_prev = L.s
             L.site_o = sites.next()
-            L.x1, _, L.h2, L.m2, L.r2 = ops.linear_ln_fwd(L.o, wbf16(att.out_proj.weight), att.out_proj.bias, ln2.weight, ln2.bias, ln2.eps,
+            L.x1, _, L.h2, L.m2, L.r2 = ops.linear_ln_fwd(L.o, wfwd(att.out_proj.weight), att.out_proj.bias, ln2.weight, ln2.bias, ln2.eps,
                                                           residual=x, drop_p=p_res, seed=seed, site=L.site_o)
             L.u = torch.empty(M, layer.fc1.weight.shape[0], device=emb.device, dtype=BF16)
-            L.a = ops.linear_fwd(L.h2, wbf16(layer.fc1.weight), layer.fc1.bias, act=ops.ACT_GELU_FWD, aux_out=L.u)
+            L.a = ops.linear_fwd(L.h2, wfwd(layer.fc1.weight), layer.fc1.bias, act=ops.ACT_GELU_FWD, aux_out=L.u)
             L.site_f = sites.next()
             if li + 1 < nlayers:
                 nl = mod.layers[li + 1].self_attn_layer_norm
-                x, _, h1n, m1n, r1n = ops.linear_ln_fwd(L.a, wbf16(layer.fc2.weight), layer.fc2.bias, nl.weight, nl.bias, nl.eps, residual=L.x1,
+                x, _, h1n, m1n, r1n = ops.linear_ln_fwd(L.a, wfwd(layer.fc2.weight), layer.fc2.bias, nl.weight, nl.bias, nl.eps, residual=L.x1,
                                                         drop_p=p_res, seed=seed, site=L.site_f)
                 nxt = (h1n, m1n, r1n)
             elif mod.final_layer_norm is not None:
                 fl = mod.final_layer_norm
-                x, out, _, st.f_mean, st.f_rstd = ops.linear_ln_fwd(L.a, wbf16(layer.fc2.weight), layer.fc2.bias, fl.weight, fl.bias, fl.eps,
+                x, out, _, st.f_mean, st.f_rstd = ops.linear_ln_fwd(L.a, wfwd(layer.fc2.weight), layer.fc2.bias, fl.weight, fl.bias, fl.eps,
                                                                     residual=L.x1, drop_p=p_res, seed=seed, site=L.site_f, want_f32=True, want_bf16=False)
             else:
-                x = ops.linear_fwd(L.a, wbf16(layer.fc2.weight), layer.fc2.bias, residual=L.x1, out_dtype=F32, drop_p=p_res, seed=seed, site=L.site_f)
+                x = ops.linear_fwd(L.a, wfwd(layer.fc2.weight), layer.fc2.bias, residual=L.x1, out_dtype=F32, drop_p=p_res, seed=seed, site=L.site_f)
             if keep:
                 st.layers.append(L)
         st.x_last = x
@@ -491,16 +491,18 @@ def _bert_layer_fwd(st, s1_32, s1_16, s2_16, key_add, W, heads, p_hid, p_att, ep
             L.fw = L.fb = None
     if L.fw is not None:
         if self_attn:
-            L.qkv = ops.linear_fwd(s1_16, L.fw[0], L.fb[1])
+            # (L.fw[3]: the forward-GEMM shadow of the fused weights; q, k, v are stored bf16 in every mode -- the attention kernels'
+            #  operand type)
+            L.qkv = ops.linear_fwd(s1_16, L.fw[3], L.fb[1], out_dtype=BF16)
             L.q, L.k, L.v = L.qkv[:, :D], L.qkv[:, D:2 * D], L.qkv[:, 2 * D:]
         else:
-            L.q = ops.linear_fwd(s1_16, wbf16(W.q_w), W.q_b)
-            L.qkv = ops.linear_fwd(s2_16, L.fw[0], L.fb[1])
+            L.q = ops.linear_fwd(s1_16, wfwd(W.q_w), W.q_b, out_dtype=BF16)
+            L.qkv = ops.linear_fwd(s2_16, L.fw[3], L.fb[1], out_dtype=BF16)
             L.k, L.v = L.qkv[:, :D], L.qkv[:, D:]
     else:
-        L.q = ops.linear_fwd(s1_16, wbf16(W.q_w), W.q_b)
-        L.k = ops.linear_fwd(s2_16, wbf16(W.k_w), W.k_b)
-        L.v = ops.linear_fwd(s2_16, wbf16(W.v_w), W.v_b)
+        L.q = ops.linear_fwd(s1_16, wfwd(W.q_w), W.q_b, out_dtype=BF16)
+        L.k = ops.linear_fwd(s2_16, wfwd(W.k_w), W.k_b, out_dtype=BF16)
+        L.v = ops.linear_fwd(s2_16, wfwd(W.v_w), W.v_b, out_dtype=BF16)
     if L.fused:
         # scores, softmax, dropout and context in one kernel: the [B,heads,Lq,Lk] tensor never reaches HBM
         L.ctx, L.stats = ops.attn_fwd(L.q, L.k, L.v, key_add, B, heads, Lq, Lk, 1.0 / math.sqrt(hd), p_att, seed, L.site_att, vl=vl)
@@ -512,17 +514,17 @@ def _bert_layer_fwd(st, s1_32, s1_16, s2_16, key_add, W, heads, p_hid, p_att, ep
                  sC=(heads * Lq * ld, Lq * ld), alpha=1.0 / math.sqrt(hd))
         L.p, L.pd = ops.softmax_fwd(S, key_add, B, heads, Lq, Lk, ld, p_att, seed, L.site_att)
         del S
-        L.ctx = torch.empty(B * Lq, D, device=s1_32.device, dtype=BF16)
+        L.ctx = torch.empty(B * Lq, D, device=s1_32.device, dtype=ops.act16())
         ops.gemm(L.pd, L.v, M=Lq, N=hd, K=Lk, lda=ld, ldb=D, transB=True, out=L.ctx, ldc=D, batch=(B, heads),
                  sA=(heads * Lq * ld, Lq * ld), sB=(Lk * D, hd), sC=(Lq * D, hd))
     L.site_o = sites.next()
     # (each closing Linear of a residual branch runs fused with the post-LN LayerNorm behind it: ops.linear_ln_fwd)
-    L.y, L.a32, L.a16, L.am, L.ar = ops.linear_ln_fwd(L.ctx, wbf16(W.o_w), W.o_b, W.ln1_w, W.ln1_b, eps, residual=s1_32, drop_p=p_hid, seed=seed,
+    L.y, L.a32, L.a16, L.am, L.ar = ops.linear_ln_fwd(L.ctx, wfwd(W.o_w), W.o_b, W.ln1_w, W.ln1_b, eps, residual=s1_32, drop_p=p_hid, seed=seed,
                                                       site=L.site_o, want_f32=True, want_bf16=True)
     L.u = torch.empty(Mq, W.i_w.shape[0], device=s1_32.device, dtype=BF16)
-    L.i = ops.linear_fwd(L.a16, wbf16(W.i_w), W.i_b, act=ops.ACT_GELU_FWD, aux_out=L.u)
+    L.i = ops.linear_fwd(L.a16, wfwd(W.i_w), W.i_b, act=ops.ACT_GELU_FWD, aux_out=L.u)
     L.site_f = sites.next()
-    L.z, out32, out16, L.zm, L.zr = ops.linear_ln_fwd(L.i, wbf16(W.o2_w), W.o2_b, W.ln2_w, W.ln2_b, eps, residual=L.a32, drop_p=p_hid, seed=seed,
+    L.z, out32, out16, L.zm, L.zr = ops.linear_ln_fwd(L.i, wfwd(W.o2_w), W.o2_b, W.ln2_w, W.ln2_b, eps, residual=L.a32, drop_p=p_hid, seed=seed,
                                                       site=L.site_f, want_f32=True, want_bf16=True)
     L.p_hid, L.p_att = p_hid, p_att
     return L, out32, out16
@@ -691,8 +693,8 @@ class CrossLayerFn(torch.autograd.Function):
             Lk = s2.shape[1]
             st = SimpleNamespace(B=B, Lq=Lq, Lk=Lk, D=D, seed=seed, Mq=B * Lq, Mk=B * Lk, vl=None)
         s1c = s1.contiguous().view(st.Mq, D)
-        s1_16 = ops.cast_bf16(s1c)
-        s2_16 = ops.cast_bf16(s2.contiguous().view(st.Mk, D))
+        s1_16 = ops.cast_act16(s1c)
+        s2_16 = ops.cast_act16(s2.contiguous().view(st.Mk, D))
         L, out32, _ = _bert_layer_fwd(st, s1c, s1_16, s2_16, None if key_add is None else key_add.contiguous(), bert_weights(layer), cfg.heads,
                                       p_hid, p_att, cfg.ln_eps, seed, sites, False)
         if any(ctx.needs_input_grad):
@@ -761,9 +763,10 @@ class InfoNCEFn(torch.autograd.Function):
         def proj(x, seq, n, dropout_p, site, pack=None):
             L = SimpleNamespace()
             rows = B * n if pack is None else pack.M
-            L.x16 = ops.cast_bf16(x.contiguous().view(rows, D), dropout_p, seed, site)
+            L.x16 = ops.cast_act16(x.contiguous().view(rows, D), dropout_p, seed, site)
             L.u = torch.empty(rows, seq[0].weight.shape[0], device=dev, dtype=BF16)
-            h = ops.linear_fwd(L.x16, wbf16(seq[0].weight), seq[0].bias, act=ops.ACT_GELU_FWD, aux_out=L.u)
+            # (h is pooled, not multiplied: bf16 in every mode)
+            h = ops.linear_fwd(L.x16, wfwd(seq[0].weight), seq[0].bias, act=ops.ACT_GELU_FWD, aux_out=L.u, out_dtype=BF16)
             Hd = h.shape[1]
             if pack is not None:
                 L.hbar = ops.seq_mean_packed_fwd(h, pack, Hd, Hd)

@@ -23,7 +23,31 @@ GELU_SAVE_GRAD = os.environ.get("MMDTI_GELU_SAVE_GRAD", "1") != "0"
 GBF_FULL_BWD = os.environ.get("MMDTI_GBF_FULL_BWD", "1") != "0"
 ACT_GELU_FWD = ACT_GELU_G if GELU_SAVE_GRAD else ACT_GELU
 ACT_GELU_DX = ACT_MUL_AUX if GELU_SAVE_GRAD else ACT_GELU_BWD
-DT_F32, DT_BF16, DT_F32_ATOMIC = 0, 1, 2
+DT_F32, DT_BF16, DT_F32_ATOMIC, DT_F16, DT_AB_F16 = 0, 1, 2, 3, 16
+
+# fp16 forward-operand mode (opt-in, MMDTI_FWD_FP16=1 / set_forward_fp16): every 16-bit tensor that feeds a FORWARD GEMM -- weights,
+# LayerNorm / GELU / attention outputs, tower 1's q | k | v -- is fp16 instead of bf16 (the reference's own AMP dtype,
+# tasks/trainer.py:181-182; v_mfma_f32_16x16x32_f16 runs at the bf16 rate).  Three more mantissa bits put encoder_rep / out_bert /
+# logits within the north star's 1e-3 of the fp32 reference (5e-4 / 2.6e-4 / 2e-4: profiles/r03_rounding_sites_fp16.json) where
+# bf16 operands cannot (4.6e-3).  The backward keeps bf16 operands (gradients need bf16's range: the reference needs a GradScaler
+# for the same reason) and converts the saved forward activations when it reads them (to_bf16): one extra pass per saved tensor.
+FWD_F16 = os.environ.get("MMDTI_FWD_FP16", "0") == "1"
+
+
+def set_forward_fp16(on: bool):
+    global FWD_F16
+    FWD_F16 = bool(on)
+
+
+def act16():
+    """dtype of the 16-bit activations that feed forward GEMMs"""
+    return F16 if FWD_F16 else BF16
+
+
+def _chk16(t, name, contiguous=True):
+    if t.dtype not in (BF16, F16):
+        raise MMDTIError(f"{name}: expected a bf16 (or, in the fp16 forward-operand mode, fp16) tensor, got {t.dtype}")
+    return _chk(t, t.dtype, name, contiguous)
 CT_REGRESS, CT_SINGLE, CT_MULTI = 0, 1, 2
 
 
@@ -60,13 +84,17 @@ def gemm(A, B, *, M, N, K, lda, ldb, out=None, ldc=None, transA=False, transB=Fa
          aux_in=None, aux_out=None, out_dtype=BF16, atomic=False, drop_p=0.0, seed=0, site=0, out_shape=None, colsum=None, arowsum=None,
          workspace=None):
     """C = epi(alpha * A.B^T); see mmdti_gemm_bf16.  A/B are bf16 tensors (any shape; lda/ldb given explicitly)."""
-    _chk(A, BF16, "gemm.A", contiguous=False)
-    _chk(B, BF16, "gemm.B", contiguous=False)
+    _chk16(A, "gemm.A", contiguous=False)
+    _chk16(B, "gemm.B", contiguous=False)
+    if A.dtype != B.dtype:
+        raise MMDTIError(f"gemm: A is {A.dtype} but B is {B.dtype} (both operands of a product share one 16-bit type)")
     ldc = N if ldc is None else ldc
     if out is None:
         shape = out_shape if out_shape is not None else ((M, N) if batch == (1, 1) else (batch[0], batch[1], M, N))
         out = torch.empty(shape, device=A.device, dtype=out_dtype)
-    c_dtype = DT_F32_ATOMIC if atomic else (DT_BF16 if out.dtype == BF16 else DT_F32)
+    c_dtype = DT_F32_ATOMIC if atomic else (DT_BF16 if out.dtype == BF16 else (DT_F16 if out.dtype == F16 else DT_F32))
+    if A.dtype == F16:
+        c_dtype |= DT_AB_F16
     if atomic and out.dtype != F32:
         raise MMDTIError("gemm: atomic accumulation needs an fp32 output")
     t0 = kernel_timer.begin("gemm")
@@ -82,8 +110,11 @@ def gemm(A, B, *, M, N, K, lda, ldb, out=None, ldc=None, transA=False, transB=Fa
     return out
 
 
-def linear_fwd(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=BF16, aux_out=None, drop_p=0.0, seed=0, site=0):
-    """y[M,N] = epi(x[M,K] . w[N,K]^T + bias)."""
+def linear_fwd(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=None, aux_out=None, drop_p=0.0, seed=0, site=0):
+    """y[M,N] = epi(x[M,K] . w[N,K]^T + bias).  out_dtype None: the 16-bit type of x (bf16, or fp16 in the fp16 forward-operand
+    mode) -- the output of a forward Linear that feeds the next one."""
+    if out_dtype is None:
+        out_dtype = x.dtype
     M, K = x.shape[0], x.shape[-1]
     N = w.shape[0]
     return gemm(x, w, M=M, N=N, K=K, lda=x.stride(0), ldb=w.stride(0), bias=bias, act=act, residual=residual,
@@ -91,10 +122,15 @@ def linear_fwd(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=BF16, 
 
 
 GEMM_LN = os.environ.get("MMDTI_GEMM_LN", "1") != "0"       # 0: the Linear and the LayerNorm that follows it as two kernels
+# Longest contraction the fused kernel takes.  Measured on MI355X (scratch/gemm_ln_bench.py, profiles/r03_gemm_ln_ab.json): at K = 512
+# (out_proj, attention.output.dense) one kernel beats the two it replaces at every row count -- 50 vs 58 us at 33 280 rows, 135 vs 155
+# at 65 536, 20 vs 28 at 1 600 --, at K = 2048 (fc2, output.dense) it loses -- 147 vs 127, 262 vs 220: with whole 512-column rows per
+# workgroup only two workgroups fit a CU, and their K loop runs ~30 % behind the 128 x 128 kernel's four.
+GEMM_LN_MAX_K = int(os.environ.get("MMDTI_GEMM_LN_MAX_K", "1024"))
 
 
 def linear_ln_eligible(x, w, residual=None):
-    return (GEMM_LN and w.shape[0] == 512 and x.shape[-1] % 64 == 0 and x.stride(-1) == 1 and x.stride(0) % 8 == 0 and w.stride(0) % 8 == 0
+    return (GEMM_LN and w.shape[0] == 512 and x.shape[-1] % 64 == 0 and x.shape[-1] <= GEMM_LN_MAX_K and x.stride(-1) == 1 and x.stride(0) % 8 == 0 and w.stride(0) % 8 == 0
             and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and x.shape[0] * x.stride(0) * 2 < 0x7fffffff
             and (residual is None or (residual.stride(-1) == 1 and residual.stride(0) % 4 == 0 and residual.data_ptr() % 16 == 0)))
 
@@ -108,18 +144,21 @@ def linear_ln_fwd(x, w, bias, gamma, beta, eps, *, residual=None, drop_p=0.0, se
         y = linear_fwd(x, w, bias, residual=residual, out_dtype=F32, drop_p=drop_p, seed=seed, site=site)
         h32, h16, mean, rstd = layernorm_fwd(y, gamma, beta, eps, want_f32=want_f32, want_bf16=want_bf16)
         return y, h32, h16, mean, rstd
-    _chk(x, BF16, "linear_ln.x", contiguous=False); _chk(w, BF16, "linear_ln.w", contiguous=False)
+    _chk16(x, "linear_ln.x", contiguous=False); _chk16(w, "linear_ln.w", contiguous=False)
+    if x.dtype != w.dtype:
+        raise MMDTIError("linear_ln_fwd: x and w must share one 16-bit type")
     M, K = x.shape
     N = w.shape[0]
     y = torch.empty(M, N, device=x.device, dtype=F32)
     h32 = torch.empty(M, N, device=x.device, dtype=F32) if want_f32 else None
-    h16 = torch.empty(M, N, device=x.device, dtype=BF16) if want_bf16 else None
+    h16 = torch.empty(M, N, device=x.device, dtype=act16()) if want_bf16 else None
     mean = torch.empty(M, device=x.device, dtype=F32)
     rstd = torch.empty(M, device=x.device, dtype=F32)
     t0 = kernel_timer.begin("gemm")
     lib().mmdti_gemm_ln_bf16(_stream(), x.data_ptr(), w.data_ptr(), _p(bias), _p(residual), M, N, K, x.stride(0), w.stride(0),
                              N if residual is None else residual.stride(0), float(drop_p), int(seed), int(site), y.data_ptr(), gamma.data_ptr(),
-                             beta.data_ptr(), float(eps), _p(h32), _p(h16), mean.data_ptr(), rstd.data_ptr())
+                             beta.data_ptr(), float(eps), _p(h32), _p(h16), mean.data_ptr(), rstd.data_ptr(),
+                             (1 if x.dtype == F16 else 0) | (2 if (h16 is not None and h16.dtype == F16) else 0))
     kernel_timer.end("gemm", t0, 2.0 * M * N * K, tag=(M, N, K, 0, 0, 1, 1, "ln", want_bf16, want_f32, residual is not None))
     return y, h32, h16, mean, rstd
 
@@ -151,6 +190,7 @@ def linear_bwd_weight(dy, x, dw, *, rows=None, db=None):
     bias gradient, taken inside the same pass over dy)."""
     M = dy.shape[0] if rows is None else rows
     N, K = dw.shape
+    x = to_bf16(x)
     if db is not None:
         _chk(db, F32, "linear_bwd_weight.db")
         if not DW_BIAS:                                  # MMDTI_DW_BIAS=0: the separate column-sum pass (A/B switch)
@@ -186,7 +226,7 @@ def linear_bwd_weight_grouped(items):
     split that fills the chip is shared by all of them, so the fp32 partial-sum traffic is a quarter of what the GEMMs need
     one at a time).  Items that do not fit the grouped kernel's shape rules run through linear_bwd_weight."""
     import ctypes
-    norm = [(dy, x, dw, db, dy.shape[0] if rows is None else rows) for dy, x, dw, db, rows in items]
+    norm = [(dy, to_bf16(x), dw, db, dy.shape[0] if rows is None else rows) for dy, x, dw, db, rows in items]
     groups = {}
     for it in norm:
         if GROUPED_DW and _dw_groupable(it[0], it[1], it[2], it[4]):
@@ -228,13 +268,14 @@ def layernorm_fwd(x, gamma, beta, eps, *, want_f32=False, want_bf16=True, row_ze
     D = x.shape[-1]
     rows = x.numel() // D
     y32 = torch.empty_like(x) if want_f32 else None
-    y16 = torch.empty(x.shape, device=x.device, dtype=BF16) if want_bf16 else None
+    y16 = torch.empty(x.shape, device=x.device, dtype=act16()) if want_bf16 else None      # (feeds a forward GEMM)
     mean = torch.empty(rows, device=x.device, dtype=F32)
     rstd = torch.empty(rows, device=x.device, dtype=F32)
     rz = _u8(row_zero)
     t0 = kernel_timer.begin("ln_fwd")
     lib().mmdti_layernorm_fwd(_stream(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), rows, D, _p(y32), _p(y16),
-                              mean.data_ptr(), rstd.data_ptr(), _p(rz), float(drop_p), int(seed), int(site))
+                              mean.data_ptr(), rstd.data_ptr(), _p(rz), float(drop_p), int(seed), int(site),
+                              int(y16 is not None and y16.dtype == F16))
     kernel_timer.end("ln_fwd", t0, float(rows) * D * (4 + (4 if want_f32 else 0) + (2 if want_bf16 else 0)))
     return y32, y16, mean, rstd
 
@@ -263,6 +304,28 @@ def cast_bf16(x, drop_p=0.0, seed=0, site=0):
     _chk(x, F32, "cast_bf16.x")
     y = torch.empty(x.shape, device=x.device, dtype=BF16)
     lib().mmdti_cast_f32_bf16(_stream(), x.data_ptr(), y.data_ptr(), x.numel(), float(drop_p), int(seed), int(site))
+    return y
+
+
+def cast_act16(x, drop_p=0.0, seed=0, site=0):
+    """fp32 -> the 16-bit type of forward GEMM inputs (bf16; fp16 in the fp16 forward-operand mode), with optional dropout"""
+    if not FWD_F16:
+        return cast_bf16(x, drop_p, seed, site)
+    _chk(x, F32, "cast_act16.x")
+    y = torch.empty(x.shape, device=x.device, dtype=F16)
+    lib().mmdti_cast_f32_f16(_stream(), x.data_ptr(), y.data_ptr(), x.numel(), float(drop_p), int(seed), int(site))
+    return y
+
+
+def to_bf16(x):
+    """A saved forward activation as the bf16 operand of a BACKWARD GEMM: itself, or (fp16 forward-operand mode) its conversion.
+    x: [rows, cols] with unit column stride (row-strided views allowed), cols % 8 == 0."""
+    if x.dtype != F16:
+        return x
+    if x.dim() != 2 or x.stride(1) != 1:
+        x = x.contiguous().view(-1, x.shape[-1])
+    y = torch.empty(x.shape, device=x.device, dtype=BF16)
+    lib().mmdti_cast_f16_bf16(_stream(), x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), y.data_ptr())
     return y
 
 
@@ -570,9 +633,11 @@ def set_pair_kept(frac):
 def pair_attn_fwd(qkv, bias_in, key_pad, B, N, H, ld, scale, drop_p=0.0, seed=0, site=0, key_tiles=None, rag_store=False, row_off=None):
     """row_off ([B+1] int32 on the device, with key_tiles): packed token rows -- qkv / o / key_pad hold molecule b's real tokens +
     at most one representative pad row at rows [row_off[b], row_off[b+1]) (packing.PackedRows); the pair planes stay positional."""
-    _chk(qkv, BF16, "pair_attn.qkv")
+    _chk16(qkv, "pair_attn.qkv")
     layout = _pair_layout_s(bias_in, "pair_attn.bias")
     tiled = pair_is_tiled(bias_in)
+    if qkv.dtype == F16 and layout != 3:
+        qkv = to_bf16(qkv)         # (the fp16 q | k | v kernels exist for the compact tiled planes; other layouts take bf16)
     rows = qkv.shape[0] if row_off is not None else B * N
     if row_off is not None:
         _chk(row_off, torch.int32, "pair_attn.row_off")
@@ -583,13 +648,14 @@ def pair_attn_fwd(qkv, bias_in, key_pad, B, N, H, ld, scale, drop_p=0.0, seed=0,
     elif qkv.shape[0] != B * N:
         raise MMDTIError(f"pair_attn_fwd: qkv has {qkv.shape[0]} rows, expected B*N = {B * N}")
     s_out = torch.empty_like(bias_in) if tiled else torch.empty(B, H, N, ld, device=qkv.device, dtype=F32)
-    o = torch.empty(rows, H * 8, device=qkv.device, dtype=BF16)
+    o = torch.empty(rows, H * 8, device=qkv.device, dtype=qkv.dtype)
     kp = _u8(key_pad)
     t0 = kernel_timer.begin("pair_attn_fwd")
     if key_tiles is not None:
         _chk(key_tiles, torch.int32, "pair_attn.key_tiles")
     lib().mmdti_pair_attn_fwd(_stream(), qkv.data_ptr(), bias_in.data_ptr(), s_out.data_ptr(), o.data_ptr(), _p(kp), B, N, H, ld,
-                              float(scale), float(drop_p), int(seed), int(site), layout, _p(key_tiles), int(rag_store), _p(row_off))
+                              float(scale), float(drop_p), int(seed), int(site), layout, _p(key_tiles), int(rag_store), _p(row_off),
+                              int(qkv.dtype == F16))
     # per (pair, head): read the bias / previous logits, write S (4 B each; compact 2 B); per (token, head): q|k|v in (48 B), o out (16 B)
     kept, es = _pair_kept if key_tiles is not None else 1.0, float(s_out.element_size())
     kernel_timer.end("pair_attn_fwd", t0, float(H) * (B * N * N * (es * kept + es * (1.0 if rag_store else kept)) + rows * 64.0))
@@ -601,6 +667,7 @@ def pair_attn_bwd(qkv, s, do, g, B, N, H, ld, scale, g_in_zero, drop_p=0.0, seed
         raise MMDTIError("pair_attn_bwd: qkv / do row counts do not match the layout")
     if row_off is not None:
         _chk(row_off, torch.int32, "pair_attn.row_off")
+    qkv = to_bf16(qkv)             # (fp16 forward-operand mode: the backward's products take the bf16 rounding of q | k | v)
     dqkv = torch.empty_like(qkv)
     tiled = pair_is_tiled(s)
     layout = _pair_layout_s(s, "pair_attn_bwd.s")
@@ -674,11 +741,12 @@ def attn_fwd(q, k, v, key_add, B, heads, Lq, Lk, scale, drop_p=0.0, seed=0, site
     rows_q = B * Lq if vl is None else vl.q_rows
     if q.shape[0] != rows_q or k.shape[0] != (B * Lk if vl is None else vl.k_rows) or (vl is not None and key_add is not None):
         raise MMDTIError("attn_fwd: row counts do not match the layout (packed sequences take no key_add)")
-    ctx = torch.empty(rows_q, D, device=q.device, dtype=BF16)
+    ctx = torch.empty(rows_q, D, device=q.device, dtype=act16())         # (feeds the output projection's forward GEMM)
     stats = torch.empty((B, heads, Lq, 2) if vl is None else (heads, rows_q, 2), device=q.device, dtype=F32)
     t0 = kernel_timer.begin("attn_fwd")
     lib().mmdti_attn_fwd(_stream(), q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(key_add), ctx.data_ptr(), stats.data_ptr(), B, heads, Lq, Lk,
-                         hd, q.stride(0), k.stride(0), D, float(scale), float(drop_p), int(seed), int(site), *(_NO_VARLEN if vl is None else vl.args()))
+                         hd, q.stride(0), k.stride(0), D, float(scale), float(drop_p), int(seed), int(site), *(_NO_VARLEN if vl is None else vl.args()),
+                         int(ctx.dtype == F16))
     kernel_timer.end("attn_fwd", t0, 4.0 * heads * hd * (B * Lq * Lk if vl is None else vl.pairs))          # flops: q.k^T and p.v
     return ctx, stats
 

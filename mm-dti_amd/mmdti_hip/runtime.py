@@ -58,6 +58,8 @@ class ParamArena:
             p.grad = self.grad[o:o + n].view(p.shape)
             p._mmdti_arena = self
         self._version: Dict[int, int] = {}
+        self.shadow16: Optional[torch.Tensor] = None      # fp16 shadow (fp16 forward-operand mode), built on first use
+        self._epoch, self._epoch16 = 0, -1                # the fp16 shadow is valid while _epoch16 == _epoch
         self.refresh_shadow()
         self.adam_m: Optional[torch.Tensor] = None
         self.adam_v: Optional[torch.Tensor] = None
@@ -68,6 +70,7 @@ class ParamArena:
         ops.lib().mmdti_cast_f32_bf16(ops._stream(), self.data.data_ptr(), self.shadow.data_ptr(), self.numel, 0.0, 0, 0)
         for p in self.params:
             self._version[id(p)] = p._version
+        self._epoch += 1
 
     def _fresh(self, p):
         """The shadow is refreshed by the constructor and by adam_step (which writes both through raw pointers).  Any
@@ -78,6 +81,7 @@ class ParamArena:
             o, n = self.offsets[id(p)], p.numel()
             ops.lib().mmdti_cast_f32_bf16(ops._stream(), self.data[o:o + n].data_ptr(), self.shadow[o:o + n].data_ptr(), n, 0.0, 0, 0)
             self._version[id(p)] = p._version
+            self._epoch += 1
 
     def zero_grad(self):
         self.grad.zero_()
@@ -90,6 +94,21 @@ class ParamArena:
         self._fresh(p)
         o, n = self.offsets[id(p)], p.numel()
         return self.shadow[o:o + n].view(p.shape)
+
+    def _fresh16(self):
+        """fp16 shadow of the whole arena (the weights of the fp16 forward-operand mode): one cast pass whenever the fp32 data
+        has changed since the last one (an optimizer step, a reload)."""
+        if self.shadow16 is None:
+            self.shadow16 = torch.empty(self.numel, device=self.data.device, dtype=torch.float16)
+        if self._epoch16 != self._epoch:
+            ops.lib().mmdti_cast_f32_f16(ops._stream(), self.data.data_ptr(), self.shadow16.data_ptr(), self.numel, 0.0, 0, 0)
+            self._epoch16 = self._epoch
+
+    def f16(self, p: torch.nn.Parameter) -> torch.Tensor:
+        self._fresh(p)
+        self._fresh16()
+        o, n = self.offsets[id(p)], p.numel()
+        return self.shadow16[o:o + n].view(p.shape)
 
     def fused(self, plist):
         """(bf16 shadow, fp32 data, fp32 grad) views spanning parameters that sit back to back in the arena (rows
@@ -105,7 +124,12 @@ class ParamArena:
         for p in plist:
             self._fresh(p)
         shape = (sum(p.shape[0] for p in plist),) + tuple(cols)
-        return self.shadow[o0:o].view(shape), self.data[o0:o].view(shape), self.grad[o0:o].view(shape)
+        w16 = None
+        if ops.FWD_F16:
+            self._fresh16()
+            w16 = self.shadow16[o0:o].view(shape)
+        # (bf16 shadow, fp32 data, fp32 gradient, forward-GEMM shadow: fp16 in the fp16 forward-operand mode, else the bf16 one)
+        return self.shadow[o0:o].view(shape), self.data[o0:o].view(shape), self.grad[o0:o].view(shape), (w16 if w16 is not None else self.shadow[o0:o].view(shape))
 
     def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, max_norm: Optional[float] = None, step_state=None):
         """torch.optim.Adam semantics (tasks/trainer.py:160) + optional global-norm clipping (:274), one fused pass.
@@ -122,6 +146,7 @@ class ParamArena:
             scale = torch.clamp(max_norm / (ss.sqrt() + 1e-6), max=1.0)
         ops.adam_step(self.data, self.grad, self.adam_m, self.adam_v, self.shadow, lr, betas[0], betas[1], eps, weight_decay,
                       self.step_count, scale, step_state)
+        self._epoch += 1            # (the fp16 shadow, if in use, is re-cast before the next forward GEMM reads it)
 
 
 class _ShadowCache:
@@ -131,15 +156,16 @@ class _ShadowCache:
     def __init__(self):
         self._c: Dict[int, tuple] = {}
 
-    def get(self, p: torch.Tensor) -> torch.Tensor:
-        key = id(p)
+    def get(self, p: torch.Tensor, f16: bool = False) -> torch.Tensor:
+        key = (id(p), f16)
         ent = self._c.get(key)
         ver = (p.data_ptr(), p._version, tuple(p.shape))
         # id() values are recycled once a parameter dies: the weak reference proves the entry belongs to THIS tensor
         if ent is None or ent[0]() is not p or ent[1] != ver:
             if len(self._c) > 4096:
                 self._c = {k: e for k, e in self._c.items() if e[0]() is not None}
-            ent = (weakref.ref(p), ver, ops.cast_bf16(p.detach().contiguous()))
+            src = p.detach().contiguous()
+            ent = (weakref.ref(p), ver, ops.cast_act16(src) if f16 else ops.cast_bf16(src))
             self._c[key] = ent
         return ent[2]
 
@@ -153,6 +179,16 @@ def wbf16(p: torch.Tensor) -> torch.Tensor:
     if arena is not None:
         return arena.bf16(p)
     return _shadow_cache.get(p)
+
+
+def wfwd(p: torch.Tensor) -> torch.Tensor:
+    """The weight as the operand of a FORWARD GEMM: the bf16 shadow, or -- fp16 forward-operand mode (ops.FWD_F16) -- the fp16 one."""
+    if not ops.FWD_F16:
+        return wbf16(p)
+    arena = getattr(p, "_mmdti_arena", None)
+    if arena is not None:
+        return arena.f16(p)
+    return _shadow_cache.get(p, f16=True)
 
 
 def fused_views(plist):
