@@ -57,7 +57,7 @@ def stats(src, dst):
     rows = list(csv.DictReader(open(find(src, "*kernel_stats.csv"))))
     rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
     with open(dst, "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline (11 steps in the trace: 2 warm-up + 5 timed + 4 extra steps of the per-family roofline timing)\n")
+        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline (every step of the run is in the trace: warm-up, timed, the mixed-length workload, the per-family roofline steps)\n")
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_ms", "avg_us", "percent", "min_us", "max_us"])
         for r in rows[:40]:
