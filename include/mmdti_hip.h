@@ -193,7 +193,10 @@ int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, const void* edg
                        tile_prefix[b+1] - tile_prefix[b] = 16-pair tiles (4x4 blocks, column block slowest) of molecule b to produce:
                        4*k_b*4*nt for its first k_b key tiles (nt = ceil(N/16); k_b as mmdti_pair_attn_fwd's key_tiles, rounded up to a
                        count its sweeps are built for).  The blocks of the all-padding key tiles behind them are not written: the ragged
-                       pair-attention kernels never read them */);
+                       pair-attention kernels never read them */,
+                       const int* row_blocks /* nullable, with tile_prefix: PACKED token rows (mmdti_pair_attn_fwd, row_off).  [B] int32 on the
+                       device: molecule b's tiles cover only its first row_blocks[b] 4-row query blocks (up to its representative pad
+                       row) -- tile_prefix[b+1] - tile_prefix[b] = 4*k_b * row_blocks[b]; no query row past it is read downstream */);
 /* Per-pair half of the backward of mmdti_gbf_bias_fwd, one pass over g = dL/d(out) (same layout flag): writes
  * do_bf16 [B*N*N, 64] = bf16(g re-laid out) and du_bf16 [B*N*N, 128] = bf16((do.W2) * gelu'(u)) -- the A operands of the two
  * weight-gradient GEMMs (dW2 = do^T.h, dW1 = du^T.feat; bias gradients are their column sums) -- and accumulates the
@@ -212,7 +215,9 @@ int mmdti_gbf_bias_bwd_full(mmdti_stream_t stream, const void* g, const float* d
                             const float* b1, const void* w2_bf16, int B, int N, int ld, int K, int F, int H, int E, int flags,
                             float* dw1, float* db1, float* dw2, float* db2, float* dmul, float* dbias, float* dmeans, float* dstds,
                             const int* tile_prefix /* nullable, tiled layout only: as in mmdti_gbf_bias_fwd, in this kernel's tile
-                            units: tile_prefix[b+1] - tile_prefix[b] = nb * min(nb, 4*k_b) blocks of real pairs, nb = ceil(N/4) */);
+                            units: tile_prefix[b+1] - tile_prefix[b] = nb * min(nb, 4*k_b) blocks of real pairs, nb = ceil(N/4) */,
+                            const int* row_blocks /* nullable, with tile_prefix: packed token rows, as in the forward: the count is then
+                            row_blocks[b] * min(nb, 4*k_b) -- the gradient of the query rows past the representative pad row is zero */);
 /* [B,N,N,H] fp32 -> [B,H,N,ld] fp32 (mm_model.py:555-556 permute(0,3,1,2).contiguous()) and its gradient
  * [B,H,N,ld] fp32 (or, tiled != 0, the [B,H,nt,nt,256] tile layout of mmdti_gbf_bias_fwd) -> [B,N,N,H] bf16 */
 int mmdti_pair_permute_fwd(mmdti_stream_t stream, const float* x, float* out, int B, int N, int H, int ld);

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void gbf_bias_fwd_kernel(const float* __res
                                                               OT* __restrict__ out, bf16_t* __restrict__ feat_out,
                                                               bf16_t* __restrict__ u_out, bf16_t* __restrict__ h_out, int B, int N,
                                                               int ld, int E, int tpm, int ugrad, int ltab,
-                                                              const int* __restrict__ tile_prefix) {
+                                                              const int* __restrict__ tile_prefix, const int* __restrict__ row_blocks) {
   static_assert(TILED || sizeof(OT) == 4, "compact pair planes exist in the tiled layout only");
   extern __shared__ __attribute__((aligned(16))) unsigned char gbf_smem[];
   bf16_t* sW1 = reinterpret_cast<bf16_t*>(gbf_smem);       // [128][136]   W1[f][k]
@@ -325,7 +325,10 @@ __global__ __launch_bounds__(512, 2) void gbf_bias_fwd_kernel(const float* __res
     if (TILED) {
       // (query block fastest: inside a 16x16 tile the 64-byte segments of rb & 3 = 0..3 are consecutive in memory, so the
       //  eight waves of a workgroup write -- and the backward reads -- whole 128-byte lines together)
-      const int cb = (int)((unsigned)tq / (unsigned)nblk), rb = tq - cb * nblk;
+      // packed token rows (row_blocks): molecule b's queries stop at its representative pad row -- only its first row_blocks[b]
+      // 4-row blocks are produced (the pair-attention kernels read no query row past it)
+      const int rbk = (rag && row_blocks) ? row_blocks[b] : nblk;
+      const int cb = (int)((unsigned)tq / (unsigned)rbk), rb = tq - cb * rbk;
       past = 4 * rb >= N || 4 * cb >= N;   // (the same for every lane of the wave)
       ii = 4 * rb + (i >> 2);
       jj = 4 * cb + (i & 3);
@@ -681,7 +684,7 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
     const float* __restrict__ bias, const float* __restrict__ means, const float* __restrict__ stds, const bf16_t* __restrict__ W1,
     const float* __restrict__ b1, const bf16_t* __restrict__ W2, float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2,
     float* __restrict__ db2, float* __restrict__ dmul, float* __restrict__ dbias, float* __restrict__ dmeans, float* __restrict__ dstds, int B,
-    int N, int ld, int E, int tpm, const int* __restrict__ tile_prefix) {
+    int N, int ld, int E, int tpm, const int* __restrict__ tile_prefix, const int* __restrict__ row_blocks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gbf_smem[];
   bf16_t* sW1 = reinterpret_cast<bf16_t*>(gbf_smem);            // [128 f][144]  W1[f][k]
   bf16_t* sW2T = sW1 + GBF_F * GBF_LW;                           // [128 f][72]   W2^T[f][h]
@@ -782,7 +785,8 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
     }
     int q, ii, jj;
     if (TILED) {
-      const int cb = (int)((unsigned)tq / (unsigned)nb), rb = tq - cb * nb;   // query block fastest: see the forward kernel
+      const int rbk = (rag && row_blocks) ? row_blocks[b] : nb;               // (packed token rows: see the forward kernel)
+      const int cb = (int)((unsigned)tq / (unsigned)rbk), rb = tq - cb * rbk;   // query block fastest: see the forward kernel
       ii = 4 * rb + (i >> 2);
       jj = 4 * cb + (i & 3);
       q = ((rb >> 2) * nt + (cb >> 2)) * 256 + (cb & 3) * 64 + (rb & 3) * 16 + i;
@@ -1120,11 +1124,12 @@ extern "C" int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, cons
                                   const float* bias, const float* means, const float* stds, const void* w1_bf16,
                                   const float* b1, const void* w2_bf16, const float* b2, int B, int N, int ld, int K, int F,
                                   int H, int E, void* out, void* feat_bf16, void* u_bf16, void* h_bf16, int flags,
-                                  const int* tile_prefix) {
+                                  const int* tile_prefix, const int* row_blocks) {
   // bit 0: tiled pair layout; bit 1: u_bf16 receives gelu'(u) instead of u; bit 2: compact planes (out is fp16; tiled only)
   const int tiled = flags & 1, ugrad = (flags >> 1) & 1, compact = (flags >> 2) & 1;
   MMDTI_REQUIRE(!compact || tiled, "gbf_bias_fwd: compact planes (flags bit 2) exist in the tiled layout only");
   MMDTI_REQUIRE(!tile_prefix || tiled, "gbf_bias_fwd: tile_prefix (ragged batches) needs the tiled pair layout");
+  MMDTI_REQUIRE(!row_blocks || tile_prefix, "gbf_bias_fwd: row_blocks (packed token rows) comes with tile_prefix");
   MMDTI_REQUIRE(dist && edge_type && mul && bias && means && stds && w1_bf16 && b1 && w2_bf16 && b2 && out, "gbf_bias_fwd: null argument");
   MMDTI_REQUIRE(edge_bytes_ok(edge_bytes), "gbf_bias_fwd: edge types must be int64, int32 or int16 (edge_bytes=%d)", edge_bytes);
   MMDTI_REQUIRE(K == GBF_K && F == GBF_F && H == GBF_H, "gbf_bias_fwd: built for %d gaussians, %d hidden, %d heads (got %d,%d,%d)",
@@ -1157,7 +1162,7 @@ extern "C" int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, cons
 #define GBF_L(SAVE, TILED, OT)                                                                                                      \
   hipLaunchKernelGGL((gbf_bias_fwd_kernel<SAVE, TILED, OT>), dim3(grid), dim3(512), smem, (hipStream_t)stream, dist, edge_type, edge_bytes, mul, bias, \
                      means, stds, (const bf16_t*)w1_bf16, b1, (const bf16_t*)w2_bf16, b2, (OT*)out, (bf16_t*)feat_bf16, (bf16_t*)u_bf16, \
-                     (bf16_t*)h_bf16, B, N, ld, E, tpm, ugrad, ltab, tile_prefix)
+                     (bf16_t*)h_bf16, B, N, ld, E, tpm, ugrad, ltab, tile_prefix, row_blocks)
   if (compact) { if (save) GBF_L(true, true, _Float16); else GBF_L(false, true, _Float16); }
   else if (save) { if (tiled) GBF_L(true, true, float); else GBF_L(true, false, float); }
   else           { if (tiled) GBF_L(false, true, float); else GBF_L(false, false, float); }
@@ -1211,10 +1216,11 @@ extern "C" int mmdti_gbf_bias_bwd_full(mmdti_stream_t stream, const void* g, con
                                        const float* mul, const float* bias, const float* means, const float* stds, const void* w1_bf16,
                                        const float* b1, const void* w2_bf16, int B, int N, int ld, int K, int F, int H, int E, int flags,
                                        float* dw1, float* db1, float* dw2, float* db2, float* dmul, float* dbias, float* dmeans,
-                                       float* dstds, const int* tile_prefix) {
+                                       float* dstds, const int* tile_prefix, const int* row_blocks) {
   const int tiled = flags & 1, compact = (flags >> 2) & 1;   // bit 0: tiled pair layout; bit 2: compact planes (g is bf16; tiled only)
   MMDTI_REQUIRE(!compact || tiled, "gbf_bias_bwd_full: compact planes (flags bit 2) exist in the tiled layout only");
   MMDTI_REQUIRE(!tile_prefix || tiled, "gbf_bias_bwd_full: tile_prefix (ragged batches) needs the tiled pair layout");
+  MMDTI_REQUIRE(!row_blocks || tile_prefix, "gbf_bias_bwd_full: row_blocks (packed token rows) comes with tile_prefix");
   MMDTI_REQUIRE(g && dist && edge_type && mul && bias && means && stds && w1_bf16 && b1 && w2_bf16 && dw1 && db1 && dw2 && db2 && dmul && dbias &&
                     dmeans && dstds, "gbf_bias_bwd_full: null argument");
   MMDTI_REQUIRE(edge_bytes_ok(edge_bytes), "gbf_bias_bwd_full: edge types must be int64, int32 or int16 (edge_bytes=%d)", edge_bytes);
@@ -1242,7 +1248,7 @@ extern "C" int mmdti_gbf_bias_bwd_full(mmdti_stream_t stream, const void* g, con
 #define GBF_FB(TILED, GT)                                                                                                          \
   hipLaunchKernelGGL((gbf_bias_bwd_full_kernel<TILED, GT>), dim3(grid), dim3(512), smem, (hipStream_t)stream, (const GT*)g, dist, edge_type, edge_bytes, mul, \
                      bias, means, stds, (const bf16_t*)w1_bf16, b1, (const bf16_t*)w2_bf16, dw1, db1, dw2, db2, dmul, dbias, dmeans, dstds, B, \
-                     N, ld, E, tpm, tile_prefix)
+                     N, ld, E, tpm, tile_prefix, row_blocks)
   if (compact) GBF_FB(true, __bf16); else if (tiled) GBF_FB(true, float); else GBF_FB(false, float);
 #undef GBF_FB
   MMDTI_LAUNCH_CHECK();

@@ -1106,6 +1106,7 @@ struct GroupProb {
 struct GroupArgs {
   GroupProb p[GROUP_MAX];
   int nprob, ntiles, K, splitk;
+  int atomic;           // small token counts: every K-split adds its partial tile straight into dW with fp32 atomics (no slab pass)
   const void* zeros;
 };
 
@@ -1122,6 +1123,8 @@ __global__ __launch_bounds__(512, 1) void gemm_big_grouped_kernel(GroupArgs g) {
   a.splitk = g.splitk; a.alpha = 1.f; a.beta = 0.f; a.bias = nullptr; a.residual = nullptr; a.ldr = 0; a.act = MMDTI_ACT_NONE;
   a.aux_in = nullptr; a.aux_out = nullptr; a.ld_aux = 0; a.c_dtype = MMDTI_DT_F32; a.drop_thresh = 0; a.drop_scale = 1.f; a.seed = 0; a.site = 0;
   a.vec_ok = 1; a.colsum = nullptr; a.stream_c = 0; a.dbg = 0; a.slab = (long long)pr.M * pr.N; a.arowsum = pr.arowsum; a.zeros = g.zeros;
+  a.c_f16 = 0;
+  if (g.atomic) { a.C = pr.C; a.ldc = pr.ldc; a.c_dtype = MMDTI_DT_F32_ATOMIC; a.slab = 0; }
   // Tile order inside a problem: the SHORT side of the tile grid runs fastest, so the ~6 consecutive tiles an XCD gets (per
   // K-split) form a compact 2 x 3 block of the output -- 5 operand pieces through that L2 instead of 7 for a 1 x 6 strip.
   const int t = wg - pr.tile0;
@@ -1675,10 +1678,16 @@ extern "C" int mmdti_linear_dw_grouped(mmdti_stream_t stream, int nprob, const v
     attr = true;
   }
   hipStream_t s = (hipStream_t)stream;
+  // Small token counts (the reference's real batch sizes, 16-32 molecules): the step is a chain of ~20 us kernels, and the slab
+  // pass is one more of them per layer -- the K-splits add into dW with fp32 atomics instead (a few MB of them: cheaper than a launch)
+  static const int atomic_rows = getenv("MMDTI_GROUPED_ATOMIC_ROWS") ? atoi(getenv("MMDTI_GROUPED_ATOMIC_ROWS")) : 4096;
+  g.atomic = rows <= atomic_rows ? 1 : 0;
   hipLaunchKernelGGL(gemm_big_grouped_kernel, dim3(tiles, 1, sk), dim3(512), smem_b, s, g);
-  long long max_n4 = 0;
-  for (int i = 0; i < nprob; ++i) max_n4 = max(max_n4, (long long)g.p[i].M * g.p[i].N / 4);
-  hipLaunchKernelGGL(grouped_reduce_kernel, dim3((unsigned)min((max_n4 + 255) / 256, 2048LL), nprob), dim3(256), 0, s, g);
+  if (!g.atomic) {
+    long long max_n4 = 0;
+    for (int i = 0; i < nprob; ++i) max_n4 = max(max_n4, (long long)g.p[i].M * g.p[i].N / 4);
+    hipLaunchKernelGGL(grouped_reduce_kernel, dim3((unsigned)min((max_n4 + 255) / 256, 2048LL), nprob), dim3(256), 0, s, g);
+  }
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }

@@ -339,7 +339,7 @@ class PairBiasFn(torch.autograd.Function):
     function through autograd from any other consumer is added on top."""
 
     @staticmethod
-    def forward(ctx, anchor, dist, edge_type, gbf, proj, ld, key_tiles_host=None):
+    def forward(ctx, anchor, dist, edge_type, gbf, proj, ld, key_tiles_host=None, rows_host=None):
         # key_tiles_host ([B] ints on the HOST, ragged batches): real key tiles per molecule -- the fused compact path then
         # neither produces the bias of the all-padding key tiles nor visits them in the backward (PairEncoderFn skips them too)
         B, N, _ = dist.shape
@@ -358,12 +358,16 @@ class PairBiasFn(torch.autograd.Function):
             keep = any(ctx.needs_input_grad) and not full  # inference: the kernel does not even write the intermediates
             tiled = ops.pair_tiled_ok(N)
             compact = tiled and ops.PAIR_COMPACT
-            pre_f = pre_b = None
+            pre_f = pre_b = rb_f = rb_b = None
             if key_tiles_host is not None and compact and full and not ops.PAIR_G_BF16:
-                pre_f, pre_b = ops.gbf_tile_prefixes(key_tiles_host, N, dist.device)
+                # (rows_host -- packed token rows: the bias of the query rows past a molecule's representative pad row is never read)
+                if rows_host is not None:
+                    pre_f, pre_b, rb_f, rb_b = ops.gbf_tile_prefixes(key_tiles_host, N, dist.device, rows_host)
+                else:
+                    pre_f, pre_b = ops.gbf_tile_prefixes(key_tiles_host, N, dist.device)
             out, saved = ops.gbf_bias_fwd(dist, edge_type, *args, wbf16(proj.linear1.weight), proj.linear1.bias,
                                           wbf16(proj.linear2.weight), proj.linear2.bias, ld, save=keep, tiled=tiled,
-                                          save_grad=ops.GELU_SAVE_GRAD, compact=compact, tile_prefix=pre_f)
+                                          save_grad=ops.GELU_SAVE_GRAD, compact=compact, tile_prefix=pre_f, row_blocks=rb_f)
             feat, u, h = saved if keep else (None, None, None)
             ugrad = ops.GELU_SAVE_GRAD
         else:
@@ -374,7 +378,7 @@ class PairBiasFn(torch.autograd.Function):
             o = ops.linear_fwd(h, wbf16(proj.linear2.weight), proj.linear2.bias, out_dtype=F32)
             out = ops.pair_permute_fwd(o, B, N, H, ld)
         ctx.st = SimpleNamespace(dist=dist, et=edge_type, feat=feat, u=u, h=h, B=B, N=N, H=H, ld=ld, fused=fused, ugrad=ugrad, full=full, slot=None,
-                                 pre_b=pre_b if fused else None)
+                                 pre_b=pre_b if fused else None, rb_b=rb_b if fused else None)
         ctx.gbf, ctx.proj = gbf, proj
         if out.dtype == torch.float16:
             ctx.st.slot = out._mmdti_grad_slot = SimpleNamespace(g=None)
@@ -401,7 +405,7 @@ class PairBiasFn(torch.autograd.Function):
             allp = [l1.weight, l1.bias, l2.weight, l2.bias] + ps
             grads = [gbuf(p) if p.requires_grad else torch.zeros_like(p) for p in allp]
             ops.gbf_bias_bwd_full(g.contiguous(), st.dist, st.et, *[p.view(-1) for p in ps], wbf16(l1.weight), l1.bias, wbf16(l2.weight),
-                                  st.ld, *[gr.view(-1) for gr in grads], tile_prefix=st.pre_b)
+                                  st.ld, *[gr.view(-1) for gr in grads], tile_prefix=st.pre_b, row_blocks=st.rb_b)
         elif st.fused and ps[0].numel() <= 4096:
             # one pass over G: re-layout, both dX products, GELU' and the Gaussian backward; only the two weight-gradient
             # GEMMs (contraction over all pairs) and their column sums remain
@@ -421,7 +425,7 @@ class PairBiasFn(torch.autograd.Function):
                 ops.gbf_features_bwd(st.dist, st.et, *[p.view(-1) for p in ps], dfeat, *[gr.view(-1) for gr in grads])
         notify_grads_ready(list(gbf.parameters()) + list(proj.parameters()))
         _join_stream_after_backward()
-        return None, None, None, None, None, None, None
+        return None, None, None, None, None, None, None, None
 
 
 class PairCompactFn(torch.autograd.Function):

@@ -301,11 +301,12 @@ class MM_Model(nn.Module):
         return self._side
 
     # ------------------------------------------------------------------ forward
-    def pair_bias(self, src_distance, src_edge_type, key_tiles_host=None):
+    def pair_bias(self, src_distance, src_edge_type, key_tiles_host=None, rows_host=None):
         """mm_model.py:553-556 fused: -> the pair bias ([B,H,N,ld] fp32, or the tiled pair layout on the hot path).  key_tiles_host
-        (ragged batches): [B] real key tiles per molecule, on the HOST."""
+        (ragged batches): [B] real key tiles per molecule, on the HOST; rows_host (packed token rows): [B] query rows per molecule."""
         N = src_distance.shape[-1]
-        return PairBiasFn.apply(self.gbf.means.weight, src_distance.float(), src_edge_type, self.gbf, self.gbf_proj, ops.pair_ld(N), key_tiles_host)
+        return PairBiasFn.apply(self.gbf.means.weight, src_distance.float(), src_edge_type, self.gbf, self.gbf_proj, ops.pair_ld(N), key_tiles_host,
+                                rows_host)
 
     def _packings(self, src_tokens, input_ids, atom_counts, token_counts, token_pad_id, packable):
         """-> (PackedRows of tower 1, PackedRows of tower 2) when this batch can and should run on packed token rows, else None.
@@ -384,7 +385,7 @@ class MM_Model(nn.Module):
             # slot of its molecule, so it gathers the pad id), the pair bias stays positional
             ids1, pad1 = src_tokens.reshape(-1)[pk1.gather], padding_mask.reshape(-1)[pk1.gather]
             xs = EmbeddingFn.apply(self.embed_tokens.weight, ids1, self.padding_idx)
-            bias_s = self.pair_bias(src_distance, src_edge_type, kt_host)
+            bias_s = self.pair_bias(src_distance, src_edge_type, kt_host, pk1.rows_host)
             if bias_s.dtype != torch.float16:         # (head / basis counts the fused pair-bias kernel is not built for: re-lay out)
                 bias_s = PairCompactFn.apply(bias_s, src_tokens.shape[1])
             encoder_rep = self.encoder.encode(xs, bias_s, pad1, key_tiles, pack=pk1)[0]

@@ -429,21 +429,30 @@ def gbf_features_bwd(dist, edge_type, mul, bias, means, stds, dfeat, dmul, dbias
                                  dstds.data_ptr())
 
 
-def gbf_tile_prefixes(key_tiles_host, N, device):
+def gbf_tile_prefixes(key_tiles_host, N, device, rows_host=None):
     """Ragged batches: the two [B+1] int32 device arrays (forward, complete backward) that tell the fused pair-bias kernels how
     many of each molecule's tiles to visit -- the 4x4 pair blocks of its first k_b key tiles, k_b = the count the ragged
-    pair-attention kernels cover (pair_key_tiles_effective).  key_tiles_host: [B] ints on the HOST (no device sync)."""
+    pair-attention kernels cover (pair_key_tiles_effective).  key_tiles_host: [B] ints on the HOST (no device sync).
+    rows_host ([B] ints on the host: packed token rows per molecule, packing.PackedRows.rows_host): the blocks stop at the molecule's
+    representative pad row as well -- then (fwd prefix, bwd prefix, fwd row blocks [B], bwd row blocks [B]) come back."""
     nt, nb = pair_tiles(N), (N + 3) // 4
     ke = torch.tensor([pair_key_tiles_effective(int(k), nt) for k in key_tiles_host.tolist()], dtype=torch.int64)
     zero = torch.zeros(1, dtype=torch.int64)
-    fwd = torch.cat([zero, torch.cumsum(4 * ke * (4 * nt), 0)])
-    bwd = torch.cat([zero, torch.cumsum(nb * torch.clamp(4 * ke, max=nb), 0)])
-    both = torch.stack([fwd, bwd]).to(torch.int32).to(device, non_blocking=True)
-    return both[0], both[1]
+    if rows_host is None:
+        fwd = torch.cat([zero, torch.cumsum(4 * ke * (4 * nt), 0)])
+        bwd = torch.cat([zero, torch.cumsum(nb * torch.clamp(4 * ke, max=nb), 0)])
+        both = torch.stack([fwd, bwd]).to(torch.int32).to(device, non_blocking=True)
+        return both[0], both[1]
+    rbk = (torch.as_tensor(rows_host, device="cpu").to(torch.int64) + 3) // 4          # 4-row query blocks up to the representative pad row
+    B = rbk.numel()
+    fwd = torch.cat([zero, torch.cumsum(4 * ke * rbk, 0)])
+    bwd = torch.cat([zero, torch.cumsum(torch.clamp(rbk, max=nb) * torch.clamp(4 * ke, max=nb), 0)])
+    flat = torch.cat([fwd, bwd, rbk, torch.clamp(rbk, max=nb)]).to(torch.int32).to(device, non_blocking=True)
+    return flat[:B + 1], flat[B + 1:2 * B + 2], flat[2 * B + 2:3 * B + 2], flat[3 * B + 2:]
 
 
 def gbf_bias_fwd(dist, edge_type, mul, bias, means, stds, w1, b1, w2, b2, ld, save=True, tiled=False, save_grad=False, compact=False,
-                 tile_prefix=None):
+                 tile_prefix=None, row_blocks=None):
     """Fused gbf + gbf_proj + permute -> (out [B,H,N,ld] fp32 -- or the tiled pair layout, fp32 or (compact) fp16 --,
     (feat, u, h) [P,128] bf16 or None)."""
     if compact and not tiled:
@@ -457,7 +466,8 @@ def gbf_bias_fwd(dist, edge_type, mul, bias, means, stds, w1, b1, w2, b2, ld, sa
     t0 = kernel_timer.begin("gbf_bias_fwd")
     lib().mmdti_gbf_bias_fwd(_stream(), dist.data_ptr(), edge_type.data_ptr(), edge_type.element_size(), mul.data_ptr(), bias.data_ptr(), means.data_ptr(), stds.data_ptr(),
                              w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), B, N, ld, K, Fh, Hh, mul.numel(), out.data_ptr(),
-                             *([t.data_ptr() for t in saved] if save else [0, 0, 0]), int(tiled) | (2 if save_grad else 0) | (4 if compact else 0), _p(tile_prefix))
+                             *([t.data_ptr() for t in saved] if save else [0, 0, 0]), int(tiled) | (2 if save_grad else 0) | (4 if compact else 0), _p(tile_prefix),
+                             _p(row_blocks))
     # algorithmic bytes per atom pair: 4 (distance) + edge type in, 64 heads x 4 B (compact: 2 B) of bias out (+ 3 x 256 B kept for the backward)
     kept = _pair_kept if tile_prefix is not None else 1.0
     kernel_timer.end("gbf_bias_fwd", t0, kept * float(B * N * N) * (4 + edge_type.element_size() + Hh * out.element_size() + (3 * 256 if save else 0)))
@@ -486,7 +496,7 @@ GBF_FULL_MAXE = 1536       # edge-type tables the complete backward kernel keeps
 
 
 def gbf_bias_bwd_full(g, dist, edge_type, mul, bias, means, stds, w1, b1, w2, ld, dw1, db1, dw2, db2, dmul, dbias, dmeans, dstds,
-                      tile_prefix=None):
+                      tile_prefix=None, row_blocks=None):
     """The whole backward of :func:`gbf_bias_fwd` in one kernel, nothing saved by the forward: all eight parameter gradients
     (fp32) are accumulated (+=) into the given buffers."""
     _chk(dist, F32, "gbf.dist"); _chk_edge(edge_type); _chk(w1, BF16, "gbf.w1"); _chk(w2, BF16, "gbf.w2")
@@ -499,7 +509,7 @@ def gbf_bias_bwd_full(g, dist, edge_type, mul, bias, means, stds, w1, b1, w2, ld
     lib().mmdti_gbf_bias_bwd_full(_stream(), g.data_ptr(), dist.data_ptr(), edge_type.data_ptr(), edge_type.element_size(), mul.data_ptr(),
                                   bias.data_ptr(), means.data_ptr(), stds.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), B, N, ld,
                                   w1.shape[1], Fh, Hh, mul.numel(), _pair_layout_g(g, "gbf_bias_bwd_full"), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(),
-                                  db2.data_ptr(), dmul.data_ptr(), dbias.data_ptr(), dmeans.data_ptr(), dstds.data_ptr(), _p(tile_prefix))
+                                  db2.data_ptr(), dmul.data_ptr(), dbias.data_ptr(), dmeans.data_ptr(), dstds.data_ptr(), _p(tile_prefix), _p(row_blocks))
     # Work unit: MFMA flops (the kernel reads 268 B per atom pair and is nowhere near HBM): per pair the recomputed
     # pre-activation (2*F*K), dO.W2 (2*H*F), du.W1 (2*F*K) and the two weight-gradient products (2*F*K + 2*H*F)
     K = w1.shape[1]

@@ -351,3 +351,66 @@ def test_packed_step_trains_with_dropout_on():
     assert np.all(np.abs(mean["padded"] - mean["packed"]) < 0.12 * np.abs(mean["padded"])), (mean, traj)
     for (la, ia), (lb, ib) in zip(traj["padded"], traj["packed"]):
         assert abs(la - lb) < 0.4 * abs(la) and abs(ia - ib) < 0.4 * abs(ia), traj
+
+
+@pytest.mark.parametrize("B,N,lens", [(4, 130, (130, 37, 64, 5)), (3, 37, (37, 16, 17)), (2, 200, (33, 199))])
+def test_gbf_bias_packed_rows_stop_at_the_representative_pad_row(ops, B, N, lens):
+    """Packed token rows at the two ends of the pair chain (row_blocks): the fused pair-bias forward produces, for each molecule, only
+    the 4-row query blocks up to its representative pad row (bit-identical there, nothing written behind them), and the complete
+    backward visits only those -- with the gradient zero behind them all eight parameter gradients equal the ragged run's."""
+    K, Fh, H, E = 128, 128, 64, 31 * 31
+    ld, nt = ops.pair_ld(N), ops.pair_tiles(N)
+    gen = G(41)
+    dist = torch.rand(B, N, N, generator=gen) * 8
+    et = torch.randint(1, E, (B, N, N), generator=gen)
+    for b, n in enumerate(lens):
+        dist[b, n:, :] = 0; dist[b, :, n:] = 0; et[b, n:, :] = 0; et[b, :, n:] = 0
+    mul, bias = 1 + 0.1 * torch.randn(E, generator=gen), 0.1 * torch.randn(E, generator=gen)
+    means, stds = torch.rand(K, generator=gen) * 3, torch.rand(K, generator=gen) * 3 - 1.5
+    w1, b1 = dev(bf(torch.randn(Fh, K, generator=gen) * 0.2)), dev(torch.randn(Fh, generator=gen) * 0.1)
+    w2, b2 = dev(bf(torch.randn(H, Fh, generator=gen) * 0.2)), dev(torch.randn(H, generator=gen) * 0.1)
+    d = [dev(t) for t in (dist, et.to(torch.int16), mul, bias, means, stds)]
+    kt = torch.tensor([(n + 15) // 16 for n in lens])
+    ke = [ops.pair_key_tiles_effective(int(k), nt) for k in kt]
+    rows = torch.tensor([min(n + 1, N) for n in lens])
+    pre_f, pre_b, rb_f, rb_b = ops.gbf_tile_prefixes(kt, N, "cuda", rows)
+    assert rb_f.tolist() == [(int(r) + 3) // 4 for r in rows] and int(pre_f[-1]) == sum(4 * k * ((int(r) + 3) // 4) for k, r in zip(ke, rows))
+    ref_f, ref_b = ops.gbf_tile_prefixes(kt, N, "cuda")
+    dense, _ = ops.gbf_bias_fwd(*d, w1, b1, w2, b2, ld, save=False, tiled=True, compact=True, tile_prefix=ref_f)
+    canary = 123.0
+    import mmdti_hip.ops as O_
+    orig_empty = O_.pair_empty
+    O_.pair_empty = lambda *a, **k: torch.full_like(orig_empty(*a, **k), canary)
+    try:
+        pk, _ = ops.gbf_bias_fwd(*d, w1, b1, w2, b2, ld, save=False, tiled=True, compact=True, tile_prefix=pre_f, row_blocks=rb_f)
+    finally:
+        O_.pair_empty = orig_empty
+    un = lambda t: ops.pair_untile(t, N)
+    for b in range(B):
+        r4 = min(4 * int(rb_f[b]), N)                                         # rows produced (4-row granularity)
+        kc = min(16 * ke[b], N)
+        assert torch.equal(un(pk)[b, :, :r4, :kc], un(dense)[b, :, :r4, :kc])
+        if r4 < N:
+            assert bool((un(pk)[b, :, r4:, :kc] == canary).all())             # query rows past the representative one: not written
+    g = ops.pair_tile(dev(torch.randn(B, H, N, N, generator=gen)), N, 0.0)
+    gu = un(g).clone()
+    for b in range(B):
+        gu[b, :, int(rows[b]):, :] = 0.0                                       # what the packed attention backward leaves: zeros behind the
+        gu[b, :, :, min(16 * ke[b], N):] = 0.0                                 # representative row and behind the kept key tiles
+    g = ops.pair_tile(gu, N, 0.0)
+    names = ("dw1", "db1", "dw2", "db2", "dmul", "dbias", "dmeans", "dstds")
+    shapes = ((Fh, K), (Fh,), (H, Fh), (H,), (E,), (E,), (K,), (K,))
+    got = {}
+    for tag, pre, rb in (("ragged", ref_b, None), ("packed", pre_b, rb_b)):
+        got[tag] = {n: torch.zeros(sh, device="cuda") for n, sh in zip(names, shapes)}
+        gg = g.clone()
+        if rb is not None:
+            ggu = un(gg).clone()
+            for b in range(B):
+                ggu[b, :, min(4 * int(rb_b[b]), N):, :] = float("nan")          # never read
+            gg = ops.pair_tile(ggu, N, 0.0)
+        ops.gbf_bias_bwd_full(gg, *d, w1, b1, w2, ld, *[got[tag][n].view(-1) for n in names], tile_prefix=pre, row_blocks=rb)
+    for n in names:
+        a, b_ = got["packed"][n], got["ragged"][n]
+        assert torch.isfinite(a).all(), n
+        assert float((a - b_).norm() / (b_.norm() + 1e-12)) < 1e-5, n
