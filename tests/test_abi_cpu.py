@@ -35,7 +35,7 @@ def test_argument_validation_happens_before_any_launch():
     with pytest.raises(_abi.MMDTIError, match="multiples of 8"):
         lib.mmdti_gemm_bf16(0, 16, 16, 16, 8, 8, 12, 12, 12, 8, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0, 0, 0, 0)
     with pytest.raises(_abi.MMDTIError, match="exceeds"):
-        lib.mmdti_pair_attn_fwd(0, 16, 16, 16, 16, 0, 1, 400, 8, 400, 0.35, 0.0, 0, 0, 0, 0, 0, 0)
+        lib.mmdti_pair_attn_fwd(0, 16, 16, 16, 16, 0, 1, 400, 8, 400, 0.35, 0.0, 0, 0, 0, 0, 0, 0, 0)
     with pytest.raises(_abi.MMDTIError, match="temperature"):
         lib.mmdti_infonce_dir(0, 16, 16, 4, 50, 0, 4, 0.0, 16, 16, 16, 16)
 
