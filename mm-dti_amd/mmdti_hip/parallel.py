@@ -114,6 +114,7 @@ class ArenaReducer:
         self.per = per
         self.buckets = [(s, min(n, s + per)) for s in range(0, n, per)]
         self.stream = torch.cuda.Stream() if (self.active and arena.grad.is_cuda) else None
+        self.algo = os.environ.get("MMDTI_REDUCE", "ring")
         self._pending = []
         # parameter -> arena range, bucket -> parameters it needs (only when the arena knows its parameters)
         self._range = {}
@@ -170,9 +171,34 @@ class ArenaReducer:
         self._pending = []
         self.overlapped = 0
 
+    def _mean_over_ranks(self, view):
+        """view <- mean over ranks.  SUM + scale rather than ReduceOp.AVG: identical result, no dependence on the collective library's
+        AVG support.  Two algorithms (MMDTI_REDUCE):
+          "ring"   (default) one RCCL all-reduce per bucket -- the library picks ring / tree for the topology;
+          "direct" reduce-scatter as ONE all-to-all (rank j receives chunk j of every rank over its own link to each of them and
+                   sums the world chunks) + all-gather of the reduced chunks: on xGMI's point-to-point mesh (7 links x ~153 GB/s
+                   per GPU) every link carries 1/world of the bucket in each phase, where a ring is bound by ONE link carrying
+                   2 (world-1)/world of it.  Cannot be timed on a 1-GPU box: opt-in until an 8-GPU run has
+                   measured it; the arithmetic is covered by the 2-rank gloo tests."""
+        if self.world <= 1:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)      # (1-rank rehearsal: exercises the collective)
+            return
+        if self.algo != "direct":
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            view.mul_(1.0 / self.world)
+            return
+        n, w = view.numel(), self.world
+        chunk = (n + w - 1) // w
+        send = view if n == chunk * w else torch.cat([view, view.new_zeros(chunk * w - n)])
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)                   # recv[j*chunk:(j+1)*chunk] = rank j's copy of MY chunk
+        mine = recv.view(w, chunk).sum(dim=0).mul_(1.0 / w)
+        dist.all_gather_into_tensor(send, mine, group=self.group)
+        if send is not view:
+            view.copy_(send[:n])
+
     def _launch(self, s, e, events=None):
         view = self.arena.grad[s:e]
-        # SUM + scale rather than ReduceOp.AVG: identical result, no dependence on the collective library's AVG support
         if self.stream is not None:
             if events is None:
                 self.stream.wait_stream(torch.cuda.current_stream())
@@ -180,13 +206,9 @@ class ArenaReducer:
                 for ev in events:
                     self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
-                if self.world > 1:
-                    view.mul_(1.0 / self.world)
+                self._mean_over_ranks(view)
         else:
-            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
-            if self.world > 1:
-                view.mul_(1.0 / self.world)
+            self._mean_over_ranks(view)
         self._pending.append((s, e))
 
     def finish(self):

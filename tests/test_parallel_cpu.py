@@ -101,6 +101,28 @@ def _worker_reducer(rank, world, initfile, out):
     dist.destroy_process_group()
 
 
+def _worker_reducer_direct(rank, world, initfile, out):
+    """MMDTI_REDUCE=direct: reduce-scatter as one all-to-all + all-gather (the xGMI-shaped alternative to a ring all-reduce) gives
+    the same mean as the all-reduce, for bucket lengths that do and do not divide by the rank count."""
+    os.environ["MMDTI_REDUCE"] = "direct"
+    _init(rank, world, initfile)
+    from mmdti_hip.parallel import ArenaReducer
+    n = 1001                                                             # last bucket: 233 floats, odd
+    arena = _FakeArena(n)
+    g = torch.Generator().manual_seed(7 + rank)
+    mine = torch.randn(n, generator=g)
+    arena.grad.copy_(mine)
+    red = ArenaReducer(arena, bucket_bytes=4 * 256)
+    assert red.algo == "direct" and red.buckets[-1] == (768, 1001)
+    red.finish()
+    both = [torch.zeros(n) for _ in range(world)]
+    dist.all_gather(both, mine)
+    torch.testing.assert_close(arena.grad, (both[0] + both[1]) / 2, rtol=1e-6, atol=1e-7)
+    if rank == 0:
+        torch.save({"ok": True}, out)
+    dist.destroy_process_group()
+
+
 class _ParamArena(_FakeArena):
     """arena stand-in that knows its parameters (sizes 300, 212, 256, 232 -> offsets 0, 300, 512, 768)."""
 
@@ -375,7 +397,7 @@ def _worker_trainer_ddp_plumbing(rank, world, initfile, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("worker", [_worker_trainer_ddp_plumbing, _worker_global_negatives, _worker_reducer, _worker_reducer_hook, _worker_step_equivalence,
+@pytest.mark.parametrize("worker", [_worker_trainer_ddp_plumbing, _worker_global_negatives, _worker_reducer, _worker_reducer_direct, _worker_reducer_hook, _worker_step_equivalence,
                                     _worker_fds_stats_identical, _worker_bucket_sampler_global_infonce, _worker_unequal_local_batches_raise])
 def test_two_ranks_gloo(worker):
     with tempfile.TemporaryDirectory() as td:
