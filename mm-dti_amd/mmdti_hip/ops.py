@@ -990,11 +990,19 @@ def step_state_advance(state, salt, base_lr, warmup, total, beta1=0.9, beta2=0.9
     lib().mmdti_seed_salt_pull(_stream(), salt.data_ptr() + 8)
 
 
-def seed_salt_reset():
-    """Back to salt 0: dropout streams are exactly what the by-value (seed, site) pairs define (the eager path's contract)."""
-    z = torch.zeros(1, device="cuda", dtype=torch.int64)
-    lib().mmdti_seed_salt_pull(_stream(), z.data_ptr())
-    torch.cuda.current_stream().synchronize()
+_zero_salt = None
+
+
+def seed_salt_reset(sync=True):
+    """Back to salt 0: dropout streams are exactly what the by-value (seed, site) pairs define (the eager path's contract).
+    sync=False: only enqueued (the zero word lives in a persistent device buffer) -- what FineTuner.step does when an eager step
+    follows graph replays."""
+    global _zero_salt
+    if _zero_salt is None:
+        _zero_salt = torch.zeros(1, device="cuda", dtype=torch.int64)
+    lib().mmdti_seed_salt_pull(_stream(), _zero_salt.data_ptr())
+    if sync:
+        torch.cuda.current_stream().synchronize()
 
 
 def probe_tr_read(stride):

@@ -62,7 +62,7 @@ class FineTuner:
         self.warmup = int(total_steps * warmup_ratio)
         self.sched_step = 0
         self.arena = ParamArena(model.parameters(), adjacent=_qkv_groups(model))
-        self._graphs, self._state, self._salt = {}, None, None
+        self._graphs, self._state, self._salt, self._salted = {}, None, None, False
         self.world = 1
         self.reducer = None
         remove_grad_ready_hook(self)
@@ -171,6 +171,10 @@ class FineTuner:
         for k, v in net_input.items():
             static_in[k].copy_(v, non_blocking=True)
         static_tgt.copy_(net_target, non_blocking=True)
+        # the device-resident step counter follows the host's: eager steps taken since the last replay (or another graph's replays)
+        # have advanced the schedule too -- one 4-byte fill, enqueued
+        self._state[0:1].fill_(float(self.sched_step))
+        self._salted = True
         graph.replay()
         self.sched_step += 1
         self.arena.step_count += 1
@@ -219,6 +223,12 @@ class FineTuner:
         return static_in, static_tgt, graph, out
 
     def step(self, net_input: dict, net_target: torch.Tensor, epoch: int = 0, use_weight: bool = False, **kw) -> StepOutput:
+        if getattr(self, "_salted", False):
+            # graph replays left their dropout salt in the kernel libraries: an eager step draws its masks from the by-value
+            # (seed, site) pairs alone, as every other engine in the process expects (enqueued, no synchronisation)
+            from . import ops
+            ops.seed_salt_reset(sync=False)
+            self._salted = False
         out = self.forward_backward(net_input, net_target, epoch, use_weight, **kw)
         self.optimizer_step()
         return out

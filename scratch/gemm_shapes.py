@@ -9,7 +9,7 @@ from mmdti_hip import functional as Fn
 from mmdti_hip.trainer import FineTuner
 model, _ = bench.build_model()
 model = model.cuda().train()
-model.overlap_towers = False; model.infonce_on_side_stream = False; model.cross_modal_module.two_streams = False; Fn.DEFER_WGRAD_LAYERS = 0; Fn.WGRAD_SIDE = False
+model.overlap_towers = False; model.infonce_on_side_stream = False; model.cross_modal_module.two_streams = False; Fn.DEFER_WGRAD_LAYERS = 0
 tuner = FineTuner(model, "classification", total_steps=1000)
 _, batch, label = bench.synth(256, 128, 256, seed=1234)
 batch = {k: v.cuda() for k, v in batch.items()}; label = label.cuda()
@@ -31,7 +31,10 @@ for tag, d in rows.items():
         out.append(dict(M=0, N=0, K=tag[2], tA=1, tB=1, batch=1, splitk=0, act=0, n_per_step=d["n"] / 3, us=us, tflops=flops / us / 1e6, bound_us=max(t_mfma, t_hbm),
                         bound="mfma", ms_per_step=d["total_ms"] / 3, frac_of_bound=max(t_mfma, t_hbm) / us, grouped=str(tag[1])))
         continue
-    M, N, K, tA, tB, nb, sk, act, obf, aux, res = tag
+    if tag[7] == "ln":
+        M, N, K = tag[:3]; tA = tB = 0; nb = 1; sk = 1; act = 9; obf = False; aux = True; res = tag[10]
+    else:
+        M, N, K, tA, tB, nb, sk, act, obf, aux, res = tag
     flops = 2.0 * M * N * K * nb
     byts = 2.0 * nb * (M * K + N * K) + (2 if obf else 4) * nb * M * N * (2 if (res or sk > 1) else 1) + (2 * M * N if aux else 0)
     t_mfma, t_hbm = flops / 2.5e15 * 1e6, byts / 6.3e12 * 1e6

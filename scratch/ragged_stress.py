@@ -19,7 +19,7 @@ load_fixture_weights(model, P)
 if os.environ.get('STRESS_NO_OVERLAP') == '1':
     model.overlap_towers = False; model.infonce_on_side_stream = False; model.cross_modal_module.two_streams = False
     from mmdti_hip import functional as Fn
-    Fn.DEFER_WGRAD_LAYERS = 0; Fn.WGRAD_SIDE = False
+    Fn.DEFER_WGRAD_LAYERS = 0
 rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 bad = 0
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):

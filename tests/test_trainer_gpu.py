@@ -449,6 +449,47 @@ def test_graphed_step_matches_eager_and_redraws_dropout():
         ops.seed_salt_reset()
 
 
+def test_graphed_step_runs_any_ragged_batch_of_the_captured_shape_and_mixes_with_eager_steps():
+    """the host-side length descriptors of a ragged batch select kernels and tile counts at CAPTURE time, so
+    a graph must not bake them in -- graphed_step drops them and runs the padded layout: two different ragged batches of one padded
+    shape replay correctly (== the eager padded step on each).  (low): an eager step between replays advances the schedule the
+    next replay uses, and the salt of the replays does not leak into the eager step's dropout masks."""
+    from mmdti_hip.trainer import FineTuner, linear_warmup_lr
+    from mmdti_hip.collate import device_payload, to_device
+    from mmdti_hip import ops
+    from g9util import product_model, tiny_cfg
+    ocfg = tiny_cfg("classification", 40)
+    m1, m2 = product_model(ocfg).cuda().train(), product_model(ocfg, strict_reference=True).cuda().train()
+    m2.load_state_dict(m1.state_dict())
+    # two ragged batches with the SAME padded shape but different molecule lengths
+    b1, y1 = O.synth_batch(8, 10, 14, ocfg, seed=31, ragged=True)
+    b2 = {k: v.flip(0).contiguous() for k, v in b1.items()}
+    y2 = y1.flip(0).contiguous()
+    assert not torch.equal(b1["src_tokens"], b2["src_tokens"]) and b1["src_tokens"].shape == b2["src_tokens"].shape
+    t1 = FineTuner(m1, "classification", learning_rate=1e-3, warmup_ratio=0.5, total_steps=8, max_norm=5.0)
+    t2 = FineTuner(m2, "classification", learning_rate=1e-3, warmup_ratio=0.5, total_steps=8, max_norm=5.0)
+    try:
+        for i, (b, y) in enumerate(((b1, y1), (b2, y2), (b1, y1))):
+            dev = to_device(device_payload(b), "cuda")                    # carries atom_counts / token_counts / packable
+            o1 = t1.graphed_step(dev, y.cuda())
+            assert m1.last_layout == "padded"
+            o2 = t2.step(dev, y.cuda())                                   # eager, padded (strict_reference)
+            assert abs(float(o1.loss) - float(o2.loss)) <= 3e-4 * abs(float(o2.loss)) + 1e-6, (i, float(o1.loss), float(o2.loss))
+        assert len(t1._graphs) == 1
+        # an eager step in between: the schedule moves on for the next replay
+        dev = to_device(device_payload(b2), "cuda")
+        m1.strict_reference = True
+        t1.step(dev, y2.cuda()); t2.step(dev, y2.cuda())
+        m1.strict_reference = False
+        assert t1.sched_step == 4 and not t1._salted
+        o1 = t1.graphed_step(dev, y2.cuda()); o2 = t2.step(dev, y2.cuda())
+        torch.cuda.synchronize()
+        assert float(t1._state[0]) == 5.0 and abs(float(t1._state[1]) - linear_warmup_lr(1e-3, 4, 4, 8)) < 1e-9
+        assert abs(float(o1.loss) - float(o2.loss)) <= 1e-3 * abs(float(o2.loss)) + 1e-6
+    finally:
+        ops.seed_salt_reset()
+
+
 def test_multilabel_classification_trains_with_ct_multi_and_bce(tmp_path):
     """the reference constructs ``multilabel_classification`` (models/mm_model.py:481-486: CT_Multi) with the
     BCE / GHM / focal loss table (models/nnmodel.py:24-34).  A 12-label toy: the step (BCE-with-logits kernel + CT_Multi + InfoNCE)
