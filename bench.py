@@ -250,6 +250,31 @@ def main():
                                            "strict_reference": True},
             "note": "packed token rows: every sequence's real tokens + ONE representative pad row weighted by the padded positions it stands for in the "
                     "unmasked InfoNCE mean (identical to the padded computation at dropout 0, equal in expectation under dropout; DESIGN.md section 3)"}
+        # Third workload: the reference's REAL batch size (finetune.py:14 batch_size=32, config/default.yaml:18 16) on the same length
+        # distribution -- a chain of ~480 small kernels per step, where launch structure, not arithmetic, sets the time
+        if args.batch > 32:
+            small = 32
+            _, sb, sy = synth(small, args.atoms, args.tokens, seed=8765 + rank, ragged=True)
+            shost = dict(packing_fields(sb), atom_counts=atom_counts(sb["src_tokens"], 0))
+            sb = dict({k: v.to(dev) for k, v in sb.items()}, **shost)
+            sy = sy.to(dev)
+            for _ in range(max(3, args.warmup)):
+                tuner.step(sb, sy, epoch=0)
+            barrier()
+            t1 = time.perf_counter()
+            n_small = max(args.steps, 20)
+            for _ in range(n_small):
+                tuner.step(sb, sy, epoch=0)
+            barrier()
+            d1 = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([d1], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                d1 = float(t)
+            workloads["small_batch"] = {
+                "workload": f"same step, {small} molecules/GPU (the reference's default batch size), mixed lengths, packed token rows",
+                "unit": "molecules/s", "steps": n_small, "value": round(small * world * n_small / d1, 2), "ms_per_step": round(d1 / n_small * 1e3, 3),
+                "layout": model.last_layout, "padded_N": int(sb["src_tokens"].shape[1])}
 
     # every kernel family in two extra modes (every rank runs them: the step holds collectives):
     #   "overlapped": streams as in the timed region (a launch's event time includes sharing the chip with the other tower);
