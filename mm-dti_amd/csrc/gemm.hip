@@ -560,6 +560,37 @@ __device__ __forceinline__ Off4 glds_offsets(int ld, int row0, int rows, int tid
   return Off4{glds_offset1<TR>(tid, ld, row0, rows), glds_offset1<TR>(tid + 256, ld, row0, rows),
               glds_offset1<TR>(tid + 512, ld, row0, rows), glds_offset1<TR>(tid + 768, ld, row0, rows)};
 }
+// LDS-DMA issued through inline assembly, for the kernels that keep DMA in flight ACROSS barriers (gemm_big_*, the deep ring):
+// the compiler's wait-count pass cannot tell a ds_read_b64_tr_b16 (an intrinsic: no alias information) from a reader of the
+// tile in flight and put `s_waitcnt vmcnt(0)` in front of the first fragment read after every barrier of the k-major
+// variants -- the counted waits of those kernels were dead code (round 3 finding, read off the ISA).  A DMA the pass does not
+// see leaves the ordering to the kernel: counted s_waitcnt vmcnt(n) + s_barrier before a staged buffer is read, vmcnt(0)
+// before LDS is reused by the epilogue.  (Loads the compiler issues itself stay correct: vmcnt retires loads in order, so
+// its own counts are at worst conservative with these in flight.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ int lds_addr_uniform(const void* p) {
+  typedef __attribute__((address_space(3))) void lptr_t;
+  return __builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lptr_t*)p);
+}
+// 16 bytes per lane from (wave-uniform base + per-lane 32-bit byte offset) to LDS at lds + lane * 16
+__device__ __forceinline__ void dma16_su(const void* sbase, uint32_t voff, const bf16_t* lds) {
+  const int m = lds_addr_uniform(lds);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(m), "v"(voff), "s"(sbase) : "memory", "m0");
+}
+// the same from a per-lane 64-bit address
+__device__ __forceinline__ void dma16_v(const void* vptr, const bf16_t* lds) {
+  const int m = lds_addr_uniform(lds);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m), "v"(vptr) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+__device__ __forceinline__ void glds_tile_asm(const bf16_t* kbase, const Off4& off, bf16_t* img, int wave) {
+  const bf16_t* d = img + wave * 512;
+  dma16_su(kbase, off.o0, d);
+  dma16_su(kbase, off.o1, d + 2048);
+  dma16_su(kbase, off.o2, d + 4096);
+  dma16_su(kbase, off.o3, d + 6144);
+}
 __device__ __forceinline__ void glds_tile(const bf16_t* kbase, const Off4& off, bf16_t* img, int wave) {
   typedef __attribute__((address_space(1))) const void gptr_t;
   typedef __attribute__((address_space(3))) void lptr_t;
@@ -573,8 +604,13 @@ __device__ __forceinline__ void glds_tile(const bf16_t* kbase, const Off4& off, 
 
 // DBUF: two (A|B) tile pairs in LDS, the DMA of tile kt+1 in flight while tile kt is multiplied (one barrier per K-step,
 // 64 KB -> 2 workgroups per CU): for the long-K split-K weight gradients, where depth of pipeline beats occupancy.
-template <bool TA, bool TB, bool DBUF, bool F16 = false>
-__global__ __launch_bounds__(256, DBUF ? 2 : 4) void gemm_glds_kernel(GemmArgs a) {
+// DBUF == 2 (DEEP): a ring of four (A|B) tile pairs (128 KB: the workgroup owns its CU), three K-steps of DMA in flight
+// across raw s_barriers, retired with counted s_waitcnt vmcnt -- for launches of at most one workgroup per CU (small
+// batches: 13-56 tiles), where nothing else on the CU hides a K-step's ~1 us fetch latency.  Same products in the same
+// order as the other two forms: bit-identical results.
+constexpr int DEEP_STAGES = 4;
+template <bool TA, bool TB, int DBUF, bool F16 = false>
+__global__ __launch_bounds__(256, DBUF == 2 ? 1 : DBUF ? 2 : 4) void gemm_glds_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
   constexpr int TILE = BM * LDT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -607,14 +643,14 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 4) void gemm_glds_kernel(GemmArgs a
                  fb2 = load_frag<TB>(IMGB, wc * 64 + 32, KK, lane), fb3 = load_frag<TB>(IMGB, wc * 64 + 48, KK, lane); \
     MF(0, 0); MF(0, 1); MF(0, 2); MF(0, 3); MF(1, 0); MF(1, 1); MF(1, 2); MF(1, 3);                \
     MF(2, 0); MF(2, 1); MF(2, 2); MF(2, 3); MF(3, 0); MF(3, 1); MF(3, 2); MF(3, 3);                \
-    if (TA && DBUF && do_rs) {                                                                     \
+    if (TA && DBUF == 1 && do_rs) {                                                                \
       rs0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa0, rs0, 0, 0, 0);                      \
       rs1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa1, rs1, 0, 0, 0);                      \
       rs2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa2, rs2, 0, 0, 0);                      \
       rs3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa3, rs3, 0, 0, 0);                      \
     }                                                                                              \
   }
-  const bool do_rs = TA && DBUF && a.arowsum != nullptr && tn == 0 && wc == 0;   // (double-buffered variant only: register room)
+  const bool do_rs = TA && DBUF == 1 && a.arowsum != nullptr && tn == 0 && wc == 0;   // (double-buffered variant only: register room)
   const bf16x8 ones = ones_frag();
   f32x4 rs0 = {0.f, 0.f, 0.f, 0.f}, rs1 = rs0, rs2 = rs0, rs3 = rs0;
   if (!DBUF) {
@@ -626,6 +662,36 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 4) void gemm_glds_kernel(GemmArgs a
       GEMM_KK(smem, smem + TILE, 1);
       __syncthreads();   // every wave has read the tile before the next fetch overwrites it
     }
+  } else if (DBUF == 2) {
+    const int nt = kt1 - kt0;
+    const bf16_t* __restrict__ A0 = A + kt0 * kstepA;
+    const bf16_t* __restrict__ B0 = B + kt0 * kstepB;
+    // (a stage past the end of the K range re-fetches the last tile into a buffer nobody reads again: every thread then
+    //  always has the same number of loads in flight, which is what the counted waits assume)
+#define DEEP_ISSUE(T)                                                                        \
+    {                                                                                        \
+      const int tt = min((T), nt - 1);                                                       \
+      bf16_t* dst = smem + ((T) % DEEP_STAGES) * (2 * TILE);                                 \
+      glds_tile_asm(A0 + tt * kstepA, offA, dst, wave);                                      \
+      glds_tile_asm(B0 + tt * kstepB, offB, dst + TILE, wave);                               \
+    }
+    DEEP_ISSUE(0); DEEP_ISSUE(1); DEEP_ISSUE(2);
+    for (int t = 0; t < nt; ++t) {
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // 8 loads per stage: stages t+1, t+2 may stay in flight
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();   // stage t has landed for every wave; every wave is done reading stage t-1
+      __builtin_amdgcn_sched_barrier(0);
+      DEEP_ISSUE(t + 3);              // -> the buffer of stage t-1
+      __builtin_amdgcn_sched_barrier(0);
+      const bf16_t* img = smem + (t % DEEP_STAGES) * (2 * TILE);
+      GEMM_KK(img, img + TILE, 0);
+      GEMM_KK(img, img + TILE, 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();     // no DMA in flight, no read outstanding: LDS is free for the epilogue
+#undef DEEP_ISSUE
   } else {
     glds_tile(A + kt0 * kstepA, offA, smem, wave);
     glds_tile(B + kt0 * kstepB, offB, smem + TILE, wave);
@@ -646,7 +712,7 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 4) void gemm_glds_kernel(GemmArgs a
   }
 #undef GEMM_KK
 #undef MF
-  if (TA && DBUF && do_rs) arowsum_flush(a, rs0, rs1, rs2, rs3, m0 + wr * 64, lane);
+  if (TA && DBUF == 1 && do_rs) arowsum_flush(a, rs0, rs1, rs2, rs3, m0 + wr * 64, lane);
   const long long coff = zo * a.sCo + zi * a.sCi;
   const bool lead = (ks == 0);
   const int g4 = (lane >> 4) * 4, l15 = lane & 15;
@@ -842,25 +908,20 @@ __device__ __forceinline__ uint32_t big_offset1(int c, int ld, int row0) {
 }
 // kbase: wave-uniform origin of the piece (K-tile origin + piece offset); d2: element distance of the thread's second chunk
 __device__ __forceinline__ void big_issue(const bf16_t* kbase, long long d2, uint32_t off, bf16_t* piece, int wave) {
-  typedef __attribute__((address_space(1))) const void gptr_t;
-  typedef __attribute__((address_space(3))) void lptr_t;
-  const char* b = reinterpret_cast<const char*>(kbase);
-  bf16_t* d = piece + wave * 512;          // wave-instruction j covers chunks j*512 + wave*64 + lane
-  __builtin_amdgcn_global_load_lds((gptr_t*)(b + off), (lptr_t*)(d), 16, 0, 0);
-  __builtin_amdgcn_global_load_lds((gptr_t*)(reinterpret_cast<const char*>(kbase + d2) + off), (lptr_t*)(d + 4096), 16, 0, 0);
+  const bf16_t* d = piece + wave * 512;    // wave-instruction j covers chunks j*512 + wave*64 + lane
+  dma16_su(kbase, off, d);
+  dma16_su(kbase + d2, off, d + 4096);
 }
 
 // The LAST K-tile of a k-major operand whose K is not a multiple of 64 (token counts of small / ragged batches): the k rows
 // past the end are fetched from a zero chunk instead -- per-lane source select; a lane's two chunks are k rows k0 and k0 + 32.
 __device__ __forceinline__ void big_issue_tail(const bf16_t* kbase, long long d2, uint32_t off, bf16_t* piece, int wave, int kv, const void* zeros, int tid) {
-  typedef __attribute__((address_space(1))) const void gptr_t;
-  typedef __attribute__((address_space(3))) void lptr_t;
   const int k0 = tid >> 4;
   const char* p0 = k0 < kv ? reinterpret_cast<const char*>(kbase) + off : reinterpret_cast<const char*>(zeros);
   const char* p1 = k0 + 32 < kv ? reinterpret_cast<const char*>(kbase + d2) + off : reinterpret_cast<const char*>(zeros);
-  bf16_t* d = piece + wave * 512;
-  __builtin_amdgcn_global_load_lds((gptr_t*)p0, (lptr_t*)(d), 16, 0, 0);
-  __builtin_amdgcn_global_load_lds((gptr_t*)p1, (lptr_t*)(d + 4096), 16, 0, 0);
+  const bf16_t* d = piece + wave * 512;
+  dma16_v(p0, d);
+  dma16_v(p1, d + 4096);
 }
 
 // C[m][n] += sum over splits of slab[s][m][n]   (the second pass of the slab form of split-K)
@@ -1474,6 +1535,8 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
                                       {gemm_glds_kernel<true, false, false>, gemm_glds_kernel<true, true, false>}};
   static const kern_t gkerns2[2][2] = {{gemm_glds_kernel<false, false, true>, gemm_glds_kernel<false, true, true>},
                                        {gemm_glds_kernel<true, false, true>, gemm_glds_kernel<true, true, true>}};
+  static const kern_t gkerns3[2][2] = {{gemm_glds_kernel<false, false, 2>, gemm_glds_kernel<false, true, 2>},
+                                       {gemm_glds_kernel<true, false, 2>, gemm_glds_kernel<true, true, 2>}};
   // LDS-DMA tile fetch for every bare-load shape except the split-K weight gradients (measured: -15...-20 % on the
   // N >= 1536 / K >= 1536 shapes, equal at 512x512, +9 % on the atomic split-K ones); MMDTI_GEMM_GLDS=0 turns it off
   static const int use_glds = getenv("MMDTI_GEMM_GLDS") ? atoi(getenv("MMDTI_GEMM_GLDS")) : 1;
@@ -1542,6 +1605,8 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
     // tall tiles when they save a whole round of the 1024 resident workgroups (see gemm_glds_tall_kernel)
     int mstep = 0;
     static const int use_tall = getenv("MMDTI_GEMM_TALL") ? atoi(getenv("MMDTI_GEMM_TALL")) : 1;
+    static const int use_deep = getenv("MMDTI_GEMM_DEEP") ? atoi(getenv("MMDTI_GEMM_DEEP")) : 1;
+    static const int deep_max_wgs = getenv("MMDTI_GEMM_DEEP_WGS") ? atoi(getenv("MMDTI_GEMM_DEEP_WGS")) : 256;
     if (use_tall && !transA && a.vec_ok && grid.z == 1 && M >= 1024) {
       const int slots = 1024, tn = cdiv(N, BN);
       const int r128 = cdiv(tiles, slots);
@@ -1558,6 +1623,23 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
       if (ab16) hipLaunchKernelGGL((gemm_glds_tall_kernel<false, true>), grid, block, smem_t, s, a, mstep);
       else if (transB) hipLaunchKernelGGL(gemm_glds_tall_kernel<true>, grid, block, smem_t, s, a, mstep);
       else hipLaunchKernelGGL(gemm_glds_tall_kernel<false>, grid, block, smem_t, s, a, mstep);
+    } else if (use_deep && tiles * (int)grid.z <= deep_max_wgs && K >= 4 * BK) {
+      // at most one workgroup per CU: the four-stage ring hides the fetch latency nothing else would (small batches)
+      const size_t smem_d = (size_t)DEEP_STAGES * 2 * BM * LDT * sizeof(bf16_t);
+      static bool deep_attr = false;
+      if (!deep_attr) {
+        const void* fns[5] = {reinterpret_cast<const void*>(gkerns3[0][0]), reinterpret_cast<const void*>(gkerns3[0][1]),
+                              reinterpret_cast<const void*>(gkerns3[1][0]), reinterpret_cast<const void*>(gkerns3[1][1]),
+                              reinterpret_cast<const void*>(gemm_glds_kernel<false, false, 2, true>)};
+        for (int i = 0; i < 5; ++i)
+          if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_d) != hipSuccess) {
+            set_error("gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", smem_d);
+            return MMDTI_ERR_LAUNCH;
+          }
+        deep_attr = true;
+      }
+      if (ab16) hipLaunchKernelGGL((gemm_glds_kernel<false, false, 2, true>), grid, block, smem_d, s, a);
+      else hipLaunchKernelGGL(gkerns3[transA ? 1 : 0][transB ? 1 : 0], grid, block, smem_d, s, a);
     } else if (ab16) {
       hipLaunchKernelGGL((gemm_glds_kernel<false, false, false, true>), grid, block, smem, s, a);
     } else {

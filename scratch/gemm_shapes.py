@@ -11,8 +11,14 @@ model, _ = bench.build_model()
 model = model.cuda().train()
 model.overlap_towers = False; model.infonce_on_side_stream = False; model.cross_modal_module.two_streams = False; Fn.DEFER_WGRAD_LAYERS = 0
 tuner = FineTuner(model, "classification", total_steps=1000)
-_, batch, label = bench.synth(256, 128, 256, seed=1234)
+GS_B, GS_RAG = int(os.environ.get("GS_BATCH", "256")), os.environ.get("GS_RAGGED") == "1"   # GS_BATCH=32 GS_RAGGED=1: the small-batch step
+_, batch, label = bench.synth(GS_B, 128, 256, seed=1234, ragged=GS_RAG)
+host = {}
+if GS_RAG:
+    from mmdti_hip.collate import packing_fields, atom_counts
+    host = dict(packing_fields(batch), atom_counts=atom_counts(batch["src_tokens"], 0))
 batch = {k: v.cuda() for k, v in batch.items()}; label = label.cuda()
+batch.update(host)
 for _ in range(3): tuner.step(batch, label)
 torch.cuda.synchronize()
 ops.kernel_timer.enable(("gemm",))
