@@ -57,7 +57,9 @@ const char* mmdti_last_error(void);
 int mmdti_abi_version(void);
 /* Run-time tuning switches (A/B measurements inside one process; defaults come from the environment variable of the same
  * upper-cased name, e.g. MMDTI_GEMM_BIG).  Known names: "gemm_big" (0 off, 1 where the shape fills the chip, 2 every
- * eligible shape); "gemm_dbg" (measurement only: 1 = the large-tile GEMM skips its epilogue).  Returns MMDTI_ERR_INVALID for an unknown name.  Not part of any reference interface. */
+ * eligible shape); "gemm_dbg" (measurement only: 1 = the large-tile GEMM skips its epilogue); "gemm_small" (1: 64 x 64 tiles for launches of
+ * few tiles -- small batches; 0: 128 x 128 everywhere) and "gemm_deep" (1: four-stage LDS-DMA ring for launches of at most one
+ * workgroup per CU); all paths give bit-identical results.  Returns MMDTI_ERR_INVALID for an unknown name.  Not part of any reference interface. */
 int mmdti_set_option(const char* name, int value);
 
 /* ---- GEMM: C = epi(alpha * A.B^T) ----------------------------------------------------------

@@ -759,6 +759,123 @@ __global__ __launch_bounds__(256, DBUF == 2 ? 1 : DBUF ? 2 : 4) void gemm_glds_k
 }
 
 // =====================================================================================================================
+// 64 x 64 tiles for SMALL launches -- the reference's default batch of 16-32 molecules gives GEMMs of 1-3 k rows: 13-56
+// tiles of 128 x 128 on 256 CUs, each a lone workgroup walking 8-32 K-steps whose fetch -> barrier -> fragment reads -> MFMA
+// chain nothing overlaps (measured: ~1.45 us per K-step single-buffered, ~0.97 us behind the four-stage ring above).  A
+// quarter of the tile per workgroup puts 4 x as many CUs to work and shortens the chain of a K-step to 8 fragment reads +
+// 8 MFMAs per wave; the (A|B) pairs arrive through a four-stage LDS-DMA ring (inline-assembly DMA, counted waits: two
+// stages stay in flight across the barrier).  A row-major ([M,K]) only; B row-major ([N,K]) or k-major ([K,N]); the
+// vector epilogue only (the dispatch keeps everything else on the 128 x 128 kernels).  Products are summed in the same
+// order as there: results are bit-identical.
+constexpr int SBM = 64, SBN = 64, SM_STAGES = 4;
+constexpr int SM_TILE = SBM * BK;      // elements of one operand tile (8 KB)
+constexpr int LDC_SM = SBN + 4;        // fp32 row stride of the epilogue's [64][68] staging image
+// [k][64] image of a k-major operand: 128-byte rows, so two consecutive k share the 64 banks; the 32-byte pieces of a row are
+// XOR-ed by ((k >> 1) & 1) | ((k >> 3) & 1) << 1 -- the eight k rows a tr-read half-wave touches (q and 8 + q, q = 0..3)
+// then land on eight distinct 32-byte bank groups.
+__device__ __forceinline__ int tr_swz64(int k) { return ((((k >> 1) & 1) | (((k >> 3) & 1) << 1))) * 16; }
+template <bool TR>
+__device__ __forceinline__ uint32_t small_offset1(int c, int ld, int row0, int rows) {   // chunk c of 512
+  if (!TR) {   // the first 64 rows of the 128-row [row][k] image
+    const int rl = c >> 3, kc = (c & 7) ^ (rl & 7);
+    const int row = min(row0 + rl, rows - 1);
+    return (uint32_t)(((long long)row * ld + kc * 8) * 2);
+  } else {
+    const int k = c >> 3, rs = (c & 7) ^ (tr_swz64(k) >> 3);
+    const int row = min(row0 + rs * 8, rows - 8);
+    return (uint32_t)(((long long)k * ld + row) * 2);
+  }
+}
+template <bool TR>
+__device__ __forceinline__ bf16x8 small_frag(const bf16_t* img, int row0, int kk, int lane) {
+  if (!TR) {
+    return load_frag<false>(img, row0, kk, lane);
+  } else {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int k = kk * 32 + (lane >> 4) * 8 + ((lane & 15) >> 2);
+    const int col = row0 + (lane & 3) * 4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + k * SBN + (col ^ tr_swz64(k))));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + (k + 4) * SBN + (col ^ tr_swz64(k + 4))));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+template <bool TB, bool F16>
+__global__ __launch_bounds__(256, 2) void gemm_small_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_n = (a.N + SBN - 1) / SBN, tiles_m = (a.M + SBM - 1) / SBM;
+  const int nwg = tiles_n * tiles_m;
+  const int orig = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+  const int m0 = tm * SBM, n0 = tn * SBN;
+  const bf16_t* __restrict__ A = a.A;
+  const bf16_t* __restrict__ B = a.B;
+  const int nt = a.K / BK;
+  const uint32_t oA0 = small_offset1<false>(tid, a.lda, m0, a.M), oA1 = small_offset1<false>(tid + 256, a.lda, m0, a.M);
+  const uint32_t oB0 = small_offset1<TB>(tid, a.ldb, n0, a.N), oB1 = small_offset1<TB>(tid + 256, a.ldb, n0, a.N);
+  const long long kstepB = TB ? (long long)BK * a.ldb : BK;
+  // (a stage past the end of the K range re-fetches the last tile into a buffer nobody reads again: every thread always has
+  //  the same number of loads in flight, which is what the counted waits assume)
+#define SM_ISSUE(T)                                                                  \
+  {                                                                                  \
+    const int tt = min((T), nt - 1);                                                 \
+    const bf16_t* dst = smem + ((T) % SM_STAGES) * (2 * SM_TILE) + wave * 512;       \
+    dma16_su(A + tt * BK, oA0, dst);                                                 \
+    dma16_su(A + tt * BK, oA1, dst + 2048);                                          \
+    dma16_su(B + tt * kstepB, oB0, dst + SM_TILE);                                   \
+    dma16_su(B + tt * kstepB, oB1, dst + SM_TILE + 2048);                            \
+  }
+  f32x4 acc[2][2] = {};
+  SM_ISSUE(0); SM_ISSUE(1); SM_ISSUE(2);
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // 4 loads per stage: stages t+1, t+2 may stay in flight
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();   // stage t has landed for every wave; every wave is done reading stage t-1
+    __builtin_amdgcn_sched_barrier(0);
+    SM_ISSUE(t + 3);                // -> the buffer of stage t-1
+    __builtin_amdgcn_sched_barrier(0);
+    const bf16_t* imgA = smem + (t % SM_STAGES) * (2 * SM_TILE);
+    const bf16_t* imgB = imgA + SM_TILE;
+    const bf16x8 fa00 = small_frag<false>(imgA, wr * 32, 0, lane), fa10 = small_frag<false>(imgA, wr * 32 + 16, 0, lane);
+    const bf16x8 fb00 = small_frag<TB>(imgB, wc * 32, 0, lane), fb10 = small_frag<TB>(imgB, wc * 32 + 16, 0, lane);
+    const bf16x8 fa01 = small_frag<false>(imgA, wr * 32, 1, lane), fa11 = small_frag<false>(imgA, wr * 32 + 16, 1, lane);
+    const bf16x8 fb01 = small_frag<TB>(imgB, wc * 32, 1, lane), fb11 = small_frag<TB>(imgB, wc * 32 + 16, 1, lane);
+    acc[0][0] = mfma32<F16>(fb00, fa00, acc[0][0]); acc[0][1] = mfma32<F16>(fb10, fa00, acc[0][1]);
+    acc[1][0] = mfma32<F16>(fb00, fa10, acc[1][0]); acc[1][1] = mfma32<F16>(fb10, fa10, acc[1][1]);
+    acc[0][0] = mfma32<F16>(fb01, fa01, acc[0][0]); acc[0][1] = mfma32<F16>(fb11, fa01, acc[0][1]);
+    acc[1][0] = mfma32<F16>(fb01, fa11, acc[1][0]); acc[1][1] = mfma32<F16>(fb11, fa11, acc[1][1]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();     // no DMA in flight, no read outstanding: LDS is free for the epilogue
+#undef SM_ISSUE
+  float* sC = reinterpret_cast<float*>(smem);
+  const int g4 = (lane >> 4) * 4, l15 = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      *reinterpret_cast<f32x4*>(sC + (wr * 32 + i * 16 + l15) * LDC_SM + wc * 32 + j * 16 + g4) = acc[i][j];
+  const EpiBias ebias = epi_bias(a, n0 + (tid & 7) * 8, true);
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int chunk = tid + it * 256;
+    const int rr = chunk >> 3, cc = (chunk & 7) * 8;
+    const int row = m0 + rr, col = n0 + cc;
+    if (row < a.M && col < a.N) epilogue_oct(a, sC + rr * LDC_SM + cc, row, col, true, 0, nullptr, ebias.b0, ebias.b1);
+  }
+}
+
+// =====================================================================================================================
 // Tall-tile variant of the LDS-DMA kernel: 144 x 128 tiles that ADVANCE by `mstep` rows (129...144), the rows past mstep
 // being computed but not stored.  Why: the resident set is 4 workgroups x 256 CUs = 1024 tiles, and the tower-1 GEMMs
 // have M = 256 molecules x 130 rows = 260 x 128 -- 1040 / 3120 / 4160 tiles, i.e. 2 / 4 / 5 rounds where 1.02 / 3.05 /
@@ -1406,6 +1523,8 @@ MMDTI_DEFINE_SALT_PULL(gemm)
 using namespace mmdti;
 
 static int g_gemm_big = getenv("MMDTI_GEMM_BIG") ? atoi(getenv("MMDTI_GEMM_BIG")) : 1;
+static int g_gemm_small = getenv("MMDTI_GEMM_SMALL") ? atoi(getenv("MMDTI_GEMM_SMALL")) : 1;   // 64 x 64 tiles for small launches
+static int g_gemm_deep = getenv("MMDTI_GEMM_DEEP") ? atoi(getenv("MMDTI_GEMM_DEEP")) : 1;      // four-stage ring at <= 1 workgroup per CU
 
 // 256 zero bytes in device memory (see GemmArgs::zeros); allocated at the first call that needs it
 static const void* zero_page() {
@@ -1422,6 +1541,8 @@ extern "C" int mmdti_set_option(const char* name, int value) {
   MMDTI_REQUIRE(name != nullptr, "set_option: null name");
   if (strcmp(name, "gemm_big") == 0) { g_gemm_big = value; return MMDTI_OK; }
   if (strcmp(name, "gemm_dbg") == 0) { g_gemm_dbg = value; return MMDTI_OK; }
+  if (strcmp(name, "gemm_small") == 0) { g_gemm_small = value; return MMDTI_OK; }
+  if (strcmp(name, "gemm_deep") == 0) { g_gemm_deep = value; return MMDTI_OK; }
   set_error("set_option: unknown option '%s'", name);
   return MMDTI_ERR_INVALID;
 }
@@ -1605,7 +1726,9 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
     // tall tiles when they save a whole round of the 1024 resident workgroups (see gemm_glds_tall_kernel)
     int mstep = 0;
     static const int use_tall = getenv("MMDTI_GEMM_TALL") ? atoi(getenv("MMDTI_GEMM_TALL")) : 1;
-    static const int use_deep = getenv("MMDTI_GEMM_DEEP") ? atoi(getenv("MMDTI_GEMM_DEEP")) : 1;
+    const int use_small = g_gemm_small;
+    static const int small_max_tiles = getenv("MMDTI_GEMM_SMALL_TILES") ? atoi(getenv("MMDTI_GEMM_SMALL_TILES")) : 128;
+    const int use_deep = g_gemm_deep;
     static const int deep_max_wgs = getenv("MMDTI_GEMM_DEEP_WGS") ? atoi(getenv("MMDTI_GEMM_DEEP_WGS")) : 256;
     if (use_tall && !transA && a.vec_ok && grid.z == 1 && M >= 1024) {
       const int slots = 1024, tn = cdiv(N, BN);
@@ -1623,6 +1746,14 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
       if (ab16) hipLaunchKernelGGL((gemm_glds_tall_kernel<false, true>), grid, block, smem_t, s, a, mstep);
       else if (transB) hipLaunchKernelGGL(gemm_glds_tall_kernel<true>, grid, block, smem_t, s, a, mstep);
       else hipLaunchKernelGGL(gemm_glds_tall_kernel<false>, grid, block, smem_t, s, a, mstep);
+    } else if (use_small && !transA && a.vec_ok && c_dtype != MMDTI_DT_F32_ATOMIC && !colsum_out && grid.z == 1 && tiles <= small_max_tiles &&
+               !(ab16 && transB)) {
+      // small launches: a quarter of the tile per workgroup, four times the CUs (see gemm_small_kernel)
+      const dim3 sgrid(cdiv(M, SBM) * cdiv(N, SBN));
+      const size_t smem_s = (size_t)SM_STAGES * 2 * SM_TILE * sizeof(bf16_t);
+      if (ab16) hipLaunchKernelGGL((gemm_small_kernel<false, true>), sgrid, block, smem_s, s, a);
+      else if (transB) hipLaunchKernelGGL((gemm_small_kernel<true, false>), sgrid, block, smem_s, s, a);
+      else hipLaunchKernelGGL((gemm_small_kernel<false, false>), sgrid, block, smem_s, s, a);
     } else if (use_deep && tiles * (int)grid.z <= deep_max_wgs && K >= 4 * BK) {
       // at most one workgroup per CU: the four-stage ring hides the fetch latency nothing else would (small batches)
       const size_t smem_d = (size_t)DEEP_STAGES * 2 * BM * LDT * sizeof(bf16_t);

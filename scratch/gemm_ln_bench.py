@@ -15,7 +15,7 @@ def bench(fn, iters=30):
     return e0.elapsed_time(e1) / iters * 1e3
 
 rows = []
-for M, K, f32 in ((33280, 512, False), (33280, 2048, False), (65536, 512, True), (65536, 2048, True), (12713, 512, False), (12713, 2048, False), (9823, 2048, True), (1600, 512, False), (1600, 2048, False)):
+for M, K, f32 in ((33280, 512, False), (33280, 2048, False), (65536, 512, True), (65536, 2048, True), (12713, 512, False), (12713, 2048, False), (9823, 2048, True), (6400, 512, False), (4800, 512, False), (3200, 512, False), (1600, 512, False), (1600, 2048, False)):
     x = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(512, K, device="cuda") * 0.05).bfloat16()
     b = torch.randn(512, device="cuda"); res = torch.randn(M, 512, device="cuda"); g = torch.ones(512, device="cuda"); be = torch.zeros(512, device="cuda")
     def fused(): ops.linear_ln_fwd(x, w, b, g, be, 1e-5, residual=res, drop_p=0.1, seed=1, site=1, want_f32=f32, want_bf16=True)

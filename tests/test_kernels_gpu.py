@@ -1146,6 +1146,43 @@ def test_gemm_tall_tiles_match_square_tiles(ops, transB, monkeypatch):
     assert torch.isfinite(yb.float()).all()
 
 
+@pytest.mark.parametrize("M,N,K", [(1695, 512, 2048), (1311, 2048, 512), (8, 64, 64), (77, 520, 128), (3000, 1536, 512), (640, 512, 192)])
+@pytest.mark.parametrize("transB", [False, True])
+def test_gemm_small_launch_paths_are_bitwise_the_128_tile_kernel(ops, M, N, K, transB):
+    """Small launches (the reference's default batch of 16-32 molecules) take 64 x 64 tiles behind a four-stage LDS-DMA ring
+    (gemm_small_kernel) or, past its tile limit, the four-stage ring on 128 x 128 tiles: both sum the same products in the
+    same order as the single-buffered 128 x 128 kernel, so every fused epilogue gives the SAME BITS on all three paths."""
+    from mmdti_hip import _abi
+    lib = _abi.lib()
+    x = dev(bf(torch.randn(M, K, generator=G(1))))
+    w = dev(bf(torch.randn(K, N, generator=G(2)))) if transB else dev(bf(torch.randn(N, K, generator=G(2))))
+    bias, res = dev(torch.randn(N, generator=G(3))), dev(torch.randn(M, N, generator=G(4)))
+    u = dev(bf(torch.randn(M, N, generator=G(5))))
+    base = dict(M=M, N=N, K=K, lda=K, ldb=(N if transB else K), transB=transB)
+    cases = [dict(bias=bias), dict(bias=bias, residual=res, out_dtype=torch.float32, drop_p=0.1, seed=5, site=2),
+             dict(bias=bias, act=ops.ACT_GELU, aux_out=torch.empty(M, N, device="cuda", dtype=torch.bfloat16)),
+             dict(act=ops.ACT_GELU_BWD, aux_in=u), dict(out_dtype=torch.float32)]
+    outs = {}
+    try:
+        for name, (small, deep) in {"small": (1, 1), "deep": (0, 1), "plain": (0, 0)}.items():
+            lib.mmdti_set_option(b"gemm_small", small); lib.mmdti_set_option(b"gemm_deep", deep)
+            outs[name] = []
+            for kw in cases:
+                kw = dict(kw)
+                if "aux_out" in kw:
+                    kw["aux_out"] = torch.empty_like(kw["aux_out"])
+                y = ops.gemm(x, w, **base, **kw)
+                outs[name].append((y.clone(), kw["aux_out"].clone() if "aux_out" in kw else None))
+    finally:
+        lib.mmdti_set_option(b"gemm_small", 1); lib.mmdti_set_option(b"gemm_deep", 1)
+    for name in ("small", "deep"):
+        for (y, aux), (y0, aux0) in zip(outs[name], outs["plain"]):
+            assert torch.equal(y, y0), name
+            assert aux is None or torch.equal(aux, aux0), name
+    wf = w.float() if transB else w.float().t()
+    close(outs["small"][4][0], x.float() @ wf, 2e-3, 2e-2 * (K ** 0.5))
+
+
 @pytest.mark.parametrize("M,K,R", [(1, 512, 0), (63, 512, 0), (64, 64, 0), (130, 2048, 0), (1000, 512, 80), (3333, 2048, 64), (33280, 512, 0), (12713, 2048, 0)])
 def test_gemm_ln_fused_matches_gemm_then_layernorm(ops, M, K, R, monkeypatch):
     """mmdti_gemm_ln_bf16: the Linear that closes a residual branch and the LayerNorm behind it in one kernel (N = 512) against the
