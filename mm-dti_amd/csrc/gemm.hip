@@ -693,20 +693,26 @@ __global__ __launch_bounds__(256, DBUF == 2 ? 1 : DBUF ? 2 : 4) void gemm_glds_k
     __builtin_amdgcn_s_barrier();     // no DMA in flight, no read outstanding: LDS is free for the epilogue
 #undef DEEP_ISSUE
   } else {
-    glds_tile(A + kt0 * kstepA, offA, smem, wave);
-    glds_tile(B + kt0 * kstepB, offB, smem + TILE, wave);
-    __syncthreads();
+    // (inline-assembly DMA here too: behind the builtin the compiler drained vmcnt in front of the first ds_read_b64_tr_b16 of
+    //  tile kt -- the prefetch of tile kt+1 never ran under the multiply on the k-major operands this variant exists for)
+    glds_tile_asm(A + kt0 * kstepA, offA, smem, wave);
+    glds_tile_asm(B + kt0 * kstepB, offB, smem + TILE, wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     int cur = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
       bf16_t* nxt = smem + (cur ^ 1) * (2 * TILE);
       if (kt + 1 < kt1) {
-        glds_tile(A + (kt + 1) * kstepA, offA, nxt, wave);
-        glds_tile(B + (kt + 1) * kstepB, offB, nxt + TILE, wave);
+        glds_tile_asm(A + (kt + 1) * kstepA, offA, nxt, wave);
+        glds_tile_asm(B + (kt + 1) * kstepB, offB, nxt + TILE, wave);
       }
+      __builtin_amdgcn_sched_barrier(0);
       const bf16_t* img = smem + cur * (2 * TILE);
       GEMM_KK(img, img + TILE, 0);
       GEMM_KK(img, img + TILE, 1);
-      __syncthreads();   // drains the DMA of tile kt+1 and closes the reads of tile kt
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the DMA of tile kt+1 has landed, the reads of tile kt are retired
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
       cur ^= 1;
     }
   }

@@ -88,10 +88,19 @@ class _Lib:
             raise MMDTIError(f"{name} failed (code {rc}): {msg.decode() if msg else '?'}")
 
     def __getattr__(self, name):
+        # (reached once per symbol: the checked caller is cached on the instance, so later lookups skip this method)
         if name.startswith("mmdti_"):
             fn = getattr(self._dll, name)
             if self.protos[name][0] is ctypes.c_int and name != "mmdti_abi_version":
-                return lambda *a: self.call(name, *a)
+                last_error = self._last_error
+
+                def checked(*a, _fn=fn, _name=name):
+                    rc = _fn(*a)
+                    if rc != 0:
+                        msg = last_error()
+                        raise MMDTIError(f"{_name} failed (code {rc}): {msg.decode() if msg else '?'}")
+                fn = checked
+            self.__dict__[name] = fn
             return fn
         raise AttributeError(name)
 

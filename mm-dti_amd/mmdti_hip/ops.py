@@ -51,8 +51,12 @@ def _chk16(t, name, contiguous=True):
 CT_REGRESS, CT_SINGLE, CT_MULTI = 0, 1, 2
 
 
+_raw_stream, _raw_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    # (torch.cuda.current_stream().cuda_stream costs ~9 us of Python per call -- a third of a small-batch step's host time)
+    return _raw_stream(_raw_device())
 
 
 def _p(t):
