@@ -90,6 +90,24 @@ def cpu_baseline(atoms, tokens, sample_B=32, iters=3, scaling_B=8):
     return out
 
 
+def pmc_traffic_family(kernel_prefix):
+    """launch-weighted mean HBM bytes per launch over EVERY kernel whose name starts with `kernel_prefix` (the GEMM family: a dozen
+    kernels and shapes), from the same PMC summary as pmc_traffic (whose passes run the headline step only)."""
+    import csv
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_hbm_traffic.csv")), reverse=True):
+        try:
+            n = b = 0.0
+            with open(path) as f:
+                for row in csv.DictReader(line for line in f if not line.startswith("#")):
+                    if row["kernel"].replace("mmdti::", "").startswith(kernel_prefix):
+                        n += float(row["launches"]); b += float(row["launches"]) * float(row["hbm_bytes_per_launch"])
+            if n:
+                return int(b / n), os.path.basename(path)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
 def pmc_traffic(kernel_prefix):
     """HBM bytes per launch of `kernel_prefix` from the NEWEST committed PMC summary (profiles/r*_bench_pmc_hbm_traffic.csv:
     separate FETCH_SIZE / WRITE_SIZE rocprofv3 passes of this command, gfx950 corrections applied by profiles/summarize.py).
@@ -132,7 +150,7 @@ def family_rooflines(summary, steps):
         rate = d["work"] / (d["total_ms"] * 1e-3)
         peak = HBM_PEAK_GBS if bound == "hbm" else MFMA_PEAK_TFS
         ach = rate / 1e9 if bound == "hbm" else rate / 1e12
-        traffic, src = pmc_traffic(prefix) if name != "gemm" else (None, None)   # (one family, many kernels and shapes: no single figure)
+        traffic, src = pmc_traffic(prefix) if name != "gemm" else pmc_traffic_family(prefix)   # (one family, many kernels: launch-weighted mean)
         rows.append({"kernel": name, "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
                      "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": src,
                      ("algorithmic_bytes_per_launch" if bound == "hbm" else "algorithmic_flop_per_launch"): int(per_launch),

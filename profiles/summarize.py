@@ -92,7 +92,7 @@ def pmc(fetch_dir, write_dir, dst):
     rows.sort(key=lambda r: -r[4] * r[1])
     with open(dst, "w") as f:
         f.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python bench.py --steps 1 --warmup 1 "
-                "--no-cpu-baseline; hbm_bytes_per_launch = 2*FETCH_SIZE_KB*1024 + WRITE_SIZE_KB*1024 (gfx950 correction of MI355X_MICROARCH.md)\n")
+                "--no-cpu-baseline --no-rooflines --no-ragged-workload (the headline step only); hbm_bytes_per_launch = 2*FETCH_SIZE_KB*1024 + WRITE_SIZE_KB*1024 (gfx950 correction of MI355X_MICROARCH.md)\n")
         w = csv.writer(f)
         w.writerow(["kernel", "launches", "FETCH_SIZE_KB_mean", "WRITE_SIZE_KB_mean", "hbm_bytes_per_launch"])
         for r in rows[:30]:
@@ -119,7 +119,7 @@ def rdreq(src, dst, src2=None):
     rows.sort(key=lambda r: -r[5] * r[1])
     with open(dst, "w") as f:
         f.write("# rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum (+ a pass with TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum)"
-                " -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-rooflines\n")
+                " -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-rooflines --no-ragged-workload\n")
         w = csv.writer(f)
         w.writerow(["kernel", "launches", "RDREQ_mean", "RDREQ_32B_mean", "read_bytes_if_64B_requests", "read_bytes_if_128B_requests",
                     "RDREQ_64B_mean", "RDREQ_128B_mean", "read_bytes_by_size"])
