@@ -41,19 +41,16 @@ struct AttnShape {
   static constexpr int NB = HD / 16;  // 16-wide head_dim blocks of an output
 };
 
-__device__ __forceinline__ uint32_t attn_rng_key(uint64_t seed, uint32_t site, uint32_t bh) {
-  seed = salted(seed);
-  return mix32((mix32((uint32_t)seed ^ (site * 0x9E3779B9u)) ^ (uint32_t)(seed >> 32)) + bh * 0x85EBCA6Bu);
-}
-// Dropout of the probabilities.  Element (query, key) belongs to QUAD = query * (key_stride / 4) + key / 4 (four consecutive
-// keys of one query), bit key & 3 of that quad's 4-bit keep mask: two avalanche hashes give four 16-bit uniforms, kept iff
-// >= thresh16 (p quantised to 1/65536).  One call per accumulator quad instead of one two-multiply hash per ELEMENT: 32-bit
-// integer multiplies issue at quarter rate, and that hash was over half of the forward kernel's VALU time.
-__device__ __forceinline__ uint32_t attn_keep4(uint32_t key, uint32_t quad, uint32_t thresh16) {
-  const uint32_t a = mix32(quad ^ key);
-  const uint32_t b = mix32(a ^ 0xB5297A4Du);
-  return ((a & 0xffffu) >= thresh16 ? 1u : 0u) | ((a >> 16) >= thresh16 ? 2u : 0u) | ((b & 0xffffu) >= thresh16 ? 4u : 0u) |
-         ((b >> 16) >= thresh16 ? 8u : 0u);
+// Dropout of the probabilities: the shared generator of common.h (Rng24: a key per (sequence, head) plane, one word per four
+// consecutive keys of a query, a threshold per query row) -- the same function in all three kernels.
+typedef Rng24 AttnRng;
+__device__ __forceinline__ AttnRng attn_rng_key(uint64_t seed, uint32_t site, uint32_t bh) { return rng24_key(seed, site, bh); }
+__device__ __forceinline__ uint32_t attn_hash24(const AttnRng& k, uint32_t ctr) { return rng24_word(k, ctr); }
+__device__ __forceinline__ uint32_t attn_row_t8(const AttnRng& k, uint32_t row, uint32_t thresh) { return rng24_row_t8(k, row, thresh); }
+// bit r of the result: element r of the quad is kept
+__device__ __forceinline__ uint32_t attn_keep4(const AttnRng& k, uint32_t quad, uint32_t t8) {
+  const uint32_t h = rng24_word(k, quad);
+  return ((h & 0xffu) >= t8 ? 1u : 0u) | (((h >> 8) & 0xffu) >= t8 ? 2u : 0u) | (((h >> 16) & 0xffu) >= t8 ? 4u : 0u) | ((h >> 24) >= t8 ? 8u : 0u);
 }
 // Logits are carried in base-2 units (scale * log2 e folded into the scale and the additive key mask), so that the softmax
 // exponential is a bare v_exp_f32.  A finite "minus infinity" mask (finfo.min) stays finite: a fully masked row then softmaxes
@@ -142,7 +139,7 @@ __device__ __forceinline__ void attn_store4(bf16_t* dst, const f32x4& a) {
 
 // ------------------------------------------------------------------------------------------------------ forward
 template <int HD, int NT>
-__global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+__global__ __launch_bounds__(512, HD == 16 ? 2 : 4) void attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                        const bf16_t* __restrict__ v, const float* __restrict__ key_add,
                                                        bf16_t* __restrict__ ctx, float* __restrict__ stats, int heads, int Lq,
                                                        int Lk, int ldq, int ldk, int ldo, float scale, uint32_t thresh16,
@@ -159,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
   attn_fill_rows<HD>(sV, v + (long long)sq.k0 * ldk + h * HD, sq.lk, NP, ldk, tid, blockDim.x);
   for (int t = tid; t < NP; t += blockDim.x) sKA[t] = t < sq.lk ? (key_add ? attn_mask2(key_add[(long long)b * Lk + t]) : 0.f) : -INFINITY;
   __syncthreads();
-  const uint32_t rkey = attn_rng_key(seed, site, (uint32_t)bh);
+  const AttnRng rkey = attn_rng_key(seed, site, (uint32_t)bh);
   const float scale2 = scale * ATTN_LOG2E;
   const int g = lane >> 4, i = lane & 15;
   const int nqt = (sq.lq + 15) >> 4;
@@ -178,23 +175,24 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
       for (int c = 0; c < KC; ++c) acc = ATTN_MFMA(attn_frag_rm<HD>(sK, t * 16, c, lane), qf[c], acc);
       const f32x4 ka = *reinterpret_cast<const f32x4*>(&sKA[t * 16 + 4 * g]);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = acc[r] * scale2 + ka[r];
+      acc = acc * scale2 + ka;     // (vector form: two v_pk_fma_f32)
       m = fmaxf(fmaxf(m, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
       S[t] = acc;
       __builtin_amdgcn_sched_barrier(0);  // keep the unrolled tiles in order: hoisted LDS fragments would spill
     }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float lsum = 0.f;
+    f32x4 ls4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+      const f32x4 d = S[t] - m;    // (two v_pk_add_f32)
+      f32x4 e;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = __builtin_amdgcn_exp2f(S[t][r] - m);
-        S[t][r] = e;
-        lsum += e;
-      }
+      for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(d[r]);
+      S[t] = e;
+      ls4 += e;
+    }
+    float lsum = (ls4[0] + ls4[1]) + (ls4[2] + ls4[3]);
     lsum += __shfl_xor(lsum, 16, 64);
     lsum += __shfl_xor(lsum, 32, 64);
     const float inv = 1.0f / lsum;
@@ -202,17 +200,19 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
     f32x4 o[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) o[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float invd = thresh16 ? inv * dscale : inv;
+    // the UNNORMALISED exponentials (<= 1) are the MFMA operand; 1 / sum (and the dropout scale) multiply the 16 outputs of a
+    // lane once instead of its 4 NT probabilities
+    const uint32_t t8 = thresh16 ? attn_row_t8(rkey, (uint32_t)qi, thresh16) : 0u;
 #pragma unroll
     for (int u = 0; u < NT / 2; ++u) {
-      f32x4 p0 = S[2 * u] * invd, p1 = S[2 * u + 1] * invd;
+      f32x4 p0 = S[2 * u], p1 = S[2 * u + 1];
       if (thresh16) {
         const uint32_t q4 = (uint32_t)qi * (NP / 4) + (2 * u) * 4 + g;
-        const uint32_t k0 = attn_keep4(rkey, q4, thresh16), k1 = attn_keep4(rkey, q4 + 4, thresh16);
+        const uint32_t h0 = attn_hash24(rkey, q4), h1 = attn_hash24(rkey, q4 + 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          p0[r] = (k0 >> r) & 1u ? p0[r] : 0.f;
-          p1[r] = (k1 >> r) & 1u ? p1[r] : 0.f;
+          p0[r] = ((h0 >> (8 * r)) & 0xffu) >= t8 ? p0[r] : 0.f;
+          p1[r] = ((h1 >> (8 * r)) & 0xffu) >= t8 ? p1[r] : 0.f;
         }
       }
       const bf16x8 pf = attn_pack(p0, p1);
@@ -220,6 +220,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
       for (int nb = 0; nb < NB; ++nb) o[nb] = ATTN_MFMA(attn_frag_tr<HD>(sV, 32 * u, 32 * u + 16, nb * 16, lane), pf, o[nb]);
       __builtin_amdgcn_sched_barrier(0);
     }
+    const float invd = thresh16 ? inv * dscale : inv;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) o[nb] = o[nb] * invd;
     if (qv) {
       bf16_t* dst = ctx + ((long long)sq.q0 + qi) * ldo + h * HD + 4 * g;
 #pragma unroll
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const bf16_t* __restric
   attn_fill_rows<HD>(sV, v + (long long)sq.k0 * ldk + h * HD, sq.lk, NP, ldk, tid, blockDim.x);
   for (int t = tid; t < NP; t += blockDim.x) sKA[t] = t < sq.lk ? (key_add ? attn_mask2(key_add[(long long)b * Lk + t]) : 0.f) : -INFINITY;
   __syncthreads();
-  const uint32_t rkey = attn_rng_key(seed, site, (uint32_t)bh);
+  const AttnRng rkey = attn_rng_key(seed, site, (uint32_t)bh);
   const float scale2 = scale * ATTN_LOG2E;
   const int g = lane >> 4, i = lane & 15;
   const int nqt = (sq.lq + 15) >> 4;
@@ -274,6 +277,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const bf16_t* __restric
     }
     float2 st = make_float2(0.f, 0.f);
     if (qv) st = *reinterpret_cast<const float2*>(stats + attn_stat_row(vl, sq, bh, h, Lq, qi) * 2);
+    const uint32_t t8 = thresh16 ? attn_row_t8(rkey, (uint32_t)qi, thresh16) : 0u;
     // sweep 1: probabilities (kept in registers, sign bit = "dropped") and the row term D = sum_j dP'_ij p_ij
     f32x4 P[NT];
     float dsum = 0.f;
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const bf16_t* __restric
         dacc = ATTN_MFMA(attn_frag_rm<HD>(sV, t * 16, c, lane), dof[c], dacc);
       }
       const f32x4 ka = *reinterpret_cast<const f32x4*>(&sKA[t * 16 + 4 * g]);
-      const uint32_t km = thresh16 ? attn_keep4(rkey, (uint32_t)qi * (NP / 4) + t * 4 + g, thresh16) : 15u;
+      const uint32_t km = thresh16 ? attn_keep4(rkey, (uint32_t)qi * (NP / 4) + t * 4 + g, t8) : 15u;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float p = __builtin_amdgcn_exp2f(acc[r] * scale2 + ka[r] - st.x) * st.y;
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const bf16_t* __restric
 
 // ------------------------------------------------------------------------------------------------------ backward: dK, dV
 template <int HD>
-__global__ __launch_bounds__(512, 2) void attn_bwd_kv_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+__global__ __launch_bounds__(512, 4) void attn_bwd_kv_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                           const bf16_t* __restrict__ v, const float* __restrict__ key_add,
                                                           const bf16_t* __restrict__ dout, const float* __restrict__ stats,
                                                           const float* __restrict__ drow, bf16_t* __restrict__ dk,
@@ -349,9 +353,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv_kernel(const bf16_t* __res
   float* sM = reinterpret_cast<float*>(sO + LQP_MAX * STR);
   float* sI = sM + LQP_MAX;
   float* sD = sI + LQP_MAX;
+  uint32_t* sT = reinterpret_cast<uint32_t*>(sD + LQP_MAX);    // dropout threshold of every query row (see attn_row_t8)
   const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const AttnSeq sq = attn_seq(vl, b, Lq, Lk);
+  const AttnRng rkey = attn_rng_key(seed, site, (uint32_t)bh);
   const int LQP = ((sq.lq + 31) >> 5) << 5;        // this sequence's queries, in 32-row steps
   attn_fill_rows<HD>(sQ, q + (long long)sq.q0 * ldq + h * HD, sq.lq, LQP, ldq, tid, blockDim.x);
   attn_fill_rows<HD>(sO, dout + (long long)sq.q0 * ldo + h * HD, sq.lq, LQP, ldo, tid, blockDim.x);
@@ -365,9 +371,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv_kernel(const bf16_t* __res
     sM[t] = st.x;
     sI[t] = st.y;
     sD[t] = d;
+    sT[t] = thresh16 ? attn_row_t8(rkey, (uint32_t)t, thresh16) : 0u;
   }
   __syncthreads();
-  const uint32_t rkey = attn_rng_key(seed, site, (uint32_t)bh);
   const int g = lane >> 4, i = lane & 15;
   // (packed rows: the representative pad row of the key side is visited too -- as a masked key, so that its dk / dv rows are
   //  WRITTEN, as zeros)
@@ -411,7 +417,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv_kernel(const bf16_t* __res
         // computes the one of query r0 + 4g + r, and the four are exchanged inside the lane quad (DPP quad_perm broadcasts)
         uint32_t kb = 15u;                             // bit r: element (query r0 + 4g + r, this lane's key) kept
         if (thresh16) {
-          const int own = (int)attn_keep4(rkey, (uint32_t)(r0 + 4 * g + (int)kbit) * qstride4 + kquad, thresh16);
+          const int qown = r0 + 4 * g + (int)kbit;
+          const int own = (int)attn_keep4(rkey, (uint32_t)qown * qstride4 + kquad, sT[qown]);
           kb = (((uint32_t)__builtin_amdgcn_update_dpp(0, own, 0x00, 0xf, 0xf, false) >> kbit) & 1u) |
                ((((uint32_t)__builtin_amdgcn_update_dpp(0, own, 0x55, 0xf, 0xf, false) >> kbit) & 1u) << 1) |
                ((((uint32_t)__builtin_amdgcn_update_dpp(0, own, 0xAA, 0xf, 0xf, false) >> kbit) & 1u) << 2) |
@@ -445,10 +452,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv_kernel(const bf16_t* __res
   }
 }
 
-static inline uint32_t thresh16_of(float p) { return p > 0.f ? (uint32_t)((double)p * 65536.0) : 0u; }
+static inline uint32_t thresh16_of(float p) { return dropout_thresh8(p); }
 static inline int attn_nt(int Lk) { return Lk <= 160 ? 10 : 16; }
 // largest dynamic LDS any launch of these kernels asks for: 2 x 256 rows x (64+16) bf16 + 3 x 256 floats
-constexpr size_t smem_max = (size_t)2 * 256 * 80 * 2 + 3 * 256 * 4;
+constexpr size_t smem_max = (size_t)2 * 256 * 80 * 2 + 4 * 256 * 4;
 
 template <typename K>
 static int attn_set_smem(K kern, size_t smem) {
@@ -530,7 +537,7 @@ extern "C" int mmdti_attn_bwd(mmdti_stream_t stream, const void* q_bf16, const v
   const int nt = attn_nt(Lk);
   const size_t smem_q = (size_t)2 * nt * 16 * (head_dim + 8) * 2 + (size_t)nt * 16 * 4;
   const int lqp = ((Lq + 31) / 32) * 32;
-  const size_t smem_kv = (size_t)2 * lqp * (head_dim + 8) * 2 + (size_t)3 * lqp * 4;
+  const size_t smem_kv = (size_t)2 * lqp * (head_dim + 8) * 2 + (size_t)4 * lqp * 4;
 #define ATTN_BQ(HD, NT)                                                                                                    \
   do {                                                                                                                     \
     static bool attr_done = false;                                                                                         \

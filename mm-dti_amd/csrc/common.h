@@ -141,37 +141,49 @@ __device__ __forceinline__ Rand4 philox4(uint64_t seed, uint32_t site, uint64_t 
   const uint32_t b = mix32(a ^ 0xB5297A4Du);
   return Rand4{a << 16, a & 0xffff0000u, b << 16, b & 0xffff0000u};
 }
-// Cheaper variant for the pair-attention probability dropout (277 M elements per layer): TWO avalanche hashes give four
-// 16-bit uniforms, compared against a 16-bit threshold (p quantised to 1/65536: |error| < 8e-6).  ~20 integer ops per 4
-// elements.  Returns a 4-bit keep mask (bit r = element r kept).
-__device__ __forceinline__ uint32_t keep4_u16(uint64_t seed, uint32_t site, uint64_t ctr, uint32_t thresh16) {
-  seed = salted(seed);
-  const uint32_t k = mix32((uint32_t)seed ^ (site * 0x9E3779B9u)) ^ (uint32_t)(seed >> 32);
-  const uint32_t a = mix32(((uint32_t)ctr ^ k) + (uint32_t)(ctr >> 32) * 0x85EBCA6Bu);
-  const uint32_t b = mix32(a ^ 0xB5297A4Du);
-  return ((a & 0xffffu) >= thresh16 ? 1u : 0u) | ((a >> 16) >= thresh16 ? 2u : 0u) | ((b & 0xffffu) >= thresh16 ? 4u : 0u) |
-         ((b >> 16) >= thresh16 ? 8u : 0u);
-}
-// The same four uniforms as keep4_u16, left in the halves of two words: element r of the quad is kept iff
-// keep4_half(w, r) >= thresh16 -- callers that select per element compare the halves directly (one SDWA compare each)
-// instead of assembling and then dissecting a bit mask.
-struct Keep4 { uint32_t a, b; };
-__device__ __forceinline__ Keep4 keep4_words(uint64_t seed, uint32_t site, uint64_t ctr) {
-  seed = salted(seed);
-  const uint32_t k = mix32((uint32_t)seed ^ (site * 0x9E3779B9u)) ^ (uint32_t)(seed >> 32);
-  const uint32_t a = mix32(((uint32_t)ctr ^ k) + (uint32_t)(ctr >> 32) * 0x85EBCA6Bu);
-  return Keep4{a, mix32(a ^ 0xB5297A4Du)};
-}
-__device__ __forceinline__ bool keep4_kept(const Keep4& w, int r, uint32_t thresh16) {
-  const uint32_t word = r < 2 ? w.a : w.b;
-  return ((r & 1) ? (word >> 16) : (word & 0xffffu)) >= thresh16;
-}
 // keep-mask for element index `idx` of dropout site `site`: one Philox call covers 4 consecutive
 // elements (idx>>2), lane picks word idx&3.  keep iff u32 >= thresh, thresh = p * 2^32.
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t site, uint64_t idx, uint32_t thresh) {
   Rand4 r = philox4(seed, site, idx >> 2);
   uint32_t w = (idx & 3) == 0 ? r.x : (idx & 3) == 1 ? r.y : (idx & 3) == 2 ? r.z : r.w;
   return w >= thresh;
+}
+// ---- the attention-probability dropout generator (fused BERT attention and pair attention: 277-537 M decisions per layer) ----
+//   * per PLANE (one (sequence or molecule, head)): a two-word key from the full avalanche of (seed, salt, site, plane) --
+//     wave-uniform, scalar registers;
+//   * per QUAD (four consecutive keys of one query; counter < 2^23): ONE 32-bit word from two FULL-RATE 24-bit multiplies,
+//     h = mul24(ctr ^ k1, C1); h ^= (h >> 12) ^ k2; h = mul24(h, C2); h ^= h >> 12 -- its four bytes are the four uniforms.
+//     (Before: two lowbias32 avalanches = four quarter-rate 32-bit multiplies per quad.  The statistics are pinned by
+//     tests/test_kernels_gpu.py::test_attn_dropout_mask_statistics on masks recovered from the kernels; on the CPU restatement
+//     the same battery rates the generator with numpy's PCG64, scratch/rng_study.py.)
+//   * an element is dropped iff its byte < t8, and t8 is drawn PER QUERY ROW: floor(256 p) + Bernoulli(frac(256 p)) from one
+//     more word (counter = row | 2^23) -- P(drop) = p to 2^-24, not p rounded to 1/256.  (Rows' thresholds differ by one count:
+//     the drops of one row are correlated at 4e-5.)
+// thresh8 = (floor(256 p) << 16) | round(65536 frac(256 p)); 0 = no dropout.
+struct Rng24 {
+  uint32_t k1, k2;
+};
+__device__ __forceinline__ Rng24 rng24_key(uint64_t seed, uint32_t site, uint32_t plane) {
+  seed = salted(seed);
+  const uint32_t a = mix32((mix32((uint32_t)seed ^ (site * 0x9E3779B9u)) ^ (uint32_t)(seed >> 32)) + plane * 0x85EBCA6Bu);
+  return Rng24{a, mix32(a ^ 0xB5297A4Du)};
+}
+__device__ __forceinline__ uint32_t rng24_word(const Rng24& k, uint32_t ctr) {
+  uint32_t h = __umul24(ctr ^ k.k1, 0x9E3779u);
+  h = h ^ (h >> 12) ^ k.k2;
+  h = __umul24(h, 0x85EBCBu);
+  return h ^ (h >> 12);
+}
+__device__ __forceinline__ uint32_t rng24_row_t8(const Rng24& k, uint32_t row, uint32_t thresh8) {
+  return (thresh8 >> 16) + ((rng24_word(k, row | 0x800000u) & 0xffffu) < (thresh8 & 0xffffu) ? 1u : 0u);
+}
+__device__ __forceinline__ bool rng24_kept(uint32_t word, int r, uint32_t t8) { return ((word >> (8 * r)) & 0xffu) >= t8; }
+static inline uint32_t dropout_thresh8(float p) {
+  if (!(p > 0.f)) return 0u;
+  const double x = (double)p * 256.0;
+  uint32_t t8 = (uint32_t)x, fr = (uint32_t)((x - (double)t8) * 65536.0 + 0.5);
+  if (fr >= 65536u) { t8 += 1; fr = 0; }
+  return (t8 << 16) | fr;
 }
 static inline uint32_t dropout_thresh(float p) {
   if (p <= 0.f) return 0u;

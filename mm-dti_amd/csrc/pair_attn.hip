@@ -174,10 +174,12 @@ __global__ __launch_bounds__(256, NT > 9 ? 2 : 4) void pair_attn_fwd_mfma_kernel
   // key tile keep per-lane predicates.  FULL: nKB == NT, so "last tile" is a compile-time index.
   const int nlast = nKB - 1;
   const bool colok = 4 * g < N - 16 * nlast;
+  const Rng24 rk = rng24_key(seed, site, (uint32_t)bh);     // dropout: the (molecule, head) plane's key (common.h)
   auto body = [&](int qb, auto edge_c, auto kt_c) {
     constexpr bool EDGE = decltype(edge_c)::value;
     constexpr int KT = decltype(kt_c)::value;   // key tiles this molecule's sweeps cover (NT unless RAG)
     const int qi = qb * 16 + c16;
+    const uint32_t t8 = thresh ? rng24_row_t8(rk, (uint32_t)qi, thresh) : 0u;   // this query row's drop threshold
     const bool qvalid = EDGE ? qi < rows : true;
     const long long rowoff = ((long long)bh * N + (qvalid ? qi : 0)) * ld;   // (also the dropout counter base)
     const pa_s16x4 zero4 = {0, 0, 0, 0};
@@ -274,9 +276,9 @@ __global__ __launch_bounds__(256, NT > 9 ? 2 : 4) void pair_attn_fwd_mfma_kernel
       {
         f32x4 p = S[t] * inv;
         if (thresh) {
-          const Keep4 kw = keep4_words(seed, site, (uint64_t)(rowoff + t * 16 + 4 * g) >> 2);
+          const uint32_t kw = rng24_word(rk, ((uint32_t)qi * (uint32_t)ld + t * 16 + 4 * g) >> 2);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) p[r] = keep4_kept(kw, r, thresh >> 16) ? p[r] : 0.f;
+          for (int r = 0; r < 4; ++r) p[r] = rng24_kept(kw, r, t8) ? p[r] : 0.f;
         }
         // O^T += V^T . P^T : A = V[keys 16t + 4g..4g+3][d = c16 & 7] (rows d >= 8 of the result are never stored), B = P^T as it sits
         const pa_s16x4 va = *reinterpret_cast<const pa_s16x4*>(sVT + (c16 & 7) * KSTR + t * 16 + 4 * g);
@@ -345,7 +347,8 @@ extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, 
   MMDTI_REQUIRE(aligned16(qkv_bf16), "pair_attn_fwd: qkv must be 16-byte aligned");
   MMDTI_REQUIRE(!tiled || (aligned16(bias_in) && aligned16(s_out)), "pair_attn_fwd: tiled pair tensors must be 16-byte aligned");
   MMDTI_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "pair_attn_fwd: dropout p out of range");
-  const uint32_t th = dropout_thresh(drop_p);
+  const uint32_t th = dropout_thresh(drop_p);     // the per-element kernel (N > 272 or unaligned rows): Philox words against p * 2^32
+  const uint32_t th8 = dropout_thresh8(drop_p);   // the MFMA kernels: the shared byte generator of common.h
   const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   dim3 grid(B * H), block(256);
   hipStream_t s = (hipStream_t)stream;
@@ -355,7 +358,7 @@ extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, 
     dim3 blk(nqb % 3 == 0 ? 192 : (nqb < 4 ? 64 * nqb : 256));
 #define PA_M(NT, TL, FL, RG, ST)                                                                                                     \
   hipLaunchKernelGGL((pair_attn_fwd_mfma_kernel<NT, TL, FL, RG, ST>), grid, blk, 0, s, (const bf16_t*)qkv_bf16, (const ST*)bias_in, \
-                     (ST*)s_out, (bf16_t*)o_bf16, key_pad, N, H, ld, scale, th, sc, (uint64_t)seed, (uint32_t)site, key_tiles, rag_store, row_off)
+                     (ST*)s_out, (bf16_t*)o_bf16, key_pad, N, H, ld, scale, th8, sc, (uint64_t)seed, (uint32_t)site, key_tiles, rag_store, row_off)
 #define PA_MT(NT)                                                                           \
   do {                                                                                      \
     if (!tiled) PA_M(NT, false, false, false, float);                                       \
@@ -366,7 +369,7 @@ extern "C" int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, 
     // still walked and no tile takes the fast path -- 25-45 % more time per real tile (N = 96 / 113 / 128 on the 9-tile kernel).
 #define PA_MH(NT, RG)                                                                                                                  \
   hipLaunchKernelGGL((pair_attn_fwd_mfma_kernel<NT, true, true, RG, _Float16, true>), grid, blk, 0, s, (const bf16_t*)qkv_bf16,       \
-                     (const _Float16*)bias_in, (_Float16*)s_out, (bf16_t*)o_bf16, key_pad, N, H, ld, scale, th, sc, (uint64_t)seed,   \
+                     (const _Float16*)bias_in, (_Float16*)s_out, (bf16_t*)o_bf16, key_pad, N, H, ld, scale, th8, sc, (uint64_t)seed,  \
                      (uint32_t)site, key_tiles, rag_store, row_off)
 #define PA_MC(NT) case NT: if (qkv_f16) { if (key_tiles) PA_MH(NT, true); else PA_MH(NT, false); } \
                            else if (key_tiles) PA_M(NT, true, true, true, _Float16); else PA_M(NT, true, true, false, _Float16); break

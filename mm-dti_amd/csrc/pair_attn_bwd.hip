@@ -217,10 +217,12 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? ((NT >= 16 && NW == 3) ? 2 : 1) :
   //  slot is 0 -- both are preserved by the stores below --, so interior tiles run without predicates or pad masking.)
   const int nlast = nKB - 1;
   const bool colok = 4 * g < N - 16 * nlast;
+  const Rng24 rk = rng24_key(seed, site, (uint32_t)bh);     // dropout: the (molecule, head) plane's key (common.h)
   auto body = [&](int qb, auto edge_c, auto kt_c) {
     constexpr bool EDGE = decltype(edge_c)::value;
     constexpr int KT = decltype(kt_c)::value;   // key tiles this molecule's sweeps cover (NT unless RAG)
     const int qi = qb * 16 + c16;
+    const uint32_t t8 = thresh ? rng24_row_t8(rk, (uint32_t)qi, thresh) : 0u;   // this query row's drop threshold
     const bool qvalid = EDGE ? qi < rows : true;
     const long long rowoff = ((long long)bh * N + (qvalid ? qi : 0)) * ld;   // (also the dropout counter base)
     const long long tbase = ((long long)bh * nKB + qb) * nKB * 256 + lane * 4;
@@ -294,10 +296,10 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? ((NT >= 16 && NW == 3) ? 2 : 1) :
         dp = PA_MFMA16(va, dob, dp);
         f32x4 pr = P[t] * inv;
         if (thresh) {
-          const Keep4 kw = keep4_words(seed, site, (uint64_t)(rowoff + t * 16 + 4 * g) >> 2);
+          const uint32_t kw = rng24_word(rk, ((uint32_t)qi * (uint32_t)ld + t * 16 + 4 * g) >> 2);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const bool kp = keep4_kept(kw, r, thresh >> 16);
+            const bool kp = rng24_kept(kw, r, t8);
             dp[r] = kp ? dp[r] * dscale : 0.f;
             dl += dp[r] * pr[r];
             pr[r] = kp ? pr[r] : -pr[r];
@@ -455,7 +457,8 @@ extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, 
   MMDTI_REQUIRE(qkv_bf16 && s && do_bf16 && g && dqkv_bf16, "pair_attn_bwd: null pointer");
   MMDTI_REQUIRE(aligned16(qkv_bf16) && aligned16(do_bf16) && aligned16(dqkv_bf16), "pair_attn_bwd: alignment");
   MMDTI_REQUIRE(!tiled || (aligned16(s) && aligned16(g)), "pair_attn_bwd: tiled pair tensors must be 16-byte aligned");
-  const uint32_t th = dropout_thresh(drop_p);
+  const uint32_t th = dropout_thresh(drop_p);     // the per-element kernel: Philox words against p * 2^32
+  const uint32_t th8 = dropout_thresh8(drop_p);   // the MFMA kernel: the shared byte generator of common.h (as its forward)
   const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   dim3 grid(B * H), block(256);
   hipStream_t st = (hipStream_t)stream;
@@ -467,7 +470,7 @@ extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, 
 #define PA_MB(NT, TL, FL, NWV, RG, ST, GT)                                                                                     \
   hipLaunchKernelGGL((pair_attn_bwd_mfma_kernel<NT, TL, FL, NWV, RG, ST, GT>), grid, blk, 0, st, (const bf16_t*)qkv_bf16,      \
                      (const ST*)s, (const bf16_t*)do_bf16, (const GT*)g, (GT*)g, (bf16_t*)dqkv_bf16, N, H, ld, scale,           \
-                     g_in_zero, th, sc, (uint64_t)seed, (uint32_t)site, key_tiles, row_off)
+                     g_in_zero, th8, sc, (uint64_t)seed, (uint32_t)site, key_tiles, row_off)
 #define PA_MBW(NT, TL, FL, RG, ST, GT)                                                      \
   do {                                                                                      \
     if (blk.x == 192) PA_MB(NT, TL, FL, 3, RG, ST, GT); else PA_MB(NT, TL, FL, 4, RG, ST, GT); \

@@ -426,6 +426,29 @@ def test_pair_attn_dropout(ops):
     assert torch.equal(o2.float().cpu(), o)
 
 
+def test_pair_attn_dropout_mask_statistics(ops):
+    """The same generator in the pair-attention kernels (a key per (molecule, head) plane, counters from (query, key / 4)):
+    masks recovered through indicator V columns (head_dim 8: eight keys per pass), 64 planes x 128 x 128 = 1 M decisions,
+    judged by the battery of test_attn_dropout_mask_statistics (defined below)."""
+    B, N, H, p_drop = 2, 128, 32, 0.1
+    D, ld, scale = H * 8, 128, 8 ** -0.5
+    bias = dev(torch.zeros(B, H, N, ld))
+    pd = torch.zeros(B, H, N, N)
+    for c0 in range(0, N, 8):
+        qkv = torch.zeros(B, N, 3, H, 8)
+        for d in range(8):
+            qkv[:, c0 + d, 2, :, d] = 1.0
+        _, o = ops.pair_attn_fwd(dev(bf(qkv.view(B * N, 3 * D))), bias, None, B, N, H, ld, scale, drop_p=p_drop, seed=77, site=5)
+        pd[..., c0:c0 + 8] = o.view(B, N, H, 8).float().cpu().permute(0, 2, 1, 3)
+    drop = (pd == 0).view(B * H, N, N)
+    kept = pd[pd != 0]
+    close(kept, torch.full_like(kept, 1.0 / N / (1 - p_drop)), 1e-2, 0)
+    z = _mask_battery(drop, p_drop)
+    assert abs(z["mean"]) < 3.0, z
+    worst = max(z, key=lambda k: abs(z[k]))
+    assert abs(z[worst]) < 4.5, (worst, z)
+
+
 # ------------------------------------------------------------------------------------------- Gaussian basis, permutes
 def _gbf_params(E, K, seed=0):
     g = G(seed)
@@ -1302,6 +1325,63 @@ def test_attn_fused_dropout_mask_consistent(ops, Lq, Lk, hd):
     # a different site gives a different mask
     ctx2, _ = ops.attn_fwd(flat(q, Lq), flat(k, Lk), flat(v, Lk), None, B, heads, Lq, Lk, scale, p_drop, seed, site + 1)
     assert not torch.equal(ctx, ctx2)
+
+
+def _mask_battery(drop, p):
+    """z-scores of a dropout mask tensor [planes, Q, K] (True = dropped) against independent Bernoulli(p) decisions: keep rate,
+    serial correlations along keys / queries / planes (incl. the quad and word strides of the generator), the two diagonals, and
+    the spread of per-row / per-column / per-plane drop rates.  (scratch/rng_study.py runs the same battery, plus byte-level
+    chi-squares, on the CPU restatement of the generator and on numpy's PCG64.)"""
+    d = drop.double() - p
+    v = p * (1 - p)
+    z = {"mean": float(d.mean()) / (v / d.numel()) ** 0.5}
+    for l in (1, 2, 3, 4, 5, 8, 16, 64):
+        if d.shape[2] > l:
+            z[f"key+{l}"] = float((d[:, :, :-l] * d[:, :, l:]).mean()) / v * d[:, :, l:].numel() ** 0.5
+    for l in (1, 2, 4, 16):
+        if d.shape[1] > l:
+            z[f"query+{l}"] = float((d[:, :-l] * d[:, l:]).mean()) / v * d[:, l:].numel() ** 0.5
+    for l in (1, 2, 8):
+        z[f"plane+{l}"] = float((d[:-l] * d[l:]).mean()) / v * d[l:].numel() ** 0.5
+    z["diag"] = float((d[:, :-1, :-1] * d[:, 1:, 1:]).mean()) / v * d[:, 1:, 1:].numel() ** 0.5
+    z["antidiag"] = float((d[:, :-1, 1:] * d[:, 1:, :-1]).mean()) / v * d[:, 1:, 1:].numel() ** 0.5
+    for name, dims in (("rows", (2,)), ("cols", (1,)), ("planes", (1, 2))):
+        m = drop.double().mean(dim=dims)
+        n = drop.numel() // m.numel()
+        z[name] = (float(m.var(unbiased=False)) / (v / n) - 1) * (m.numel() / 2) ** 0.5
+    return z
+
+
+@pytest.mark.parametrize("p_drop", [0.1, 0.35])
+def test_attn_dropout_mask_statistics(ops, p_drop):
+    """The attention-probability dropout generator (common.h Rng24: two full-rate 24-bit multiplies per four keys, a drop
+    threshold per query row so that P(drop) = p and not p rounded to 1/256), judged on masks RECOVERED from the fused attention
+    forward (uniform probabilities, indicator V columns): 2 x 16 planes x 256 x 256 = 2.1 M decisions per site, two sites (layers).
+    Every statistic within 4.5 sigma (25 statistics x 2 sites: 3 sigma would fail one run in eight by chance); the keep rate
+    itself within 3 sigma -- which also tells p = 0.1 from 26/256 = 0.1016 (15 sigma apart at this sample size)."""
+    B, heads, L, hd = 2, 16, 256, 32
+    D = heads * hd
+    q = torch.zeros(B * L, D, device="cuda", dtype=torch.bfloat16)            # all logits 0: every probability 1 / L
+    planes = []
+    for site in (3, 4):
+        pd = torch.zeros(B, heads, L, L)
+        for c0 in range(0, L, hd):
+            vi = torch.zeros(B, L, heads, hd)
+            for c in range(hd):
+                vi[:, c0 + c, :, c] = 1.0
+            ctx, _ = ops.attn_fwd(q, q, dev(bf(vi.view(B * L, D))), None, B, heads, L, L, 1.0, p_drop, 20240607, site)
+            pd[..., c0:c0 + hd] = ctx.view(B, L, heads, hd).float().cpu().permute(0, 2, 1, 3)
+        drop = (pd == 0).view(B * heads, L, L)
+        kept = pd[pd != 0]
+        close(kept, torch.full_like(kept, 1.0 / L / (1 - p_drop)), 1e-2, 0)      # the survivors carry 1 / (1 - p), not 1 / (1 - t8 / 256)
+        z = _mask_battery(drop, p_drop)
+        assert abs(z["mean"]) < 3.0, (site, z)
+        worst = max(z, key=lambda k: abs(z[k]))
+        assert abs(z[worst]) < 4.5, (site, worst, z)
+        planes.append(drop)
+    # two sites (layers) draw unrelated masks
+    a, b = planes[0].double() - p_drop, planes[1].double() - p_drop
+    assert abs(float((a * b).mean()) / (p_drop * (1 - p_drop)) * a.numel() ** 0.5) < 4.0
 
 
 def test_attn_fused_rejects_unsupported_shapes(ops):
