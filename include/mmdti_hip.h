@@ -237,7 +237,7 @@ int mmdti_pair_permute_bwd(mmdti_stream_t stream, const float* g, void* out_bf16
  *      attn_weights fp16; tasks/trainer.py:266-282).  Each layer rounds S once (to nearest even, saturating at 65504) and its own
  *      softmax runs on the rounded value, so forward and backward see the same logits.  The gradient chain g stays fp32;
  *   7  (backward only, opt-in) as 3 with g as bf16: another third less traffic, at a cost in gradient fidelity wherever sums
- *      over pairs cancel (measured: DESIGN.md); no ragged form. */
+ *      over pairs cancel (measured: DESIGN.md); dense and ragged (key_tiles / row_off) forms like layout 3. */
 int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, const void* bias_in, void* s_out,
                         void* o_bf16, const unsigned char* key_pad, int B, int N, int H, int ld, float scale,
                         float drop_p, unsigned long long seed, unsigned int site, int layout,

@@ -125,6 +125,7 @@ void salt_pull_gemm(hipStream_t s, const unsigned long long* src);
 void salt_pull_layernorm(hipStream_t s, const unsigned long long* src);
 void salt_pull_pair_attn(hipStream_t s, const unsigned long long* src);
 void salt_pull_pair_attn_bwd(hipStream_t s, const unsigned long long* src);
+void salt_pull_pair_attn_bwd_g16(hipStream_t s, const unsigned long long* src);
 void salt_pull_attn(hipStream_t s, const unsigned long long* src);
 void salt_pull_elementwise(hipStream_t s, const unsigned long long* src);
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {

@@ -791,6 +791,7 @@ extern "C" int mmdti_seed_salt_pull(mmdti_stream_t stream, const unsigned long l
   salt_pull_layernorm(s, salt);
   salt_pull_pair_attn(s, salt);
   salt_pull_pair_attn_bwd(s, salt);
+  salt_pull_pair_attn_bwd_g16(s, salt);
   salt_pull_attn(s, salt);
   salt_pull_elementwise(s, salt);
   MMDTI_LAUNCH_CHECK();

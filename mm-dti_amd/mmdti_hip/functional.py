@@ -156,8 +156,8 @@ class PairEncoderFn(torch.autograd.Function):
         H = mod.attention_heads
         tiled = ops.pair_is_tiled(bias)        # [B,H,nt,nt,256] tile layout (see ops.pair_tile) or row-major [B,H,N,ld]
         compact = tiled and bias.dtype == torch.float16     # logits chain as fp16 (ops.PAIR_COMPACT, PairBiasFn)
-        if not compact or ops.PAIR_G_BF16:
-            key_tiles = None                   # (only the compact tiled kernels with fp32 gradients have a ragged form)
+        if not compact:
+            key_tiles = None                   # (only the compact tiled kernels have a ragged form)
         if pack is not None and key_tiles is None:
             raise ops.MMDTIError("PairEncoderFn: packed rows need the compact tiled pair layout and key_tiles")
         if aux_grads and (compact or pack is not None):
@@ -359,7 +359,7 @@ class PairBiasFn(torch.autograd.Function):
             tiled = ops.pair_tiled_ok(N)
             compact = tiled and ops.PAIR_COMPACT
             pre_f = pre_b = rb_f = rb_b = None
-            if key_tiles_host is not None and compact and full and not ops.PAIR_G_BF16:
+            if key_tiles_host is not None and compact and full:
                 # (rows_host -- packed token rows: the bias of the query rows past a molecule's representative pad row is never read)
                 if rows_host is not None:
                     pre_f, pre_b, rb_f, rb_b = ops.gbf_tile_prefixes(key_tiles_host, N, dist.device, rows_host)

@@ -316,7 +316,7 @@ class MM_Model(nn.Module):
         if token_pad_id is not None and int(token_pad_id) not in (-1, int(self.bert.cfg.pad_idx)):
             return None                                   # masked SMILES slots do not hold the pad id: their rows are not one row
         (B, N), L = src_tokens.shape, input_ids.shape[1]
-        if not (ops.PAIR_COMPACT and not ops.PAIR_G_BF16 and ops.pair_tiled_ok(N)):
+        if not (ops.PAIR_COMPACT and ops.pair_tiled_ok(N)):
             return None                                   # (the packed pair kernels exist for the compact tiled planes)
         c = self._pack_cache
         if c is not None and c[0] is atom_counts and c[1] is token_counts and c[2] == (B, N, L, src_tokens.device):

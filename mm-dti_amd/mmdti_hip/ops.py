@@ -688,8 +688,6 @@ def pair_attn_bwd(qkv, s, do, g, B, N, H, ld, scale, g_in_zero, drop_p=0.0, seed
     if pair_is_tiled(g) != tiled or not (g.dtype == F32 or (g.dtype == BF16 and s.dtype == F16)):
         raise MMDTIError("pair_attn_bwd: S and G must share one pair layout (fp32 gradients, or bf16 gradients with fp16 logits)")
     if g.dtype == BF16:
-        if key_tiles is not None:
-            raise MMDTIError("pair_attn_bwd: the ragged form (key_tiles) needs fp32 gradients")
         layout |= 4
     t0 = kernel_timer.begin("pair_attn_bwd")
     lib().mmdti_pair_attn_bwd(_stream(), qkv.data_ptr(), s.data_ptr(), do.data_ptr(), g.data_ptr(), dqkv.data_ptr(), B, N, H, ld,

@@ -342,14 +342,13 @@ def test_pair_attn_compact_planes_are_the_fp32_kernels_plus_rounding(ops, B, N, 
     with pytest.raises(ops.MMDTIError):
         ops.pair_attn_bwd(qkv, s32, dO, g16, B, N, H, ld, scale, False)            # bf16 gradients only go with fp16 logits
     with pytest.raises(ops.MMDTIError):
-        ops.pair_attn_bwd(qkv, s16, dO, g16, B, N, H, ld, scale, False, key_tiles=torch.ones(B, dtype=torch.int32, device="cuda"))
-    with pytest.raises(ops.MMDTIError):
         ops.pair_attn_fwd(qkv, dev(bias).half(), None, B, N, H, ld, scale)         # fp16 row-major planes do not exist
 
 
 @pytest.mark.parametrize("B,N,H,lens,p", [(4, 130, 8, (130, 37, 64, 5), 0.0), (3, 100, 64, (100, 17, 81), 0.1), (2, 258, 8, (40, 258), 0.0), (2, 16, 8, (3, 16), 0.0),
                                           (5, 200, 4, (200, 33, 90, 150, 177), 0.1), (4, 240, 8, (10, 70, 130, 240), 0.0)])
-def test_pair_attn_ragged_key_tile_skipping_equals_dense(ops, B, N, H, lens, p):
+@pytest.mark.parametrize("gdt", [torch.float32, torch.bfloat16])
+def test_pair_attn_ragged_key_tile_skipping_equals_dense(ops, B, N, H, lens, p, gdt):
     """Ragged batches (compact tiled planes): with key_tiles = ceil(length / 16) per molecule the kernels neither load, compute
     nor store the all-padding key tiles.  Everything that is defined must equal the dense run bit for bit: O, dqkv, S and G on
     the kept tiles; rag_store writes -inf into the skipped S tiles (the dense run has -inf there too); skipped G tiles stay as
@@ -391,7 +390,7 @@ def test_pair_attn_ragged_key_tile_skipping_equals_dense(ops, B, N, H, lens, p):
     assert torch.equal(o2_r, o2_d) and torch.equal(rows(s2_r), rows(s2_d))
     # backward
     g_in = torch.zeros(B, H, N, ld); g_in[..., :N] = torch.randn(B, H, N, N, generator=G(4)).masked_fill(key_pad.view(B, 1, 1, N), 0.0)
-    g_0 = ops.pair_tile(dev(g_in), N, 0.0)
+    g_0 = ops.pair_tile(dev(g_in), N, 0.0).to(gdt)      # the gradient chain in fp32 (layout 3) or bf16 (layout 7): both have the ragged form
     g_d = g_0.clone(); g_r = g_0.clone()
     dq_d = ops.pair_attn_bwd(qkv, s_d, dO, g_d, B, N, H, ld, scale, False, **kw)
     dq_r = ops.pair_attn_bwd(qkv, s_poison, dO, g_r, B, N, H, ld, scale, False, key_tiles=kt, **kw)
