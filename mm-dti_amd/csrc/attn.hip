@@ -200,12 +200,14 @@ __global__ __launch_bounds__(512, HD == 16 ? 2 : 4) void attn_fwd_kernel(const b
     f32x4 o[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) o[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // the UNNORMALISED exponentials (<= 1) are the MFMA operand; 1 / sum (and the dropout scale) multiply the 16 outputs of a
-    // lane once instead of its 4 NT probabilities
+    // (the NORMALISED probabilities are what is rounded to bf16 for the MFMA -- the rounding site of the oracle's contract.  Folding
+    //  1 / sum into the 16 outputs of a lane instead saves 24 packed multiplies per query block, changes nothing in time -- the
+    //  kernel is latency-bound -- and moved the regression contrastive loss from 1.0e-3 to 1.3e-3 of the oracle's: not taken)
+    const float invd = thresh16 ? inv * dscale : inv;
     const uint32_t t8 = thresh16 ? attn_row_t8(rkey, (uint32_t)qi, thresh16) : 0u;
 #pragma unroll
     for (int u = 0; u < NT / 2; ++u) {
-      f32x4 p0 = S[2 * u], p1 = S[2 * u + 1];
+      f32x4 p0 = S[2 * u] * invd, p1 = S[2 * u + 1] * invd;
       if (thresh16) {
         const uint32_t q4 = (uint32_t)qi * (NP / 4) + (2 * u) * 4 + g;
         const uint32_t h0 = attn_hash24(rkey, q4), h1 = attn_hash24(rkey, q4 + 4);
@@ -220,9 +222,6 @@ __global__ __launch_bounds__(512, HD == 16 ? 2 : 4) void attn_fwd_kernel(const b
       for (int nb = 0; nb < NB; ++nb) o[nb] = ATTN_MFMA(attn_frag_tr<HD>(sV, 32 * u, 32 * u + 16, nb * 16, lane), pf, o[nb]);
       __builtin_amdgcn_sched_barrier(0);
     }
-    const float invd = thresh16 ? inv * dscale : inv;
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) o[nb] = o[nb] * invd;
     if (qv) {
       bf16_t* dst = ctx + ((long long)sq.q0 + qi) * ldo + h * HD + 4 * g;
 #pragma unroll

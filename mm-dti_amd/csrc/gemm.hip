@@ -1319,6 +1319,109 @@ __global__ __launch_bounds__(512, 1) void gemm_big_grouped_kernel(GroupArgs g) {
   big_tile<true, true>(a, tm, tn, blockIdx.z, smem);
 }
 
+// The same grouped weight gradients for SMALL token counts (batches of 16-32 molecules: 1-4 k rows).  There the 256 x 256 launch is
+// 48 tiles x a 5-way K split of five K-tiles each, whose partials meet in 60 MB of fp32 atomics: 62-92 us per layer, a sixth of the
+// step's GPU time at 32 molecules.  Here: 64 x 64 tiles (768 of them for a tower-1 layer: every CU busy without any K split), the
+// four-stage LDS-DMA ring of gemm_small_kernel with both operands k-major, the K tail zero-filled by per-lane source select, and
+// dW += as a plain read-modify-write -- one workgroup owns a tile, so the result is also bitwise reproducible.
+template <int STAGES>
+__global__ __launch_bounds__(256, STAGES == 3 ? 3 : 2) void gemm_small_dw_grouped_kernel(GroupArgs g) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int wg = xcd_remap(blockIdx.x, g.ntiles);
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < GROUP_MAX; ++i) pi += (i < g.nprob && wg >= g.p[i].tile0) ? 1 : 0;
+  const GroupProb& pr = g.p[pi];
+  const int t = wg - pr.tile0;
+  const int tm = t / pr.tiles_n, tn = t - tm * pr.tiles_n;
+  const int m0 = tm * SBM, n0 = tn * SBN;
+  const bf16_t* __restrict__ A = pr.A;     // dy [rows][N_out]
+  const bf16_t* __restrict__ B = pr.B;     // x  [rows][N_in]
+  const int nt = (g.K + BK - 1) / BK;
+  const int ktail = g.K - (nt - 1) * BK;   // valid k rows of the last K-tile (BK: no tail)
+  const uint32_t oA0 = small_offset1<true>(tid, pr.lda, m0, pr.M), oA1 = small_offset1<true>(tid + 256, pr.lda, m0, pr.M);
+  const uint32_t oB0 = small_offset1<true>(tid, pr.ldb, n0, pr.N), oB1 = small_offset1<true>(tid + 256, pr.ldb, n0, pr.N);
+  const long long kstepA = (long long)BK * pr.lda, kstepB = (long long)BK * pr.ldb;
+  const int k0 = tid >> 3;                 // k row of this thread's first chunk; its second is k0 + 32
+  // (a stage past the end of the K range re-fetches the last tile; the partial tile always through the masked form)
+#define SDW_ISSUE(T)                                                                                   \
+  {                                                                                                    \
+    const int tt = min((T), nt - 1);                                                                   \
+    const bf16_t* dst = smem + ((T) % STAGES) * (2 * SM_TILE) + wave * 512;                         \
+    const bf16_t* ka = A + tt * kstepA;                                                                \
+    const bf16_t* kb = B + tt * kstepB;                                                                \
+    if (tt == nt - 1 && ktail != BK) {                                                                 \
+      const char* z = reinterpret_cast<const char*>(g.zeros);                                          \
+      dma16_v(k0 < ktail ? reinterpret_cast<const char*>(ka) + oA0 : z, dst);                          \
+      dma16_v(k0 + 32 < ktail ? reinterpret_cast<const char*>(ka) + oA1 : z, dst + 2048);              \
+      dma16_v(k0 < ktail ? reinterpret_cast<const char*>(kb) + oB0 : z, dst + SM_TILE);                \
+      dma16_v(k0 + 32 < ktail ? reinterpret_cast<const char*>(kb) + oB1 : z, dst + SM_TILE + 2048);    \
+    } else {                                                                                           \
+      dma16_su(ka, oA0, dst);                                                                          \
+      dma16_su(ka, oA1, dst + 2048);                                                                   \
+      dma16_su(kb, oB0, dst + SM_TILE);                                                                \
+      dma16_su(kb, oB1, dst + SM_TILE + 2048);                                                         \
+    }                                                                                                  \
+  }
+  f32x4 acc[2][2] = {};
+  const bool do_rs = pr.arowsum != nullptr && tn == 0 && wc == 0;    // bias gradient: row sums of dy^T, once per row tile
+  const bf16x8 ones = ones_frag();
+  f32x4 rs0 = {0.f, 0.f, 0.f, 0.f}, rs1 = rs0;
+  SDW_ISSUE(0); SDW_ISSUE(1);
+  if (STAGES == 4) SDW_ISSUE(2);
+  for (int t2 = 0; t2 < nt; ++t2) {
+    if (STAGES == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    SDW_ISSUE(t2 + STAGES - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const bf16_t* imgA = smem + (t2 % STAGES) * (2 * SM_TILE);
+    const bf16_t* imgB = imgA + SM_TILE;
+    const bf16x8 fa00 = small_frag<true>(imgA, wr * 32, 0, lane), fa10 = small_frag<true>(imgA, wr * 32 + 16, 0, lane);
+    const bf16x8 fb00 = small_frag<true>(imgB, wc * 32, 0, lane), fb10 = small_frag<true>(imgB, wc * 32 + 16, 0, lane);
+    const bf16x8 fa01 = small_frag<true>(imgA, wr * 32, 1, lane), fa11 = small_frag<true>(imgA, wr * 32 + 16, 1, lane);
+    const bf16x8 fb01 = small_frag<true>(imgB, wc * 32, 1, lane), fb11 = small_frag<true>(imgB, wc * 32 + 16, 1, lane);
+    acc[0][0] = mfma32<false>(fb00, fa00, acc[0][0]); acc[0][1] = mfma32<false>(fb10, fa00, acc[0][1]);
+    acc[1][0] = mfma32<false>(fb00, fa10, acc[1][0]); acc[1][1] = mfma32<false>(fb10, fa10, acc[1][1]);
+    acc[0][0] = mfma32<false>(fb01, fa01, acc[0][0]); acc[0][1] = mfma32<false>(fb11, fa01, acc[0][1]);
+    acc[1][0] = mfma32<false>(fb01, fa11, acc[1][0]); acc[1][1] = mfma32<false>(fb11, fa11, acc[1][1]);
+    if (do_rs) {
+      rs0 = mfma32<false>(ones, fa00, rs0); rs1 = mfma32<false>(ones, fa10, rs1);
+      rs0 = mfma32<false>(ones, fa01, rs0); rs1 = mfma32<false>(ones, fa11, rs1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#undef SDW_ISSUE
+  if (do_rs && lane < 16) {      // (one workgroup per row tile adds: reproducible)
+    atomicAdd(pr.arowsum + m0 + wr * 32 + lane, rs0[0]);
+    atomicAdd(pr.arowsum + m0 + wr * 32 + 16 + lane, rs1[0]);
+  }
+  float* sC = reinterpret_cast<float*>(smem);
+  const int g4 = (lane >> 4) * 4, l15 = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      *reinterpret_cast<f32x4*>(sC + (wr * 32 + i * 16 + l15) * LDC_SM + wc * 32 + j * 16 + g4) = acc[i][j];
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {      // 64 rows x 16 quads: dW += tile (this workgroup owns it)
+    const int chunk = tid + it * 256;
+    const int rr = chunk >> 4, cc = (chunk & 15) * 4;
+    float4* dst = reinterpret_cast<float4*>(pr.C + (long long)(m0 + rr) * pr.ldc + n0 + cc);
+    const float4 v = *reinterpret_cast<const float4*>(sC + rr * LDC_SM + cc);
+    float4 c = *dst;
+    c.x += v.x; c.y += v.y; c.z += v.z; c.w += v.w;
+    *dst = c;
+  }
+}
+
 // dW_i += sum over splits of slab_i[s]   (all problems of a group in one launch; blockIdx.y = problem)
 __global__ __launch_bounds__(256) void grouped_reduce_kernel(GroupArgs g) {
   const GroupProb& pr = g.p[blockIdx.y];
@@ -1853,7 +1956,7 @@ extern "C" int mmdti_linear_dw_grouped(mmdti_stream_t stream, int nprob, const v
                                        const int* ldx, const int* lddw, int rows, void* workspace, long long workspace_bytes) {
   MMDTI_REQUIRE(nprob >= 1 && nprob <= GROUP_MAX, "linear_dw_grouped: 1..%d problems (got %d)", GROUP_MAX, nprob);
   MMDTI_REQUIRE(dy_bf16 && x_bf16 && dw && n_out && n_in && ldy && ldx && lddw, "linear_dw_grouped: null argument table");
-  MMDTI_REQUIRE(rows >= 512, "linear_dw_grouped: at least 512 rows (got %d)", rows);   // (any count: a K tail is zero-filled in the kernel)
+  MMDTI_REQUIRE(rows >= 64, "linear_dw_grouped: at least 64 rows (got %d)", rows);   // (any count: a K tail is zero-filled in the kernel)
   MMDTI_REQUIRE(workspace && aligned16(workspace), "linear_dw_grouped: a 16-byte aligned workspace is required");
   GroupArgs g;
   g.nprob = nprob; g.K = rows;
@@ -1875,6 +1978,23 @@ extern "C" int mmdti_linear_dw_grouped(mmdti_stream_t stream, int nprob, const v
     elems += (long long)n_out[i] * n_in[i];
   }
   for (int i = nprob; i < GROUP_MAX; ++i) { g.p[i] = g.p[0]; g.p[i].tile0 = 0x7fffffff; }
+  hipStream_t s = (hipStream_t)stream;
+  // small token counts: 64 x 64 tiles, no K split, plain += (gemm_small_dw_grouped_kernel)
+  static const int small_rows = getenv("MMDTI_GROUPED_SMALL_ROWS") ? atoi(getenv("MMDTI_GROUPED_SMALL_ROWS")) : 4096;
+  if (rows <= small_rows && g_gemm_small) {
+    GroupArgs gs = g;
+    int st = 0;
+    for (int i = 0; i < nprob; ++i) {
+      gs.p[i].tile0 = st; gs.p[i].tiles_n = n_in[i] / SBN;
+      st += (n_out[i] / SBM) * gs.p[i].tiles_n;
+    }
+    gs.ntiles = st; gs.splitk = 1; gs.atomic = 0;
+    static const int dw_stages = getenv("MMDTI_GROUPED_SMALL_STAGES") ? atoi(getenv("MMDTI_GROUPED_SMALL_STAGES")) : 3;   // (three stages = 48 KB: three workgroups per CU; measured -2 % on the step against four)
+    if (dw_stages == 3) hipLaunchKernelGGL(gemm_small_dw_grouped_kernel<3>, dim3(st), dim3(256), (size_t)3 * 2 * SM_TILE * sizeof(bf16_t), s, gs);
+    else hipLaunchKernelGGL(gemm_small_dw_grouped_kernel<4>, dim3(st), dim3(256), (size_t)4 * 2 * SM_TILE * sizeof(bf16_t), s, gs);
+    MMDTI_LAUNCH_CHECK();
+    return MMDTI_OK;
+  }
   g.ntiles = tiles;
   const int kts = cdiv(rows, BK);
   int sk = max(1, min(kts / 4, 256 / max(1, tiles)));   // floor: all workgroups resident in ONE round
@@ -1896,7 +2016,6 @@ extern "C" int mmdti_linear_dw_grouped(mmdti_stream_t stream, int nprob, const v
     }
     attr = true;
   }
-  hipStream_t s = (hipStream_t)stream;
   // Small token counts (the reference's real batch sizes, 16-32 molecules): the step is a chain of ~20 us kernels, and the slab
   // pass is one more of them per layer -- the K-splits add into dW with fp32 atomics instead (a few MB of them: cheaper than a launch)
   static const int atomic_rows = getenv("MMDTI_GROUPED_ATOMIC_ROWS") ? atoi(getenv("MMDTI_GROUPED_ATOMIC_ROWS")) : 4096;

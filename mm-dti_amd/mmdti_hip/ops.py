@@ -215,7 +215,7 @@ GROUPED_DW = os.environ.get("MMDTI_GROUPED_DW", "1") != "0"
 
 
 # (any row count: the kernel zero-fills the tail of the last 64-row K-tile)
-GROUPED_DW_MIN_ROWS = int(os.environ.get("MMDTI_GROUPED_DW_MIN_ROWS", "1024"))
+GROUPED_DW_MIN_ROWS = int(os.environ.get("MMDTI_GROUPED_DW_MIN_ROWS", "128"))    # (64 x 64-tile kernel below 4096 rows: any count from 64 up)
 
 
 def _dw_groupable(dy, x, dw, rows):

@@ -1423,6 +1423,43 @@ def test_grouped_weight_gradients(ops, rows):
             close(db, rb, 2e-3, 2e-2)
 
 
+@pytest.mark.parametrize("rows", [1695, 1311, 513, 4096, 577, 130])
+def test_grouped_weight_gradients_small_token_counts_are_reproducible(ops, rows):
+    """Batches of 16-32 molecules (<= 4096 rows): the grouped weight gradients run on 64 x 64 tiles without a K split and add into
+    dW by read-modify-write (gemm_small_dw_grouped_kernel) -- against fp32 torch, against the 256 x 256 split-K launch they
+    replace, and bit-identical from run to run (one workgroup owns a tile; the split-K launch adds with fp32 atomics)."""
+    from mmdti_hip import _abi
+    lib = _abi.lib()
+    g = G(12)
+    shapes = [(1536, 512), (512, 512), (2048, 512), (512, 2048)]
+    base = []
+    for i, (no, ni) in enumerate(shapes):
+        big = bf(torch.randn(rows, no + 64, generator=g)).cuda()
+        dy = big[:, :no] if i == 0 else bf(torch.randn(rows, no, generator=g)).cuda()
+        base.append((dy, bf(torch.randn(rows, ni, generator=g)).cuda(), torch.randn(no, ni, generator=g).cuda(),
+                     torch.randn(no, generator=g).cuda() if i != 2 else None))
+
+    def run():
+        items = [(dy, x, dw.clone(), None if db is None else db.clone(), None) for dy, x, dw, db in base]
+        ops.linear_bwd_weight_grouped(items)
+        return [(it[2], it[3]) for it in items]
+
+    a, b = run(), run()
+    for (dwa, dba), (dwb, dbb) in zip(a, b):
+        assert torch.equal(dwa, dwb) and (dba is None or torch.equal(dba, dbb))
+    try:
+        lib.mmdti_set_option(b"gemm_small", 0)
+        c = run()
+    finally:
+        lib.mmdti_set_option(b"gemm_small", 1)
+    for (dy, x, dw, db), (dwa, dba), (dwc, dbc) in zip(base, a, c):
+        close(dwa, dw + dy.float().t() @ x.float(), 2e-3, 2e-2)
+        close(dwa, dwc, 1e-4, 1e-2)                                 # (split-K order + atomics on the other side)
+        if db is not None:
+            close(dba, db + dy.float().sum(0), 2e-3, 2e-2)
+            close(dba, dbc, 1e-4, 1e-2)
+
+
 @pytest.mark.parametrize("rows", [3616, 200, 1000])
 def test_weight_gradient_with_ragged_token_count(ops, rows):
     """Weight gradients over a token count that is not a multiple of the 64-deep K tile (small batches take the predicated

@@ -288,7 +288,10 @@ def test_packed_step_equals_padded_step_at_dropout_zero(task):
                            grads={n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
     a, b = res["padded"], res["packed"]
     for k in ("infonce", "ct", "loss"):
-        assert abs(a[k] - b[k]) <= 1e-6 * abs(a[k]) + 1e-7, (k, a[k], b[k])
+        # (the contrastive loss divides feature products by its temperature 0.07 before exp / log: the 1e-7 sum-order noise of the
+        #  pooled features arrives ~ 14 x larger in it -- measured 1.1e-5 relative on the regression configuration)
+        rel = 3e-5 if k == "ct" else 1e-6
+        assert abs(a[k] - b[k]) <= rel * abs(a[k]) + 1e-7, (k, a[k], b[k])
     assert rel_l2(b["logits"], a["logits"]) < 1e-6
     assert set(a["grads"]) == set(b["grads"])
     worst = ("", 0.0)
