@@ -50,3 +50,27 @@ torch.cuda.synchronize()
 line = f"issue split per step: total {tot / 50 * 1e3:.2f} ms = forward+loss {(tot - bw - op) / 50 * 1e3:.2f} + backward {bw / 50 * 1e3:.2f} + optimizer {op / 50 * 1e3:.2f}"
 print(line)
 open(os.path.join(ROOT, "gpurun_out", "host_profile.txt"), "a").write(line + "\n")
+
+# ---- the backward runs on autograd's device thread: profile THAT thread (a cProfile enabled from inside the first backward node)
+import threading
+from mmdti_hip import functional as Fn
+bw_prof = {}
+orig_bw = Fn.CELossFn.backward
+def hooked(ctx, *a):
+    tid = threading.get_ident()
+    if tid not in bw_prof:
+        bw_prof[tid] = cProfile.Profile(); bw_prof[tid].enable()
+    return orig_bw(ctx, *a)
+Fn.CELossFn.backward = staticmethod(hooked)
+torch.Tensor.backward = orig_backward
+for _ in range(50): tuner.step(batch, label, epoch=0)
+torch.cuda.synchronize()
+for tid, prf in bw_prof.items():
+    s2 = io.StringIO()
+    try:
+        prf.create_stats(); pstats.Stats(prf, stream=s2).sort_stats("tottime").print_stats(40)
+    except Exception as e:
+        s2.write(f"(could not read the backward thread's profile: {e})")
+    txt = "\n==== backward thread, 50 steps ====\n" + s2.getvalue()
+    print(txt[:7000])
+    open(os.path.join(ROOT, "gpurun_out", "host_profile.txt"), "a").write(txt)
