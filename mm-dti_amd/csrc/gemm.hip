@@ -1838,7 +1838,7 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
     const int use_small = g_gemm_small;
     static const int small_max_tiles = getenv("MMDTI_GEMM_SMALL_TILES") ? atoi(getenv("MMDTI_GEMM_SMALL_TILES")) : 128;
     const int use_deep = g_gemm_deep;
-    static const int deep_max_wgs = getenv("MMDTI_GEMM_DEEP_WGS") ? atoi(getenv("MMDTI_GEMM_DEEP_WGS")) : 256;
+    const int deep_max_wgs = 256;                     // (one workgroup per CU)
     if (use_tall && !transA && a.vec_ok && grid.z == 1 && M >= 1024) {
       const int slots = 1024, tn = cdiv(N, BN);
       const int r128 = cdiv(tiles, slots);
@@ -1989,9 +1989,8 @@ extern "C" int mmdti_linear_dw_grouped(mmdti_stream_t stream, int nprob, const v
       st += (n_out[i] / SBM) * gs.p[i].tiles_n;
     }
     gs.ntiles = st; gs.splitk = 1; gs.atomic = 0;
-    static const int dw_stages = getenv("MMDTI_GROUPED_SMALL_STAGES") ? atoi(getenv("MMDTI_GROUPED_SMALL_STAGES")) : 3;   // (three stages = 48 KB: three workgroups per CU; measured -2 % on the step against four)
-    if (dw_stages == 3) hipLaunchKernelGGL(gemm_small_dw_grouped_kernel<3>, dim3(st), dim3(256), (size_t)3 * 2 * SM_TILE * sizeof(bf16_t), s, gs);
-    else hipLaunchKernelGGL(gemm_small_dw_grouped_kernel<4>, dim3(st), dim3(256), (size_t)4 * 2 * SM_TILE * sizeof(bf16_t), s, gs);
+    // (three stages = 48 KB: three workgroups per CU; measured -2 % on the step against a four-stage ring at two per CU)
+    hipLaunchKernelGGL(gemm_small_dw_grouped_kernel<3>, dim3(st), dim3(256), (size_t)3 * 2 * SM_TILE * sizeof(bf16_t), s, gs);
     MMDTI_LAUNCH_CHECK();
     return MMDTI_OK;
   }
@@ -2018,8 +2017,8 @@ extern "C" int mmdti_linear_dw_grouped(mmdti_stream_t stream, int nprob, const v
   }
   // Small token counts (the reference's real batch sizes, 16-32 molecules): the step is a chain of ~20 us kernels, and the slab
   // pass is one more of them per layer -- the K-splits add into dW with fp32 atomics instead (a few MB of them: cheaper than a launch)
-  static const int atomic_rows = getenv("MMDTI_GROUPED_ATOMIC_ROWS") ? atoi(getenv("MMDTI_GROUPED_ATOMIC_ROWS")) : 4096;
-  g.atomic = rows <= atomic_rows ? 1 : 0;
+  // (reached only with the 64 x 64 kernel switched off: gemm_small = 0)
+  g.atomic = rows <= 4096 ? 1 : 0;
   hipLaunchKernelGGL(gemm_big_grouped_kernel, dim3(tiles, 1, sk), dim3(512), smem_b, s, g);
   if (!g.atomic) {
     long long max_n4 = 0;
