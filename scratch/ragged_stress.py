@@ -51,11 +51,18 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     # Two runs of the SAME dense step are not bit-identical either (loss kernels and split-K / table gradients use fp32 atomics:
     # the loss moves by an ulp, bottom-of-the-network gradients by up to 2e-3 after the bf16 casts of the backward chain amplify
     # it): the ragged step has to sit inside that band, not at zero.
-    ok = (abs(float(ld) - float(lr)) <= 3e-7 * abs(float(ld)) and worst_t[1] <= max(3 * noise_t[1], 5e-3) and worst[1] < 0.1
+    # (the gbf tables' gradients are ill-conditioned enough that two runs of the SAME dense step differ by up to 2e-1 there -- trial 61
+    #  of seed 11: dense vs dense 2.1e-1, ragged vs dense 1.2e-1 --, so their bound follows the dense step's own noise on that parameter)
+    ok = (abs(float(ld) - float(lr)) <= 3e-7 * abs(float(ld)) and worst_t[1] <= max(3 * noise_t[1], 5e-3)
+          and worst[1] < max(0.1, 3 * rel_l2(gd2[worst[0]], gd[worst[0]]))
           and bool(torch.isfinite(lr)) and all(bool(torch.isfinite(v).all()) for v in gr.values()))
     if not torch.equal(ld, ld2): print("   !! dense forward not repeatable:", float(ld), float(ld2))
     if not torch.equal(ld, lr): print("   !! ragged forward differs:", float(ld), float(lr), float(ld - lr))
     print(f"      non-gbf worst {worst_t[0]} {worst_t[1]:.1e} (dense vs dense {noise_t[0]} {noise_t[1]:.1e})")
+    if not ok:      # the dense step's own run-to-run noise on the parameter that decided, and the size of that gradient
+        wn = worst[0]
+        print(f"      {wn}: dense vs dense {rel_l2(gd2[wn], gd[wn]):.1e}; |grad| {float(gd[wn].norm()):.3e}, |ragged - dense| {float((gr[wn] - gd[wn]).norm()):.3e}, "
+              f"|dense' - dense| {float((gd2[wn] - gd[wn]).norm()):.3e}")
     bad += not ok
     print(f"trial {trial:2d} B={B} N={N:3d} lens={counts.tolist()} loss dense {float(ld):.7f} dense again {float(ld2):.7f} ragged {float(lr):.7f} | worst grad {worst[0]} {worst[1]:.1e} (dense vs dense: {noise[0]} {noise[1]:.1e}) {'ok' if ok else 'FAIL'}")
 print("failures:", bad)
