@@ -112,6 +112,23 @@ int mmdti_linear_dw_grouped(mmdti_stream_t stream, int nprob, const void* const*
                             const int* ldx, const int* lddw, int rows, void* workspace, long long workspace_bytes);
 int mmdti_linear_dw_grouped_splits(int tiles, int rows);
 
+/* ---- one Uni-Mol encoder layer's backward behind one call (launch sequencing in the library: at 16-32 molecules the Python
+ * side of ~500 launches per step sets the pace).  Replaces the per-layer body of the encoder backward -- unicore
+ * TransformerEncoderLayer as driven by models/transformers.py:136-139 -- with the SAME eight launches the op-by-op host path
+ * issues (fc2 / fc1 input gradients, LayerNorm-2 backward, out_proj input gradient, pair-attention backward, in_proj input
+ * gradient, LayerNorm-1 backward, grouped weight gradients): bit-identical results.  Shapes and the workspace layout: layers.hip. */
+int mmdti_unimol_layer_bwd(mmdti_stream_t stream, int M, int B, int N, int H, int D, int F, int ld, float scale,
+                           float p_res, float p_att, unsigned long long seed, unsigned int site_f_below, unsigned int site_o,
+                           unsigned int site_att, const float* dx_in, const void* dy2, float* dx_out, void* dx16_out,
+                           float* db_below, const void* a_act, const void* u_aux, int act_dx, const void* h2, const float* x1,
+                           const float* m2, const float* r2, const void* o_att, const void* qkv, const void* s_logits,
+                           const void* h1, const float* x0, const float* m1, const float* r1, const void* w_fc2,
+                           const void* w_fc1, const void* w_out, const void* w_in, const float* g_ln2, const float* g_ln1,
+                           float* dw_fc2, float* dw_fc1, float* dw_out, float* dw_in, float* db_fc1, float* db_out,
+                           float* db_in, float* dg_ln2, float* dbt_ln2, float* dg_ln1, float* dbt_ln1, void* G,
+                           int pair_layout, int g_in_zero, const int* key_tiles, const int* row_off, void* ws,
+                           long long ws_bytes);
+
 /* ---- LayerNorm (unicore LayerNorm eps 1e-5: transformers.py:69,71,114,161; BertLayerNorm eps 1e-12:
  * mm_module.py:320-333; HF nn.LayerNorm) -------------------------------------------------------
  * y = LN(x)*gamma+beta, then optional dropout, then rows with row_zero[r]!=0 forced to 0

@@ -63,6 +63,9 @@ def _lin_bwd_params_many(calls, raw_items=()):
         ops.colsum(dy, gb, cols=cols)
 
 
+# one C call per layer backward where the library has a sequencer for the variant at hand (csrc/layers.hip): the launch order,
+# kernels and arguments of the op-by-op path below, minus ~140 us of Python per layer -- what paces a step of 16-32 molecules
+LAYER_SEQ = os.environ.get("MMDTI_LAYER_SEQ", "1") != "0"
 POOL_THEN_PROJECT = os.environ.get("MMDTI_INFONCE_POOL_FIRST", "1") != "0"      # InfoNCE head: pool the GELU outputs, then project
 
 
@@ -276,7 +279,10 @@ class PairEncoderFn(torch.autograd.Function):
                 G[..., N:] = 0.0
         below = [Lb.site_f for Lb in st.layers[:-1]]      # site of the FFN dropout of the layer UNDER each layer
         deferred, deferred_layers = [], []
-        n_defer = DEFER_WGRAD_LAYERS if dout.is_cuda else 0
+        # (holding weight gradients back for the end pays where the pair-bias backward has work to hide -- large batches; at a few
+        #  thousand rows every launch is latency-bound and the held layers would only miss the sequenced path below)
+        n_defer = DEFER_WGRAD_LAYERS if (dout.is_cuda and M >= 8192) else 0
+        seq_ok, seq_ws = _unimol_seq_workspace(st, mod) if (LAYER_SEQ and dout.is_cuda and st.layers) else (False, None)
         for li, layer, L in zip(range(len(st.layers) - 1, -1, -1), reversed(mod.layers), reversed(st.layers)):
             att, ln1, ln2 = layer.self_attn, layer.self_attn_layer_norm, layer.final_layer_norm
             hold = li < n_defer                          # this layer's weight gradients wait for the end (see _launch_deferred_wgrads)
@@ -284,6 +290,15 @@ class PairEncoderFn(torch.autograd.Function):
 
             def _wgrad(*args, **kw):
                 pending.append((args, kw))
+            if seq_ok and dx16 is not None and not hold:
+                g_zero = G is None
+                if g_zero:
+                    G = (torch.empty if st.kt is None else torch.zeros)(L.s.shape, device=L.s.device, dtype=ops.pair_grad_dtype(L.s))
+                dx, dx16 = _unimol_layer_bwd_seq(st, layer, L, dx, dx16, G, g_zero, scale, seq_ws,
+                                                 None if li == 0 else (below[li - 1], gbuf(mod.layers[li - 1].fc2.bias)))
+                L.__dict__.clear()
+                notify_grads_ready(layer.parameters())
+                continue
             # ---- FFN:  x2 = x1 + drop(fc2(gelu(fc1(LN2(x1)))))
             # (dx16 = bf16 dropout-backward copy of dx, written by the LayerNorm backward that produced dx)
             dy2 = dx16 if dx16 is not None else ops.cast_bf16(dx, st.p_res, seed, L.site_f)
@@ -328,6 +343,44 @@ class PairEncoderFn(torch.autograd.Function):
         _launch_deferred_wgrads(deferred, deferred_layers)
         _join_stream_after_backward()
         return (demb if st.packed else demb.view(B, N, D)), G, None, None, None, None, None, None
+
+
+def _unimol_seq_workspace(st, mod):
+    """-> (usable, workspace) for mmdti_unimol_layer_bwd: the variant the library sequences is the hot one -- bf16 operands (not the
+    fp16 forward-operand mode), every parameter trainable, dimensions the grouped weight-gradient kernels take, no per-launch event
+    timing requested.  The workspace holds one layer's temporaries and is shared by all layers of this backward."""
+    lay = mod.layers[0]
+    D, F, M = st.D, lay.fc1.weight.shape[0], st.M
+    ok = (not ops.FWD_F16 and not ops.kernel_timer.names and ops.GROUPED_DW and D % 256 == 0 and F % 256 == 0 and M >= ops.GROUPED_DW_MIN_ROWS
+          and all(p.requires_grad for p in mod.parameters()))
+    if not ok:
+        return False, None
+    tiles = (D // 256) * (F // 256) * 2 + (D // 256) ** 2 * 4
+    sk = ops.lib()._dll.mmdti_linear_dw_grouped_splits(tiles, M)
+    nbytes = (M * F + 7 * M * D) * 2 + M * D * 4 + sk * (2 * D * F + 4 * D * D) * 4
+    return True, torch.empty(nbytes + 256, device=st.emb.device, dtype=torch.uint8)
+
+
+def _unimol_layer_bwd_seq(st, layer, L, dx, dx16, G, g_zero, scale, ws, below):
+    """One Uni-Mol layer's backward as ONE library call (csrc/layers.hip): -> (dx, dx16) for the layer below (dx16 None at the
+    lowest layer).  Same launches, arguments and order as the op-by-op body of PairEncoderFn.backward."""
+    att, ln1, ln2 = layer.self_attn, layer.self_attn_layer_norm, layer.final_layer_norm
+    M, D, F = st.M, st.D, layer.fc1.weight.shape[0]
+    dx_out = torch.empty_like(dx)
+    dx16_out = torch.empty(M, D, device=dx.device, dtype=BF16) if below is not None else None
+    layout = ops._pair_layout_s(L.s, "pair_attn_bwd.s") | (4 if G.dtype == BF16 else 0)
+    p = ops._p
+    ops.lib().mmdti_unimol_layer_bwd(
+        ops._stream(), M, st.B, st.N, st.H, D, F, st.ld, float(scale), float(st.p_res), float(st.p_att), int(st.seed),
+        int(below[0]) if below is not None else 0, int(L.site_o), int(L.site_att), dx.data_ptr(), dx16.data_ptr(), dx_out.data_ptr(), p(dx16_out),
+        p(below[1]) if below is not None else 0, L.a.data_ptr(), L.u.data_ptr(), ops.ACT_GELU_DX, L.h2.data_ptr(), L.x1.data_ptr(), L.m2.data_ptr(),
+        L.r2.data_ptr(), L.o.data_ptr(), L.qkv.data_ptr(), L.s.data_ptr(), L.h1.data_ptr(), L.x.data_ptr(), L.m1.data_ptr(), L.r1.data_ptr(),
+        wbf16(layer.fc2.weight).data_ptr(), wbf16(layer.fc1.weight).data_ptr(), wbf16(att.out_proj.weight).data_ptr(), wbf16(att.in_proj.weight).data_ptr(),
+        ln2.weight.data_ptr(), ln1.weight.data_ptr(), gbuf(layer.fc2.weight).data_ptr(), gbuf(layer.fc1.weight).data_ptr(),
+        gbuf(att.out_proj.weight).data_ptr(), gbuf(att.in_proj.weight).data_ptr(), gbuf(layer.fc1.bias).data_ptr(), gbuf(att.out_proj.bias).data_ptr(),
+        gbuf(att.in_proj.bias).data_ptr(), gbuf(ln2.weight).data_ptr(), gbuf(ln2.bias).data_ptr(), gbuf(ln1.weight).data_ptr(), gbuf(ln1.bias).data_ptr(),
+        G.data_ptr(), layout, int(g_zero), p(st.kt), p(st.row_off), (ws.data_ptr() + 255) // 256 * 256, ws.numel() - 256)
+    return dx_out, dx16_out
 
 
 # ------------------------------------------------------------------------------------------------- Gaussian pair bias

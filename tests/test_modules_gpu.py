@@ -282,6 +282,73 @@ def test_unimol_tower_hot_path_layout_vs_oracle(M, compact, monkeypatch):
     compare_param_grads(got, P, 5e-2, skip=("gbf_proj.linear2.bias",))
 
 
+@pytest.mark.parametrize("packed", [False, True])
+def test_unimol_layer_backward_sequenced_in_the_library_equals_the_op_by_op_path(M, packed, monkeypatch):
+    """csrc/layers.hip issues the eight launches of a Uni-Mol layer's backward from ONE call (functional.LAYER_SEQ; the Python side
+    of a layer is what paces 16-32 molecule steps): the same kernels, arguments and order as the op-by-op path, so everything
+    without atomics -- the input gradient and the pair-bias gradient chain -- is BIT-identical, and the parameter gradients agree
+    to the atomics' noise.  Training mode (all dropout sites live), dense and packed token rows, 3 layers (the two lower ones are
+    sequenced; DEFER_WGRAD is switched off so that none is held back)."""
+    from mmdti_hip import functional as Fn, ops
+    from mmdti_hip.functional import PairBiasFn
+    from mmdti_hip.runtime import dropout_state
+    from mmdti_hip.packing import PackedRows
+    monkeypatch.setattr(Fn, "DEFER_WGRAD_LAYERS", 0)
+    B, N, D, H, K, V = 6, 40, 512, 64, 128, 31                      # (packed: 174 rows -- the grouped weight gradients want >= 128)
+    ucfg = O.UniMolCfg(layers=3, dim=D, ffn=256, heads=H, K=K, vocab=V)
+    cfg = O.ModelCfg(unimol=ucfg, roberta=O.RobertaCfg(layers=1, dim=64, heads=4, ffn=128, vocab=40, max_pos=40), cross=O.CrossCfg(dim=64, heads=4, ffn=128))
+    P = O.init_params(cfg, seed=3, std=0.06)
+    g = torch.Generator().manual_seed(6)
+    lens = [40, 23, 31, 12, 35, 28]
+    pad = torch.zeros(B, N, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        pad[b, n:] = True
+    emb, dist = torch.randn(B, N, D, generator=g), torch.rand(B, N, N, generator=g) * 6
+    et = torch.randint(0, V * V, (B, N, N), generator=g)
+    enc = M.tr.TransformerEncoderWithPair(encoder_layers=3, embed_dim=D, ffn_embed_dim=256, attention_heads=H, no_final_head_layer_norm=True).cuda().train()
+    gbf, proj = M.mm.GaussianLayer(K, V * V).cuda(), M.mm.NonLinearHead(K, H, "gelu").cuda()
+    load_params(enc, P, "encoder."); load_params(gbf, P, "gbf."); load_params(proj, P, "gbf_proj.")
+    counts = torch.tensor(lens)
+    kt_host = (counts + 15) // 16
+    kt = kt_host.to(torch.int32).cuda()
+    pk = PackedRows(counts, N, "cuda") if packed else None
+
+    def run(seq):
+        monkeypatch.setattr(Fn, "LAYER_SEQ", seq)
+        for m in (enc, gbf, proj):
+            m.zero_grad(set_to_none=True)
+        dropout_state.reseed(4242)
+        if packed:
+            e = emb.cuda().reshape(B * N, D)[pk.gather].clone().requires_grad_()
+            bias = PairBiasFn.apply(gbf.means.weight, dist.cuda(), et.cuda(), gbf, proj, ops.pair_ld(N), kt_host, pk.rows_host)
+            x = enc.encode(e, bias, pad.cuda().reshape(-1)[pk.gather], kt, pack=pk)[0]
+        else:
+            e = emb.cuda().clone().requires_grad_()
+            bias = PairBiasFn.apply(gbf.means.weight, dist.cuda(), et.cuda(), gbf, proj, ops.pair_ld(N), kt_host)
+            x = enc.encode(e, bias, pad.cuda(), kt)[0]
+        w = torch.randn(x.shape, generator=torch.Generator().manual_seed(9)).cuda()
+        (x * w).sum().backward()
+        torch.cuda.synchronize()
+        grads = {n: p.grad.clone() for mod, pre in ((enc, "encoder."), (gbf, "gbf."), (proj, "gbf_proj.")) for n, p in ((pre + k, v) for k, v in mod.named_parameters())
+                 if p.grad is not None}
+        return x.detach().clone(), e.grad.clone(), grads
+
+    calls = []
+    real = Fn._unimol_layer_bwd_seq
+    monkeypatch.setattr(Fn, "_unimol_layer_bwd_seq", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    x0, de0, g0 = run(False)
+    assert not calls
+    x1, de1, g1 = run(True)
+    assert len(calls) == 3                                            # every layer of this backward went through the library call
+    assert torch.equal(x0, x1)
+    assert torch.equal(de0, de1)                                      # no atomics on the activation-gradient chain: the same bits
+    assert set(g0) == set(g1)
+    for n in g0:
+        d = float((g0[n].double() - g1[n].double()).norm()) / (float(g0[n].double().norm()) + 1e-30)
+        lim = 0.3 if n.startswith("gbf") else 2e-4                    # (pair-bias tables: ill-conditioned sums, bounded by the dense path's own noise)
+        assert d < lim, (n, d)
+
+
 # --------------------------------------------------------------------------------------------- tower 2 (golden G6)
 @pytest.mark.parametrize("impl", ["eager", "sdpa"])
 def test_roberta_tower_golden(M, golden, impl):
