@@ -112,11 +112,20 @@ int mmdti_linear_dw_grouped(mmdti_stream_t stream, int nprob, const void* const*
                             const int* ldx, const int* lddw, int rows, void* workspace, long long workspace_bytes);
 int mmdti_linear_dw_grouped_splits(int tiles, int rows);
 
-/* ---- one Uni-Mol encoder layer's backward behind one call (launch sequencing in the library: at 16-32 molecules the Python
- * side of ~500 launches per step sets the pace).  Replaces the per-layer body of the encoder backward -- unicore
+/* ---- one Uni-Mol encoder layer's forward / backward behind one call each (launch sequencing in the library: at 16-32 molecules
+ * the Python side of ~500 launches per step sets the pace).  Replaces the per-layer body of the encoder forward / backward -- unicore
  * TransformerEncoderLayer as driven by models/transformers.py:136-139 -- with the SAME eight launches the op-by-op host path
  * issues (fc2 / fc1 input gradients, LayerNorm-2 backward, out_proj input gradient, pair-attention backward, in_proj input
  * gradient, LayerNorm-1 backward, grouped weight gradients): bit-identical results.  Shapes and the workspace layout: layers.hip. */
+int mmdti_unimol_layer_fwd(mmdti_stream_t stream, int M, int B, int N, int H, int D, int F, int ld, float scale, float p_res,
+                           float p_att, unsigned long long seed, unsigned int site_att, unsigned int site_o, unsigned int site_f,
+                           const float* x, const void* h1, const void* s_in, const unsigned char* key_pad, int pair_layout,
+                           const int* key_tiles, int rag_store, const int* row_off, const void* w_in, const float* b_in,
+                           const void* w_out, const float* b_out, const float* g_ln2, const float* bt_ln2, float eps2,
+                           const void* w_fc1, const float* b_fc1, int act_fwd, const void* w_fc2, const float* b_fc2,
+                           int next_mode, const float* g_next, const float* bt_next, float eps_next, int ln_max_k, void* qkv,
+                           void* s_out, void* o_att, float* x1, void* h2, float* m2, float* r2, void* u_aux, void* a_act,
+                           float* x_out, void* ln_out, float* mn, float* rn);
 int mmdti_unimol_layer_bwd(mmdti_stream_t stream, int M, int B, int N, int H, int D, int F, int ld, float scale,
                            float p_res, float p_att, unsigned long long seed, unsigned int site_f_below, unsigned int site_o,
                            unsigned int site_att, const float* dx_in, const void* dy2, float* dx_out, void* dx16_out,

@@ -15,7 +15,56 @@ inline int dx_gemm(mmdti_stream_t s, const void* dy, int ldy, const void* w, int
   return mmdti_gemm_bf16(s, dy, w, out, M, n_out, n_in, ldy, ldw, n_out, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.f, 0.f, nullptr, nullptr, n_out, act, aux_in,
                          nullptr, aux_in ? ld_aux : n_out, MMDTI_DT_BF16, 0.f, 0ull, 0u, nullptr, nullptr, nullptr, 0);
 }
+// y[M, n_out] = epi(x[M, n_in] . w[n_out, n_in]^T + bias)   (ops.linear_fwd)
+inline int fwd_gemm(mmdti_stream_t s, const void* x, int ldx, const void* w, int ldw, const float* bias, void* out, int M, int n_out, int n_in,
+                    int act, void* aux_out, const float* residual, int c_dtype, float drop_p, unsigned long long seed, unsigned int site) {
+  return mmdti_gemm_bf16(s, x, w, out, M, n_out, n_in, ldx, ldw, n_out, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.f, 0.f, bias, residual, n_out, act, nullptr,
+                         aux_out, n_out, c_dtype, drop_p, seed, site, nullptr, nullptr, nullptr, 0);
+}
+// the Linear that closes a residual branch + the LayerNorm behind it (ops.linear_ln_fwd): one kernel for 512-wide outputs up to
+// ln_max_k deep, else the GEMM and the LayerNorm kernels back to back.  ln_f32 / ln_bf16: either may be null.
+inline int closer(mmdti_stream_t s, const void* x, const void* w, const float* bias, const float* residual, int M, int n_out, int n_in, float drop_p,
+                  unsigned long long seed, unsigned int site, float* y, const float* gamma, const float* beta, float eps, float* ln_f32,
+                  void* ln_bf16, float* mean, float* rstd, int ln_max_k) {
+  if (n_out == 512 && n_in % 64 == 0 && n_in <= ln_max_k)
+    return mmdti_gemm_ln_bf16(s, x, w, bias, residual, M, n_out, n_in, n_in, n_in, n_out, drop_p, seed, site, y, gamma, beta, eps, ln_f32, ln_bf16, mean,
+                              rstd, 0);
+  if (int e = fwd_gemm(s, x, n_in, w, n_in, bias, y, M, n_out, n_in, MMDTI_ACT_NONE, nullptr, residual, MMDTI_DT_F32, drop_p, seed, site)) return e;
+  return mmdti_layernorm_fwd(s, y, gamma, beta, eps, M, n_out, ln_f32, ln_bf16, mean, rstd, nullptr, 0.f, 0ull, 0u, 0);
+}
 }  // namespace
+
+/* Forward of one Uni-Mol encoder layer behind one call: replaces the per-layer body of PairEncoderFn.forward (functional.py) with
+ * the same launches -- in_proj, pair attention, out_proj + residual + dropout + LayerNorm-2, fc1 + GELU (saving gelu' or u as
+ * act_fwd says), fc2 + residual + dropout and the LayerNorm that reads its output (next_mode 1: the next layer's LayerNorm-1 -> bf16;
+ * 2: the encoder's final LayerNorm -> fp32; 0: none).  h1 [M,D] bf16 is this layer's LayerNorm-1 output (written by the closer of the
+ * layer above or by the caller), x [M,D] fp32 the residual stream.  Every output is the caller's (they are the backward's saved
+ * tensors): qkv [M,3D], s_out (pair logits, layout as s_in), o [M,D], x1 [M,D] f32, h2 [M,D], m2 / r2 [M], u / a [M,F], x_out [M,D]
+ * f32, ln_out ([M,D] bf16 or f32 by next_mode), mn / rn [M]. */
+extern "C" int mmdti_unimol_layer_fwd(mmdti_stream_t stream, int M, int B, int N, int H, int D, int F, int ld, float scale, float p_res,
+                                      float p_att, unsigned long long seed, unsigned int site_att, unsigned int site_o, unsigned int site_f,
+                                      const float* x, const void* h1, const void* s_in, const unsigned char* key_pad, int pair_layout,
+                                      const int* key_tiles, int rag_store, const int* row_off, const void* w_in, const float* b_in,
+                                      const void* w_out, const float* b_out, const float* g_ln2, const float* bt_ln2, float eps2,
+                                      const void* w_fc1, const float* b_fc1, int act_fwd, const void* w_fc2, const float* b_fc2,
+                                      int next_mode, const float* g_next, const float* bt_next, float eps_next, int ln_max_k, void* qkv,
+                                      void* s_out, void* o_att, float* x1, void* h2, float* m2, float* r2, void* u_aux, void* a_act,
+                                      float* x_out, void* ln_out, float* mn, float* rn) {
+  MMDTI_REQUIRE(M > 0 && D > 0 && F > 0 && D % 8 == 0 && F % 8 == 0 && next_mode >= 0 && next_mode <= 2, "unimol_layer_fwd: bad shape / mode");
+  MMDTI_REQUIRE(x && h1 && s_in && w_in && w_out && g_ln2 && bt_ln2 && w_fc1 && w_fc2 && qkv && s_out && o_att && x1 && h2 && m2 && r2 && u_aux && a_act && x_out,
+                "unimol_layer_fwd: null argument");
+  MMDTI_REQUIRE(next_mode == 0 || (g_next && bt_next && ln_out && mn && rn), "unimol_layer_fwd: the next LayerNorm needs its parameters and outputs");
+  if (int e = fwd_gemm(stream, h1, D, w_in, D, b_in, qkv, M, 3 * D, D, MMDTI_ACT_NONE, nullptr, nullptr, MMDTI_DT_BF16, 0.f, 0ull, 0u)) return e;
+  if (int e = mmdti_pair_attn_fwd(stream, qkv, s_in, s_out, o_att, key_pad, B, N, H, ld, scale, p_att, seed, site_att, pair_layout, key_tiles, rag_store,
+                                  row_off, 0))
+    return e;
+  if (int e = closer(stream, o_att, w_out, b_out, x, M, D, D, p_res, seed, site_o, x1, g_ln2, bt_ln2, eps2, nullptr, h2, m2, r2, ln_max_k)) return e;
+  if (int e = fwd_gemm(stream, h2, D, w_fc1, D, b_fc1, a_act, M, F, D, act_fwd, u_aux, nullptr, MMDTI_DT_BF16, 0.f, 0ull, 0u)) return e;
+  if (next_mode == 0)
+    return fwd_gemm(stream, a_act, F, w_fc2, F, b_fc2, x_out, M, D, F, MMDTI_ACT_NONE, nullptr, x1, MMDTI_DT_F32, p_res, seed, site_f);
+  return closer(stream, a_act, w_fc2, b_fc2, x1, M, D, F, p_res, seed, site_f, x_out, g_next, bt_next, eps_next, next_mode == 2 ? (float*)ln_out : nullptr,
+                next_mode == 1 ? ln_out : nullptr, mn, rn, ln_max_k);
+}
 
 /* Backward of one Uni-Mol encoder layer (pre-LN: x1 = x + drop(out_proj(attn(LN1(x)))), x2 = x1 + drop(fc2(gelu(fc1(LN2(x1))))));
  * replaces the per-layer body of PairEncoderFn.backward (functional.py) -- transformers.py:136-139 through unicore's

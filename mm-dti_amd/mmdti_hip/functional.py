@@ -200,6 +200,8 @@ class PairEncoderFn(torch.autograd.Function):
         nlayers = len(mod.layers)
         nxt = None
         out = None
+        seq = LAYER_SEQ and emb.is_cuda and not ops.FWD_F16 and not ops.kernel_timer.names and D == H * 8
+        kp0 = ops._u8(padding_mask) if seq else None
         for li, layer in enumerate(mod.layers):
             L = SimpleNamespace(x=x)
             ln1, ln2 = layer.self_attn_layer_norm, layer.final_layer_norm
@@ -208,6 +210,21 @@ class PairEncoderFn(torch.autograd.Function):
                 _, L.h1, L.m1, L.r1 = ops.layernorm_fwd(x, ln1.weight, ln1.bias, ln1.eps)
             else:
                 L.h1, L.m1, L.r1 = nxt
+            if seq:
+                # the layer's six launches from ONE library call (csrc/layers.hip: the same kernels, arguments and order as below)
+                L.site_att, L.site_o, L.site_f = sites.next(), sites.next(), sites.next()
+                last = li == nlayers - 1
+                nl = mod.layers[li + 1].self_attn_layer_norm if not last else mod.final_layer_norm
+                x, ln_out, mn, rn = _unimol_layer_fwd_seq(st, layer, L, s_prev, kp0 if li == 0 else None, key_tiles, last and pack is None, row_off,
+                                                          scale, nl, 0 if nl is None else (2 if last else 1))
+                s_prev = L.s
+                if not last:
+                    nxt = (ln_out, mn, rn)
+                elif nl is not None:
+                    out, st.f_mean, st.f_rstd = ln_out, mn, rn
+                if keep:
+                    st.layers.append(L)
+                continue
             L.qkv = ops.linear_fwd(L.h1, wfwd(att.in_proj.weight), att.in_proj.bias)
             L.site_att = sites.next()
             # (ragged batches: all-padding key tiles are skipped; the last layer writes them as -inf because its S is returned)
@@ -343,6 +360,35 @@ class PairEncoderFn(torch.autograd.Function):
         _launch_deferred_wgrads(deferred, deferred_layers)
         _join_stream_after_backward()
         return (demb if st.packed else demb.view(B, N, D)), G, None, None, None, None, None, None
+
+
+def _unimol_layer_fwd_seq(st, layer, L, s_prev, key_pad, key_tiles, rag_store, row_off, scale, nl, next_mode):
+    """One Uni-Mol layer's forward as ONE library call (csrc/layers.hip); fills L with the tensors the backward reads and returns
+    (x_out fp32, LayerNorm output of x_out | None, its mean, its rstd)."""
+    att, ln2 = layer.self_attn, layer.final_layer_norm
+    M, D, F = st.M, st.D, layer.fc1.weight.shape[0]
+    dev = L.x.device
+    e = torch.empty
+    L.qkv, L.o = e(M, 3 * D, device=dev, dtype=BF16), e(M, D, device=dev, dtype=BF16)
+    L.s = torch.empty_like(s_prev) if ops.pair_is_tiled(s_prev) else e(st.B, st.H, st.N, st.ld, device=dev, dtype=F32)
+    L.x1, L.h2 = e(M, D, device=dev, dtype=F32), e(M, D, device=dev, dtype=BF16)
+    L.m2, L.r2 = e(M, device=dev, dtype=F32), e(M, device=dev, dtype=F32)
+    L.u, L.a = e(M, F, device=dev, dtype=BF16), e(M, F, device=dev, dtype=BF16)
+    x_out = e(M, D, device=dev, dtype=F32)
+    ln_out = mn = rn = None
+    if next_mode:
+        ln_out = e(M, D, device=dev, dtype=BF16 if next_mode == 1 else F32)
+        mn, rn = e(M, device=dev, dtype=F32), e(M, device=dev, dtype=F32)
+    p = ops._p
+    ops.lib().mmdti_unimol_layer_fwd(
+        ops._stream(), M, st.B, st.N, st.H, D, F, st.ld, float(scale), float(st.p_res), float(st.p_att), int(st.seed), int(L.site_att), int(L.site_o),
+        int(L.site_f), L.x.data_ptr(), L.h1.data_ptr(), s_prev.data_ptr(), p(key_pad), ops._pair_layout_s(s_prev, "pair_attn.bias"), p(key_tiles),
+        int(rag_store), p(row_off), wfwd(att.in_proj.weight).data_ptr(), p(att.in_proj.bias), wfwd(att.out_proj.weight).data_ptr(), p(att.out_proj.bias),
+        ln2.weight.data_ptr(), ln2.bias.data_ptr(), float(ln2.eps), wfwd(layer.fc1.weight).data_ptr(), p(layer.fc1.bias), ops.ACT_GELU_FWD,
+        wfwd(layer.fc2.weight).data_ptr(), p(layer.fc2.bias), next_mode, p(nl.weight) if nl is not None else 0, p(nl.bias) if nl is not None else 0,
+        float(nl.eps) if nl is not None else 0.0, ops.GEMM_LN_MAX_K if ops.GEMM_LN else 0, L.qkv.data_ptr(), L.s.data_ptr(), L.o.data_ptr(),
+        L.x1.data_ptr(), L.h2.data_ptr(), L.m2.data_ptr(), L.r2.data_ptr(), L.u.data_ptr(), L.a.data_ptr(), x_out.data_ptr(), p(ln_out), p(mn), p(rn))
+    return x_out, ln_out, mn, rn
 
 
 def _unimol_seq_workspace(st, mod):
