@@ -138,6 +138,27 @@ int mmdti_unimol_layer_bwd(mmdti_stream_t stream, int M, int B, int N, int H, in
                            int pair_layout, int g_in_zero, const int* key_tiles, const int* row_off, void* ws,
                            long long ws_bytes);
 
+/* The same for one post-LN BERT layer with self-attention, fused q | k | v projection and the fused attention kernels (HF RobertaLayer
+ * reached from models/mm_model.py:562): six launches forward, eight backward.  Shapes and the workspace layout: layers.hip. */
+int mmdti_bert_layer_fwd(mmdti_stream_t stream, int Mq, int B, int L, int heads, int D, int F, float scale, float p_hid, float p_att,
+                         unsigned long long seed, unsigned int site_att, unsigned int site_o, unsigned int site_f,
+                         const float* s1_32, const void* s1_16, const float* key_add, const int* q_off, const int* k_off,
+                         const int* k_cnt, int q_rows, const void* w_qkv, const float* b_qkv, const void* w_o, const float* b_o,
+                         const float* g_ln1, const float* bt_ln1, const void* w_i, const float* b_i, int act_fwd,
+                         const void* w_o2, const float* b_o2, const float* g_ln2, const float* bt_ln2, float eps, int ln_max_k,
+                         void* qkv, void* ctx, float* stats, float* y, float* a32, void* a16, float* am, float* ar, void* u_aux,
+                         void* i_act, float* z, float* out32, void* out16, float* zm, float* zr);
+int mmdti_bert_layer_bwd(mmdti_stream_t stream, int Mq, int B, int L, int heads, int D, int F, float scale, float p_hid, float p_att,
+                         unsigned long long seed, unsigned int site_att, unsigned int site_o, unsigned int site_f,
+                         const float* dout, float* ds1, const void* s1_16, const float* key_add, const int* q_off,
+                         const int* k_off, const int* k_cnt, int q_rows, const void* qkv, const void* ctx, const float* stats,
+                         const float* y, const void* a16, const float* am, const float* ar, const void* u_aux, int act_dx,
+                         const void* i_act, const float* z, const float* zm, const float* zr, const void* w_qkv,
+                         const void* w_o, const void* w_i, const void* w_o2, const float* g_ln1, const float* g_ln2,
+                         float* dw_qkv, int lddw_qkv, float* db_qkv, float* dw_o, float* db_o, float* dw_i, float* db_i,
+                         float* dw_o2, float* db_o2, float* dg_ln1, float* dbt_ln1, float* dg_ln2, float* dbt_ln2, void* ws,
+                         long long ws_bytes);
+
 /* ---- LayerNorm (unicore LayerNorm eps 1e-5: transformers.py:69,71,114,161; BertLayerNorm eps 1e-12:
  * mm_module.py:320-333; HF nn.LayerNorm) -------------------------------------------------------
  * y = LN(x)*gamma+beta, then optional dropout, then rows with row_zero[r]!=0 forced to 0

@@ -126,3 +126,92 @@ extern "C" int mmdti_unimol_layer_bwd(mmdti_stream_t stream, int M, int B, int N
   const int ldy[4] = {D, F, D, 3 * D}, ldx[4] = {F, D, D, D}, lddw[4] = {F, D, D, D};
   return mmdti_linear_dw_grouped(stream, 4, dys, xs, dws, dbs, n_out, n_in, ldy, ldx, lddw, M, slabs, slab_bytes);
 }
+
+/* Forward of one post-LN BERT layer with SELF-attention, the q | k | v projection as one GEMM and the fused attention kernels
+ * (HF RobertaLayer reached from models/mm_model.py:562; the variant functional._bert_layer_fwd takes on the hot path): the same six
+ * launches behind one call.  s1_32 / s1_16 [Mq,D]: the layer input (fp32 residual stream and its bf16 copy); w_qkv [3D,D], b_qkv [3D]
+ * the fused projection.  Outputs (the backward's saved tensors): qkv [Mq,3D], ctx [Mq,D], stats, y [Mq,D] f32 (pre-LN1), a32 / a16
+ * (LN1 output), am / ar, u / i_act [Mq,F], z [Mq,D] f32 (pre-LN2), out32 / out16 (LN2 output), zm / zr.  Packed sequences: q_off ... as
+ * mmdti_attn_fwd (null / 0: dense, key_add [B,Lq] nullable). */
+extern "C" int mmdti_bert_layer_fwd(mmdti_stream_t stream, int Mq, int B, int L, int heads, int D, int F, float scale, float p_hid, float p_att,
+                                    unsigned long long seed, unsigned int site_att, unsigned int site_o, unsigned int site_f,
+                                    const float* s1_32, const void* s1_16, const float* key_add, const int* q_off, const int* k_off,
+                                    const int* k_cnt, int q_rows, const void* w_qkv, const float* b_qkv, const void* w_o, const float* b_o,
+                                    const float* g_ln1, const float* bt_ln1, const void* w_i, const float* b_i, int act_fwd,
+                                    const void* w_o2, const float* b_o2, const float* g_ln2, const float* bt_ln2, float eps, int ln_max_k,
+                                    void* qkv, void* ctx, float* stats, float* y, float* a32, void* a16, float* am, float* ar, void* u_aux,
+                                    void* i_act, float* z, float* out32, void* out16, float* zm, float* zr) {
+  MMDTI_REQUIRE(Mq > 0 && D > 0 && F > 0 && heads > 0 && D % heads == 0, "bert_layer_fwd: bad shape");
+  MMDTI_REQUIRE(s1_32 && s1_16 && w_qkv && w_o && g_ln1 && bt_ln1 && w_i && w_o2 && g_ln2 && bt_ln2 && qkv && ctx && stats && y && a32 && a16 && am && ar &&
+                    u_aux && i_act && z && out32 && out16 && zm && zr, "bert_layer_fwd: null argument");
+  const int hd = D / heads;
+  const char* qp = reinterpret_cast<const char*>(qkv);
+  if (int e = fwd_gemm(stream, s1_16, D, w_qkv, D, b_qkv, qkv, Mq, 3 * D, D, MMDTI_ACT_NONE, nullptr, nullptr, MMDTI_DT_BF16, 0.f, 0ull, 0u)) return e;
+  if (int e = mmdti_attn_fwd(stream, qp, qp + (size_t)D * 2, qp + (size_t)2 * D * 2, key_add, ctx, stats, B, heads, L, L, hd, 3 * D, 3 * D, D,
+                             scale, p_att, seed, site_att, q_off, k_off, k_cnt, q_rows, 0))
+    return e;
+  if (int e = closer(stream, ctx, w_o, b_o, s1_32, Mq, D, D, p_hid, seed, site_o, y, g_ln1, bt_ln1, eps, a32, a16, am, ar, ln_max_k)) return e;
+  if (int e = fwd_gemm(stream, a16, D, w_i, D, b_i, i_act, Mq, F, D, act_fwd, u_aux, nullptr, MMDTI_DT_BF16, 0.f, 0ull, 0u)) return e;
+  return closer(stream, i_act, w_o2, b_o2, a32, Mq, D, F, p_hid, seed, site_f, z, g_ln2, bt_ln2, eps, out32, out16, zm, zr, ln_max_k);
+}
+
+/* Backward of the same layer: LayerNorm-2 backward, the FFN's two input gradients, LayerNorm-1 backward (its output fed the FFN and
+ * the residual: dy_add), the attention output projection's input gradient, the fused attention backward (dq | dk | dv written
+ * straight into one [Mq,3D] gradient), the fused projection's input gradient accumulated into ds1, and the four weight gradients as
+ * one grouped launch.  dout [Mq,D] fp32 -> ds1 [Mq,D] fp32 (written).
+ *   ws: dzb [Mq,D] | du [Mq,F] | da [Mq,D] | dyb [Mq,D] | dctx [Mq,D] | dqkv [Mq,3D] (bf16) | dz [Mq,D] f32 | drow [heads*rows] f32 | slabs. */
+extern "C" int mmdti_bert_layer_bwd(mmdti_stream_t stream, int Mq, int B, int L, int heads, int D, int F, float scale, float p_hid, float p_att,
+                                    unsigned long long seed, unsigned int site_att, unsigned int site_o, unsigned int site_f,
+                                    const float* dout, float* ds1, const void* s1_16, const float* key_add, const int* q_off,
+                                    const int* k_off, const int* k_cnt, int q_rows, const void* qkv, const void* ctx, const float* stats,
+                                    const float* y, const void* a16, const float* am, const float* ar, const void* u_aux, int act_dx,
+                                    const void* i_act, const float* z, const float* zm, const float* zr, const void* w_qkv,
+                                    const void* w_o, const void* w_i, const void* w_o2, const float* g_ln1, const float* g_ln2,
+                                    float* dw_qkv, int lddw_qkv, float* db_qkv, float* dw_o, float* db_o, float* dw_i, float* db_i,
+                                    float* dw_o2, float* db_o2, float* dg_ln1, float* dbt_ln1, float* dg_ln2, float* dbt_ln2, void* ws,
+                                    long long ws_bytes) {
+  MMDTI_REQUIRE(Mq > 0 && D > 0 && F > 0 && heads > 0 && D % heads == 0, "bert_layer_bwd: bad shape");
+  MMDTI_REQUIRE(dout && ds1 && s1_16 && qkv && ctx && stats && y && a16 && am && ar && u_aux && i_act && z && zm && zr && w_qkv && w_o && w_i && w_o2 &&
+                    g_ln1 && g_ln2 && dw_qkv && dw_o && dw_i && dw_o2 && ws, "bert_layer_bwd: null argument");
+  const int hd = D / heads;
+  const long long MD = (long long)Mq * D, MF = (long long)Mq * F;
+  const long long nrow = q_off ? (long long)heads * q_rows : (long long)B * heads * L;
+  const long long fixed = (MF + 7 * MD) * 2 + MD * 4 + ((nrow * 4 + 15) / 16) * 16;
+  MMDTI_REQUIRE(ws_bytes >= fixed && aligned16(ws), "bert_layer_bwd: workspace too small (%lld bytes for the temporaries alone)", fixed);
+  char* wp = reinterpret_cast<char*>(ws);
+  void* dzb = wp;  wp += MD * 2;
+  void* du = wp;   wp += MF * 2;
+  void* da = wp;   wp += MD * 2;
+  void* dyb = wp;  wp += MD * 2;
+  void* dctx = wp; wp += MD * 2;
+  char* dqkv = wp; wp += 3 * MD * 2;
+  float* dz = reinterpret_cast<float*>(wp); wp += MD * 4;
+  float* drow = reinterpret_cast<float*>(wp); wp += ((nrow * 4 + 15) / 16) * 16;
+  void* slabs = wp;
+  const long long slab_bytes = ws_bytes - fixed;
+  if (int e = mmdti_layernorm_bwd(stream, dout, MMDTI_DT_F32, nullptr, z, g_ln2, zm, zr, Mq, D, nullptr, dz, dg_ln2, dbt_ln2, nullptr, 0.f, 0ull, 0u, dzb, p_hid,
+                                  site_f, db_o2))
+    return e;
+  if (int e = dx_gemm(stream, dzb, D, w_o2, F, du, Mq, F, D, act_dx, u_aux, F)) return e;
+  if (int e = dx_gemm(stream, du, F, w_i, D, da, Mq, D, F, MMDTI_ACT_NONE, nullptr, 0)) return e;
+  if (int e = mmdti_layernorm_bwd(stream, da, MMDTI_DT_BF16, dz, y, g_ln1, am, ar, Mq, D, nullptr, ds1, dg_ln1, dbt_ln1, nullptr, 0.f, 0ull, 0u, dyb, p_hid,
+                                  site_o, db_o))
+    return e;
+  if (int e = dx_gemm(stream, dyb, D, w_o, D, dctx, Mq, D, D, MMDTI_ACT_NONE, nullptr, 0)) return e;
+  const char* qp = reinterpret_cast<const char*>(qkv);
+  if (int e = mmdti_attn_bwd(stream, qp, qp + (size_t)D * 2, qp + (size_t)2 * D * 2, key_add, dctx, stats, drow, dqkv, dqkv + (size_t)D * 2,
+                             dqkv + (size_t)2 * D * 2, B, heads, L, L, hd, 3 * D, 3 * D, D, 3 * D, 3 * D, scale, p_att, seed, site_att, q_off,
+                             k_off, k_cnt, q_rows))
+    return e;
+  // ds1 += dqkv . W_qkv   (fp32, beta = 1)
+  if (int e = mmdti_gemm_bf16(stream, dqkv, w_qkv, ds1, Mq, D, 3 * D, 3 * D, D, D, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.f, 1.f, nullptr, nullptr, D, MMDTI_ACT_NONE,
+                              nullptr, nullptr, D, MMDTI_DT_F32, 0.f, 0ull, 0u, nullptr, nullptr, nullptr, 0))
+    return e;
+  const void* dys[4] = {dqkv, dzb, du, dyb};
+  const void* xs[4] = {s1_16, i_act, a16, ctx};
+  float* dws[4] = {dw_qkv, dw_o2, dw_i, dw_o};
+  float* dbs[4] = {db_qkv, nullptr, db_i, nullptr};
+  const int n_out[4] = {3 * D, D, F, D}, n_in[4] = {D, F, D, D};
+  const int ldy[4] = {3 * D, D, F, D}, ldx[4] = {D, F, D, D}, lddw[4] = {lddw_qkv, F, D, D};
+  return mmdti_linear_dw_grouped(stream, 4, dys, xs, dws, dbs, n_out, n_in, ldy, ldx, lddw, Mq, slabs, slab_bytes);
+}

@@ -592,6 +592,11 @@ def _bert_layer_fwd(st, s1_32, s1_16, s2_16, key_add, W, heads, p_hid, p_att, ep
         L.fw, L.fb = fused_views(plist_w), fused_views(plist_b)
         if L.fw is None or L.fb is None:
             L.fw = L.fb = None
+    L.seq = False
+    if (LAYER_SEQ and self_attn and L.fw is not None and s1_32.is_cuda and not ops.FWD_F16 and not ops.kernel_timer.names and D % 256 == 0
+            and W.i_w.shape[0] % 256 == 0 and Mq >= ops.GROUPED_DW_MIN_ROWS and ops.GROUPED_DW):
+        # the layer's six launches from ONE library call (csrc/layers.hip: the same kernels, arguments and order as below)
+        return _bert_layer_fwd_seq(st, L, s1_32, s1_16, key_add, W, heads, p_hid, p_att, eps, seed, sites)
     if L.fw is not None:
         if self_attn:
             # (L.fw[3]: the forward-GEMM shadow of the fused weights; q, k, v are stored bf16 in every mode -- the attention kernels'
@@ -639,6 +644,9 @@ def _bert_layer_bwd(st, L, dout, seed):
     Mq, Mk, vl = st.Mq, st.Mk, st.vl
     W, heads, ld = L.W, L.heads, L.ld
     hd = D // heads
+    if getattr(L, "seq", False) and not ops.kernel_timer.names and all(gbuf(p) is not None for p in (W.o_w, W.o_b, W.i_w, W.i_b, W.o2_w, W.o2_b, W.ln1_w, W.ln1_b,
+                                                                                                        W.ln2_w, W.ln2_b)):
+        return _bert_layer_bwd_seq(st, L, dout, seed), None
     pend, raw = [], []                     # the layer's weight gradients leave as one grouped launch (see _lin_bwd_params_many)
     dz, dzb = ops.layernorm_bwd(dout, L.z, W.ln2_w, L.zm, L.zr, gbuf(W.ln2_w), gbuf(W.ln2_b), bf16_copy=(L.p_hid, L.site_f, gbuf(W.o2_b)))
     pend.append(((dzb, L.i, W.o2_w, W.o2_b), dict(bias_done=True)))
@@ -702,6 +710,57 @@ def _bert_layer_bwd(st, L, dout, seed):
     ds2 = ops.gemm(dk, wbf16(W.k_w), M=Mk, N=D, K=D, lda=D, ldb=D, transB=True, out_dtype=F32)
     ops.gemm(dv, wbf16(W.v_w), M=Mk, N=D, K=D, lda=D, ldb=D, transB=True, out=ds2, ldc=D, beta=1.0)
     return ds1, ds2
+
+
+def _bert_layer_fwd_seq(st, L, s1_32, s1_16, key_add, W, heads, p_hid, p_att, eps, seed, sites):
+    """_bert_layer_fwd's self-attention / fused-projection / fused-attention variant as ONE library call (csrc/layers.hip)."""
+    B, Lq, D, Mq, vl = st.B, st.Lq, st.D, st.Mq, st.vl
+    F = W.i_w.shape[0]
+    dev = s1_32.device
+    e = torch.empty
+    L.site_o, L.site_f = sites.next(), sites.next()          # (L.site_att was drawn by the caller: the same numbering as the op-by-op path)
+    L.qkv, L.ctx = e(Mq, 3 * D, device=dev, dtype=BF16), e(Mq, D, device=dev, dtype=BF16)
+    L.q, L.k, L.v = L.qkv[:, :D], L.qkv[:, D:2 * D], L.qkv[:, 2 * D:]
+    L.stats = e((B, heads, Lq, 2) if vl is None else (heads, Mq, 2), device=dev, dtype=F32)
+    L.y, L.a32, L.a16 = e(Mq, D, device=dev, dtype=F32), e(Mq, D, device=dev, dtype=F32), e(Mq, D, device=dev, dtype=BF16)
+    L.am, L.ar, L.zm, L.zr = (e(Mq, device=dev, dtype=F32) for _ in range(4))
+    L.u, L.i = e(Mq, F, device=dev, dtype=BF16), e(Mq, F, device=dev, dtype=BF16)
+    L.z, out32, out16 = e(Mq, D, device=dev, dtype=F32), e(Mq, D, device=dev, dtype=F32), e(Mq, D, device=dev, dtype=BF16)
+    L.fused, L.seq, L.p_hid, L.p_att = True, True, p_hid, p_att
+    p = ops._p
+    ops.lib().mmdti_bert_layer_fwd(
+        ops._stream(), Mq, B, Lq, heads, D, F, float(1.0 / math.sqrt(D // heads)), float(p_hid), float(p_att), int(seed), int(L.site_att), int(L.site_o),
+        int(L.site_f), s1_32.data_ptr(), s1_16.data_ptr(), p(key_add), *(ops._NO_VARLEN if vl is None else vl.args()), L.fw[3].data_ptr(),
+        L.fb[1].data_ptr(), wfwd(W.o_w).data_ptr(), p(W.o_b), W.ln1_w.data_ptr(), W.ln1_b.data_ptr(), wfwd(W.i_w).data_ptr(), p(W.i_b), ops.ACT_GELU_FWD,
+        wfwd(W.o2_w).data_ptr(), p(W.o2_b), W.ln2_w.data_ptr(), W.ln2_b.data_ptr(), float(eps), ops.GEMM_LN_MAX_K if ops.GEMM_LN else 0,
+        L.qkv.data_ptr(), L.ctx.data_ptr(), L.stats.data_ptr(), L.y.data_ptr(), L.a32.data_ptr(), L.a16.data_ptr(), L.am.data_ptr(), L.ar.data_ptr(),
+        L.u.data_ptr(), L.i.data_ptr(), L.z.data_ptr(), out32.data_ptr(), out16.data_ptr(), L.zm.data_ptr(), L.zr.data_ptr())
+    return L, out32, out16
+
+
+def _bert_layer_bwd_seq(st, L, dout, seed):
+    """_bert_layer_bwd of a layer that went through _bert_layer_fwd_seq, as ONE library call -> ds1 (fp32)."""
+    B, Lq, D, Mq, vl = st.B, st.Lq, st.D, st.Mq, st.vl
+    W, heads = L.W, L.heads
+    F = W.i_w.shape[0]
+    dout = dout.contiguous()
+    ds1 = torch.empty(Mq, D, device=dout.device, dtype=F32)
+    tiles = 3 * (D // 256) ** 2 + 2 * (D // 256) * (F // 256) + (D // 256) ** 2
+    sk = ops.lib()._dll.mmdti_linear_dw_grouped_splits(tiles, Mq)
+    nrow = heads * Mq if vl is not None else B * heads * Lq
+    nbytes = (Mq * F + 7 * Mq * D) * 2 + Mq * D * 4 + (nrow * 4 + 15) // 16 * 16 + sk * (4 * D * D + 2 * D * F) * 4
+    ws = torch.empty(nbytes + 256, device=dout.device, dtype=torch.uint8)
+    p = ops._p
+    ops.lib().mmdti_bert_layer_bwd(
+        ops._stream(), Mq, B, Lq, heads, D, F, float(1.0 / math.sqrt(D // heads)), float(L.p_hid), float(L.p_att), int(seed), int(L.site_att), int(L.site_o),
+        int(L.site_f), dout.data_ptr(), ds1.data_ptr(), L.s1_16.data_ptr(), p(L.key_add), *(ops._NO_VARLEN if vl is None else vl.args()),
+        L.qkv.data_ptr(), L.ctx.data_ptr(), L.stats.data_ptr(), L.y.data_ptr(), L.a16.data_ptr(), L.am.data_ptr(), L.ar.data_ptr(), L.u.data_ptr(),
+        ops.ACT_GELU_DX, L.i.data_ptr(), L.z.data_ptr(), L.zm.data_ptr(), L.zr.data_ptr(), L.fw[0].data_ptr(), wbf16(W.o_w).data_ptr(),
+        wbf16(W.i_w).data_ptr(), wbf16(W.o2_w).data_ptr(), W.ln1_w.data_ptr(), W.ln2_w.data_ptr(), L.fw[2].data_ptr(), L.fw[2].stride(0),
+        L.fb[2].view(-1).data_ptr(), gbuf(W.o_w).data_ptr(), gbuf(W.o_b).data_ptr(), gbuf(W.i_w).data_ptr(), gbuf(W.i_b).data_ptr(),
+        gbuf(W.o2_w).data_ptr(), gbuf(W.o2_b).data_ptr(), gbuf(W.ln1_w).data_ptr(), gbuf(W.ln1_b).data_ptr(), gbuf(W.ln2_w).data_ptr(),
+        gbuf(W.ln2_b).data_ptr(), (ws.data_ptr() + 255) // 256 * 256, ws.numel() - 256)
+    return ds1
 
 
 def bert_weights(layer) -> SimpleNamespace:
