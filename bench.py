@@ -276,11 +276,11 @@ def main():
             shost = dict(packing_fields(sb), atom_counts=atom_counts(sb["src_tokens"], 0))
             sb = dict({k: v.to(dev) for k, v in sb.items()}, **shost)
             sy = sy.to(dev)
-            for _ in range(max(3, args.warmup)):
+            for _ in range(max(10, args.warmup)):
                 tuner.step(sb, sy, epoch=0)
             barrier()
             t1 = time.perf_counter()
-            n_small = max(args.steps, 20)
+            n_small = max(args.steps, 50)        # (8 ms steps paced by launch issue: short runs scatter by a millisecond)
             for _ in range(n_small):
                 tuner.step(sb, sy, epoch=0)
             barrier()
