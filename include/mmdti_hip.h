@@ -43,11 +43,15 @@ typedef void* mmdti_stream_t;
 #define MMDTI_DT_F32 0
 #define MMDTI_DT_BF16 1
 #define MMDTI_DT_F32_ATOMIC 2 /* atomicAdd into fp32 C (split-K / gradient accumulation) */
-/* fp16 forward-operand mode (opt-in; the reference's own AMP dtype, tasks/trainer.py:181-182 -- three more mantissa bits than bf16
- * at the same matrix-pipe rate; profiles/r03_rounding_sites_fp16.json): */
+/* fp16 forward operands (the default precision mode since round 4; the reference's own AMP dtype, tasks/trainer.py:181-182 -- three
+ * more mantissa bits than bf16 at the same matrix-pipe rate; profiles/r03_rounding_sites_fp16.json): */
 #define MMDTI_DT_F16 3        /* the 16-bit output is fp16 instead of bf16 */
 #define MMDTI_DT_AB_F16 16    /* OR-ed into mmdti_gemm_bf16's c_dtype: A and B hold fp16 (forward Linear shapes only: row-major A,
                                  weight-layout B, no split-K, no batch) */
+#define MMDTI_DT_B_F16 32     /* OR-ed into mmdti_gemm_bf16's c_dtype: B holds fp16 beside a bf16 A -- the weight gradient dW += dy^T.x
+                                 (transA = transB = 1, MMDTI_DT_F32_ATOMIC) whose x is a forward activation saved as fp16.  The tile is
+                                 fetched as it lies in memory and converted to bf16 (round to nearest even: the values
+                                 mmdti_cast_f16_bf16 would write) between LDS and the matrix pipe; no pass over HBM */
 
 #define MMDTI_CT_REGRESS 0
 #define MMDTI_CT_SINGLE 1
@@ -109,7 +113,9 @@ int mmdti_gemm_ln_bf16(mmdti_stream_t stream, const void* A_bf16, const void* W_
  * them into dw.  The argument tables are HOST arrays of nprob entries. */
 int mmdti_linear_dw_grouped(mmdti_stream_t stream, int nprob, const void* const* dy_bf16, const void* const* x_bf16,
                             float* const* dw, float* const* db, const int* n_out, const int* n_in, const int* ldy,
-                            const int* ldx, const int* lddw, int rows, void* workspace, long long workspace_bytes);
+                            const int* ldx, const int* lddw, int rows, void* workspace, long long workspace_bytes,
+                            int x_f16 /* 1: every x[i] holds fp16 (saved forward activations of the fp16 forward-operand mode),
+                                         converted to bf16 between LDS and the matrix pipe -- see MMDTI_DT_B_F16 */);
 int mmdti_linear_dw_grouped_splits(int tiles, int rows);
 
 /* ---- one Uni-Mol encoder layer's forward / backward behind one call each (launch sequencing in the library: at 16-32 molecules
@@ -125,7 +131,9 @@ int mmdti_unimol_layer_fwd(mmdti_stream_t stream, int M, int B, int N, int H, in
                            const void* w_fc1, const float* b_fc1, int act_fwd, const void* w_fc2, const float* b_fc2,
                            int next_mode, const float* g_next, const float* bt_next, float eps_next, int ln_max_k, void* qkv,
                            void* s_out, void* o_att, float* x1, void* h2, float* m2, float* r2, void* u_aux, void* a_act,
-                           float* x_out, void* ln_out, float* mn, float* rn);
+                           float* x_out, void* ln_out, float* mn, float* rn,
+                           int fwd_f16 /* 1: the fp16 forward-operand mode -- every 16-bit operand of a forward GEMM (h1, weights, q | k | v,
+                                          o_att, h2, a_act, a 16-bit ln_out) holds fp16; pair_layout 3 only */);
 int mmdti_unimol_layer_bwd(mmdti_stream_t stream, int M, int B, int N, int H, int D, int F, int ld, float scale,
                            float p_res, float p_att, unsigned long long seed, unsigned int site_f_below, unsigned int site_o,
                            unsigned int site_att, const float* dx_in, const void* dy2, float* dx_out, void* dx16_out,
@@ -136,7 +144,7 @@ int mmdti_unimol_layer_bwd(mmdti_stream_t stream, int M, int B, int N, int H, in
                            float* dw_fc2, float* dw_fc1, float* dw_out, float* dw_in, float* db_fc1, float* db_out,
                            float* db_in, float* dg_ln2, float* dbt_ln2, float* dg_ln1, float* dbt_ln1, void* G,
                            int pair_layout, int g_in_zero, const int* key_tiles, const int* row_off, void* ws,
-                           long long ws_bytes);
+                           long long ws_bytes, int fwd_f16 /* 1: the saved a_act, h2, o_att, h1, qkv hold fp16 (weights: the bf16 shadow) */);
 
 /* The same for one post-LN BERT layer with self-attention, fused q | k | v projection and the fused attention kernels (HF RobertaLayer
  * reached from models/mm_model.py:562): six launches forward, eight backward.  Shapes and the workspace layout: layers.hip. */
@@ -147,7 +155,8 @@ int mmdti_bert_layer_fwd(mmdti_stream_t stream, int Mq, int B, int L, int heads,
                          const float* g_ln1, const float* bt_ln1, const void* w_i, const float* b_i, int act_fwd,
                          const void* w_o2, const float* b_o2, const float* g_ln2, const float* bt_ln2, float eps, int ln_max_k,
                          void* qkv, void* ctx, float* stats, float* y, float* a32, void* a16, float* am, float* ar, void* u_aux,
-                         void* i_act, float* z, float* out32, void* out16, float* zm, float* zr);
+                         void* i_act, float* z, float* out32, void* out16, float* zm, float* zr,
+                         int fwd_f16 /* 1: s1_16, the weights, ctx, a16, i_act, out16 hold fp16 (q | k | v stay bf16) */);
 int mmdti_bert_layer_bwd(mmdti_stream_t stream, int Mq, int B, int L, int heads, int D, int F, float scale, float p_hid, float p_att,
                          unsigned long long seed, unsigned int site_att, unsigned int site_o, unsigned int site_f,
                          const float* dout, float* ds1, const void* s1_16, const float* key_add, const int* q_off,
@@ -157,7 +166,7 @@ int mmdti_bert_layer_bwd(mmdti_stream_t stream, int Mq, int B, int L, int heads,
                          const void* w_o, const void* w_i, const void* w_o2, const float* g_ln1, const float* g_ln2,
                          float* dw_qkv, int lddw_qkv, float* db_qkv, float* dw_o, float* db_o, float* dw_i, float* db_i,
                          float* dw_o2, float* db_o2, float* dg_ln1, float* dbt_ln1, float* dg_ln2, float* dbt_ln2, void* ws,
-                         long long ws_bytes);
+                         long long ws_bytes, int fwd_f16 /* 1: the saved s1_16, ctx, a16, i_act hold fp16 (weights: the bf16 shadow) */);
 
 /* ---- LayerNorm (unicore LayerNorm eps 1e-5: transformers.py:69,71,114,161; BertLayerNorm eps 1e-12:
  * mm_module.py:320-333; HF nn.LayerNorm) -------------------------------------------------------
@@ -304,14 +313,17 @@ int mmdti_pair_attn_fwd(mmdti_stream_t stream, const void* qkv_bf16, const void*
                         indexed by POSITION: query position i of molecule b is packed row row_off[b] + i; query rows past the
                         representative one are neither computed nor stored. */,
                         int qkv_f16 /* != 0 (layout 3 only): qkv holds fp16 and o_bf16 receives fp16 -- the fp16 forward-operand
-                        mode (MMDTI_DT_AB_F16); the backward takes bf16 copies */);
+                        mode (MMDTI_DT_AB_F16); the backward converts q | k | v on its way into LDS */);
 /* g (in/out, same layout as s; fp32, or bf16 for layout 7): on entry dL/dS_l from the layers above (ignored if g_in_zero), on
  * exit dL/dS_l total = dL/d(bias_in).  dqkv: [B,N,3*H*8] bf16.  key_tiles: as in the forward; the skipped tiles of g are neither
  * read nor written (hand in a zero-initialised g for a ragged batch). */
 int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, const void* s, const void* do_bf16, void* g,
                         void* dqkv_bf16, int B, int N, int H, int ld, float scale, int g_in_zero, float drop_p,
                         unsigned long long seed, unsigned int site, int layout, const int* key_tiles,
-                        const int* row_off /* nullable: packed token rows of qkv / do_bf16 / dqkv_bf16, as in the forward */);
+                        const int* row_off /* nullable: packed token rows of qkv / do_bf16 / dqkv_bf16, as in the forward */,
+                        int qkv_f16 /* != 0 (tiled layouts): qkv holds the fp16 q | k | v the forward multiplied; the kernel rounds them to
+                        bf16 (to nearest even: the values mmdti_cast_f16_bf16 would write) on their way into LDS -- the backward's
+                        products keep bf16 operands, whose range activation gradients need.  do_bf16 / dqkv_bf16 stay bf16 */);
 
 /* ---- Row softmax over materialised scores (HF eager_attention_forward :158-183; BertCoAttention
  * mm_module.py:497-514) ------------------------------------------------------------------------
@@ -451,12 +463,13 @@ int mmdti_bce_logits_loss(mmdti_stream_t stream, const float* logits, const floa
 /* sum of squares of g into out[0] (atomic; zero first) */
 int mmdti_sumsq_f32(mmdti_stream_t stream, const float* g, long long n, float* out);
 /* Adam (torch.optim.Adam semantics, eps outside sqrt of bias-corrected v): p,m,v updated in place; also refreshes the
- * bf16 shadow copy of p.  grad is multiplied by *grad_scale_dev (device scalar, e.g. clip coefficient) if non-null.
+ * bf16 shadow copy of p (the backward GEMMs' weights) and, when p_f16 is given, the fp16 one (the forward GEMMs' weights in the fp16
+ * forward-operand mode; saturating).  grad is multiplied by *grad_scale_dev (device scalar, e.g. clip coefficient) if non-null.
  * step_state_dev (nullable): the device-resident schedule of mmdti_step_state_advance -- when given, lr and the bias
  * corrections are read from it and the by-value lr / step are ignored (a captured HIP graph replays with fresh values). */
 int mmdti_adam_step(mmdti_stream_t stream, float* p, const float* g, float* m, float* v, void* p_bf16, long long n,
                     float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                    const float* grad_scale_dev, const float* step_state_dev);
+                    const float* grad_scale_dev, const float* step_state_dev, void* p_f16 /* nullable */);
 /* Device-resident step state, so that a whole fine-tune step (tasks/trainer.py:177-283) can be captured in ONE HIP graph
  * and replayed: state[4] fp32 = {optimizer steps taken, this step's learning rate (HF linear warm-up / decay,
  * tasks/trainer.py:161-162), 1-beta1^t, sqrt(1-beta2^t)}; salt[2] u64 = {counter, mixed word}.  Call once at the top of

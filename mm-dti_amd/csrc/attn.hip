@@ -228,8 +228,8 @@ __global__ __launch_bounds__(512, HD == 16 ? 2 : 4) void attn_fwd_kernel(const b
       for (int nb = 0; nb < NB; ++nb) {
         if (ctx_f16) {   // the context feeds the output projection's forward GEMM: fp16 in the fp16 forward-operand mode
           uint2 pk;
-          pk.x = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)o[nb][0]) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)o[nb][1]) << 16);
-          pk.y = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)o[nb][2]) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)o[nb][3]) << 16);
+          pk.x = f2h_sat2(o[nb][0], o[nb][1]);
+          pk.y = f2h_sat2(o[nb][2], o[nb][3]);
           *reinterpret_cast<uint2*>(dst + nb * 16) = pk;
         } else {
           attn_store4(dst + nb * 16, o[nb]);

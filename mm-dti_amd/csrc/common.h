@@ -38,6 +38,32 @@ __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint3
 // round-to-nearest-even; NaN stays NaN, +-inf stays inf.  gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32):
 // one instruction instead of the six of the integer formulation.
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+// two fp32 -> one word of fp16 bits, round to nearest even, SATURATING: a value past the fp16 range leaves as +-65504 instead of +-inf
+// (an inf in a forward GEMM operand would turn the whole row into NaN at the next product; the reference's AMP run has the same
+// exposure and no guard -- this is the safer contract, pinned by tests/test_fp16_mode_gpu.py).  Three instructions per pair
+// (v_cvt_pk_f16_f32, v_pk_min_f16, v_pk_max_f16) against one for bf16: the store epilogues are VALU-bound at K = 512.  +-inf clamp
+// too, and a NaN does not survive the min / max (IEEE minNum) -- the fp32 residual stream written beside every 16-bit copy keeps it.
+__device__ __forceinline__ uint32_t f2h_sat2(float lo, float hi) {
+  typedef _Float16 h16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2v_t __attribute__((ext_vector_type(2)));
+  h16x2_t v = __builtin_convertvector(f32x2v_t{lo, hi}, h16x2_t);
+  const h16x2_t mx = {(_Float16)65504.f, (_Float16)65504.f};
+  v = __builtin_elementwise_min(v, mx);
+  v = __builtin_elementwise_max(v, -mx);
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ uint16_t f2h_sat(float f) { return (uint16_t)(f2h_sat2(f, f) & 0xffffu); }
+// eight fp16 values (one 16-byte chunk) -> their eight bf16 roundings (fp16 -> fp32 is exact, then round to nearest even):
+// element for element what mmdti_cast_f16_bf16 writes
+__device__ __forceinline__ uint4 h2bf8(const uint4& u) {
+  typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+  const f16x8_t h = __builtin_bit_cast(f16x8_t, u);
+  bf16x8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (__bf16)(float)h[e];
+  return __builtin_bit_cast(uint4, o);
+}
 
 // ---- wave-level reductions (64 lanes) on the DPP crossbar -------------------------------------------------------
 // v_*_dpp reads a neighbour lane as part of a normal VALU op (~1 issue slot) whereas __shfl_xor lowers to ds_bpermute

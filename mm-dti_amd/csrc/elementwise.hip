@@ -23,7 +23,7 @@ static inline int grid_for(long long n, int per_block) {
 }
 
 // ---------------------------------------------------------------- casts / dropout / axpy
-__device__ __forceinline__ bf16_t f2h16(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }
+__device__ __forceinline__ bf16_t f2h16(float f) { return f2h_sat(f); }
 
 // F16: the 16-bit output is fp16 (the fp16 forward-operand mode), else bf16
 template <bool F16>
@@ -499,7 +499,7 @@ __global__ void step_state_advance_kernel(float* __restrict__ st, unsigned long 
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, bf16_t* __restrict__ pb, long long n, float lr, float b1,
+                                                   float* __restrict__ v, bf16_t* __restrict__ pb, bf16_t* __restrict__ ph, long long n, float lr, float b1,
                                                    float b2, float eps, float wd, float bc1, float bc2_sqrt,
                                                    const float* __restrict__ gscale, const float* __restrict__ state) {
   const float gs = gscale ? *gscale : 1.0f;
@@ -520,6 +520,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     pi -= (lr / bc1) * mi / denom;
     p[i] = pi;
     if (pb) pb[i] = f2bf(pi);
+    if (ph) ph[i] = f2h_sat(pi);      // the fp16 shadow the forward GEMMs read (fp16 forward-operand mode)
   }
 }
 
@@ -765,12 +766,12 @@ extern "C" int mmdti_sumsq_f32(mmdti_stream_t stream, const float* g, long long 
 
 extern "C" int mmdti_adam_step(mmdti_stream_t stream, float* p, const float* g, float* m, float* v, void* p_bf16,
                                long long n, float lr, float beta1, float beta2, float eps, float weight_decay,
-                               int step, const float* grad_scale_dev, const float* step_state_dev) {
+                               int step, const float* grad_scale_dev, const float* step_state_dev, void* p_f16) {
   MMDTI_REQUIRE(p && g && m && v && n > 0 && (step >= 1 || step_state_dev), "adam_step: bad arguments");
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                     (bf16_t*)p_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale_dev, step_state_dev);
+                     (bf16_t*)p_bf16, (bf16_t*)p_f16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale_dev, step_state_dev);
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }

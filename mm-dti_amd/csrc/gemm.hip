@@ -36,10 +36,28 @@ __device__ __forceinline__ f32x4 mfma32(const bf16x8& b, const bf16x8& a, const 
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c, 0, 0, 0);
   }
 }
-__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+__device__ __forceinline__ uint16_t f2h(float f) { return f2h_sat(f); }
 // two fp32 -> one 32-bit word of bf16 (f16 == 0) or fp16 values
 __device__ __forceinline__ uint32_t pack16x2(int f16, float lo, float hi) {
-  return f16 ? ((uint32_t)f2h(lo) | ((uint32_t)f2h(hi) << 16)) : ((uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16));
+  return f16 ? f2h_sat2(lo, hi) : ((uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16));
+}
+
+// A fragment of 8 fp16 values as the 8 bf16 values of their round-to-nearest-even conversion (fp16 -> fp32 is exact, then
+// v_cvt_pk_bf16_f32): what mmdti_cast_f16_bf16 writes, element for element.  Default precision mode (fp16 forward operands): a saved
+// forward activation is the B operand of a weight-gradient GEMM whose A operand -- an activation gradient -- needs bf16's range, so the
+// fp16 tile is fetched as it lies in memory and converted on its way from LDS to the matrix pipe instead of in a pass over HBM.
+__device__ __forceinline__ bf16x8 frag_h2bf(const bf16x8& v) {
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  const f16x8 h = __builtin_bit_cast(f16x8, v);
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (__bf16)(float)h[e];
+  return o;
+}
+template <bool CVT>
+__device__ __forceinline__ bf16x8 frag_cvt(const bf16x8& v) {
+  if constexpr (CVT) return frag_h2bf(v);
+  else return v;
 }
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -384,7 +402,9 @@ __device__ __forceinline__ void epilogue_colsum(const GemmArgs& a, float* lds, c
   }
 }
 
-template <bool TA, bool TB, bool FAST, bool F16 = false>
+// BCVT: B holds fp16 and is converted to bf16 fragment by fragment (frag_h2bf) -- the weight-gradient forms, A = dy (bf16), B = a
+// saved forward activation of the fp16 forward-operand mode
+template <bool TA, bool TB, bool FAST, bool F16 = false, bool BCVT = false>
 __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(GemmArgs a) {
   // LDS image: [buf 0: A | B][buf 1: A | B]; addressed by integer offsets from ONE __shared__ base so that every access
   // stays a ds_* instruction (pointer arrays indexed at run time decay to flat loads + scratch).
@@ -453,8 +473,8 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(GemmArgs a) {
   {                                                                                                \
     const bf16x8 fa0 = load_frag<TA>(IMGA, wr * 64 + 0, KK, lane), fa1 = load_frag<TA>(IMGA, wr * 64 + 16, KK, lane), \
                  fa2 = load_frag<TA>(IMGA, wr * 64 + 32, KK, lane), fa3 = load_frag<TA>(IMGA, wr * 64 + 48, KK, lane); \
-    const bf16x8 fb0 = load_frag<TB>(IMGB, wc * 64 + 0, KK, lane), fb1 = load_frag<TB>(IMGB, wc * 64 + 16, KK, lane), \
-                 fb2 = load_frag<TB>(IMGB, wc * 64 + 32, KK, lane), fb3 = load_frag<TB>(IMGB, wc * 64 + 48, KK, lane); \
+    const bf16x8 fb0 = frag_cvt<BCVT>(load_frag<TB>(IMGB, wc * 64 + 0, KK, lane)), fb1 = frag_cvt<BCVT>(load_frag<TB>(IMGB, wc * 64 + 16, KK, lane)), \
+                 fb2 = frag_cvt<BCVT>(load_frag<TB>(IMGB, wc * 64 + 32, KK, lane)), fb3 = frag_cvt<BCVT>(load_frag<TB>(IMGB, wc * 64 + 48, KK, lane)); \
     MF(0, 0); MF(0, 1); MF(0, 2); MF(0, 3); MF(1, 0); MF(1, 1); MF(1, 2); MF(1, 3);                \
     MF(2, 0); MF(2, 1); MF(2, 2); MF(2, 3); MF(3, 0); MF(3, 1); MF(3, 2); MF(3, 3);                \
   }
@@ -609,7 +629,7 @@ __device__ __forceinline__ void glds_tile(const bf16_t* kbase, const Off4& off, 
 // batches: 13-56 tiles), where nothing else on the CU hides a K-step's ~1 us fetch latency.  Same products in the same
 // order as the other two forms: bit-identical results.
 constexpr int DEEP_STAGES = 4;
-template <bool TA, bool TB, int DBUF, bool F16 = false>
+template <bool TA, bool TB, int DBUF, bool F16 = false, bool BCVT = false>
 __global__ __launch_bounds__(256, DBUF == 2 ? 1 : DBUF ? 2 : 4) void gemm_glds_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
   constexpr int TILE = BM * LDT;
@@ -639,8 +659,8 @@ __global__ __launch_bounds__(256, DBUF == 2 ? 1 : DBUF ? 2 : 4) void gemm_glds_k
   {                                                                                                \
     const bf16x8 fa0 = load_frag<TA>(IMGA, wr * 64 + 0, KK, lane), fa1 = load_frag<TA>(IMGA, wr * 64 + 16, KK, lane), \
                  fa2 = load_frag<TA>(IMGA, wr * 64 + 32, KK, lane), fa3 = load_frag<TA>(IMGA, wr * 64 + 48, KK, lane); \
-    const bf16x8 fb0 = load_frag<TB>(IMGB, wc * 64 + 0, KK, lane), fb1 = load_frag<TB>(IMGB, wc * 64 + 16, KK, lane), \
-                 fb2 = load_frag<TB>(IMGB, wc * 64 + 32, KK, lane), fb3 = load_frag<TB>(IMGB, wc * 64 + 48, KK, lane); \
+    const bf16x8 fb0 = frag_cvt<BCVT>(load_frag<TB>(IMGB, wc * 64 + 0, KK, lane)), fb1 = frag_cvt<BCVT>(load_frag<TB>(IMGB, wc * 64 + 16, KK, lane)), \
+                 fb2 = frag_cvt<BCVT>(load_frag<TB>(IMGB, wc * 64 + 32, KK, lane)), fb3 = frag_cvt<BCVT>(load_frag<TB>(IMGB, wc * 64 + 48, KK, lane)); \
     MF(0, 0); MF(0, 1); MF(0, 2); MF(0, 3); MF(1, 0); MF(1, 1); MF(1, 2); MF(1, 3);                \
     MF(2, 0); MF(2, 1); MF(2, 2); MF(2, 3); MF(3, 0); MF(3, 1); MF(3, 2); MF(3, 3);                \
     if (TA && DBUF == 1 && do_rs) {                                                                \
@@ -1070,9 +1090,12 @@ struct Frag4 {
   bf16x8 f0, f1, f2, f3;
 };
 
-// one 256 x 256 output tile (tm, tn), K-split ks of a.splitk
-template <bool TA, bool TB>
+// one 256 x 256 output tile (tm, tn), K-split ks of a.splitk.  F16: both operands hold fp16 (forward shapes).  BCVT: B holds fp16 and
+// is converted to bf16 in registers (frag_h2bf) at the end of the phase that read it from LDS, while the matrix pipe drains that
+// phase's MFMAs; A is bf16 (weight gradients: A = dy, B = a saved forward activation).
+template <bool TA, bool TB, bool F16 = false, bool BCVT = false>
 __device__ __forceinline__ void big_tile(const GemmArgs& a, int tm, int tn, int ks, bf16_t* smem) {
+  static_assert(!(F16 && (TA || TB || BCVT)), "fp16 operands: the forward (row-major A, weight-layout B) form only");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
   const int m0 = tm * BBM, n0 = tn * BBN;
@@ -1127,17 +1150,19 @@ __device__ __forceinline__ void big_tile(const GemmArgs& a, int tm, int tn, int 
 #define BIG_LDB(F, BUF, KK)                                                                                          \
   F.f0 = load_frag<TB>(BUF + 2 * BIG_PIECE, wc * 32 + 0, KK, lane); F.f1 = load_frag<TB>(BUF + 2 * BIG_PIECE, wc * 32 + 16, KK, lane); \
   F.f2 = load_frag<TB>(BUF + 3 * BIG_PIECE, wc * 32 + 0, KK, lane); F.f3 = load_frag<TB>(BUF + 3 * BIG_PIECE, wc * 32 + 16, KK, lane)
-#define BMF(R, C, FA, FB) acc[R][C] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB.f##C, FA.f##R, acc[(R) + RB][C], 0, 0, 0)
   // 16 MFMAs: the wave's four row tiles of A half H (acc rows H*4 + 0..3) x its four column tiles, one k half
 #define BIG_MF8(H, FA, FB, R0, R1)                                                                                   \
-  acc[H * 4 + R0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB.f0, FA.f##R0, acc[H * 4 + R0][0], 0, 0, 0);         \
-  acc[H * 4 + R0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB.f1, FA.f##R0, acc[H * 4 + R0][1], 0, 0, 0);         \
-  acc[H * 4 + R0][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB.f2, FA.f##R0, acc[H * 4 + R0][2], 0, 0, 0);         \
-  acc[H * 4 + R0][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB.f3, FA.f##R0, acc[H * 4 + R0][3], 0, 0, 0);         \
-  acc[H * 4 + R1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB.f0, FA.f##R1, acc[H * 4 + R1][0], 0, 0, 0);         \
-  acc[H * 4 + R1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB.f1, FA.f##R1, acc[H * 4 + R1][1], 0, 0, 0);         \
-  acc[H * 4 + R1][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB.f2, FA.f##R1, acc[H * 4 + R1][2], 0, 0, 0);         \
-  acc[H * 4 + R1][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB.f3, FA.f##R1, acc[H * 4 + R1][3], 0, 0, 0)
+  acc[H * 4 + R0][0] = mfma32<F16>(FB.f0, FA.f##R0, acc[H * 4 + R0][0]);                                              \
+  acc[H * 4 + R1][0] = mfma32<F16>(FB.f0, FA.f##R1, acc[H * 4 + R1][0]);                                              \
+  acc[H * 4 + R0][1] = mfma32<F16>(FB.f1, FA.f##R0, acc[H * 4 + R0][1]);                                              \
+  acc[H * 4 + R1][1] = mfma32<F16>(FB.f1, FA.f##R1, acc[H * 4 + R1][1]);                                              \
+  acc[H * 4 + R0][2] = mfma32<F16>(FB.f2, FA.f##R0, acc[H * 4 + R0][2]);                                              \
+  acc[H * 4 + R1][2] = mfma32<F16>(FB.f2, FA.f##R1, acc[H * 4 + R1][2]);                                              \
+  acc[H * 4 + R0][3] = mfma32<F16>(FB.f3, FA.f##R0, acc[H * 4 + R0][3]);                                              \
+  acc[H * 4 + R1][3] = mfma32<F16>(FB.f3, FA.f##R1, acc[H * 4 + R1][3])
+// (B fragments first used by this phase arrive as fp16 when BCVT: converted in place, once per K half)
+#define BIG_CVTB(FB)                                                                                                 \
+  if constexpr (BCVT) { FB.f0 = frag_h2bf(FB.f0); FB.f1 = frag_h2bf(FB.f1); FB.f2 = frag_h2bf(FB.f2); FB.f3 = frag_h2bf(FB.f3); }
 #define BIG_RS(ACC, FA)                                                                                              \
   if (do_rs) {                                                                                                       \
     const bf16x8 s0 = wc == 0 ? FA.f0 : wc == 1 ? FA.f1 : wc == 2 ? FA.f2 : FA.f3;                                    \
@@ -1146,7 +1171,10 @@ __device__ __forceinline__ void big_tile(const GemmArgs& a, int tm, int tn, int 
   // one phase: the LDS reads of the NEXT phase's fragments and the DMA of a later tile's piece are issued first / in
   // the middle and run under this phase's 16 MFMAs (which use fragments read one phase earlier); every read is retired
   // before the closing barrier, so the region it came from may be restaged in the next phase
-#define BIG_PHASE(H, FA, FB, RSACC, LOADS, ISSUE, WAITS)                                                              \
+  // POST (BCVT): the fp16 B fragments this phase READ are converted to bf16 once its own MFMAs are issued -- the wave's VALU
+  // works while the matrix pipe drains them (16 MFMAs take 128 cycles to issue and 256 to execute), before the DMA wait.  At the top
+  // of the consuming phase the same 48 conversions held the idle matrix pipe back: +14 % on the launch, measured.
+#define BIG_PHASE(H, FA, FB, RSACC, LOADS, ISSUE, WAITS, POST)                                                        \
   LOADS;                                                                                                             \
   __builtin_amdgcn_sched_barrier(0);                                                                                 \
   __builtin_amdgcn_s_setprio(1);                                                                                     \
@@ -1157,27 +1185,31 @@ __device__ __forceinline__ void big_tile(const GemmArgs& a, int tm, int tn, int 
   BIG_MF8(H, FA, FB, 2, 3);                                                                                          \
   BIG_RS(RSACC, FA);                                                                                                 \
   __builtin_amdgcn_s_setprio(0);                                                                                     \
-  WAITS;                                                                                                             \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                                                                 \
+  POST;                                                                                                              \
+  __builtin_amdgcn_sched_barrier(0);                                                                                 \
+  WAITS;                                                                                                             \
   __builtin_amdgcn_sched_barrier(0);                                                                                 \
   __builtin_amdgcn_s_barrier();                                                                                      \
   __builtin_amdgcn_sched_barrier(0)
 
   BIG_LDA(FAx, smem, 0);
   BIG_LDB(FBx, smem, 0);
+  BIG_CVTB(FBx);
   for (int t = 0; t < nt; ++t) {
     bf16_t* cur = smem + (t & 1) * BIG_BUF;
     bf16_t* oth = smem + ((t & 1) ^ 1) * BIG_BUF;
     // c1: (A0, k 0..31)   | read A1 k-half 0            | DMA A0(t+1) -> other buffer (free since phase 4 of tile t-1)
-    BIG_PHASE(0, FAx, FBx, rs0, BIG_LDA(FAy, cur + BIG_PIECE, 0), BIG_ISSUE(BIG_A(t + 1), dA2, oA, t + 1, oth), (void)0);
+    BIG_PHASE(0, FAx, FBx, rs0, BIG_LDA(FAy, cur + BIG_PIECE, 0), BIG_ISSUE(BIG_A(t + 1), dA2, oA, t + 1, oth), (void)0, (void)0);
     // c2: (A1, k 0..31)   | read A1 and B k-half 1      | DMA A1(t+1) -> other buffer (free since phase 3 of tile t-1)
     BIG_PHASE(1, FAy, FBx, rs1, BIG_LDA(FAx, cur + BIG_PIECE, 1); BIG_LDB(FBy, cur, 1),
-              BIG_ISSUE(BIG_A(t + 1) + hA, dA2, oA, t + 1, oth + BIG_PIECE), (void)0);
+              BIG_ISSUE(BIG_A(t + 1) + hA, dA2, oA, t + 1, oth + BIG_PIECE), (void)0, BIG_CVTB(FBy));
     // c3: (A1, k 32..63)  | read A0 k-half 1            | DMA B0(t+2) -> this buffer (B was last read in phase 2); wait: A0(t+1), B(t+1) landed
-    BIG_PHASE(1, FAx, FBy, rs1, BIG_LDA(FAy, cur, 1), BIG_ISSUE(BIG_B(t + 2), dB2, oB, t + 2, cur + 2 * BIG_PIECE), BIG_WAIT(4));
+    BIG_PHASE(1, FAx, FBy, rs1, BIG_LDA(FAy, cur, 1), BIG_ISSUE(BIG_B(t + 2), dB2, oB, t + 2, cur + 2 * BIG_PIECE), BIG_WAIT(4), (void)0);
     // c4: (A0, k 32..63)  | read A0, B of tile t+1      | DMA B1(t+2) -> this buffer; wait: A1(t+1) landed
     BIG_PHASE(0, FAy, FBy, rs0, BIG_LDA(FAx, oth, 0); BIG_LDB(FBx, oth, 0),
-              BIG_ISSUE(BIG_B(t + 2) + hB, dB2, oB, t + 2, cur + 3 * BIG_PIECE), BIG_WAIT(4));
+              BIG_ISSUE(BIG_B(t + 2) + hB, dB2, oB, t + 2, cur + 3 * BIG_PIECE), BIG_WAIT(4), BIG_CVTB(FBx));
   }
   BIG_WAIT(0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1185,7 +1217,7 @@ __device__ __forceinline__ void big_tile(const GemmArgs& a, int tm, int tn, int 
 #undef BIG_PHASE
 #undef BIG_ISSUE
 #undef BIG_MF8
-#undef BMF
+#undef BIG_CVTB
 #undef BIG_LDA
 #undef BIG_LDB
 #undef BIG_WAIT
@@ -1263,13 +1295,13 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, bool F16 = false, bool BCVT = false>
 __global__ __launch_bounds__(512, 1) void gemm_big_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
   const int tiles_n = (a.N + BBN - 1) / BBN, tiles_m = (a.M + BBM - 1) / BBM;
   const int wg = xcd_remap(blockIdx.x, tiles_n * tiles_m);
   const int tm = wg / tiles_n;
-  big_tile<TA, TB>(a, tm, wg - tm * tiles_n, blockIdx.z, smem);
+  big_tile<TA, TB, F16, BCVT>(a, tm, wg - tm * tiles_n, blockIdx.z, smem);
 }
 
 // ---- grouped weight gradients ------------------------------------------------------------------------------------------
@@ -1294,6 +1326,7 @@ struct GroupArgs {
   const void* zeros;
 };
 
+template <bool BCVT>
 __global__ __launch_bounds__(512, 1) void gemm_big_grouped_kernel(GroupArgs g) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
   const int wg = xcd_remap(blockIdx.x, g.ntiles);
@@ -1316,7 +1349,7 @@ __global__ __launch_bounds__(512, 1) void gemm_big_grouped_kernel(GroupArgs g) {
   int tm, tn;
   if (tiles_m < pr.tiles_n) { tn = t / tiles_m; tm = t - tn * tiles_m; }
   else { tm = t / pr.tiles_n; tn = t - tm * pr.tiles_n; }
-  big_tile<true, true>(a, tm, tn, blockIdx.z, smem);
+  big_tile<true, true, false, BCVT>(a, tm, tn, blockIdx.z, smem);
 }
 
 // The same grouped weight gradients for SMALL token counts (batches of 16-32 molecules: 1-4 k rows).  There the 256 x 256 launch is
@@ -1324,7 +1357,7 @@ __global__ __launch_bounds__(512, 1) void gemm_big_grouped_kernel(GroupArgs g) {
 // step's GPU time at 32 molecules.  Here: 64 x 64 tiles (768 of them for a tower-1 layer: every CU busy without any K split), the
 // four-stage LDS-DMA ring of gemm_small_kernel with both operands k-major, the K tail zero-filled by per-lane source select, and
 // dW += as a plain read-modify-write -- one workgroup owns a tile, so the result is also bitwise reproducible.
-template <int STAGES>
+template <int STAGES, bool BCVT = false>
 __global__ __launch_bounds__(256, STAGES == 3 ? 3 : 2) void gemm_small_dw_grouped_kernel(GroupArgs g) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1381,9 +1414,9 @@ __global__ __launch_bounds__(256, STAGES == 3 ? 3 : 2) void gemm_small_dw_groupe
     const bf16_t* imgA = smem + (t2 % STAGES) * (2 * SM_TILE);
     const bf16_t* imgB = imgA + SM_TILE;
     const bf16x8 fa00 = small_frag<true>(imgA, wr * 32, 0, lane), fa10 = small_frag<true>(imgA, wr * 32 + 16, 0, lane);
-    const bf16x8 fb00 = small_frag<true>(imgB, wc * 32, 0, lane), fb10 = small_frag<true>(imgB, wc * 32 + 16, 0, lane);
+    const bf16x8 fb00 = frag_cvt<BCVT>(small_frag<true>(imgB, wc * 32, 0, lane)), fb10 = frag_cvt<BCVT>(small_frag<true>(imgB, wc * 32 + 16, 0, lane));
     const bf16x8 fa01 = small_frag<true>(imgA, wr * 32, 1, lane), fa11 = small_frag<true>(imgA, wr * 32 + 16, 1, lane);
-    const bf16x8 fb01 = small_frag<true>(imgB, wc * 32, 1, lane), fb11 = small_frag<true>(imgB, wc * 32 + 16, 1, lane);
+    const bf16x8 fb01 = frag_cvt<BCVT>(small_frag<true>(imgB, wc * 32, 1, lane)), fb11 = frag_cvt<BCVT>(small_frag<true>(imgB, wc * 32 + 16, 1, lane));
     acc[0][0] = mfma32<false>(fb00, fa00, acc[0][0]); acc[0][1] = mfma32<false>(fb10, fa00, acc[0][1]);
     acc[1][0] = mfma32<false>(fb00, fa10, acc[1][0]); acc[1][1] = mfma32<false>(fb10, fa10, acc[1][1]);
     acc[0][0] = mfma32<false>(fb01, fa01, acc[0][0]); acc[0][1] = mfma32<false>(fb11, fa01, acc[0][1]);
@@ -1684,12 +1717,15 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
   MMDTI_REQUIRE(sAo % 8 == 0 && sAi % 8 == 0 && sBo % 8 == 0 && sBi % 8 == 0, "gemm: batch strides must be multiples of 8");
   MMDTI_REQUIRE(batch_outer >= 1 && batch_inner >= 1 && splitk >= 1, "gemm: batch/splitk must be >= 1");
   const bool ab16 = (c_dtype & MMDTI_DT_AB_F16) != 0;       // A and B hold fp16 (forward shapes only)
-  c_dtype &= ~MMDTI_DT_AB_F16;
+  const bool bcvt = (c_dtype & MMDTI_DT_B_F16) != 0;        // B holds fp16, converted to bf16 in registers (weight-gradient shapes only)
+  c_dtype &= ~(MMDTI_DT_AB_F16 | MMDTI_DT_B_F16);
   const int c_f16 = c_dtype == MMDTI_DT_F16;
   if (c_f16) c_dtype = MMDTI_DT_BF16;
   MMDTI_REQUIRE(c_dtype == MMDTI_DT_F32 || c_dtype == MMDTI_DT_BF16 || c_dtype == MMDTI_DT_F32_ATOMIC, "gemm: bad c_dtype");
   MMDTI_REQUIRE(!ab16 || (!transA && !transB && splitk == 1 && !arowsum_out && batch_outer * batch_inner == 1),
                 "gemm: fp16 operands are built for the forward Linear shapes (row-major A, weight-layout B, no split-K, no batch)");
+  MMDTI_REQUIRE(!bcvt || (!ab16 && transA && transB && batch_outer * batch_inner == 1 && c_dtype == MMDTI_DT_F32_ATOMIC),
+                "gemm: an fp16 B beside a bf16 A is built for the weight-gradient shapes (both operands k-major, fp32 accumulation into C, no batch)");
   MMDTI_REQUIRE(!c_f16 || !colsum_out, "gemm: colsum_out with an fp16 output is not supported");
   MMDTI_REQUIRE(splitk == 1 || c_dtype == MMDTI_DT_F32_ATOMIC, "gemm: splitk>1 needs the atomic fp32 output mode");
   MMDTI_REQUIRE(splitk == 1 || (act == MMDTI_ACT_NONE && drop_p == 0.f), "gemm: splitk>1 cannot fuse act/dropout");
@@ -1779,17 +1815,21 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
   // 256 x 256 tiles with the DMA in flight across barriers (gemm_big_kernel): MMDTI_GEMM_BIG=0 off, 1 (default) where
   // the shape fills the chip, 2 every eligible shape
   const int use_big = g_gemm_big;
-  const bool big_ok = !ab16 && fast && use_big && batch_outer * batch_inner == 1 && !colsum_out && M >= 256 && N >= 256 &&
+  const bool big_ok = fast && use_big && batch_outer * batch_inner == 1 && !colsum_out && M >= 256 && N >= 256 &&
                       (c_dtype == MMDTI_DT_F32_ATOMIC || a.vec_ok) && M % 256 == 0 && N % 256 == 0;
   if (big_ok && (use_big == 2 || big_shape_pays(M, N, K, splitk, transA, transB, aux_in != nullptr))) {
     typedef void (*bkern_t)(GemmArgs);
     static const bkern_t bkerns[2][2] = {{gemm_big_kernel<false, false>, gemm_big_kernel<false, true>},
                                          {gemm_big_kernel<true, false>, gemm_big_kernel<true, true>}};
+    // [4]: fp16 operands (forward shapes); [5]: fp16 B converted in registers (weight gradients)
+    static const bkern_t bkerns_all[6] = {bkerns[0][0], bkerns[0][1], bkerns[1][0], bkerns[1][1], gemm_big_kernel<false, false, true>,
+                                          gemm_big_kernel<true, true, false, true>};
+    const bkern_t bk = ab16 ? bkerns_all[4] : (bcvt ? bkerns_all[5] : bkerns[transA ? 1 : 0][transB ? 1 : 0]);
     const size_t smem_b = (size_t)2 * BIG_BUF * sizeof(bf16_t);
     static bool big_attr = false;
     if (!big_attr) {
-      for (int i = 0; i < 4; ++i)
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(bkerns[i >> 1][i & 1]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b) != hipSuccess) {
+      for (int i = 0; i < 6; ++i)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(bkerns_all[i]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b) != hipSuccess) {
           set_error("gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", smem_b);
           return MMDTI_ERR_LAUNCH;
         }
@@ -1812,24 +1852,44 @@ extern "C" int mmdti_gemm_bf16(mmdti_stream_t stream, const void* A, const void*
       // split ks stores its partial tile into slab ks (vector epilogue, plain stores); splitk_reduce_kernel adds the sum into C
       GemmArgs p = a;
       p.C = workspace; p.ldc = N; p.c_dtype = MMDTI_DT_F32; p.beta = 0.f; p.vec_ok = 1; p.stream_c = 0; p.slab = slab;
-      hipLaunchKernelGGL(bkerns[transA ? 1 : 0][transB ? 1 : 0], bgrid, dim3(512), smem_b, s, p);
+      hipLaunchKernelGGL(bk, bgrid, dim3(512), smem_b, s, p);
       const long long n4 = slab / 4;
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)min((n4 + 255) / 256, 4096LL)), dim3(256), 0, s, (const float*)workspace,
                          reinterpret_cast<float*>(C), M, N, ldc, sk);
     } else {
-      hipLaunchKernelGGL(bkerns[transA ? 1 : 0][transB ? 1 : 0], bgrid, dim3(512), smem_b, s, a);
+      hipLaunchKernelGGL(bk, bgrid, dim3(512), smem_b, s, a);
     }
     MMDTI_LAUNCH_CHECK();
     return MMDTI_OK;
   }
   if (arowsum_out) {
-    if (dbuf_path) {
+    if (dbuf_path || (bcvt && fast && use_glds)) {
       a.arowsum = arowsum_out;
     } else if (int e = mmdti_colsum_bf16(stream, A, K, M, lda, arowsum_out)) {
       return e;
     }
   }
-  if (dbuf_path)
+  if (bcvt) {
+    // weight gradient with an fp16 activation operand: the double-buffered LDS-DMA kernel on bare-load shapes (whatever the split), the
+    // register-staged one otherwise
+    if (fast && use_glds) {
+      a.arowsum = arowsum_out;
+      hipLaunchKernelGGL((gemm_glds_kernel<true, true, 1, false, true>), grid, block, 4 * (size_t)BM * LDT * sizeof(bf16_t), s, a);
+    } else {
+      static bool attr_cv = false;
+      if (!attr_cv) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<true, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<true, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+          set_error("gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", smem);
+          return MMDTI_ERR_LAUNCH;
+        }
+        attr_cv = true;
+      }
+      if (fast) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, true, false, true>), grid, block, smem, s, a);
+      else hipLaunchKernelGGL((gemm_bf16_kernel<true, true, false, false, true>), grid, block, smem, s, a);
+    }
+  }
+  else if (dbuf_path)
     hipLaunchKernelGGL(gkerns2[transA ? 1 : 0][transB ? 1 : 0], grid, block, 4 * (size_t)BM * LDT * sizeof(bf16_t), s, a);
   else if (fast && use_glds && splitk == 1) {
     // tall tiles when they save a whole round of the 1024 resident workgroups (see gemm_glds_tall_kernel)
@@ -1953,7 +2013,7 @@ extern "C" int mmdti_gemm_ln_bf16(mmdti_stream_t stream, const void* A_bf16, con
 
 extern "C" int mmdti_linear_dw_grouped(mmdti_stream_t stream, int nprob, const void* const* dy_bf16, const void* const* x_bf16,
                                        float* const* dw, float* const* db, const int* n_out, const int* n_in, const int* ldy,
-                                       const int* ldx, const int* lddw, int rows, void* workspace, long long workspace_bytes) {
+                                       const int* ldx, const int* lddw, int rows, void* workspace, long long workspace_bytes, int x_f16) {
   MMDTI_REQUIRE(nprob >= 1 && nprob <= GROUP_MAX, "linear_dw_grouped: 1..%d problems (got %d)", GROUP_MAX, nprob);
   MMDTI_REQUIRE(dy_bf16 && x_bf16 && dw && n_out && n_in && ldy && ldx && lddw, "linear_dw_grouped: null argument table");
   MMDTI_REQUIRE(rows >= 64, "linear_dw_grouped: at least 64 rows (got %d)", rows);   // (any count: a K tail is zero-filled in the kernel)
@@ -1990,7 +2050,8 @@ extern "C" int mmdti_linear_dw_grouped(mmdti_stream_t stream, int nprob, const v
     }
     gs.ntiles = st; gs.splitk = 1; gs.atomic = 0;
     // (three stages = 48 KB: three workgroups per CU; measured -2 % on the step against a four-stage ring at two per CU)
-    hipLaunchKernelGGL(gemm_small_dw_grouped_kernel<3>, dim3(st), dim3(256), (size_t)3 * 2 * SM_TILE * sizeof(bf16_t), s, gs);
+    if (x_f16) hipLaunchKernelGGL((gemm_small_dw_grouped_kernel<3, true>), dim3(st), dim3(256), (size_t)3 * 2 * SM_TILE * sizeof(bf16_t), s, gs);
+    else hipLaunchKernelGGL((gemm_small_dw_grouped_kernel<3, false>), dim3(st), dim3(256), (size_t)3 * 2 * SM_TILE * sizeof(bf16_t), s, gs);
     MMDTI_LAUNCH_CHECK();
     return MMDTI_OK;
   }
@@ -2009,7 +2070,8 @@ extern "C" int mmdti_linear_dw_grouped(mmdti_stream_t stream, int nprob, const v
   const size_t smem_b = (size_t)2 * BIG_BUF * sizeof(bf16_t);
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_grouped_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_grouped_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b) != hipSuccess) {
       set_error("linear_dw_grouped: hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", smem_b);
       return MMDTI_ERR_LAUNCH;
     }
@@ -2019,7 +2081,8 @@ extern "C" int mmdti_linear_dw_grouped(mmdti_stream_t stream, int nprob, const v
   // pass is one more of them per layer -- the K-splits add into dW with fp32 atomics instead (a few MB of them: cheaper than a launch)
   // (reached only with the 64 x 64 kernel switched off: gemm_small = 0)
   g.atomic = rows <= 4096 ? 1 : 0;
-  hipLaunchKernelGGL(gemm_big_grouped_kernel, dim3(tiles, 1, sk), dim3(512), smem_b, s, g);
+  if (x_f16) hipLaunchKernelGGL(gemm_big_grouped_kernel<true>, dim3(tiles, 1, sk), dim3(512), smem_b, s, g);
+  else hipLaunchKernelGGL(gemm_big_grouped_kernel<false>, dim3(tiles, 1, sk), dim3(512), smem_b, s, g);
   if (!g.atomic) {
     long long max_n4 = 0;
     for (int i = 0; i < nprob; ++i) max_n4 = max(max_n4, (long long)g.p[i].M * g.p[i].N / 4);

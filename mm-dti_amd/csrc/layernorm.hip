@@ -62,8 +62,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     if (y16) {
       uint2 pk;
       if (y16_f16) {   // fp16 forward-operand mode
-        pk.x = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)o[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)o[1]) << 16);
-        pk.y = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)o[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)o[3]) << 16);
+        pk.x = f2h_sat2(o[0], o[1]);
+        pk.y = f2h_sat2(o[2], o[3]);
       } else {
         pk.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
         pk.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);

@@ -25,12 +25,15 @@ inline int fwd_gemm(mmdti_stream_t s, const void* x, int ldx, const void* w, int
 // ln_max_k deep, else the GEMM and the LayerNorm kernels back to back.  ln_f32 / ln_bf16: either may be null.
 inline int closer(mmdti_stream_t s, const void* x, const void* w, const float* bias, const float* residual, int M, int n_out, int n_in, float drop_p,
                   unsigned long long seed, unsigned int site, float* y, const float* gamma, const float* beta, float eps, float* ln_f32,
-                  void* ln_bf16, float* mean, float* rstd, int ln_max_k) {
+                  void* ln_bf16, float* mean, float* rstd, int ln_max_k, int f16) {
+  // f16: the fp16 forward-operand mode -- x and w hold fp16, the 16-bit LayerNorm output is fp16
   if (n_out == 512 && n_in % 64 == 0 && n_in <= ln_max_k)
     return mmdti_gemm_ln_bf16(s, x, w, bias, residual, M, n_out, n_in, n_in, n_in, n_out, drop_p, seed, site, y, gamma, beta, eps, ln_f32, ln_bf16, mean,
-                              rstd, 0);
-  if (int e = fwd_gemm(s, x, n_in, w, n_in, bias, y, M, n_out, n_in, MMDTI_ACT_NONE, nullptr, residual, MMDTI_DT_F32, drop_p, seed, site)) return e;
-  return mmdti_layernorm_fwd(s, y, gamma, beta, eps, M, n_out, ln_f32, ln_bf16, mean, rstd, nullptr, 0.f, 0ull, 0u, 0);
+                              rstd, f16 ? 3 : 0);
+  if (int e = fwd_gemm(s, x, n_in, w, n_in, bias, y, M, n_out, n_in, MMDTI_ACT_NONE, nullptr, residual, MMDTI_DT_F32 | (f16 ? MMDTI_DT_AB_F16 : 0), drop_p, seed,
+                       site))
+    return e;
+  return mmdti_layernorm_fwd(s, y, gamma, beta, eps, M, n_out, ln_f32, ln_bf16, mean, rstd, nullptr, 0.f, 0ull, 0u, f16 ? 1 : 0);
 }
 }  // namespace
 
@@ -49,21 +52,25 @@ extern "C" int mmdti_unimol_layer_fwd(mmdti_stream_t stream, int M, int B, int N
                                       const void* w_fc1, const float* b_fc1, int act_fwd, const void* w_fc2, const float* b_fc2,
                                       int next_mode, const float* g_next, const float* bt_next, float eps_next, int ln_max_k, void* qkv,
                                       void* s_out, void* o_att, float* x1, void* h2, float* m2, float* r2, void* u_aux, void* a_act,
-                                      float* x_out, void* ln_out, float* mn, float* rn) {
+                                      float* x_out, void* ln_out, float* mn, float* rn, int fwd_f16) {
   MMDTI_REQUIRE(M > 0 && D > 0 && F > 0 && D % 8 == 0 && F % 8 == 0 && next_mode >= 0 && next_mode <= 2, "unimol_layer_fwd: bad shape / mode");
   MMDTI_REQUIRE(x && h1 && s_in && w_in && w_out && g_ln2 && bt_ln2 && w_fc1 && w_fc2 && qkv && s_out && o_att && x1 && h2 && m2 && r2 && u_aux && a_act && x_out,
                 "unimol_layer_fwd: null argument");
   MMDTI_REQUIRE(next_mode == 0 || (g_next && bt_next && ln_out && mn && rn), "unimol_layer_fwd: the next LayerNorm needs its parameters and outputs");
-  if (int e = fwd_gemm(stream, h1, D, w_in, D, b_in, qkv, M, 3 * D, D, MMDTI_ACT_NONE, nullptr, nullptr, MMDTI_DT_BF16, 0.f, 0ull, 0u)) return e;
+  // fwd_f16 (the fp16 forward-operand mode; compact pair planes only): h1, the four weights, q | k | v, o_att, h2, a_act and a 16-bit
+  // ln_out hold fp16; u_aux (the saved gelu', read by the backward) stays bf16
+  MMDTI_REQUIRE(!fwd_f16 || pair_layout == 3, "unimol_layer_fwd: fp16 forward operands need the compact pair planes (layout 3)");
+  const int ab = fwd_f16 ? MMDTI_DT_AB_F16 : 0, o16 = (fwd_f16 ? MMDTI_DT_F16 : MMDTI_DT_BF16) | ab;
+  if (int e = fwd_gemm(stream, h1, D, w_in, D, b_in, qkv, M, 3 * D, D, MMDTI_ACT_NONE, nullptr, nullptr, o16, 0.f, 0ull, 0u)) return e;
   if (int e = mmdti_pair_attn_fwd(stream, qkv, s_in, s_out, o_att, key_pad, B, N, H, ld, scale, p_att, seed, site_att, pair_layout, key_tiles, rag_store,
-                                  row_off, 0))
+                                  row_off, fwd_f16 ? 1 : 0))
     return e;
-  if (int e = closer(stream, o_att, w_out, b_out, x, M, D, D, p_res, seed, site_o, x1, g_ln2, bt_ln2, eps2, nullptr, h2, m2, r2, ln_max_k)) return e;
-  if (int e = fwd_gemm(stream, h2, D, w_fc1, D, b_fc1, a_act, M, F, D, act_fwd, u_aux, nullptr, MMDTI_DT_BF16, 0.f, 0ull, 0u)) return e;
+  if (int e = closer(stream, o_att, w_out, b_out, x, M, D, D, p_res, seed, site_o, x1, g_ln2, bt_ln2, eps2, nullptr, h2, m2, r2, ln_max_k, fwd_f16)) return e;
+  if (int e = fwd_gemm(stream, h2, D, w_fc1, D, b_fc1, a_act, M, F, D, act_fwd, u_aux, nullptr, o16, 0.f, 0ull, 0u)) return e;
   if (next_mode == 0)
-    return fwd_gemm(stream, a_act, F, w_fc2, F, b_fc2, x_out, M, D, F, MMDTI_ACT_NONE, nullptr, x1, MMDTI_DT_F32, p_res, seed, site_f);
+    return fwd_gemm(stream, a_act, F, w_fc2, F, b_fc2, x_out, M, D, F, MMDTI_ACT_NONE, nullptr, x1, MMDTI_DT_F32 | ab, p_res, seed, site_f);
   return closer(stream, a_act, w_fc2, b_fc2, x1, M, D, F, p_res, seed, site_f, x_out, g_next, bt_next, eps_next, next_mode == 2 ? (float*)ln_out : nullptr,
-                next_mode == 1 ? ln_out : nullptr, mn, rn, ln_max_k);
+                next_mode == 1 ? ln_out : nullptr, mn, rn, ln_max_k, fwd_f16);
 }
 
 /* Backward of one Uni-Mol encoder layer (pre-LN: x1 = x + drop(out_proj(attn(LN1(x)))), x2 = x1 + drop(fc2(gelu(fc1(LN2(x1))))));
@@ -84,7 +91,7 @@ extern "C" int mmdti_unimol_layer_bwd(mmdti_stream_t stream, int M, int B, int N
                                       float* dw_fc2, float* dw_fc1, float* dw_out, float* dw_in, float* db_fc1, float* db_out,
                                       float* db_in, float* dg_ln2, float* dbt_ln2, float* dg_ln1, float* dbt_ln1, void* G,
                                       int pair_layout, int g_in_zero, const int* key_tiles, const int* row_off, void* ws,
-                                      long long ws_bytes) {
+                                      long long ws_bytes, int fwd_f16) {
   MMDTI_REQUIRE(M > 0 && D > 0 && F > 0 && D % 8 == 0 && F % 8 == 0, "unimol_layer_bwd: bad shape");
   MMDTI_REQUIRE(dx_in && dy2 && dx_out && a_act && u_aux && h2 && x1 && m2 && r2 && o_att && qkv && s_logits && h1 && x0 && m1 && r1 && w_fc2 && w_fc1 &&
                     w_out && w_in && g_ln2 && g_ln1 && dw_fc2 && dw_fc1 && dw_out && dw_in && G && ws,
@@ -110,7 +117,9 @@ extern "C" int mmdti_unimol_layer_bwd(mmdti_stream_t stream, int M, int B, int N
     return e;
   // ---- attention
   if (int e = dx_gemm(stream, dy1, D, w_out, D, dob, M, D, D, MMDTI_ACT_NONE, nullptr, 0)) return e;
-  if (int e = mmdti_pair_attn_bwd(stream, qkv, s_logits, dob, G, dqkv, B, N, H, ld, scale, g_in_zero, p_att, seed, site_att, pair_layout, key_tiles, row_off))
+  // (fwd_f16: the saved a_act, h2, o_att, h1 and q | k | v hold fp16 -- converted inside the kernels that read them)
+  if (int e = mmdti_pair_attn_bwd(stream, qkv, s_logits, dob, G, dqkv, B, N, H, ld, scale, g_in_zero, p_att, seed, site_att, pair_layout, key_tiles, row_off,
+                                  fwd_f16 ? 1 : 0))
     return e;
   if (int e = dx_gemm(stream, dqkv, 3 * D, w_in, D, dh1, M, D, 3 * D, MMDTI_ACT_NONE, nullptr, 0)) return e;
   if (int e = mmdti_layernorm_bwd(stream, dh1, MMDTI_DT_BF16, nullptr, x0, g_ln1, m1, r1, M, D, dx_mid, dx_out, dg_ln1, dbt_ln1, nullptr, 0.f, 0ull, 0u,
@@ -124,7 +133,7 @@ extern "C" int mmdti_unimol_layer_bwd(mmdti_stream_t stream, int M, int B, int N
   float* dbs[4] = {nullptr, db_fc1, nullptr, db_in};
   const int n_out[4] = {D, F, D, 3 * D}, n_in[4] = {F, D, D, D};
   const int ldy[4] = {D, F, D, 3 * D}, ldx[4] = {F, D, D, D}, lddw[4] = {F, D, D, D};
-  return mmdti_linear_dw_grouped(stream, 4, dys, xs, dws, dbs, n_out, n_in, ldy, ldx, lddw, M, slabs, slab_bytes);
+  return mmdti_linear_dw_grouped(stream, 4, dys, xs, dws, dbs, n_out, n_in, ldy, ldx, lddw, M, slabs, slab_bytes, fwd_f16 ? 1 : 0);
 }
 
 /* Forward of one post-LN BERT layer with SELF-attention, the q | k | v projection as one GEMM and the fused attention kernels
@@ -140,19 +149,22 @@ extern "C" int mmdti_bert_layer_fwd(mmdti_stream_t stream, int Mq, int B, int L,
                                     const float* g_ln1, const float* bt_ln1, const void* w_i, const float* b_i, int act_fwd,
                                     const void* w_o2, const float* b_o2, const float* g_ln2, const float* bt_ln2, float eps, int ln_max_k,
                                     void* qkv, void* ctx, float* stats, float* y, float* a32, void* a16, float* am, float* ar, void* u_aux,
-                                    void* i_act, float* z, float* out32, void* out16, float* zm, float* zr) {
+                                    void* i_act, float* z, float* out32, void* out16, float* zm, float* zr, int fwd_f16) {
   MMDTI_REQUIRE(Mq > 0 && D > 0 && F > 0 && heads > 0 && D % heads == 0, "bert_layer_fwd: bad shape");
   MMDTI_REQUIRE(s1_32 && s1_16 && w_qkv && w_o && g_ln1 && bt_ln1 && w_i && w_o2 && g_ln2 && bt_ln2 && qkv && ctx && stats && y && a32 && a16 && am && ar &&
                     u_aux && i_act && z && out32 && out16 && zm && zr, "bert_layer_fwd: null argument");
   const int hd = D / heads;
   const char* qp = reinterpret_cast<const char*>(qkv);
-  if (int e = fwd_gemm(stream, s1_16, D, w_qkv, D, b_qkv, qkv, Mq, 3 * D, D, MMDTI_ACT_NONE, nullptr, nullptr, MMDTI_DT_BF16, 0.f, 0ull, 0u)) return e;
+  // fwd_f16 (the fp16 forward-operand mode): s1_16, the four weights, ctx, a16, i_act and out16 hold fp16; q | k | v stay bf16 (the
+  // attention kernels' operand type in every mode), u_aux too
+  const int ab = fwd_f16 ? MMDTI_DT_AB_F16 : 0;
+  if (int e = fwd_gemm(stream, s1_16, D, w_qkv, D, b_qkv, qkv, Mq, 3 * D, D, MMDTI_ACT_NONE, nullptr, nullptr, MMDTI_DT_BF16 | ab, 0.f, 0ull, 0u)) return e;
   if (int e = mmdti_attn_fwd(stream, qp, qp + (size_t)D * 2, qp + (size_t)2 * D * 2, key_add, ctx, stats, B, heads, L, L, hd, 3 * D, 3 * D, D,
-                             scale, p_att, seed, site_att, q_off, k_off, k_cnt, q_rows, 0))
+                             scale, p_att, seed, site_att, q_off, k_off, k_cnt, q_rows, fwd_f16 ? 1 : 0))
     return e;
-  if (int e = closer(stream, ctx, w_o, b_o, s1_32, Mq, D, D, p_hid, seed, site_o, y, g_ln1, bt_ln1, eps, a32, a16, am, ar, ln_max_k)) return e;
-  if (int e = fwd_gemm(stream, a16, D, w_i, D, b_i, i_act, Mq, F, D, act_fwd, u_aux, nullptr, MMDTI_DT_BF16, 0.f, 0ull, 0u)) return e;
-  return closer(stream, i_act, w_o2, b_o2, a32, Mq, D, F, p_hid, seed, site_f, z, g_ln2, bt_ln2, eps, out32, out16, zm, zr, ln_max_k);
+  if (int e = closer(stream, ctx, w_o, b_o, s1_32, Mq, D, D, p_hid, seed, site_o, y, g_ln1, bt_ln1, eps, a32, a16, am, ar, ln_max_k, fwd_f16)) return e;
+  if (int e = fwd_gemm(stream, a16, D, w_i, D, b_i, i_act, Mq, F, D, act_fwd, u_aux, nullptr, (fwd_f16 ? MMDTI_DT_F16 : MMDTI_DT_BF16) | ab, 0.f, 0ull, 0u)) return e;
+  return closer(stream, i_act, w_o2, b_o2, a32, Mq, D, F, p_hid, seed, site_f, z, g_ln2, bt_ln2, eps, out32, out16, zm, zr, ln_max_k, fwd_f16);
 }
 
 /* Backward of the same layer: LayerNorm-2 backward, the FFN's two input gradients, LayerNorm-1 backward (its output fed the FFN and
@@ -169,7 +181,7 @@ extern "C" int mmdti_bert_layer_bwd(mmdti_stream_t stream, int Mq, int B, int L,
                                     const void* w_o, const void* w_i, const void* w_o2, const float* g_ln1, const float* g_ln2,
                                     float* dw_qkv, int lddw_qkv, float* db_qkv, float* dw_o, float* db_o, float* dw_i, float* db_i,
                                     float* dw_o2, float* db_o2, float* dg_ln1, float* dbt_ln1, float* dg_ln2, float* dbt_ln2, void* ws,
-                                    long long ws_bytes) {
+                                    long long ws_bytes, int fwd_f16) {
   MMDTI_REQUIRE(Mq > 0 && D > 0 && F > 0 && heads > 0 && D % heads == 0, "bert_layer_bwd: bad shape");
   MMDTI_REQUIRE(dout && ds1 && s1_16 && qkv && ctx && stats && y && a16 && am && ar && u_aux && i_act && z && zm && zr && w_qkv && w_o && w_i && w_o2 &&
                     g_ln1 && g_ln2 && dw_qkv && dw_o && dw_i && dw_o2 && ws, "bert_layer_bwd: null argument");
@@ -213,5 +225,6 @@ extern "C" int mmdti_bert_layer_bwd(mmdti_stream_t stream, int Mq, int B, int L,
   float* dbs[4] = {db_qkv, nullptr, db_i, nullptr};
   const int n_out[4] = {3 * D, D, F, D}, n_in[4] = {D, F, D, D};
   const int ldy[4] = {3 * D, D, F, D}, ldx[4] = {D, F, D, D}, lddw[4] = {lddw_qkv, F, D, D};
-  return mmdti_linear_dw_grouped(stream, 4, dys, xs, dws, dbs, n_out, n_in, ldy, ldx, lddw, Mq, slabs, slab_bytes);
+  // (fwd_f16: the saved s1_16, i_act, a16 and ctx hold fp16 -- converted between LDS and the matrix pipe)
+  return mmdti_linear_dw_grouped(stream, 4, dys, xs, dws, dbs, n_out, n_in, ldy, ldx, lddw, Mq, slabs, slab_bytes, fwd_f16 ? 1 : 0);
 }

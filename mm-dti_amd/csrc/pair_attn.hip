@@ -292,8 +292,8 @@ __global__ __launch_bounds__(256, NT > 9 ? 2 : 4) void pair_attn_fwd_mfma_kernel
     if (qvalid && g < 2) {
       uint2 pk;
       if constexpr (F16) {   // (o feeds out_proj's forward GEMM: fp16 like every forward GEMM operand of this mode)
-        pk.x = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)oacc[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)oacc[1]) << 16);
-        pk.y = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)oacc[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)oacc[3]) << 16);
+        pk.x = f2h_sat2(oacc[0], oacc[1]);
+        pk.y = f2h_sat2(oacc[2], oacc[3]);
       } else {
         pk.x = (uint32_t)f2bf(oacc[0]) | ((uint32_t)f2bf(oacc[1]) << 16);
         pk.y = (uint32_t)f2bf(oacc[2]) | ((uint32_t)f2bf(oacc[3]) << 16);

@@ -154,7 +154,7 @@ using namespace mmdti;
 extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, const void* s, const void* do_bf16,
                                    void* g, void* dqkv_bf16, int B, int N, int H, int ld, float scale,
                                    int g_in_zero, float drop_p, unsigned long long seed, unsigned int site, int layout,
-                                   const int* key_tiles, const int* row_off) {
+                                   const int* key_tiles, const int* row_off, int qkv_f16) {
   // bit 0: tiled planes; bit 1: compact planes (s is fp16; tiled only); bit 2: g is bf16 (with bit 1 only)
   const int tiled = layout & 1, compact = (layout >> 1) & 1, g16 = (layout >> 2) & 1;
   if (int e = check_common("pair_attn_bwd", B, N, H, ld)) return e;
@@ -179,7 +179,7 @@ extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, 
 #define PA_MB(NT, TL, FL, NWV, RG, ST, GT)                                                                                     \
   hipLaunchKernelGGL((pair_attn_bwd_mfma_kernel<NT, TL, FL, NWV, RG, ST, GT>), grid, blk, 0, st, (const bf16_t*)qkv_bf16,      \
                      (const ST*)s, (const bf16_t*)do_bf16, (const GT*)g, (GT*)g, (bf16_t*)dqkv_bf16, N, H, ld, scale,           \
-                     g_in_zero, th8, sc, (uint64_t)seed, (uint32_t)site, key_tiles, row_off)
+                     g_in_zero, th8, sc, (uint64_t)seed, (uint32_t)site, key_tiles, row_off, qkv_f16)
 #define PA_MBW(NT, TL, FL, RG, ST, GT)                                                      \
   do {                                                                                      \
     if (blk.x == 192) PA_MB(NT, TL, FL, 3, RG, ST, GT); else PA_MB(NT, TL, FL, 4, RG, ST, GT); \
@@ -191,8 +191,8 @@ extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, 
   } while (0)
     // (compact planes -- the hot path -- have one instantiation per tile count, for fp32 and for bf16 gradients: pair_attn_bwd_mfma.h)
     if (compact) {
-      if (g16) pa_bwd_compact_launch_g16(nqb, grid, blk, st, qkv_bf16, s, do_bf16, g, dqkv_bf16, N, H, ld, scale, g_in_zero, th8, sc, seed, site, key_tiles, row_off);
-      else pa_bwd_compact_launch<float>(nqb, grid, blk, st, qkv_bf16, s, do_bf16, g, dqkv_bf16, N, H, ld, scale, g_in_zero, th8, sc, seed, site, key_tiles, row_off);
+      if (g16) pa_bwd_compact_launch_g16(nqb, grid, blk, st, qkv_bf16, s, do_bf16, g, dqkv_bf16, N, H, ld, scale, g_in_zero, th8, sc, seed, site, key_tiles, row_off, qkv_f16);
+      else pa_bwd_compact_launch<float>(nqb, grid, blk, st, qkv_bf16, s, do_bf16, g, dqkv_bf16, N, H, ld, scale, g_in_zero, th8, sc, seed, site, key_tiles, row_off, qkv_f16);
     } else if (nqb <= 5) PA_MBT(5); else if (nqb <= 9) PA_MBT(9); else if (nqb <= 13) PA_MBT(13); else PA_MBT(17);
 #undef PA_MBW
 #undef PA_MBT
@@ -200,6 +200,7 @@ extern "C" int mmdti_pair_attn_bwd(mmdti_stream_t stream, const void* qkv_bf16, 
     MMDTI_LAUNCH_CHECK();
     return MMDTI_OK;
   }
+  MMDTI_REQUIRE(!qkv_f16, "pair_attn_bwd: fp16 q | k | v are read by the MFMA kernels only (ld %% 4 == 0, N <= 272, 16-byte aligned pair tensors)");
 #define PA_B(NCH)                                                                                                   \
   hipLaunchKernelGGL((pair_attn_bwd_kernel<NCH>), grid, block, 0, st, (const bf16_t*)qkv_bf16, (const float*)s,    \
                      (const bf16_t*)do_bf16, (float*)g, (bf16_t*)dqkv_bf16, N, H, ld, scale, g_in_zero, th, sc,            \

@@ -15,7 +15,7 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? ((NT >= 16 && NW == 3) ? 2 : 1) :
                                                                  bf16_t* __restrict__ dqkv, int N, int H, int ld, float scale,
                                                                  int g_in_zero, uint32_t thresh, float dscale, uint64_t seed,
                                                                  uint32_t site, const int* __restrict__ key_tiles,
-                                                                 const int* __restrict__ row_off) {
+                                                                 const int* __restrict__ row_off, int qkv_f16) {
   static_assert(TILED || (sizeof(ST) == 4 && sizeof(GT) == 4), "compact pair tensors exist in the tiled layout only");
   static_assert(!RAG || sizeof(ST) == 2, "key-tile skipping is built for the compact layout only");
   constexpr int NP = NT * 16;
@@ -52,6 +52,9 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? ((NT >= 16 && NW == 3) ? 2 : 1) :
       kk = *reinterpret_cast<const uint4*>(base + (long long)t * D3 + D);
       vv = *reinterpret_cast<const uint4*>(base + (long long)t * D3 + 2 * D);
       dd = *reinterpret_cast<const uint4*>(dO + ((long long)row0 + t) * D + h * HD);
+      // (fp16 forward operands: the forward multiplied the fp16 q | k | v; the backward's products take their bf16 rounding -- the
+      //  values mmdti_cast_f16_bf16 would write -- converted here, on the way into LDS, instead of in a pass over HBM)
+      if (qkv_f16) { q = h2bf8(q); kk = h2bf8(kk); vv = h2bf8(vv); }
     }
     *reinterpret_cast<uint4*>(sQ + t * 8) = q;      // (t = NP, NP + 1: the zeroed tails)
     *reinterpret_cast<uint4*>(sD + t * 8) = dd;
@@ -303,11 +306,11 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? ((NT >= 16 && NW == 3) ? 2 : 1) :
 template <typename GT>
 static inline void pa_bwd_compact_launch(int nqb, dim3 grid, dim3 blk, hipStream_t st, const void* qkv_bf16, const void* s, const void* do_bf16,
                                          void* g, void* dqkv_bf16, int N, int H, int ld, float scale, int g_in_zero, uint32_t th8, float sc,
-                                         unsigned long long seed, unsigned int site, const int* key_tiles, const int* row_off) {
+                                         unsigned long long seed, unsigned int site, const int* key_tiles, const int* row_off, int qkv_f16) {
 #define PA_MBH(NT, NWV, RG)                                                                                                   \
   hipLaunchKernelGGL((pair_attn_bwd_mfma_kernel<NT, true, true, NWV, RG, _Float16, GT>), grid, blk, 0, st, (const bf16_t*)qkv_bf16, \
                      (const _Float16*)s, (const bf16_t*)do_bf16, (const GT*)g, (GT*)g, (bf16_t*)dqkv_bf16, N, H, ld, scale,    \
-                     g_in_zero, th8, sc, (uint64_t)seed, (uint32_t)site, key_tiles, row_off)
+                     g_in_zero, th8, sc, (uint64_t)seed, (uint32_t)site, key_tiles, row_off, qkv_f16)
 #define PA_MBC(NT)                                                                                   \
   case NT:                                                                                           \
     if (key_tiles) PA_MBH(NT, ((NT % 3 == 0 || NT >= 16 || NT == 5) ? 3 : 4), true);                 \
@@ -323,6 +326,6 @@ static inline void pa_bwd_compact_launch(int nqb, dim3 grid, dim3 blk, hipStream
 // the bf16-gradient build of the same launcher (pair_attn_bwd_g16.hip)
 void pa_bwd_compact_launch_g16(int nqb, dim3 grid, dim3 blk, hipStream_t st, const void* qkv_bf16, const void* s, const void* do_bf16, void* g,
                                void* dqkv_bf16, int N, int H, int ld, float scale, int g_in_zero, uint32_t th8, float sc,
-                               unsigned long long seed, unsigned int site, const int* key_tiles, const int* row_off);
+                               unsigned long long seed, unsigned int site, const int* key_tiles, const int* row_off, int qkv_f16);
 
 }  // namespace mmdti

@@ -200,7 +200,8 @@ class PairEncoderFn(torch.autograd.Function):
         nlayers = len(mod.layers)
         nxt = None
         out = None
-        seq = LAYER_SEQ and emb.is_cuda and not ops.FWD_F16 and not ops.kernel_timer.names and D == H * 8
+        # (fp16 forward operands: the library's sequence covers the compact pair planes -- the only layout with fp16 q | k | v kernels)
+        seq = LAYER_SEQ and emb.is_cuda and (compact or not ops.FWD_F16) and not ops.kernel_timer.names and D == H * 8
         kp0 = ops._u8(padding_mask) if seq else None
         for li, layer in enumerate(mod.layers):
             L = SimpleNamespace(x=x)
@@ -369,15 +370,16 @@ def _unimol_layer_fwd_seq(st, layer, L, s_prev, key_pad, key_tiles, rag_store, r
     M, D, F = st.M, st.D, layer.fc1.weight.shape[0]
     dev = L.x.device
     e = torch.empty
-    L.qkv, L.o = e(M, 3 * D, device=dev, dtype=BF16), e(M, D, device=dev, dtype=BF16)
+    a16 = L.h1.dtype                          # bf16, or fp16 (fp16 forward operands): the type of every forward GEMM input of the layer
+    L.qkv, L.o = e(M, 3 * D, device=dev, dtype=a16), e(M, D, device=dev, dtype=a16)
     L.s = torch.empty_like(s_prev) if ops.pair_is_tiled(s_prev) else e(st.B, st.H, st.N, st.ld, device=dev, dtype=F32)
-    L.x1, L.h2 = e(M, D, device=dev, dtype=F32), e(M, D, device=dev, dtype=BF16)
+    L.x1, L.h2 = e(M, D, device=dev, dtype=F32), e(M, D, device=dev, dtype=a16)
     L.m2, L.r2 = e(M, device=dev, dtype=F32), e(M, device=dev, dtype=F32)
-    L.u, L.a = e(M, F, device=dev, dtype=BF16), e(M, F, device=dev, dtype=BF16)
+    L.u, L.a = e(M, F, device=dev, dtype=BF16), e(M, F, device=dev, dtype=a16)
     x_out = e(M, D, device=dev, dtype=F32)
     ln_out = mn = rn = None
     if next_mode:
-        ln_out = e(M, D, device=dev, dtype=BF16 if next_mode == 1 else F32)
+        ln_out = e(M, D, device=dev, dtype=a16 if next_mode == 1 else F32)
         mn, rn = e(M, device=dev, dtype=F32), e(M, device=dev, dtype=F32)
     p = ops._p
     ops.lib().mmdti_unimol_layer_fwd(
@@ -387,17 +389,17 @@ def _unimol_layer_fwd_seq(st, layer, L, s_prev, key_pad, key_tiles, rag_store, r
         ln2.weight.data_ptr(), ln2.bias.data_ptr(), float(ln2.eps), wfwd(layer.fc1.weight).data_ptr(), p(layer.fc1.bias), ops.ACT_GELU_FWD,
         wfwd(layer.fc2.weight).data_ptr(), p(layer.fc2.bias), next_mode, p(nl.weight) if nl is not None else 0, p(nl.bias) if nl is not None else 0,
         float(nl.eps) if nl is not None else 0.0, ops.GEMM_LN_MAX_K if ops.GEMM_LN else 0, L.qkv.data_ptr(), L.s.data_ptr(), L.o.data_ptr(),
-        L.x1.data_ptr(), L.h2.data_ptr(), L.m2.data_ptr(), L.r2.data_ptr(), L.u.data_ptr(), L.a.data_ptr(), x_out.data_ptr(), p(ln_out), p(mn), p(rn))
+        L.x1.data_ptr(), L.h2.data_ptr(), L.m2.data_ptr(), L.r2.data_ptr(), L.u.data_ptr(), L.a.data_ptr(), x_out.data_ptr(), p(ln_out), p(mn), p(rn),
+        int(a16 == torch.float16))
     return x_out, ln_out, mn, rn
 
 
 def _unimol_seq_workspace(st, mod):
-    """-> (usable, workspace) for mmdti_unimol_layer_bwd: the variant the library sequences is the hot one -- bf16 operands (not the
-    fp16 forward-operand mode), every parameter trainable, dimensions the grouped weight-gradient kernels take, no per-launch event
+    """-> (usable, workspace) for mmdti_unimol_layer_bwd: the variant the library sequences is the hot one -- every parameter trainable, dimensions the grouped weight-gradient kernels take, no per-launch event
     timing requested.  The workspace holds one layer's temporaries and is shared by all layers of this backward."""
     lay = mod.layers[0]
     D, F, M = st.D, lay.fc1.weight.shape[0], st.M
-    ok = (not ops.FWD_F16 and not ops.kernel_timer.names and ops.GROUPED_DW and D % 256 == 0 and F % 256 == 0 and M >= ops.GROUPED_DW_MIN_ROWS
+    ok = (not ops.kernel_timer.names and ops.GROUPED_DW and D % 256 == 0 and F % 256 == 0 and M >= ops.GROUPED_DW_MIN_ROWS
           and all(p.requires_grad for p in mod.parameters()))
     if not ok:
         return False, None
@@ -425,7 +427,8 @@ def _unimol_layer_bwd_seq(st, layer, L, dx, dx16, G, g_zero, scale, ws, below):
         ln2.weight.data_ptr(), ln1.weight.data_ptr(), gbuf(layer.fc2.weight).data_ptr(), gbuf(layer.fc1.weight).data_ptr(),
         gbuf(att.out_proj.weight).data_ptr(), gbuf(att.in_proj.weight).data_ptr(), gbuf(layer.fc1.bias).data_ptr(), gbuf(att.out_proj.bias).data_ptr(),
         gbuf(att.in_proj.bias).data_ptr(), gbuf(ln2.weight).data_ptr(), gbuf(ln2.bias).data_ptr(), gbuf(ln1.weight).data_ptr(), gbuf(ln1.bias).data_ptr(),
-        G.data_ptr(), layout, int(g_zero), p(st.kt), p(st.row_off), (ws.data_ptr() + 255) // 256 * 256, ws.numel() - 256)
+        G.data_ptr(), layout, int(g_zero), p(st.kt), p(st.row_off), (ws.data_ptr() + 255) // 256 * 256, ws.numel() - 256,
+        int(L.h1.dtype == torch.float16))
     return dx_out, dx16_out
 
 
@@ -593,7 +596,7 @@ def _bert_layer_fwd(st, s1_32, s1_16, s2_16, key_add, W, heads, p_hid, p_att, ep
         if L.fw is None or L.fb is None:
             L.fw = L.fb = None
     L.seq = False
-    if (LAYER_SEQ and self_attn and L.fw is not None and s1_32.is_cuda and not ops.FWD_F16 and not ops.kernel_timer.names and D % 256 == 0
+    if (LAYER_SEQ and self_attn and L.fw is not None and s1_32.is_cuda and not ops.kernel_timer.names and D % 256 == 0
             and W.i_w.shape[0] % 256 == 0 and Mq >= ops.GROUPED_DW_MIN_ROWS and ops.GROUPED_DW):
         # the layer's six launches from ONE library call (csrc/layers.hip: the same kernels, arguments and order as below)
         return _bert_layer_fwd_seq(st, L, s1_32, s1_16, key_add, W, heads, p_hid, p_att, eps, seed, sites)
@@ -719,13 +722,14 @@ def _bert_layer_fwd_seq(st, L, s1_32, s1_16, key_add, W, heads, p_hid, p_att, ep
     dev = s1_32.device
     e = torch.empty
     L.site_o, L.site_f = sites.next(), sites.next()          # (L.site_att was drawn by the caller: the same numbering as the op-by-op path)
-    L.qkv, L.ctx = e(Mq, 3 * D, device=dev, dtype=BF16), e(Mq, D, device=dev, dtype=BF16)
+    a16 = s1_16.dtype                         # bf16, or fp16 (fp16 forward operands); q | k | v and the saved gelu' stay bf16 in every mode
+    L.qkv, L.ctx = e(Mq, 3 * D, device=dev, dtype=BF16), e(Mq, D, device=dev, dtype=a16)
     L.q, L.k, L.v = L.qkv[:, :D], L.qkv[:, D:2 * D], L.qkv[:, 2 * D:]
     L.stats = e((B, heads, Lq, 2) if vl is None else (heads, Mq, 2), device=dev, dtype=F32)
-    L.y, L.a32, L.a16 = e(Mq, D, device=dev, dtype=F32), e(Mq, D, device=dev, dtype=F32), e(Mq, D, device=dev, dtype=BF16)
+    L.y, L.a32, L.a16 = e(Mq, D, device=dev, dtype=F32), e(Mq, D, device=dev, dtype=F32), e(Mq, D, device=dev, dtype=a16)
     L.am, L.ar, L.zm, L.zr = (e(Mq, device=dev, dtype=F32) for _ in range(4))
-    L.u, L.i = e(Mq, F, device=dev, dtype=BF16), e(Mq, F, device=dev, dtype=BF16)
-    L.z, out32, out16 = e(Mq, D, device=dev, dtype=F32), e(Mq, D, device=dev, dtype=F32), e(Mq, D, device=dev, dtype=BF16)
+    L.u, L.i = e(Mq, F, device=dev, dtype=BF16), e(Mq, F, device=dev, dtype=a16)
+    L.z, out32, out16 = e(Mq, D, device=dev, dtype=F32), e(Mq, D, device=dev, dtype=F32), e(Mq, D, device=dev, dtype=a16)
     L.fused, L.seq, L.p_hid, L.p_att = True, True, p_hid, p_att
     p = ops._p
     ops.lib().mmdti_bert_layer_fwd(
@@ -734,7 +738,8 @@ def _bert_layer_fwd_seq(st, L, s1_32, s1_16, key_add, W, heads, p_hid, p_att, ep
         L.fb[1].data_ptr(), wfwd(W.o_w).data_ptr(), p(W.o_b), W.ln1_w.data_ptr(), W.ln1_b.data_ptr(), wfwd(W.i_w).data_ptr(), p(W.i_b), ops.ACT_GELU_FWD,
         wfwd(W.o2_w).data_ptr(), p(W.o2_b), W.ln2_w.data_ptr(), W.ln2_b.data_ptr(), float(eps), ops.GEMM_LN_MAX_K if ops.GEMM_LN else 0,
         L.qkv.data_ptr(), L.ctx.data_ptr(), L.stats.data_ptr(), L.y.data_ptr(), L.a32.data_ptr(), L.a16.data_ptr(), L.am.data_ptr(), L.ar.data_ptr(),
-        L.u.data_ptr(), L.i.data_ptr(), L.z.data_ptr(), out32.data_ptr(), out16.data_ptr(), L.zm.data_ptr(), L.zr.data_ptr())
+        L.u.data_ptr(), L.i.data_ptr(), L.z.data_ptr(), out32.data_ptr(), out16.data_ptr(), L.zm.data_ptr(), L.zr.data_ptr(),
+        int(a16 == torch.float16))
     return L, out32, out16
 
 
@@ -759,7 +764,7 @@ def _bert_layer_bwd_seq(st, L, dout, seed):
         wbf16(W.i_w).data_ptr(), wbf16(W.o2_w).data_ptr(), W.ln1_w.data_ptr(), W.ln2_w.data_ptr(), L.fw[2].data_ptr(), L.fw[2].stride(0),
         L.fb[2].view(-1).data_ptr(), gbuf(W.o_w).data_ptr(), gbuf(W.o_b).data_ptr(), gbuf(W.i_w).data_ptr(), gbuf(W.i_b).data_ptr(),
         gbuf(W.o2_w).data_ptr(), gbuf(W.o2_b).data_ptr(), gbuf(W.ln1_w).data_ptr(), gbuf(W.ln1_b).data_ptr(), gbuf(W.ln2_w).data_ptr(),
-        gbuf(W.ln2_b).data_ptr(), (ws.data_ptr() + 255) // 256 * 256, ws.numel() - 256)
+        gbuf(W.ln2_b).data_ptr(), (ws.data_ptr() + 255) // 256 * 256, ws.numel() - 256, int(L.s1_16.dtype == torch.float16))
     return ds1
 
 

@@ -23,15 +23,17 @@ GELU_SAVE_GRAD = os.environ.get("MMDTI_GELU_SAVE_GRAD", "1") != "0"
 GBF_FULL_BWD = os.environ.get("MMDTI_GBF_FULL_BWD", "1") != "0"
 ACT_GELU_FWD = ACT_GELU_G if GELU_SAVE_GRAD else ACT_GELU
 ACT_GELU_DX = ACT_MUL_AUX if GELU_SAVE_GRAD else ACT_GELU_BWD
-DT_F32, DT_BF16, DT_F32_ATOMIC, DT_F16, DT_AB_F16 = 0, 1, 2, 3, 16
+DT_F32, DT_BF16, DT_F32_ATOMIC, DT_F16, DT_AB_F16, DT_B_F16 = 0, 1, 2, 3, 16, 32
 
-# fp16 forward-operand mode (opt-in, MMDTI_FWD_FP16=1 / set_forward_fp16): every 16-bit tensor that feeds a FORWARD GEMM -- weights,
-# LayerNorm / GELU / attention outputs, tower 1's q | k | v -- is fp16 instead of bf16 (the reference's own AMP dtype,
-# tasks/trainer.py:181-182; v_mfma_f32_16x16x32_f16 runs at the bf16 rate).  Three more mantissa bits put encoder_rep / out_bert /
-# logits within the north star's 1e-3 of the fp32 reference (5e-4 / 2.6e-4 / 2e-4: profiles/r03_rounding_sites_fp16.json) where
-# bf16 operands cannot (4.6e-3).  The backward keeps bf16 operands (gradients need bf16's range: the reference needs a GradScaler
-# for the same reason) and converts the saved forward activations when it reads them (to_bf16): one extra pass per saved tensor.
-FWD_F16 = os.environ.get("MMDTI_FWD_FP16", "0") == "1"
+# fp16 forward operands (the DEFAULT since round 4; MMDTI_FWD_FP16=0 / set_forward_fp16(False) is the A/B switch back to bf16): every
+# 16-bit tensor that feeds a FORWARD GEMM -- weights, LayerNorm / GELU / attention outputs, tower 1's q | k | v -- is fp16 instead of
+# bf16 (the reference's own AMP dtype, tasks/trainer.py:181-182; v_mfma_f32_16x16x32_f16 runs at the bf16 rate).  Three more mantissa
+# bits put encoder_rep / out_bert / logits within the north star's 1e-3 of the fp32 reference (6.0e-4 / 4.8e-4 / 7e-4 measured;
+# profiles/r03_rounding_sites_fp16.json) where bf16 operands cannot (4.6e-3).  The backward keeps bf16 operands (gradients need bf16's
+# range: the reference needs a GradScaler for the same reason); a saved fp16 activation is converted INSIDE the kernel that reads it --
+# the weight-gradient GEMMs between LDS and the matrix pipe (MMDTI_DT_B_F16), the pair-attention backward on its way into LDS -- so the
+# mode costs no pass over HBM.  Every fp16 store saturates at +-65504 (common.h f2h_sat).
+FWD_F16 = os.environ.get("MMDTI_FWD_FP16", "1") != "0"
 
 
 def set_forward_fp16(on: bool):
@@ -90,14 +92,19 @@ def gemm(A, B, *, M, N, K, lda, ldb, out=None, ldc=None, transA=False, transB=Fa
     """C = epi(alpha * A.B^T); see mmdti_gemm_bf16.  A/B are bf16 tensors (any shape; lda/ldb given explicitly)."""
     _chk16(A, "gemm.A", contiguous=False)
     _chk16(B, "gemm.B", contiguous=False)
-    if A.dtype != B.dtype:
+    # (one 16-bit type per product, except the weight gradient dW += dy^T.x of a saved fp16 activation x beside a bf16 dy: the kernel
+    #  converts x between LDS and the matrix pipe -- MMDTI_DT_B_F16)
+    b_cvt = A.dtype == BF16 and B.dtype == F16 and transA and transB and atomic and batch == (1, 1)
+    if A.dtype != B.dtype and not b_cvt:
         raise MMDTIError(f"gemm: A is {A.dtype} but B is {B.dtype} (both operands of a product share one 16-bit type)")
     ldc = N if ldc is None else ldc
     if out is None:
         shape = out_shape if out_shape is not None else ((M, N) if batch == (1, 1) else (batch[0], batch[1], M, N))
         out = torch.empty(shape, device=A.device, dtype=out_dtype)
     c_dtype = DT_F32_ATOMIC if atomic else (DT_BF16 if out.dtype == BF16 else (DT_F16 if out.dtype == F16 else DT_F32))
-    if A.dtype == F16:
+    if b_cvt:
+        c_dtype |= DT_B_F16
+    elif A.dtype == F16:
         c_dtype |= DT_AB_F16
     if atomic and out.dtype != F32:
         raise MMDTIError("gemm: atomic accumulation needs an fp32 output")
@@ -194,7 +201,8 @@ def linear_bwd_weight(dy, x, dw, *, rows=None, db=None):
     bias gradient, taken inside the same pass over dy)."""
     M = dy.shape[0] if rows is None else rows
     N, K = dw.shape
-    x = to_bf16(x)
+    if x.dtype == F16 and (x.dim() != 2 or x.stride(1) != 1):
+        x = x.contiguous().view(-1, x.shape[-1])        # (an fp16 x is converted inside the GEMM: see gemm())
     if db is not None:
         _chk(db, F32, "linear_bwd_weight.db")
         if not DW_BIAS:                                  # MMDTI_DW_BIAS=0: the separate column-sum pass (A/B switch)
@@ -219,7 +227,7 @@ GROUPED_DW_MIN_ROWS = int(os.environ.get("MMDTI_GROUPED_DW_MIN_ROWS", "128"))   
 
 
 def _dw_groupable(dy, x, dw, rows):
-    return (dy.dtype == BF16 and x.dtype == BF16 and dw.dtype == F32 and dy.stride(-1) == 1 and x.stride(-1) == 1 and dw.stride(-1) == 1 and
+    return (dy.dtype == BF16 and x.dtype in (BF16, F16) and dw.dtype == F32 and dy.stride(-1) == 1 and x.stride(-1) == 1 and dw.stride(-1) == 1 and
             dw.shape[0] % 256 == 0 and dw.shape[1] % 256 == 0 and rows >= GROUPED_DW_MIN_ROWS and dy.stride(0) % 8 == 0 and
             x.stride(0) % 8 == 0 and dw.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and dw.data_ptr() % 16 == 0)
 
@@ -230,14 +238,16 @@ def linear_bwd_weight_grouped(items):
     split that fills the chip is shared by all of them, so the fp32 partial-sum traffic is a quarter of what the GEMMs need
     one at a time).  Items that do not fit the grouped kernel's shape rules run through linear_bwd_weight."""
     import ctypes
-    norm = [(dy, to_bf16(x), dw, db, dy.shape[0] if rows is None else rows) for dy, x, dw, db, rows in items]
+    # (an fp16 x -- a saved forward activation of the fp16 forward-operand mode -- is converted to bf16 inside the kernel, between LDS
+    #  and the matrix pipe; a launch takes one operand type, so the groups are keyed by it as well)
+    norm = [(dy, x, dw, db, dy.shape[0] if rows is None else rows) for dy, x, dw, db, rows in items]
     groups = {}
     for it in norm:
         if GROUPED_DW and _dw_groupable(it[0], it[1], it[2], it[4]):
-            groups.setdefault(it[4], []).append(it)
+            groups.setdefault((it[4], it[1].dtype), []).append(it)
         else:
             linear_bwd_weight(it[0], it[1], it[2], rows=it[4], db=it[3])
-    for rows, grp in groups.items():
+    for (rows, xdt), grp in groups.items():
         while grp:
             chunk, grp = grp[:8], grp[8:]
             if len(chunk) == 1:
@@ -254,7 +264,7 @@ def linear_bwd_weight_grouped(items):
                                           vp(*[it[2].data_ptr() for it in chunk]), vp(*[_p(it[3]) for it in chunk]),
                                           ip(*[it[2].shape[0] for it in chunk]), ip(*[it[2].shape[1] for it in chunk]),
                                           ip(*[it[0].stride(0) for it in chunk]), ip(*[it[1].stride(0) for it in chunk]),
-                                          ip(*[it[2].stride(0) for it in chunk]), rows, ws.data_ptr(), ws.numel() * 4)
+                                          ip(*[it[2].stride(0) for it in chunk]), rows, ws.data_ptr(), ws.numel() * 4, int(xdt == F16))
             work = sum(2.0 * it[2].shape[0] * it[2].shape[1] * rows for it in chunk)
             kernel_timer.end("gemm", t0, work, tag=("grouped_dw", tuple((it[2].shape[0], it[2].shape[1]) for it in chunk), rows))
 
@@ -681,9 +691,11 @@ def pair_attn_bwd(qkv, s, do, g, B, N, H, ld, scale, g_in_zero, drop_p=0.0, seed
         raise MMDTIError("pair_attn_bwd: qkv / do row counts do not match the layout")
     if row_off is not None:
         _chk(row_off, torch.int32, "pair_attn.row_off")
-    qkv = to_bf16(qkv)             # (fp16 forward-operand mode: the backward's products take the bf16 rounding of q | k | v)
-    dqkv = torch.empty_like(qkv)
     tiled = pair_is_tiled(s)
+    if qkv.dtype == F16 and not (tiled and N <= 272):
+        qkv = to_bf16(qkv)         # (the per-element fallback kernel reads bf16 only)
+    # (fp16 forward operands: the backward's products take the bf16 rounding of q | k | v -- converted by the kernel on the way into LDS)
+    dqkv = torch.empty(qkv.shape, device=qkv.device, dtype=BF16)
     layout = _pair_layout_s(s, "pair_attn_bwd.s")
     if pair_is_tiled(g) != tiled or not (g.dtype == F32 or (g.dtype == BF16 and s.dtype == F16)):
         raise MMDTIError("pair_attn_bwd: S and G must share one pair layout (fp32 gradients, or bf16 gradients with fp16 logits)")
@@ -691,7 +703,7 @@ def pair_attn_bwd(qkv, s, do, g, B, N, H, ld, scale, g_in_zero, drop_p=0.0, seed
         layout |= 4
     t0 = kernel_timer.begin("pair_attn_bwd")
     lib().mmdti_pair_attn_bwd(_stream(), qkv.data_ptr(), s.data_ptr(), do.data_ptr(), g.data_ptr(), dqkv.data_ptr(), B, N, H, ld,
-                              float(scale), int(g_in_zero), float(drop_p), int(seed), int(site), layout, _p(key_tiles), _p(row_off))
+                              float(scale), int(g_in_zero), float(drop_p), int(seed), int(site), layout, _p(key_tiles), _p(row_off), int(qkv.dtype == F16))
     # per (pair, head): read S, read + write G (4 B each, compact 2 B; the first layer reads no G); per (token, head): 7 x 16 B rows
     kept = _pair_kept if key_tiles is not None else 1.0
     kernel_timer.end("pair_attn_bwd", t0, float(H) * (B * N * N * kept * (s.element_size() + g.element_size() * (1 if g_in_zero else 2)) + qkv.shape[0] * 112.0))
@@ -978,10 +990,11 @@ def sumsq(g, out):
     return out
 
 
-def adam_step(p, g, m, v, p_bf16, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None, step_state=None):
-    """step_state: the device-resident schedule (step_state_advance) -- lr / step are then read on the device."""
+def adam_step(p, g, m, v, p_bf16, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None, step_state=None, p_f16=None):
+    """step_state: the device-resident schedule (step_state_advance) -- lr / step are then read on the device.  p_f16: the fp16 weight
+    shadow of the fp16 forward-operand mode, refreshed in the same pass as the bf16 one."""
     lib().mmdti_adam_step(_stream(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(p_bf16), p.numel(), float(lr), float(beta1),
-                          float(beta2), float(eps), float(weight_decay), int(step), _p(grad_scale), _p(step_state))
+                          float(beta2), float(eps), float(weight_decay), int(step), _p(grad_scale), _p(step_state), _p(p_f16))
 
 
 def step_state_advance(state, salt, base_lr, warmup, total, beta1=0.9, beta2=0.999):

@@ -144,9 +144,13 @@ class ParamArena:
             ops.sumsq(self.grad, ss)
             # clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1 (tiny scalar math; stays on device, no sync)
             scale = torch.clamp(max_norm / (ss.sqrt() + 1e-6), max=1.0)
+        # (the Adam pass writes BOTH 16-bit shadows -- bf16 for the backward GEMMs, fp16 for the forward ones -- through raw pointers:
+        #  a captured graph's replays keep them fresh too; the fp16 one exists once a forward GEMM has asked for it)
         ops.adam_step(self.data, self.grad, self.adam_m, self.adam_v, self.shadow, lr, betas[0], betas[1], eps, weight_decay,
-                      self.step_count, scale, step_state)
-        self._epoch += 1            # (the fp16 shadow, if in use, is re-cast before the next forward GEMM reads it)
+                      self.step_count, scale, step_state, p_f16=self.shadow16 if self._epoch16 == self._epoch else None)
+        self._epoch += 1
+        if self.shadow16 is not None and self._epoch16 == self._epoch - 1:
+            self._epoch16 = self._epoch
 
 
 class _ShadowCache:

@@ -60,7 +60,7 @@ def stats(src, dst):
         f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline (every step of the run is in the trace: warm-up, timed, the mixed-length workload, the per-family roofline steps)\n")
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_ms", "avg_us", "percent", "min_us", "max_us"])
-        for r in rows[:40]:
+        for r in rows[:int(os.environ.get("SUMMARIZE_TOP", "40"))]:
             w.writerow([short(r["Name"]), r["Calls"], f'{float(r["TotalDurationNs"]) / 1e6:.3f}', f'{float(r["AverageNs"]) / 1e3:.2f}',
                         f'{float(r["Percentage"]):.2f}', f'{float(r["MinNs"]) / 1e3:.2f}', f'{float(r["MaxNs"]) / 1e3:.2f}'])
 

@@ -209,3 +209,135 @@ def test_fp16_mode_trains(fp16_mode):
     l0 = float(FineTuner(model2, "classification", learning_rate=3e-4, total_steps=50, warmup_ratio=0.0).step(d, label.cuda()).loss)
     _ops.set_forward_fp16(True)
     assert abs(l0 - losses[0]) < 3e-3 * abs(l0), (l0, losses[0])
+
+
+# ------------------------------------------------------------------------------------------- round 4: no conversion pass
+@pytest.mark.parametrize("rows", [33280, 4096 + 64 * 3, 8192 + 1, 1695, 513, 130])
+def test_weight_gradients_convert_fp16_activations_inside_the_kernel(ops, rows):
+    """dW += dy^T.x with x a saved fp16 activation (MMDTI_DT_B_F16 / x_f16): the tile is fetched as fp16 and rounded to bf16 between LDS
+    and the matrix pipe.  The grouped kernels (slab split-K above 4096 rows, one workgroup per tile below) have no atomics, so the
+    result must equal -- bit for bit -- the same launch on the separately converted tensor (ops.to_bf16: the pass this replaces)."""
+    g = G(rows)
+    shapes = [(512, 2048), (2048, 512), (1536, 512), (512, 512)]
+    base = []
+    for i, (no, ni) in enumerate(shapes):
+        dy = bf(torch.randn(rows, no, generator=g)).cuda()
+        wide = (torch.randn(rows, ni + 64, generator=g) * 3).half().cuda()
+        x = wide[:, :ni] if i == 3 else wide[:, :ni].contiguous()        # (one row-strided view)
+        base.append((dy, x, torch.randn(no, ni, generator=g).cuda(), torch.randn(no, generator=g).cuda() if i != 1 else None))
+
+    def run(conv):
+        items = [(dy, conv(x), dw.clone(), None if db is None else db.clone(), None) for dy, x, dw, db in base]
+        ops.linear_bwd_weight_grouped(items)
+        return [(it[2], it[3]) for it in items]
+
+    a, b = run(lambda x: x), run(ops.to_bf16)
+    for (dy, x, dw, db), (dwa, dba), (dwb, dbb) in zip(base, a, b):
+        assert torch.equal(dwa, dwb), float((dwa - dwb).abs().max())
+        if dba is not None:                     # (the bias gradient rides on dy alone; above 4096 rows its K-splits meet in fp32 atomics)
+            close(dba, dbb, 1e-5, 1e-3) if rows > 4096 else None
+            assert rows > 4096 or torch.equal(dba, dbb)
+        close(dwa, dw + dy.float().t() @ x.float().bfloat16().float(), 2e-3, 2e-2)
+    # the single-problem launch (fp32 atomics between K splits: equal up to their order) -- bare-load and ragged shapes
+    for no, ni in ((512, 264), (1536, 512)):
+        dy = bf(torch.randn(rows, no, generator=g)).cuda()
+        x = (torch.randn(rows, ni, generator=g) * 3).half().cuda()
+        dw, db = torch.ones(no, ni).cuda(), torch.ones(no).cuda()
+        ops.linear_bwd_weight(dy, x, dw, db=db)
+        close(dw, 1.0 + dy.float().t() @ x.float().bfloat16().float(), 2e-3, 2e-2)
+        close(db, 1.0 + dy.float().sum(0), 2e-3, 2e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(65536, 512, 2048), (65536, 2048, 512), (65536, 1536, 512)])
+def test_gemm_256_tiles_with_fp16_operands(ops, M, N, K):
+    """The 256 x 256 pipelined kernel's fp16 instantiation (tower 2's forward shapes) against the 128 x 128 kernels on the same operands."""
+    from mmdti_hip import _abi
+    lib = _abi.lib()
+    g = G(M + N)
+    x, w = h16(torch.randn(M, K, generator=g)).cuda(), h16(torch.randn(N, K, generator=g) * 0.1).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    u = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    y_big = ops.linear_fwd(x, w, b, act=ops.ACT_GELU_FWD, aux_out=u)
+    try:
+        lib.mmdti_set_option(b"gemm_big", 0)
+        u0 = torch.empty_like(u)
+        y_128 = ops.linear_fwd(x, w, b, act=ops.ACT_GELU_FWD, aux_out=u0)
+    finally:
+        lib.mmdti_set_option(b"gemm_big", 1)
+    assert y_big.dtype == torch.float16
+    close(y_big, y_128, 2e-3, 2e-3)
+    close(u, u0, 1e-2, 1e-2)
+    ref = torch.nn.functional.gelu(x[:512].float() @ w.float().t() + b)
+    close(y_big[:512], ref, 2e-3, 2e-3)
+
+
+def test_fp16_stores_saturate_instead_of_overflowing(ops, fp16_mode):
+    """Every fp16 epilogue clamps a value past the fp16 range to +-65504 (common.h f2h_sat2): an inf in a forward GEMM operand would
+    turn the next product's whole row into NaN.  +-inf inputs clamp too; a NaN does not survive the packed min / max (the fp32
+    stream written beside every 16-bit copy keeps it)."""
+    big = 7.0e4
+    # cast
+    x = torch.tensor([[big, -big, 1.0, float("inf"), float("-inf"), float("nan"), 65504.0, 65520.0]]).repeat(4, 64).cuda()
+    y = ops.cast_act16(x).float()
+    assert y.dtype == torch.float32 and float(y[0, 0]) == 65504.0 and float(y[0, 1]) == -65504.0 and float(y[0, 2]) == 1.0
+    assert float(y[0, 3]) == 65504.0 and float(y[0, 4]) == -65504.0 and math.isfinite(float(y[0, 5])) and float(y[0, 7]) == 65504.0
+    # GEMM epilogue (fp16 out, + GELU) -- 128 x 128, small-tile and 256 x 256 kernels
+    for M in (256, 2048, 65536):
+        a = torch.full((M, 512), 16.0).half().cuda()
+        w = torch.full((512, 512), 16.0).half().cuda()
+        w[1::2] = -16.0                                                        # odd output columns: -131072
+        out = ops.linear_fwd(a, w, None)
+        assert out.dtype == torch.float16 and torch.isfinite(out).all()
+        assert float(out[:, 0].min()) == 65504.0 and float(out[:, 1].max()) == -65504.0
+        u = torch.empty(M, 512, device="cuda", dtype=torch.bfloat16)
+        act = ops.linear_fwd(a, w, None, act=ops.ACT_GELU_FWD, aux_out=u)
+        assert torch.isfinite(act).all() and float(act[:, 0].min()) == 65504.0 and float(act[:, 1].abs().max()) == 0.0
+    # LayerNorm output and the fused Linear + LayerNorm
+    gam, bet = torch.full((512,), 1.0e5).cuda(), torch.zeros(512).cuda()
+    xs = torch.randn(300, 512, generator=G(1)).cuda()
+    _, h, _, _ = ops.layernorm_fwd(xs, gam, bet, 1e-5)
+    assert h.dtype == torch.float16 and torch.isfinite(h).all() and float(h.float().abs().max()) == 65504.0
+    a, w = h16(torch.randn(300, 512, generator=G(2))).cuda(), h16(torch.randn(512, 512, generator=G(3)) * 0.05).cuda()
+    _, _, hf, _, _ = ops.linear_ln_fwd(a, w, None, gam, bet, 1e-5, residual=xs)
+    assert hf.dtype == torch.float16 and torch.isfinite(hf).all() and float(hf.float().abs().max()) == 65504.0
+    # attention contexts: values at the edge of the range times the 1 / (1 - p) of dropout
+    B, heads, L, hd = 2, 8, 64, 64
+    q = bf(torch.randn(B * L, heads * hd, generator=G(4))).cuda()
+    v = torch.full((B * L, heads * hd), 65280.0).bfloat16().cuda()
+    ctx, _ = ops.attn_fwd(q, q, v, None, B, heads, L, L, 0.125, drop_p=0.5, seed=3, site=1)
+    assert ctx.dtype == torch.float16 and torch.isfinite(ctx).all() and float(ctx.float().max()) == 65504.0
+    Bm, N, H = 2, 40, 8
+    qkv = torch.randn(Bm * N, 3 * H * 8, generator=G(5)).half().cuda()
+    qkv[:, 2 * H * 8:] = 65504.0
+    bias = ops.pair_tile(torch.zeros(Bm, H, N, ops.pair_ld(N)).cuda(), N).half()
+    _, o = ops.pair_attn_fwd(qkv, bias, None, Bm, N, H, ops.pair_ld(N), 8 ** -0.5, drop_p=0.5, seed=3, site=2)
+    assert o.dtype == torch.float16 and torch.isfinite(o).all() and float(o.float().max()) == 65504.0
+    # the optimizer's fp16 weight shadow
+    p = torch.tensor([6.55e4, -6.55e4, 1.0, 0.0] * 4).cuda()
+    gr = torch.tensor([-1.0, 1.0, 0.0, 0.0] * 4).cuda()
+    m, vv = torch.zeros_like(p), torch.zeros_like(p)
+    pb, ph = torch.empty(16, device="cuda", dtype=torch.bfloat16), torch.empty(16, device="cuda", dtype=torch.float16)
+    ops.adam_step(p, gr, m, vv, pb, 100.0, 0.9, 0.999, 1e-6, 0.0, 1, p_f16=ph)
+    assert float(p[0]) > 65504.0 and float(ph[0]) == 65504.0 and float(ph[1]) == -65504.0 and float(ph[2]) == 1.0
+    assert torch.equal(pb.float(), p.bfloat16().float())
+
+
+def test_fp16_weight_shadow_follows_graph_replays(fp16_mode):
+    """The Adam pass writes both 16-bit weight shadows through raw pointers, so a captured step's replays keep the fp16 one fresh: an
+    eager evaluation after replays must read the weights of the last optimizer step (the shadow used to be re-cast by
+    epoch bookkeeping the replay does not advance)."""
+    from mmdti_hip.trainer import FineTuner
+    from mmdti_hip.runtime import wfwd
+    ocfg = refarch_cfg("classification", 600)
+    ocfg.unimol.layers, ocfg.roberta.layers = 2, 2
+    batch, label = O.synth_batch(8, 24, 30, ocfg, seed=3, ragged=False)
+    d = {k: v.cuda() for k, v in batch.items()}
+    model = product_model(ocfg).cuda().train()
+    load_fixture_weights(model, O.init_params(ocfg, seed=5, std=0.05))
+    tuner = FineTuner(model, "classification", learning_rate=1e-3, total_steps=50, warmup_ratio=0.0)
+    tuner.step(d, label.cuda())
+    for _ in range(3):
+        tuner.graphed_step(d, label.cuda())
+    torch.cuda.synchronize()
+    for w in (model.encoder.layers[0].fc1.weight, model.encoder.layers[1].self_attn.in_proj.weight, list(model.bert.layers)[1].output.dense.weight):
+        assert torch.equal(wfwd(w), w.detach().half())
