@@ -47,12 +47,21 @@ __device__ __forceinline__ uint32_t pack16x2(int f16, float lo, float hi) {
 // forward activation is the B operand of a weight-gradient GEMM whose A operand -- an activation gradient -- needs bf16's range, so the
 // fp16 tile is fetched as it lies in memory and converted on its way from LDS to the matrix pipe instead of in a pass over HBM.
 __device__ __forceinline__ bf16x8 frag_h2bf(const bf16x8& v) {
+#if defined(BCVT_EXP) && BCVT_EXP == 1
+  return v;
+#elif defined(BCVT_EXP) && BCVT_EXP == 2
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 w = __builtin_bit_cast(u32x4, v);
+  for (int e = 0; e < 4; ++e) w[e] = (w[e] >> 3) + 0x38003800u;
+  return __builtin_bit_cast(bf16x8, w);
+#else
   typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
   const f16x8 h = __builtin_bit_cast(f16x8, v);
   bf16x8 o;
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = (__bf16)(float)h[e];
   return o;
+#endif
 }
 template <bool CVT>
 __device__ __forceinline__ bf16x8 frag_cvt(const bf16x8& v) {
@@ -1049,22 +1058,38 @@ __device__ __forceinline__ uint32_t big_offset1(int c, int ld, int row0) {
     return (uint32_t)(((long long)k * ld + row0 + rs * 8) * 2);
   }
 }
-// kbase: wave-uniform origin of the piece (K-tile origin + piece offset); d2: element distance of the thread's second chunk
-__device__ __forceinline__ void big_issue(const bf16_t* kbase, long long d2, uint32_t off, bf16_t* piece, int wave) {
-  const bf16_t* d = piece + wave * 512;    // wave-instruction j covers chunks j*512 + wave*64 + lane
-  dma16_su(kbase, off, d);
-  dma16_su(kbase + d2, off, d + 4096);
+// The DMA of one 16 KB piece: two 16-byte chunks per thread.  Everything wave-uniform stays on the scalar side -- the source is a scalar
+// pointer (K-tile origin + piece offset) + ONE per-thread 32-bit offset, the LDS destination an integer the caller keeps in an SGPR
+// (piece base + 1 KB per wave; the second chunk 8 KB further).  Round 4, read off the ISA: handing these helpers LDS POINTERS cost, per
+// issue, a generic-to-LDS address cast with its null check, two v_readfirstlane and a 64-bit multiply for the K-tile origin -- some
+// 140 non-essential vector instructions per K-tile and wave in a loop whose every VALU instruction shows up in the launch time.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+// (readfirstlane: folded away where the compiler can prove m0v uniform -- the hot loops --, and what keeps the "s" constraint honest
+//  where its uniformity analysis gives up)
+__device__ __forceinline__ void dma16_m0(const void* sbase, uint32_t voff, int m0v) {
+  const int m = __builtin_amdgcn_readfirstlane(m0v);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(m), "v"(voff), "s"(sbase) : "memory", "m0");
+}
+__device__ __forceinline__ void dma16_m0v(const void* vptr, int m0v) {
+  const int m = __builtin_amdgcn_readfirstlane(m0v);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m), "v"(vptr) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+// kbase: wave-uniform origin of the piece; d2b: byte distance of a thread's second chunk; m0v: LDS byte address of the wave's slot
+__device__ __forceinline__ void big_issue(const char* kbase, long long d2b, uint32_t off, int m0v) {
+  dma16_m0(kbase, off, m0v);
+  dma16_m0(kbase + d2b, off, m0v + 8192);
 }
 
 // The LAST K-tile of a k-major operand whose K is not a multiple of 64 (token counts of small / ragged batches): the k rows
 // past the end are fetched from a zero chunk instead -- per-lane source select; a lane's two chunks are k rows k0 and k0 + 32.
-__device__ __forceinline__ void big_issue_tail(const bf16_t* kbase, long long d2, uint32_t off, bf16_t* piece, int wave, int kv, const void* zeros, int tid) {
+__device__ __forceinline__ void big_issue_tail(const char* kbase, long long d2b, uint32_t off, int m0v, int kv, const void* zeros, int tid) {
   const int k0 = tid >> 4;
-  const char* p0 = k0 < kv ? reinterpret_cast<const char*>(kbase) + off : reinterpret_cast<const char*>(zeros);
-  const char* p1 = k0 + 32 < kv ? reinterpret_cast<const char*>(kbase + d2) + off : reinterpret_cast<const char*>(zeros);
-  const bf16_t* d = piece + wave * 512;
-  dma16_v(p0, d);
-  dma16_v(p1, d + 4096);
+  const char* p0 = k0 < kv ? kbase + off : reinterpret_cast<const char*>(zeros);
+  const char* p1 = k0 + 32 < kv ? kbase + d2b + off : reinterpret_cast<const char*>(zeros);
+  dma16_m0v(p0, m0v);
+  dma16_m0v(p1, m0v + 8192);
 }
 
 // C[m][n] += sum over splits of slab[s][m][n]   (the second pass of the slab form of split-K)
@@ -1091,12 +1116,16 @@ struct Frag4 {
 };
 
 // one 256 x 256 output tile (tm, tn), K-split ks of a.splitk.  F16: both operands hold fp16 (forward shapes).  BCVT: B holds fp16 and
-// is converted to bf16 in registers (frag_h2bf) at the end of the phase that read it from LDS, while the matrix pipe drains that
-// phase's MFMAs; A is bf16 (weight gradients: A = dy, B = a saved forward activation).
-template <bool TA, bool TB, bool F16 = false, bool BCVT = false>
+// is converted to bf16 in registers (frag_h2bf), half behind the MFMAs of the phase that reads it from LDS, half among the MFMAs of
+// the first phase that multiplies it (BIG_PHASE: POST, CV); A is bf16 (weight gradients: A = dy, B = a saved forward activation).
+// TAIL (both operands k-major only): K is not a multiple of 64 -- the split that holds the last K-tile fetches it through the masked
+// form; without it the loop carries no tail test at all.
+template <bool TA, bool TB, bool F16 = false, bool BCVT = false, bool TAIL = false>
 __device__ __forceinline__ void big_tile(const GemmArgs& a, int tm, int tn, int ks, bf16_t* smem) {
   static_assert(!(F16 && (TA || TB || BCVT)), "fp16 operands: the forward (row-major A, weight-layout B) form only");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  static_assert(!TAIL || (TA && TB), "a K tail exists with both operands k-major only");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (scalar: DMA destinations and the bias-gradient branch stay off the vector side)
   const int wr = wave >> 2, wc = wave & 3;
   const int m0 = tm * BBM, n0 = tn * BBN;
   const int ktiles = (a.K + BK - 1) / BK;     // (a K tail only with both operands k-major: host-checked)
@@ -1105,51 +1134,65 @@ __device__ __forceinline__ void big_tile(const GemmArgs& a, int tm, int tn, int 
   const int kt0 = ks * per, kt1 = min(ktiles, kt0 + per);
   if (kt0 >= kt1) return;
   const int nt = kt1 - kt0;
-  const int tail_t = (TA && TB && ktail != BK && kt1 == ktiles) ? nt - 1 : 0x7fffffff;   // split-local index of the partial tile
-  const bf16_t* __restrict__ A = a.A + (long long)kt0 * (TA ? (long long)BK * a.lda : BK);
-  const bf16_t* __restrict__ B = a.B + (long long)kt0 * (TB ? (long long)BK * a.ldb : BK);
-  const long long kstepA = TA ? (long long)BK * a.lda : BK, kstepB = TB ? (long long)BK * a.ldb : BK;
+  const bool tail_split = TAIL && ktail != BK && kt1 == ktiles;      // this split ends on the partial tile (its local index nt - 1)
+  const long long kstepA = (TA ? (long long)BK * a.lda : BK) * 2, kstepB = (TB ? (long long)BK * a.ldb : BK) * 2;     // bytes per K-tile
+  const char* __restrict__ A = reinterpret_cast<const char*>(a.A) + (long long)kt0 * kstepA;
+  const char* __restrict__ B = reinterpret_cast<const char*>(a.B) + (long long)kt0 * kstepB;
   // (M and N are multiples of 256 here -- host-checked -- so no source row is clamped and the eight per-thread source
   //  offsets reduce to ONE per operand plus wave-uniform constants that fold into the scalar tile base)
   const uint32_t oA = big_offset1<TA>(tid, a.lda, m0), oB = big_offset1<TB>(tid, a.ldb, n0);
-  const long long dA2 = TA ? (long long)32 * a.lda : (long long)64 * a.lda;    // second chunk of a thread (tid + 512), elements
-  const long long dB2 = TB ? (long long)32 * a.ldb : (long long)64 * a.ldb;
-  const long long hA = TA ? 128 : (long long)128 * a.lda;                       // piece 1 vs piece 0: 128 rows further
-  const long long hB = TB ? 128 : (long long)128 * a.ldb;
+  const long long dA2 = (TA ? (long long)32 * a.lda : (long long)64 * a.lda) * 2;    // second chunk of a thread (tid + 512), bytes
+  const long long dB2 = (TB ? (long long)32 * a.ldb : (long long)64 * a.ldb) * 2;
+  const long long hA = (TA ? 128 : (long long)128 * a.lda) * 2;                       // piece 1 vs piece 0: 128 rows further, bytes
+  const long long hB = (TB ? 128 : (long long)128 * a.ldb) * 2;
   f32x4 acc[8][4] = {};
   const bool do_rs = TA && a.arowsum != nullptr && tn == 0;   // bias gradient: row sums of op(A), one row tile of each half per wave column
   const bf16x8 ones = ones_frag();
   f32x4 rs0 = {0.f, 0.f, 0.f, 0.f}, rs1 = rs0;
+  // LDS layout: piece P (0..3 = A0, A1, B0, B1) of buffer Q (0, 1) at element offset (2 P + Q) * BIG_PIECE -- the two buffers of a
+  // piece side by side, so that BOTH sit within the 64 KB immediate-offset reach of one fragment address register (with the buffers
+  // 64 KB apart the unrolled loop needed a second set of address registers and spilled them: scratch reloads behind s_waitcnt vmcnt(0)
+  // in the middle of the DMA pipeline).  lds_w: LDS byte address of this wave's 1 KB slot in piece 0 of buffer 0.
+#define BIG_AT(P, Q) ((2 * (P) + (Q)) * BIG_PIECE)
+  const int lds_w = lds_addr_uniform(smem) + wave * 1024;
+  // K-tile origins of the pieces still to be issued: tile min(t + 1, nt - 1) of A, tile min(t + 2, nt - 1) of B (a tile index past
+  // the split's end re-fetches its last tile -- harmless, those regions are never read again); advanced by scalar adds
+  const char* pA1 = A + (nt > 1 ? kstepA : 0);
+  const char* pB2 = B + (nt > 2 ? 2 * kstepB : (nt > 1 ? kstepB : 0));
 
-#define BIG_TILE(T) min((T), nt - 1)
-#define BIG_A(T) (A + BIG_TILE(T) * kstepA)
-#define BIG_B(T) (B + BIG_TILE(T) * kstepB)
 #define BIG_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
-  // (a tile index past the split's end re-fetches its last tile: if that one is the partial tile, through the masked form too)
-#define BIG_ISSUE(KB, D2, OFF, T, DST)                                                      \
+  // IDX: split-local index of the tile being fetched (tested only when the split ends on a partial tile)
+#define BIG_ISSUE(KB, D2, OFF, IDX, M0V)                                                    \
   {                                                                                         \
-    if (TA && TB && BIG_TILE(T) >= tail_t) big_issue_tail(KB, D2, OFF, DST, wave, ktail, a.zeros, tid); \
-    else big_issue(KB, D2, OFF, DST, wave);                                                 \
+    if (TAIL && tail_split && (IDX) >= nt - 1) big_issue_tail(KB, D2, OFF, M0V, ktail, a.zeros, tid); \
+    else big_issue(KB, D2, OFF, M0V);                                                       \
   }
   // prologue: every piece of tile 0; of tile 1 the two B pieces (the steady state enters a tile with them in flight)
-  BIG_ISSUE(BIG_A(0), dA2, oA, 0, smem);
-  BIG_ISSUE(BIG_B(0), dB2, oB, 0, smem + 2 * BIG_PIECE);
-  BIG_ISSUE(BIG_B(0) + hB, dB2, oB, 0, smem + 3 * BIG_PIECE);
-  BIG_ISSUE(BIG_A(0) + hA, dA2, oA, 0, smem + BIG_PIECE);
-  BIG_ISSUE(BIG_B(1), dB2, oB, 1, smem + BIG_BUF + 2 * BIG_PIECE);
-  BIG_ISSUE(BIG_B(1) + hB, dB2, oB, 1, smem + BIG_BUF + 3 * BIG_PIECE);
+  {
+    const char* pB1 = B + (nt > 1 ? kstepB : 0);
+    BIG_ISSUE(A, dA2, oA, 0, lds_w + 2 * BIG_AT(0, 0));
+    BIG_ISSUE(B, dB2, oB, 0, lds_w + 2 * BIG_AT(2, 0));
+    BIG_ISSUE(B + hB, dB2, oB, 0, lds_w + 2 * BIG_AT(3, 0));
+    BIG_ISSUE(A + hA, dA2, oA, 0, lds_w + 2 * BIG_AT(1, 0));
+    BIG_ISSUE(pB1, dB2, oB, 1, lds_w + 2 * BIG_AT(2, 1));
+    BIG_ISSUE(pB1 + hB, dB2, oB, 1, lds_w + 2 * BIG_AT(3, 1));
+  }
   BIG_WAIT(4);
   __builtin_amdgcn_s_barrier();
 
   Frag4 FAx, FAy, FBx, FBy;
-  // fragments of one k half (KK): A = the four 16-row tiles of the wave's rows in piece IMG; B = the wave's four 16-column
-  // tiles, two from each B piece
+  // fragments of one k half (KK): A = the four 16-row tiles of the wave's rows in piece IMG -- fragment j is row tile (j + wc) & 3 of
+  // the wave's 64 rows, so that the tile whose row sums this wave column takes (the bias gradient: BIG_RS) is ALWAYS f0: picking
+  // "fragment wc" at run time cost a run of v_cndmask and exec-mask branches in every phase; the relabelling is free (loop-invariant
+  // address arithmetic here, the same rotation where the epilogue maps accumulators to rows).  B = the wave's four 16-column tiles,
+  // two from each B piece
+  const int ra0 = wr * 64 + (wc & 3) * 16, ra1 = wr * 64 + ((wc + 1) & 3) * 16, ra2 = wr * 64 + ((wc + 2) & 3) * 16, ra3 = wr * 64 + ((wc + 3) & 3) * 16;
 #define BIG_LDA(F, IMG, KK)                                                                                          \
-  F.f0 = load_frag<TA>(IMG, wr * 64 + 0, KK, lane);  F.f1 = load_frag<TA>(IMG, wr * 64 + 16, KK, lane);               \
-  F.f2 = load_frag<TA>(IMG, wr * 64 + 32, KK, lane); F.f3 = load_frag<TA>(IMG, wr * 64 + 48, KK, lane)
-#define BIG_LDB(F, BUF, KK)                                                                                          \
-  F.f0 = load_frag<TB>(BUF + 2 * BIG_PIECE, wc * 32 + 0, KK, lane); F.f1 = load_frag<TB>(BUF + 2 * BIG_PIECE, wc * 32 + 16, KK, lane); \
-  F.f2 = load_frag<TB>(BUF + 3 * BIG_PIECE, wc * 32 + 0, KK, lane); F.f3 = load_frag<TB>(BUF + 3 * BIG_PIECE, wc * 32 + 16, KK, lane)
+  F.f0 = load_frag<TA>(IMG, ra0, KK, lane); F.f1 = load_frag<TA>(IMG, ra1, KK, lane);                                 \
+  F.f2 = load_frag<TA>(IMG, ra2, KK, lane); F.f3 = load_frag<TA>(IMG, ra3, KK, lane)
+#define BIG_LDB(F, Q, KK)                                                                                            \
+  F.f0 = load_frag<TB>(smem + BIG_AT(2, Q), wc * 32 + 0, KK, lane); F.f1 = load_frag<TB>(smem + BIG_AT(2, Q), wc * 32 + 16, KK, lane); \
+  F.f2 = load_frag<TB>(smem + BIG_AT(3, Q), wc * 32 + 0, KK, lane); F.f3 = load_frag<TB>(smem + BIG_AT(3, Q), wc * 32 + 16, KK, lane)
   // 16 MFMAs: the wave's four row tiles of A half H (acc rows H*4 + 0..3) x its four column tiles, one k half
 #define BIG_MF8(H, FA, FB, R0, R1)                                                                                   \
   acc[H * 4 + R0][0] = mfma32<F16>(FB.f0, FA.f##R0, acc[H * 4 + R0][0]);                                              \
@@ -1160,70 +1203,103 @@ __device__ __forceinline__ void big_tile(const GemmArgs& a, int tm, int tn, int 
   acc[H * 4 + R1][2] = mfma32<F16>(FB.f2, FA.f##R1, acc[H * 4 + R1][2]);                                              \
   acc[H * 4 + R0][3] = mfma32<F16>(FB.f3, FA.f##R0, acc[H * 4 + R0][3]);                                              \
   acc[H * 4 + R1][3] = mfma32<F16>(FB.f3, FA.f##R1, acc[H * 4 + R1][3])
-// (B fragments first used by this phase arrive as fp16 when BCVT: converted in place, once per K half)
-#define BIG_CVTB(FB)                                                                                                 \
-  if constexpr (BCVT) { FB.f0 = frag_h2bf(FB.f0); FB.f1 = frag_h2bf(FB.f1); FB.f2 = frag_h2bf(FB.f2); FB.f3 = frag_h2bf(FB.f3); }
+  // the same 16 MFMAs column tile by column tile (BCVT: the phases that use a B fragment set first)
+#define BIG_MF4(H, FA, FB, C)                                                                                        \
+  acc[H * 4 + 0][C] = mfma32<F16>(FB.f##C, FA.f0, acc[H * 4 + 0][C]);                                                 \
+  acc[H * 4 + 1][C] = mfma32<F16>(FB.f##C, FA.f1, acc[H * 4 + 1][C]);                                                 \
+  acc[H * 4 + 2][C] = mfma32<F16>(FB.f##C, FA.f2, acc[H * 4 + 2][C]);                                                 \
+  acc[H * 4 + 3][C] = mfma32<F16>(FB.f##C, FA.f3, acc[H * 4 + 3][C])
+  // one MFMA, then three of the twelve conversion instructions of the NEXT column tile's fragment, four times over
+#define BIG_MIX4()                                                                                                   \
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);               \
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);               \
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);               \
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0)
+  // (do_rs is a scalar condition: one s_cbranch around one MFMA)
 #define BIG_RS(ACC, FA)                                                                                              \
-  if (do_rs) {                                                                                                       \
-    const bf16x8 s0 = wc == 0 ? FA.f0 : wc == 1 ? FA.f1 : wc == 2 ? FA.f2 : FA.f3;                                    \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, s0, ACC, 0, 0, 0);                                            \
-  }
+  if (do_rs) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, FA.f0, ACC, 0, 0, 0)
   // one phase: the LDS reads of the NEXT phase's fragments and the DMA of a later tile's piece are issued first / in
   // the middle and run under this phase's 16 MFMAs (which use fragments read one phase earlier); every read is retired
   // before the closing barrier, so the region it came from may be restaged in the next phase
-  // POST (BCVT): the fp16 B fragments this phase READ are converted to bf16 once its own MFMAs are issued -- the wave's VALU
-  // works while the matrix pipe drains them (16 MFMAs take 128 cycles to issue and 256 to execute), before the DMA wait.  At the top
-  // of the consuming phase the same 48 conversions held the idle matrix pipe back: +14 % on the launch, measured.
-#define BIG_PHASE(H, FA, FB, RSACC, LOADS, ISSUE, WAITS, POST)                                                        \
+  // BCVT: the four B fragments of a K half arrive from LDS as fp16 and are converted in place (frag_h2bf: 12 VALU instructions
+  // each): f2, f3 behind the MFMAs of the phase that read them (POST), f0 at the top of the next phase and f1 three instructions
+  // behind each of f0's MFMAs (CV, sched_group_barrier).  Every one of them shows up in the launch time wherever it is put (measured:
+  // all 48 at the top of the consuming phase +14 %, behind the loading phase's MFMAs +10.6 %, interleaved +10.6 %, split +11 %; with the
+  // conversion replaced by nothing +0 %, by 8 instead of 12 instructions +7 %): the loop is paced by each wave's instruction stream.
+#define BIG_PHASE(H, FA, FB, RSACC, LOADS, ISSUE, WAITS, CV, POSTFB)                                                  \
   LOADS;                                                                                                             \
   __builtin_amdgcn_sched_barrier(0);                                                                                 \
   __builtin_amdgcn_s_setprio(1);                                                                                     \
-  BIG_MF8(H, FA, FB, 0, 1);                                                                                          \
-  __builtin_amdgcn_sched_barrier(0);                                                                                 \
-  ISSUE;                                                                                                             \
-  __builtin_amdgcn_sched_barrier(0);                                                                                 \
-  BIG_MF8(H, FA, FB, 2, 3);                                                                                          \
+  if constexpr (BCVT && CV) {                                                                                        \
+    FB.f0 = frag_h2bf(FB.f0);                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    BIG_MF4(H, FA, FB, 0); FB.f1 = frag_h2bf(FB.f1); BIG_MIX4();                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    BIG_MF4(H, FA, FB, 1);                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    ISSUE;                                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    BIG_MF4(H, FA, FB, 2);                                                                                           \
+    BIG_MF4(H, FA, FB, 3);                                                                                           \
+  } else {                                                                                                           \
+    BIG_MF8(H, FA, FB, 0, 1);                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    ISSUE;                                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    BIG_MF8(H, FA, FB, 2, 3);                                                                                        \
+  }                                                                                                                  \
   BIG_RS(RSACC, FA);                                                                                                 \
   __builtin_amdgcn_s_setprio(0);                                                                                     \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                 \
-  __builtin_amdgcn_sched_barrier(0);                                                                                 \
-  POST;                                                                                                              \
-  __builtin_amdgcn_sched_barrier(0);                                                                                 \
+  if constexpr (BCVT && !(CV)) {   /* (the phases that READ a B fragment set: its second half converted under the MFMAs' drain) */ \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    POSTFB.f2 = frag_h2bf(POSTFB.f2); POSTFB.f3 = frag_h2bf(POSTFB.f3);                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+  }                                                                                                                  \
   WAITS;                                                                                                             \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                 \
   __builtin_amdgcn_sched_barrier(0);                                                                                 \
   __builtin_amdgcn_s_barrier();                                                                                      \
   __builtin_amdgcn_sched_barrier(0)
+  // one K-tile out of buffer Q (0 / 1; R: the other one).  Both are compile-time, so every fragment read is a base register + an
+  // immediate and every DMA destination lds_w + a constant: the K loop is unrolled by two.
+#define BIG_KTILE(Q, R, T)                                                                                            \
+  {                                                                                                                  \
+    /* c1: (A0, k 0..31)   | read A1 k-half 0            | DMA A0(t+1) -> other buffer (free since phase 4 of tile t-1) */ \
+    BIG_PHASE(0, FAx, FBx, rs0, BIG_LDA(FAy, smem + BIG_AT(1, Q), 0), BIG_ISSUE(pA1, dA2, oA, (T) + 1, lds_w + 2 * BIG_AT(0, R)), (void)0, true, FBx); \
+    /* c2: (A1, k 0..31)   | read A1 and B k-half 1      | DMA A1(t+1) -> other buffer (free since phase 3 of tile t-1) */ \
+    BIG_PHASE(1, FAy, FBx, rs1, BIG_LDA(FAx, smem + BIG_AT(1, Q), 1); BIG_LDB(FBy, Q, 1),                             \
+              BIG_ISSUE(pA1 + hA, dA2, oA, (T) + 1, lds_w + 2 * BIG_AT(1, R)), (void)0, false, FBy);                   \
+    /* c3: (A1, k 32..63)  | read A0 k-half 1            | DMA B0(t+2) -> this buffer (B was last read in phase 2); wait: A0(t+1), B(t+1) landed */ \
+    BIG_PHASE(1, FAx, FBy, rs1, BIG_LDA(FAy, smem + BIG_AT(0, Q), 1), BIG_ISSUE(pB2, dB2, oB, (T) + 2, lds_w + 2 * BIG_AT(2, Q)), BIG_WAIT(4), true, FBy); \
+    /* c4: (A0, k 32..63)  | read A0, B of tile t+1      | DMA B1(t+2) -> this buffer; wait: A1(t+1) landed */          \
+    BIG_PHASE(0, FAy, FBy, rs0, BIG_LDA(FAx, smem + BIG_AT(0, R), 0); BIG_LDB(FBx, R, 0),                             \
+              BIG_ISSUE(pB2 + hB, dB2, oB, (T) + 2, lds_w + 2 * BIG_AT(3, Q)), BIG_WAIT(4), false, FBx);               \
+    pA1 += ((T) + 2 < nt) ? kstepA : 0;                                                                              \
+    pB2 += ((T) + 3 < nt) ? kstepB : 0;                                                                              \
+  }
 
-  BIG_LDA(FAx, smem, 0);
-  BIG_LDB(FBx, smem, 0);
-  BIG_CVTB(FBx);
-  for (int t = 0; t < nt; ++t) {
-    bf16_t* cur = smem + (t & 1) * BIG_BUF;
-    bf16_t* oth = smem + ((t & 1) ^ 1) * BIG_BUF;
-    // c1: (A0, k 0..31)   | read A1 k-half 0            | DMA A0(t+1) -> other buffer (free since phase 4 of tile t-1)
-    BIG_PHASE(0, FAx, FBx, rs0, BIG_LDA(FAy, cur + BIG_PIECE, 0), BIG_ISSUE(BIG_A(t + 1), dA2, oA, t + 1, oth), (void)0, (void)0);
-    // c2: (A1, k 0..31)   | read A1 and B k-half 1      | DMA A1(t+1) -> other buffer (free since phase 3 of tile t-1)
-    BIG_PHASE(1, FAy, FBx, rs1, BIG_LDA(FAx, cur + BIG_PIECE, 1); BIG_LDB(FBy, cur, 1),
-              BIG_ISSUE(BIG_A(t + 1) + hA, dA2, oA, t + 1, oth + BIG_PIECE), (void)0, BIG_CVTB(FBy));
-    // c3: (A1, k 32..63)  | read A0 k-half 1            | DMA B0(t+2) -> this buffer (B was last read in phase 2); wait: A0(t+1), B(t+1) landed
-    BIG_PHASE(1, FAx, FBy, rs1, BIG_LDA(FAy, cur, 1), BIG_ISSUE(BIG_B(t + 2), dB2, oB, t + 2, cur + 2 * BIG_PIECE), BIG_WAIT(4), (void)0);
-    // c4: (A0, k 32..63)  | read A0, B of tile t+1      | DMA B1(t+2) -> this buffer; wait: A1(t+1) landed
-    BIG_PHASE(0, FAy, FBy, rs0, BIG_LDA(FAx, oth, 0); BIG_LDB(FBx, oth, 0),
-              BIG_ISSUE(BIG_B(t + 2) + hB, dB2, oB, t + 2, cur + 3 * BIG_PIECE), BIG_WAIT(4), BIG_CVTB(FBx));
+  BIG_LDA(FAx, smem + BIG_AT(0, 0), 0);
+  BIG_LDB(FBx, 0, 0);
+  if constexpr (BCVT) { FBx.f2 = frag_h2bf(FBx.f2); FBx.f3 = frag_h2bf(FBx.f3); }
+  for (int t = 0; t < nt; t += 2) {
+    BIG_KTILE(0, 1, t);
+    if (t + 1 >= nt) break;
+    BIG_KTILE(1, 0, t + 1);
   }
   BIG_WAIT(0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();   // no DMA in flight, no read outstanding: LDS is free for the epilogue
+#undef BIG_KTILE
+#undef BIG_AT
 #undef BIG_PHASE
 #undef BIG_ISSUE
 #undef BIG_MF8
-#undef BIG_CVTB
+#undef BIG_MF4
+#undef BIG_MIX4
 #undef BIG_LDA
 #undef BIG_LDB
 #undef BIG_WAIT
-#undef BIG_A
-#undef BIG_B
-#undef BIG_TILE
   const int l15 = lane & 15, g4 = (lane >> 4) * 4;
   if (a.dbg & 1) {   // loop-only timing: keep the accumulators live, store nothing in practice
     float keep = 0.f;
@@ -1241,14 +1317,16 @@ __device__ __forceinline__ void big_tile(const GemmArgs& a, int tm, int tn, int 
 #undef BIG_RS
   const bool lead = (ks == 0);
   const long long coff = a.slab * ks;      // (slab mode: every split owns a private fp32 copy of the output)
-  // accumulator (R = H*4 + i, C = G*2 + j): row m0 + H*128 + wr*64 + i*16 + (lane & 15), columns n0 + G*128 + wc*32 + j*16 + 4*(lane >> 4) + {0..3}
+  // accumulator (R = H*4 + i, C = G*2 + j): row m0 + H*128 + wr*64 + ((i + wc) & 3)*16 + (lane & 15) (the rotation of BIG_LDA), columns
+  // n0 + G*128 + wc*32 + j*16 + 4*(lane >> 4) + {0..3}
+  const int rl0 = wc & 3, rl1 = (wc + 1) & 3, rl2 = (wc + 2) & 3, rl3 = (wc + 3) & 3;
   if (a.c_dtype != MMDTI_DT_F32_ATOMIC && a.vec_ok) {
     // four passes of 64 rows through a [64][260] fp32 image; 512 threads then run the fused epilogue on 8 contiguous columns each
     float* sC = reinterpret_cast<float*>(smem);
 #define BSTG(R, L, C) *reinterpret_cast<f32x4*>(sC + ((L) * 16 + l15) * LDC_B + ((C) >> 1) * 128 + wc * 32 + ((C) & 1) * 16 + g4) = acc[R][C]
 #define BSTG_ROW(R, L) BSTG(R, L, 0); BSTG(R, L, 1); BSTG(R, L, 2); BSTG(R, L, 3)
 #define BIG_PASS(P)                                                                                                   \
-    if (wr == ((P) & 1)) { BSTG_ROW(((P) >> 1) * 4 + 0, 0); BSTG_ROW(((P) >> 1) * 4 + 1, 1); BSTG_ROW(((P) >> 1) * 4 + 2, 2); BSTG_ROW(((P) >> 1) * 4 + 3, 3); } \
+    if (wr == ((P) & 1)) { BSTG_ROW(((P) >> 1) * 4 + 0, rl0); BSTG_ROW(((P) >> 1) * 4 + 1, rl1); BSTG_ROW(((P) >> 1) * 4 + 2, rl2); BSTG_ROW(((P) >> 1) * 4 + 3, rl3); } \
     __syncthreads();                                                                                                  \
     for (int it = 0; it < 4; ++it) {                                                                                  \
       const int chunk = tid + it * 512;                                                                               \
@@ -1279,7 +1357,7 @@ __device__ __forceinline__ void big_tile(const GemmArgs& a, int tm, int tn, int 
     __builtin_amdgcn_wave_barrier();                                                                 \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                           \
     for (int rr = 0; rr < 16; ++rr)                                                                  \
-      epi_elem(a, sW[rr * LDC_W + lane], m0 + ((R) >> 2) * 128 + wr * 64 + ((R) & 3) * 16 + rr, n0 + (lane >> 5) * 128 + wc * 32 + (lane & 31), lead, 0); \
+      epi_elem(a, sW[rr * LDC_W + lane], m0 + ((R) >> 2) * 128 + wr * 64 + ((((R) & 3) + wc) & 3) * 16 + rr, n0 + (lane >> 5) * 128 + wc * 32 + (lane & 31), lead, 0); \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                           \
     __builtin_amdgcn_wave_barrier();                                                                 \
   }
@@ -1295,13 +1373,14 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
 
-template <bool TA, bool TB, bool F16 = false, bool BCVT = false>
+// TAIL: K % 64 != 0 (both operands k-major) -- a kernel of its own, so that the common case carries neither its tests nor its registers
+template <bool TA, bool TB, bool F16 = false, bool BCVT = false, bool TAIL = false>
 __global__ __launch_bounds__(512, 1) void gemm_big_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
   const int tiles_n = (a.N + BBN - 1) / BBN, tiles_m = (a.M + BBM - 1) / BBM;
   const int wg = xcd_remap(blockIdx.x, tiles_n * tiles_m);
   const int tm = wg / tiles_n;
-  big_tile<TA, TB, F16, BCVT>(a, tm, wg - tm * tiles_n, blockIdx.z, smem);
+  big_tile<TA, TB, F16, BCVT, TAIL>(a, tm, wg - tm * tiles_n, blockIdx.z, smem);
 }
 
 // ---- grouped weight gradients ------------------------------------------------------------------------------------------
@@ -1326,7 +1405,7 @@ struct GroupArgs {
   const void* zeros;
 };
 
-template <bool BCVT>
+template <bool BCVT, bool TAIL>
 __global__ __launch_bounds__(512, 1) void gemm_big_grouped_kernel(GroupArgs g) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
   const int wg = xcd_remap(blockIdx.x, g.ntiles);
@@ -1349,7 +1428,7 @@ __global__ __launch_bounds__(512, 1) void gemm_big_grouped_kernel(GroupArgs g) {
   int tm, tn;
   if (tiles_m < pr.tiles_n) { tn = t / tiles_m; tm = t - tn * tiles_m; }
   else { tm = t / pr.tiles_n; tn = t - tm * pr.tiles_n; }
-  big_tile<true, true, false, BCVT>(a, tm, tn, blockIdx.z, smem);
+  big_tile<true, true, false, BCVT, TAIL>(a, tm, tn, blockIdx.z, smem);
 }
 
 // The same grouped weight gradients for SMALL token counts (batches of 16-32 molecules: 1-4 k rows).  There the 256 x 256 launch is
@@ -2070,8 +2149,10 @@ extern "C" int mmdti_linear_dw_grouped(mmdti_stream_t stream, int nprob, const v
   const size_t smem_b = (size_t)2 * BIG_BUF * sizeof(bf16_t);
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_grouped_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_grouped_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_grouped_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_grouped_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_grouped_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_grouped_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b) != hipSuccess) {
       set_error("linear_dw_grouped: hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", smem_b);
       return MMDTI_ERR_LAUNCH;
     }
@@ -2081,8 +2162,14 @@ extern "C" int mmdti_linear_dw_grouped(mmdti_stream_t stream, int nprob, const v
   // pass is one more of them per layer -- the K-splits add into dW with fp32 atomics instead (a few MB of them: cheaper than a launch)
   // (reached only with the 64 x 64 kernel switched off: gemm_small = 0)
   g.atomic = rows <= 4096 ? 1 : 0;
-  if (x_f16) hipLaunchKernelGGL(gemm_big_grouped_kernel<true>, dim3(tiles, 1, sk), dim3(512), smem_b, s, g);
-  else hipLaunchKernelGGL(gemm_big_grouped_kernel<false>, dim3(tiles, 1, sk), dim3(512), smem_b, s, g);
+  const bool ktail = rows % BK != 0;
+  if (x_f16) {
+    if (ktail) hipLaunchKernelGGL((gemm_big_grouped_kernel<true, true>), dim3(tiles, 1, sk), dim3(512), smem_b, s, g);
+    else hipLaunchKernelGGL((gemm_big_grouped_kernel<true, false>), dim3(tiles, 1, sk), dim3(512), smem_b, s, g);
+  } else {
+    if (ktail) hipLaunchKernelGGL((gemm_big_grouped_kernel<false, true>), dim3(tiles, 1, sk), dim3(512), smem_b, s, g);
+    else hipLaunchKernelGGL((gemm_big_grouped_kernel<false, false>), dim3(tiles, 1, sk), dim3(512), smem_b, s, g);
+  }
   if (!g.atomic) {
     long long max_n4 = 0;
     for (int i = 0; i < nprob; ++i) max_n4 = max(max_n4, (long long)g.p[i].M * g.p[i].N / 4);
