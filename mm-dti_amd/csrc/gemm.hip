@@ -613,6 +613,31 @@ __device__ __forceinline__ void dma16_v(const void* vptr, const bf16_t* lds) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m), "v"(vptr) : "memory", "m0");
 }
 #pragma clang diagnostic pop
+// LDS-DMA with everything wave-uniform on the scalar side: the source is a scalar pointer + ONE per-thread 32-bit offset, the LDS
+// destination an INTEGER byte address the caller keeps in an SGPR (lane i lands at m0v + 16 i).  Round 4, read off the ISA: handing the
+// DMA helpers LDS POINTERS cost, per issue, a generic-to-LDS address cast with its null check and v_readfirstlane moves, the builtin
+// form a 64-bit per-lane address add -- 24 (128 x 128 kernels) to 140 (256 x 256 weight gradients) non-essential vector instructions
+// per K-tile and wave, in loops whose every VALU instruction shows up in the launch time.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+// (readfirstlane: folded away where the compiler can prove m0v uniform -- the hot loops --, and what keeps the "s" constraint honest
+//  where its uniformity analysis gives up)
+__device__ __forceinline__ void dma16_m0(const void* sbase, uint32_t voff, int m0v) {
+  const int m = __builtin_amdgcn_readfirstlane(m0v);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(m), "v"(voff), "s"(sbase) : "memory", "m0");
+}
+__device__ __forceinline__ void dma16_m0v(const void* vptr, int m0v) {
+  const int m = __builtin_amdgcn_readfirstlane(m0v);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m), "v"(vptr) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+// one 128 x 64 operand tile: four chunks per thread, 4 KB apart in the image (m0v: the wave's 1 KB slot of the image)
+__device__ __forceinline__ void glds_tile_m0(const void* kbase, const Off4& off, int m0v) {
+  dma16_m0(kbase, off.o0, m0v);
+  dma16_m0(kbase, off.o1, m0v + 4096);
+  dma16_m0(kbase, off.o2, m0v + 8192);
+  dma16_m0(kbase, off.o3, m0v + 12288);
+}
 __device__ __forceinline__ void glds_tile_asm(const bf16_t* kbase, const Off4& off, bf16_t* img, int wave) {
   const bf16_t* d = img + wave * 512;
   dma16_su(kbase, off.o0, d);
@@ -682,11 +707,19 @@ __global__ __launch_bounds__(256, DBUF == 2 ? 1 : DBUF ? 2 : 4) void gemm_glds_k
   const bool do_rs = TA && DBUF == 1 && a.arowsum != nullptr && tn == 0 && wc == 0;   // (double-buffered variant only: register room)
   const bf16x8 ones = ones_frag();
   f32x4 rs0 = {0.f, 0.f, 0.f, 0.f}, rs1 = rs0, rs2 = rs0, rs3 = rs0;
+  // LDS byte address of this wave's 1 KB slot of the A image of stage 0 (the B image 16 KB further, a stage's pair 32 KB)
+  const int lds_w = lds_addr_uniform(smem) + __builtin_amdgcn_readfirstlane(wave) * 1024;
+  constexpr int TB2 = TILE * 2;
   if (!DBUF) {
+    const char* pa = reinterpret_cast<const char*>(A + kt0 * kstepA);
+    const char* pb = reinterpret_cast<const char*>(B + kt0 * kstepB);
     for (int kt = kt0; kt < kt1; ++kt) {
-      glds_tile(A + kt * kstepA, offA, smem, wave);
-      glds_tile(B + kt * kstepB, offB, smem + TILE, wave);
-      __syncthreads();   // (the compiler drains vmcnt before the barrier: the DMA'd tile is visible to every wave)
+      glds_tile_m0(pa, offA, lds_w);
+      glds_tile_m0(pb, offB, lds_w + TB2);
+      pa += kstepA * 2;
+      pb += kstepB * 2;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the DMA is issued from inline assembly: the compiler does not count it)
+      __syncthreads();   // the DMA'd tile is visible to every wave
       GEMM_KK(smem, smem + TILE, 0);
       GEMM_KK(smem, smem + TILE, 1);
       __syncthreads();   // every wave has read the tile before the next fetch overwrites it
@@ -700,9 +733,9 @@ __global__ __launch_bounds__(256, DBUF == 2 ? 1 : DBUF ? 2 : 4) void gemm_glds_k
 #define DEEP_ISSUE(T)                                                                        \
     {                                                                                        \
       const int tt = min((T), nt - 1);                                                       \
-      bf16_t* dst = smem + ((T) % DEEP_STAGES) * (2 * TILE);                                 \
-      glds_tile_asm(A0 + tt * kstepA, offA, dst, wave);                                      \
-      glds_tile_asm(B0 + tt * kstepB, offB, dst + TILE, wave);                               \
+      const int dst = lds_w + ((T) % DEEP_STAGES) * (2 * TB2);                               \
+      glds_tile_m0(A0 + tt * kstepA, offA, dst);                                             \
+      glds_tile_m0(B0 + tt * kstepB, offB, dst + TB2);                                       \
     }
     DEEP_ISSUE(0); DEEP_ISSUE(1); DEEP_ISSUE(2);
     for (int t = 0; t < nt; ++t) {
@@ -724,16 +757,16 @@ __global__ __launch_bounds__(256, DBUF == 2 ? 1 : DBUF ? 2 : 4) void gemm_glds_k
   } else {
     // (inline-assembly DMA here too: behind the builtin the compiler drained vmcnt in front of the first ds_read_b64_tr_b16 of
     //  tile kt -- the prefetch of tile kt+1 never ran under the multiply on the k-major operands this variant exists for)
-    glds_tile_asm(A + kt0 * kstepA, offA, smem, wave);
-    glds_tile_asm(B + kt0 * kstepB, offB, smem + TILE, wave);
+    glds_tile_m0(A + kt0 * kstepA, offA, lds_w);
+    glds_tile_m0(B + kt0 * kstepB, offB, lds_w + TB2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     int cur = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
-      bf16_t* nxt = smem + (cur ^ 1) * (2 * TILE);
+      const int nxt = lds_w + (cur ^ 1) * (2 * TB2);
       if (kt + 1 < kt1) {
-        glds_tile_asm(A + (kt + 1) * kstepA, offA, nxt, wave);
-        glds_tile_asm(B + (kt + 1) * kstepB, offB, nxt + TILE, wave);
+        glds_tile_m0(A + (kt + 1) * kstepA, offA, nxt);
+        glds_tile_m0(B + (kt + 1) * kstepB, offB, nxt + TB2);
       }
       __builtin_amdgcn_sched_barrier(0);
       const bf16_t* img = smem + cur * (2 * TILE);
@@ -858,14 +891,15 @@ __global__ __launch_bounds__(256, 2) void gemm_small_kernel(GemmArgs a) {
   const long long kstepB = TB ? (long long)BK * a.ldb : BK;
   // (a stage past the end of the K range re-fetches the last tile into a buffer nobody reads again: every thread always has
   //  the same number of loads in flight, which is what the counted waits assume)
+  const int lds_w = lds_addr_uniform(smem) + __builtin_amdgcn_readfirstlane(wave) * 1024;   // (scalar-side DMA addressing: see dma16_m0)
 #define SM_ISSUE(T)                                                                  \
   {                                                                                  \
     const int tt = min((T), nt - 1);                                                 \
-    const bf16_t* dst = smem + ((T) % SM_STAGES) * (2 * SM_TILE) + wave * 512;       \
-    dma16_su(A + tt * BK, oA0, dst);                                                 \
-    dma16_su(A + tt * BK, oA1, dst + 2048);                                          \
-    dma16_su(B + tt * kstepB, oB0, dst + SM_TILE);                                   \
-    dma16_su(B + tt * kstepB, oB1, dst + SM_TILE + 2048);                            \
+    const int dst = lds_w + ((T) % SM_STAGES) * (4 * SM_TILE);                       \
+    dma16_m0(A + tt * BK, oA0, dst);                                                 \
+    dma16_m0(A + tt * BK, oA1, dst + 4096);                                          \
+    dma16_m0(B + tt * kstepB, oB0, dst + 2 * SM_TILE);                               \
+    dma16_m0(B + tt * kstepB, oB1, dst + 2 * SM_TILE + 4096);                        \
   }
   f32x4 acc[2][2] = {};
   SM_ISSUE(0); SM_ISSUE(1); SM_ISSUE(2);
@@ -948,8 +982,6 @@ __global__ __launch_bounds__(256, 4) void gemm_glds_tall_kernel(GemmArgs a, int 
   const Off4 offB = glds_offsets<TB>(a.ldb, n0, a.N, tid);
   const long long kstepB = TB ? (long long)BK * a.ldb : BK;
   f32x4 acc[9][2] = {};
-  typedef __attribute__((address_space(1))) const void gptr_t;
-  typedef __attribute__((address_space(3))) void lptr_t;
 #define TMF(I) acc[I][0] = mfma32<F16>(fb0, fa##I, acc[I][0]); \
                acc[I][1] = mfma32<F16>(fb1, fa##I, acc[I][1])
 #define TALL_KK(KK)                                                                                   \
@@ -968,15 +1000,21 @@ __global__ __launch_bounds__(256, 4) void gemm_glds_tall_kernel(GemmArgs a, int 
       TMF(5); TMF(6); TMF(7); TMF(8);                                                                 \
     }                                                                                                 \
   }
+  // (scalar-side DMA addressing: see dma16_m0)
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int lds_a = lds_addr_uniform(imgA) + wave_s * 1024, lds_b = lds_addr_uniform(imgB) + wave_s * 1024;
+  const char* pa = reinterpret_cast<const char*>(A);
+  const char* pb = reinterpret_cast<const char*>(B);
   for (int kt = 0; kt < ktiles; ++kt) {
-    const char* ab = reinterpret_cast<const char*>(A + (long long)kt * BK);
-    bf16_t* d = imgA + wave * 512;
-    __builtin_amdgcn_global_load_lds((gptr_t*)(ab + oA[0]), (lptr_t*)(d), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t*)(ab + oA[1]), (lptr_t*)(d + 2048), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t*)(ab + oA[2]), (lptr_t*)(d + 4096), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t*)(ab + oA[3]), (lptr_t*)(d + 6144), 16, 0, 0);
-    if (wave < 2) __builtin_amdgcn_global_load_lds((gptr_t*)(ab + oA[4]), (lptr_t*)(d + 8192), 16, 0, 0);
-    glds_tile(B + kt * kstepB, offB, imgB, wave);
+    dma16_m0(pa, oA[0], lds_a);
+    dma16_m0(pa, oA[1], lds_a + 4096);
+    dma16_m0(pa, oA[2], lds_a + 8192);
+    dma16_m0(pa, oA[3], lds_a + 12288);
+    if (wave_s < 2) dma16_m0(pa, oA[4], lds_a + 16384);
+    glds_tile_m0(pb, offB, lds_b);
+    pa += BK * 2;
+    pb += kstepB * 2;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (inline-assembly DMA: not counted by the compiler)
     __syncthreads();
     TALL_KK(0);
     TALL_KK(1);
@@ -1058,24 +1096,6 @@ __device__ __forceinline__ uint32_t big_offset1(int c, int ld, int row0) {
     return (uint32_t)(((long long)k * ld + row0 + rs * 8) * 2);
   }
 }
-// The DMA of one 16 KB piece: two 16-byte chunks per thread.  Everything wave-uniform stays on the scalar side -- the source is a scalar
-// pointer (K-tile origin + piece offset) + ONE per-thread 32-bit offset, the LDS destination an integer the caller keeps in an SGPR
-// (piece base + 1 KB per wave; the second chunk 8 KB further).  Round 4, read off the ISA: handing these helpers LDS POINTERS cost, per
-// issue, a generic-to-LDS address cast with its null check, two v_readfirstlane and a 64-bit multiply for the K-tile origin -- some
-// 140 non-essential vector instructions per K-tile and wave in a loop whose every VALU instruction shows up in the launch time.
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-// (readfirstlane: folded away where the compiler can prove m0v uniform -- the hot loops --, and what keeps the "s" constraint honest
-//  where its uniformity analysis gives up)
-__device__ __forceinline__ void dma16_m0(const void* sbase, uint32_t voff, int m0v) {
-  const int m = __builtin_amdgcn_readfirstlane(m0v);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(m), "v"(voff), "s"(sbase) : "memory", "m0");
-}
-__device__ __forceinline__ void dma16_m0v(const void* vptr, int m0v) {
-  const int m = __builtin_amdgcn_readfirstlane(m0v);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m), "v"(vptr) : "memory", "m0");
-}
-#pragma clang diagnostic pop
 // kbase: wave-uniform origin of the piece; d2b: byte distance of a thread's second chunk; m0v: LDS byte address of the wave's slot
 __device__ __forceinline__ void big_issue(const char* kbase, long long d2b, uint32_t off, int m0v) {
   dma16_m0(kbase, off, m0v);
@@ -1458,23 +1478,24 @@ __global__ __launch_bounds__(256, STAGES == 3 ? 3 : 2) void gemm_small_dw_groupe
   const long long kstepA = (long long)BK * pr.lda, kstepB = (long long)BK * pr.ldb;
   const int k0 = tid >> 3;                 // k row of this thread's first chunk; its second is k0 + 32
   // (a stage past the end of the K range re-fetches the last tile; the partial tile always through the masked form)
+  const int lds_w = lds_addr_uniform(smem) + __builtin_amdgcn_readfirstlane(wave) * 1024;   // (scalar-side DMA addressing: see dma16_m0)
 #define SDW_ISSUE(T)                                                                                   \
   {                                                                                                    \
     const int tt = min((T), nt - 1);                                                                   \
-    const bf16_t* dst = smem + ((T) % STAGES) * (2 * SM_TILE) + wave * 512;                         \
+    const int dst = lds_w + ((T) % STAGES) * (4 * SM_TILE);                                            \
     const bf16_t* ka = A + tt * kstepA;                                                                \
     const bf16_t* kb = B + tt * kstepB;                                                                \
     if (tt == nt - 1 && ktail != BK) {                                                                 \
       const char* z = reinterpret_cast<const char*>(g.zeros);                                          \
-      dma16_v(k0 < ktail ? reinterpret_cast<const char*>(ka) + oA0 : z, dst);                          \
-      dma16_v(k0 + 32 < ktail ? reinterpret_cast<const char*>(ka) + oA1 : z, dst + 2048);              \
-      dma16_v(k0 < ktail ? reinterpret_cast<const char*>(kb) + oB0 : z, dst + SM_TILE);                \
-      dma16_v(k0 + 32 < ktail ? reinterpret_cast<const char*>(kb) + oB1 : z, dst + SM_TILE + 2048);    \
+      dma16_m0v(k0 < ktail ? reinterpret_cast<const char*>(ka) + oA0 : z, dst);                        \
+      dma16_m0v(k0 + 32 < ktail ? reinterpret_cast<const char*>(ka) + oA1 : z, dst + 4096);            \
+      dma16_m0v(k0 < ktail ? reinterpret_cast<const char*>(kb) + oB0 : z, dst + 2 * SM_TILE);          \
+      dma16_m0v(k0 + 32 < ktail ? reinterpret_cast<const char*>(kb) + oB1 : z, dst + 2 * SM_TILE + 4096); \
     } else {                                                                                           \
-      dma16_su(ka, oA0, dst);                                                                          \
-      dma16_su(ka, oA1, dst + 2048);                                                                   \
-      dma16_su(kb, oB0, dst + SM_TILE);                                                                \
-      dma16_su(kb, oB1, dst + SM_TILE + 2048);                                                         \
+      dma16_m0(ka, oA0, dst);                                                                          \
+      dma16_m0(ka, oA1, dst + 4096);                                                                   \
+      dma16_m0(kb, oB0, dst + 2 * SM_TILE);                                                            \
+      dma16_m0(kb, oB1, dst + 2 * SM_TILE + 4096);                                                     \
     }                                                                                                  \
   }
   f32x4 acc[2][2] = {};
@@ -1617,8 +1638,6 @@ __global__ __launch_bounds__(512, 4) void gemm_ln_kernel(GemmLnArgs a) {
     const int rl = c >> 3, kc = (c & 7) ^ (rl & 7);
     oB[j] = (uint32_t)(((long long)rl * a.ldb + kc * 8) * 2);
   }
-  typedef __attribute__((address_space(1))) const void gptr_t;
-  typedef __attribute__((address_space(3))) void lptr_t;
   f32x4 acc[R][4] = {};
   const int ktiles = a.K / BK;
   constexpr int A_CHUNKS = ROWS * 8;
@@ -1632,15 +1651,19 @@ __global__ __launch_bounds__(512, 4) void gemm_ln_kernel(GemmLnArgs a) {
       LMF(I, 0); LMF(I, 1); LMF(I, 2); LMF(I, 3);                                                       \
     }                                                                                                   \
   }
+  // (scalar-side DMA addressing: see dma16_m0)
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int lds_a = lds_addr_uniform(imgA) + wave_s * 1024, lds_b = lds_addr_uniform(imgB) + wave_s * 1024;
+  const char* ab = reinterpret_cast<const char*>(a.A);
+  const char* bb = reinterpret_cast<const char*>(a.W);
   for (int kt = 0; kt < ktiles; ++kt) {
-    const char* ab = reinterpret_cast<const char*>(a.A + (long long)kt * BK);
-    const char* bb = reinterpret_cast<const char*>(a.W + (long long)kt * BK);
-    __builtin_amdgcn_global_load_lds((gptr_t*)(ab + oA[0]), (lptr_t*)(imgA + wave * 512), 16, 0, 0);
-    if (A_CHUNKS > 512 && wave * 64 + 512 < A_CHUNKS)
-      __builtin_amdgcn_global_load_lds((gptr_t*)(ab + oA[1]), (lptr_t*)(imgA + 4096 + wave * 512), 16, 0, 0);
+    dma16_m0(ab, oA[0], lds_a);
+    if (A_CHUNKS > 512 && wave_s * 64 + 512 < A_CHUNKS) dma16_m0(ab, oA[1], lds_a + 8192);
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t*)(bb + oB[j]), (lptr_t*)(imgB + j * 4096 + wave * 512), 16, 0, 0);
+    for (int j = 0; j < 8; ++j) dma16_m0(bb, oB[j], lds_b + j * 8192);
+    ab += BK * 2;
+    bb += BK * 2;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (inline-assembly DMA: not counted by the compiler)
     __syncthreads();
     LN_KK(0);
     LN_KK(1);
