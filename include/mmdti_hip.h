@@ -267,7 +267,9 @@ int mmdti_gbf_bias_bwd(mmdti_stream_t stream, const void* g, const float* dist, 
  * :190-208 and GaussianLayer :211-236): the forward saves nothing -- each 128-pair block recomputes basis / pre-activation /
  * hidden from dist and edge_type, forms do and du, and accumulates ALL parameter gradients on chip (MFMA, contraction over the
  * pairs staged transposed in LDS), flushing once per workgroup: dw1 [128,128], db1 [128], dw2 [64,128], db2 [64], dmul/dbias [E],
- * dmeans/dstds [128] (fp32, +=).  g: dL/d(out) in the layout of flags bits 0 and 2.  K=128, F=128, H=64, E <= 1536. */
+ * dmeans/dstds [128] (fp32, +=).  g: dL/d(out) in the layout of flags bits 0 and 2.  K=128, F=128, H=64, E <= 1536.  An fp32 g
+ * enters its products as a bf16 high + a bf16 low part: the rows of g sum to zero and padded query rows repeat one basis vector, so
+ * a g rounded to bf16 leaves coherent residues where the exact sums cancel. */
 int mmdti_gbf_bias_bwd_full(mmdti_stream_t stream, const void* g, const float* dist, const void* edge_type, int edge_bytes,
                             const float* mul, const float* bias, const float* means, const float* stds, const void* w1_bf16,
                             const float* b1, const void* w2_bf16, int B, int N, int ld, int K, int F, int H, int E, int flags,
@@ -275,7 +277,13 @@ int mmdti_gbf_bias_bwd_full(mmdti_stream_t stream, const void* g, const float* d
                             const int* tile_prefix /* nullable, tiled layout only: as in mmdti_gbf_bias_fwd, in this kernel's tile
                             units: tile_prefix[b+1] - tile_prefix[b] = nb * min(nb, 4*k_b) blocks of real pairs, nb = ceil(N/4) */,
                             const int* row_blocks /* nullable, with tile_prefix: packed token rows, as in the forward: the count is then
-                            row_blocks[b] * min(nb, 4*k_b) -- the gradient of the query rows past the representative pad row is zero */);
+                            row_blocks[b] * min(nb, 4*k_b) -- the gradient of the query rows past the representative pad row is zero */,
+                            void* workspace /* nullable; mmdti_gbf_bias_bwd_full_workspace(E) bytes, 16-byte aligned: every workgroup stores
+                            its partial sums to its own slab and a second kernel folds the slabs in a fixed order -- the eight gradients
+                            are then bitwise reproducible from run to run; without it the partials meet in fp32 atomics */,
+                            long long workspace_bytes);
+/* bytes of workspace for mmdti_gbf_bias_bwd_full with E edge types (a value, not a status code) */
+int mmdti_gbf_bias_bwd_full_workspace(int E);
 /* [B,N,N,H] fp32 -> [B,H,N,ld] fp32 (mm_model.py:555-556 permute(0,3,1,2).contiguous()) and its gradient
  * [B,H,N,ld] fp32 (or, tiled != 0, the [B,H,nt,nt,256] tile layout of mmdti_gbf_bias_fwd) -> [B,N,N,H] bf16 */
 int mmdti_pair_permute_fwd(mmdti_stream_t stream, const float* x, float* out, int B, int N, int H, int ld);

@@ -663,6 +663,9 @@ __global__ __launch_bounds__(256, 2) void gbf_bias_bwd_kernel(const GT* __restri
 // bytes per lane, the transposing reads of a half-wave hit 32 distinct bank pairs.
 constexpr int GBF_LW = 144;       // LDS row stride (elements) of W1 [128 f][144] and of the two pair tiles [128 pairs][144]
 constexpr int GBF_FULL_MAXE = 1536;   // 4 per-edge-type fp32 tables next to 126 KB of tiles in the CU's 160 KB
+// per-workgroup slab of partial gradients (fp32 elements): dW1 [F][K] | dW2 [H][F] | db1 [F] | db2 [H] | dmeans [K] | dstds [K] | dmul [E] | dbias [E]
+constexpr int GBF_SLAB_B1 = GBF_F * GBF_K + GBF_H * GBF_F, GBF_SLAB_B2 = GBF_SLAB_B1 + GBF_F, GBF_SLAB_MU = GBF_SLAB_B2 + GBF_H,
+              GBF_SLAB_SG = GBF_SLAB_MU + GBF_K, GBF_SLAB = GBF_SLAB_SG + GBF_K;
 constexpr size_t gbf_full_smem(int E) {
   return (size_t)(GBF_F * GBF_LW + GBF_F * GBF_W2S + 2 * 128 * GBF_LW) * 2 + (size_t)(4 * GBF_K + GBF_F + 2 * 128 + 4 * E) * 4;
 }
@@ -684,7 +687,7 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
     const float* __restrict__ bias, const float* __restrict__ means, const float* __restrict__ stds, const bf16_t* __restrict__ W1,
     const float* __restrict__ b1, const bf16_t* __restrict__ W2, float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2,
     float* __restrict__ db2, float* __restrict__ dmul, float* __restrict__ dbias, float* __restrict__ dmeans, float* __restrict__ dstds, int B,
-    int N, int ld, int E, int tpm, const int* __restrict__ tile_prefix, const int* __restrict__ row_blocks) {
+    int N, int ld, int E, int tpm, const int* __restrict__ tile_prefix, const int* __restrict__ row_blocks, float* __restrict__ slab) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gbf_smem[];
   bf16_t* sW1 = reinterpret_cast<bf16_t*>(gbf_smem);            // [128 f][144]  W1[f][k]
   bf16_t* sW2T = sW1 + GBF_F * GBF_LW;                           // [128 f][72]   W2^T[f][h]
@@ -739,6 +742,7 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
   const bf16_t* const t0lo = T0 + trow + tswz;
   const bf16_t* const t0hi = T0 + trow + (64 ^ tswz);
   const bf16_t* const t1lo = t0lo + 128 * GBF_LW;
+  const bf16_t* const t1hi = t0hi + 128 * GBF_LW;               // (phase B2: the low parts of dO in the unused half of T1's columns)
   const bf16_t* const t0w = T0 + trow + ((16 * wave) ^ tswz);   // column block = this wave
   const bf16_t* const t1w = t0w + 128 * GBF_LW;
   const int rswz = ((i >> 3) & 1) << 6;                          // row reads of T1: pair row 16j + i
@@ -830,13 +834,26 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
     const float* kconst = reinterpret_cast<const float*>(gbf_smem + o_kconst);
     fetch(tile + stride, n_act, n_valid, n_d, n_e, n_gv);
     // ------------------------------------------------------------------------------------------------ phase A
-    gbf16x8 oB[2], hB[4];
+    // The incoming gradient enters the two products that contract it -- du = (W2^T . dO) . gelu' here, dW2 / db2 in phase B2 -- as a
+    // bf16 high part + a bf16 low part (16 mantissa bits, two MFMAs).  Rows of G sum to zero over the keys, and every (pad query,
+    // real key) pair of a molecule has the same basis and hidden vector: in exact arithmetic their contributions cancel, with G
+    // rounded to bf16 they left 2^-9-sized residues summed coherently over thousands of pairs (round 4: the four table gradients of
+    // a mixed-length batch 5 x further from the fp32 oracle than the 16-bit contract's own emulation is).
+    constexpr bool SPLIT_G = sizeof(GT) == 4;      // (a bf16 gradient chain -- opt-in -- has no low part)
+    gbf16x8 oB[2], oL[2], hB[4];
     if (!valid) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) gv[j] = 0.f;
     }
     oB[0] = gbf_pack8(gv);
     oB[1] = gbf_pack8(gv + 8);
+    if constexpr (SPLIT_G) {
+      float lo[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) lo[j] = gv[j] - (float)oB[j >> 3][j & 7];
+      oL[0] = gbf_pack8(lo);
+      oL[1] = gbf_pack8(lo + 8);
+    }
     const float y = sMul[e] * d + sBia[e];
     if (g == 0) sY[ploc] = y;
     if (act) {
@@ -858,6 +875,7 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
           for (int c = 0; c < 2; ++c) {
             const gbf16x8 wf = *reinterpret_cast<const gbf16x8*>(w2row + 16 * ft * GBF_W2S + 32 * c);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, oB[c], acc, 0, 0, 0);
+            if constexpr (SPLIT_G) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, oL[c], acc, 0, 0, 0);
           }
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
@@ -926,8 +944,7 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
         }
         const float yj = sY[16 * j + i];
         const gf32x2 yy = {yj, yj};
-        const uint2 db = gbf_pack4(acc);                 // dbasis passes through bf16 like the unfused chain
-        gf32x2 dy2 = {0.f, 0.f};
+        gf32x2 dy2 = {0.f, 0.f};                          // (dbasis stays fp32 on its way into the Gaussian backward)
 #define GBF_G2(LO, DV0, DV1)                                                                                   \
         {                                                                                                      \
           const gf32x2 is2 = {kis[LO], kis[LO + 1]};                                                           \
@@ -942,8 +959,8 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
           const gf32x2 w = t * (z * zs - is2);                                                                 \
           asg[LO] += w[0]; asg[LO + 1] += w[1];                                                                \
         }
-        GBF_G2(0, __uint_as_float(db.x << 16), __uint_as_float(db.x & 0xffff0000u))
-        GBF_G2(2, __uint_as_float(db.y << 16), __uint_as_float(db.y & 0xffff0000u))
+        GBF_G2(0, acc[0], acc[1])
+        GBF_G2(2, acc[2], acc[3])
 #undef GBF_G2
         float dy = dy2[0] + dy2[1];
         dy += __shfl_xor(dy, 16, 64);
@@ -961,6 +978,10 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
     }
     *reinterpret_cast<gbf16x8*>(r1lo + 8 * g) = oB[0];              // dO: heads 32c + 8g ..
     *reinterpret_cast<gbf16x8*>(r1lo + 32 + 8 * g) = oB[1];
+    if constexpr (SPLIT_G) {                                         // ... and its low parts in columns 64 + head
+      *reinterpret_cast<gbf16x8*>(r1hi + 8 * g) = oL[0];
+      *reinterpret_cast<gbf16x8*>(r1hi + 32 + 8 * g) = oL[1];
+    }
     if (g == 0) {
       const float dyv = sDy[ploc];
       sDy[ploc] = 0.f;
@@ -977,11 +998,19 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
       for (int hb = 0; hb < 4; ++hb) {
         const gbf16x8 fa = GBF_TFRAG(t1lo + 16 * hb, sstep);   // dO^T rows 16*hb .. (heads < 64: the low swizzle half)
         aW2[hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, aW2[hb], 0, 0, 0);
+        if constexpr (SPLIT_G) {
+          const gbf16x8 fl = GBF_TFRAG(t1hi + 16 * hb, sstep);
+          aW2[hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl, fb, aW2[hb], 0, 0, 0);
+        }
       }
       // db2 of head block wave & 3 (waves 4..7 repeat it and drop it at the flush).  Unconditional on purpose: MFMA ignores
       // EXEC, a predicated one would still run -- on operands whose masked-off set-up did not.
       const gbf16x8 fo = GBF_TFRAG(t1lo + 16 * (wave & 3), sstep);
       aB2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fo, ones, aB2, 0, 0, 0);
+      if constexpr (SPLIT_G) {
+        const gbf16x8 fol = GBF_TFRAG(t1hi + 16 * (wave & 3), sstep);
+        aB2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fol, ones, aB2, 0, 0, 0);
+      }
     }
 #undef GBF_TFRAG
 #undef GBF_SWZ
@@ -990,20 +1019,35 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
 #pragma unroll
     for (int j = 0; j < 16; ++j) gv[j] = n_gv[j];
   }
-  // ---- flush.  Accumulator tile: rows 4g + r, column i.
+  // ---- flush.  Accumulator tile: rows 4g + r, column i.  With a slab (the default: ops hands one in) every workgroup stores its
+  // partial sums to its own [GBF_SLAB + 2 E] fp32 slot and gbf_slab_reduce_kernel folds the slots in a FIXED order -- bitwise
+  // reproducible gradients; without one the partials meet in fp32 atomics (order-dependent in the last bits).
+  float* const sl = slab ? slab + (long long)blockIdx.x * (GBF_SLAB + 2 * E) : nullptr;
 #pragma unroll
   for (int kb = 0; kb < 8; ++kb)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(dW1 + (long long)(16 * wave + 4 * g + r) * GBF_K + 16 * kb + i, aW1[kb][r]);
+    for (int r = 0; r < 4; ++r) {
+      const int o = (16 * wave + 4 * g + r) * GBF_K + 16 * kb + i;
+      if (sl) sl[o] = aW1[kb][r]; else atomicAdd(dW1 + o, aW1[kb][r]);
+    }
 #pragma unroll
   for (int hb = 0; hb < 4; ++hb)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(dW2 + (long long)(16 * hb + 4 * g + r) * GBF_F + 16 * wave + i, aW2[hb][r]);
+    for (int r = 0; r < 4; ++r) {
+      const int o = (16 * hb + 4 * g + r) * GBF_F + 16 * wave + i;
+      if (sl) sl[GBF_F * GBF_K + o] = aW2[hb][r]; else atomicAdd(dW2 + o, aW2[hb][r]);
+    }
   if (i == 0) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      atomicAdd(db1 + 16 * wave + 4 * g + r, aB1[r]);
-      if (wave < 4) atomicAdd(db2 + 16 * wave + 4 * g + r, aB2[r]);
+      const int o = 16 * wave + 4 * g + r;
+      if (sl) {
+        sl[GBF_SLAB_B1 + o] = aB1[r];
+        if (wave < 4) sl[GBF_SLAB_B2 + o] = aB2[r];
+      } else {
+        atomicAdd(db1 + o, aB1[r]);
+        if (wave < 4) atomicAdd(db2 + o, aB2[r]);
+      }
     }
   }
 #pragma unroll
@@ -1013,16 +1057,41 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
     sgv += __shfl_xor(sgv, 1, 64); sgv += __shfl_xor(sgv, 2, 64); sgv += __shfl_xor(sgv, 4, 64); sgv += __shfl_xor(sgv, 8, 64);
     if (i == 0) {
       const int k = 16 * wave + 4 * g + r;
-      atomicAdd(dmeans + k, a);
-      atomicAdd(dstds + k, stds[k] < 0.f ? -sgv : sgv);   // d|std|/dstd
+      const float ds = stds[k] < 0.f ? -sgv : sgv;        // d|std|/dstd
+      if (sl) { sl[GBF_SLAB_MU + k] = a; sl[GBF_SLAB_SG + k] = ds; }
+      else { atomicAdd(dmeans + k, a); atomicAdd(dstds + k, ds); }
     }
   }
   __syncthreads();
   for (int c = tid; c < E; c += 512) {
     const float a = hist[c], bb = hist[E + c];
-    if (a != 0.f) atomicAdd(dmul + c, a);
-    if (bb != 0.f) atomicAdd(dbias + c, bb);
+    if (sl) { sl[GBF_SLAB + c] = a; sl[GBF_SLAB + E + c] = bb; }
+    else {
+      if (a != 0.f) atomicAdd(dmul + c, a);
+      if (bb != 0.f) atomicAdd(dbias + c, bb);
+    }
   }
+}
+
+// dst += sum over the workgroups' slab slots, slot 0 first (one thread per gradient element: fixed order, no atomics)
+__global__ __launch_bounds__(256) void gbf_slab_reduce_kernel(const float* __restrict__ slab, int nwg, int E, float* __restrict__ dW1, float* __restrict__ db1,
+                                                              float* __restrict__ dW2, float* __restrict__ db2, float* __restrict__ dmul,
+                                                              float* __restrict__ dbias, float* __restrict__ dmeans, float* __restrict__ dstds) {
+  const int SL = GBF_SLAB + 2 * E;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= SL) return;
+  float t = 0.f;
+  for (int w = 0; w < nwg; ++w) t += slab[(long long)w * SL + e];
+  float* dst;
+  if (e < GBF_F * GBF_K) dst = dW1 + e;
+  else if (e < GBF_SLAB_B1) dst = dW2 + (e - GBF_F * GBF_K);
+  else if (e < GBF_SLAB_B2) dst = db1 + (e - GBF_SLAB_B1);
+  else if (e < GBF_SLAB_MU) dst = db2 + (e - GBF_SLAB_B2);
+  else if (e < GBF_SLAB_SG) dst = dmeans + (e - GBF_SLAB_MU);
+  else if (e < GBF_SLAB) dst = dstds + (e - GBF_SLAB_SG);
+  else if (e < GBF_SLAB + E) dst = dmul + (e - GBF_SLAB);
+  else dst = dbias + (e - GBF_SLAB - E);
+  *dst += t;
 }
 
 // Tiled G ([B,H,nt,nt,256], tiles in accumulator order) -> [B,N,N,H] bf16.  One block per (molecule, query block, key
@@ -1216,7 +1285,7 @@ extern "C" int mmdti_gbf_bias_bwd_full(mmdti_stream_t stream, const void* g, con
                                        const float* mul, const float* bias, const float* means, const float* stds, const void* w1_bf16,
                                        const float* b1, const void* w2_bf16, int B, int N, int ld, int K, int F, int H, int E, int flags,
                                        float* dw1, float* db1, float* dw2, float* db2, float* dmul, float* dbias, float* dmeans,
-                                       float* dstds, const int* tile_prefix, const int* row_blocks) {
+                                       float* dstds, const int* tile_prefix, const int* row_blocks, void* workspace, long long workspace_bytes) {
   const int tiled = flags & 1, compact = (flags >> 2) & 1;   // bit 0: tiled pair layout; bit 2: compact planes (g is bf16; tiled only)
   MMDTI_REQUIRE(!compact || tiled, "gbf_bias_bwd_full: compact planes (flags bit 2) exist in the tiled layout only");
   MMDTI_REQUIRE(!tile_prefix || tiled, "gbf_bias_bwd_full: tile_prefix (ragged batches) needs the tiled pair layout");
@@ -1248,9 +1317,17 @@ extern "C" int mmdti_gbf_bias_bwd_full(mmdti_stream_t stream, const void* g, con
 #define GBF_FB(TILED, GT)                                                                                                          \
   hipLaunchKernelGGL((gbf_bias_bwd_full_kernel<TILED, GT>), dim3(grid), dim3(512), smem, (hipStream_t)stream, (const GT*)g, dist, edge_type, edge_bytes, mul, \
                      bias, means, stds, (const bf16_t*)w1_bf16, b1, (const bf16_t*)w2_bf16, dw1, db1, dw2, db2, dmul, dbias, dmeans, dstds, B, \
-                     N, ld, E, tpm, tile_prefix, row_blocks)
+                     N, ld, E, tpm, tile_prefix, row_blocks, slab)
+  // (a workspace of at least grid slots: partial sums in per-workgroup slabs + a fixed-order reduce; else fp32 atomics)
+  const long long SL = GBF_SLAB + 2 * (long long)E;
+  float* slab = (workspace && aligned16(workspace) && workspace_bytes >= (long long)grid * SL * 4) ? reinterpret_cast<float*>(workspace) : nullptr;
   if (compact) GBF_FB(true, __bf16); else if (tiled) GBF_FB(true, float); else GBF_FB(false, float);
 #undef GBF_FB
+  if (slab)
+    hipLaunchKernelGGL(gbf_slab_reduce_kernel, dim3(cdiv(SL, 256)), dim3(256), 0, (hipStream_t)stream, slab, grid, E, dw1, db1, dw2, db2, dmul, dbias, dmeans, dstds);
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }
+
+/* bytes of workspace that make mmdti_gbf_bias_bwd_full reproducible (one slab per workgroup of its persistent grid, at most 256) */
+extern "C" int mmdti_gbf_bias_bwd_full_workspace(int E) { return (int)(256ll * (GBF_SLAB + 2ll * (E > 0 ? E : 0)) * 4); }

@@ -38,31 +38,50 @@ __global__ __launch_bounds__(256) void seq_mean_bwd_kernel(const float* __restri
     dx[row * ld + d] = f2bf(d < D ? dout[(long long)b * D + d] / (float)S : 0.f);
 }
 
-// Wide rows (D % 8 == 0): 16-byte loads, 32 rows per workgroup, partial sums added into a zeroed output -- the InfoNCE head
-// pools the 512-wide GELU outputs of every token (pool first, project after: mean_t(W2 h_t + b2) = W2 mean_t(h_t) + b2).
-__global__ __launch_bounds__(256) void seq_mean_fwd_vec_kernel(const bf16_t* __restrict__ x, int S, int D, int ld, float* __restrict__ out) {
-  extern __shared__ float red[];                // [4][D]
-  const int b = blockIdx.x, s0 = blockIdx.y * 32;
-  const int cpr = D >> 3;                       // 8-column pieces per row
-  for (int c = threadIdx.x; c < cpr * 4; c += 256) {   // 4 row phases x cpr pieces
-    const int piece = c % cpr, phase = c / cpr;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int r = phase; r < 32 && s0 + r < S; r += 4) {
-      const uint4 u = *reinterpret_cast<const uint4*>(x + ((long long)b * S + s0 + r) * ld + piece * 8);
+// Wide rows (D % 8 == 0): 16-byte loads -- the InfoNCE head pools the 512-wide GELU outputs of every token (pool first, project
+// after: mean_t(W2 h_t + b2) = W2 mean_t(h_t) + b2).  One workgroup per (sequence, 64-column slice): 32 row phases x 8 pieces, the
+// phases folded through LDS in a FIXED order.  (Rounds 1-3 split a sequence's rows over workgroups that met in fp32 atomics: the
+// pooled embedding -- a forward activation -- differed by an ulp from run to run, and every gradient of the step with it; found as
+// the source of the run-to-run noise in the step's ill-conditioned gradient sums, DESIGN.md "determinism".)
+// row_off / n_real non-null: packed token rows (see mmdti_seq_mean_packed_fwd) -- the representative pad row weighted by the number
+// of padded positions it stands for.
+__global__ __launch_bounds__(256) void seq_mean_fwd_vec_kernel(const bf16_t* __restrict__ x, int S, int D, int ld, const int* __restrict__ row_off,
+                                                               const int* __restrict__ n_real, float* __restrict__ out) {
+  __shared__ float red[32][65];
+  const int b = blockIdx.x, c0 = blockIdx.y * 64;
+  const int piece = threadIdx.x & 7, phase = threadIdx.x >> 3;
+  long long r0 = (long long)b * S;
+  int rows = S, nr = S;
+  float wpad = 1.f;
+  if (row_off) {
+    r0 = row_off[b];
+    rows = row_off[b + 1] - row_off[b];
+    nr = n_real[b];
+    wpad = (float)(S - nr);
+  }
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int col = c0 + piece * 8;
+  if (col < D) {
+    for (int r = phase; r < rows; r += 32) {
+      const uint4 u = *reinterpret_cast<const uint4*>(x + (r0 + r) * ld + col);
       const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
+      const float w = r < nr ? 1.f : wpad;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        acc[2 * e] += __uint_as_float(w4[e] << 16);
-        acc[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u);
+        acc[2 * e] += w * __uint_as_float(w4[e] << 16);
+        acc[2 * e + 1] += w * __uint_as_float(w4[e] & 0xffff0000u);
       }
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) red[phase * D + piece * 8 + e] = acc[e];
   }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[phase][piece * 8 + e] = acc[e];
   __syncthreads();
-  const float inv = 1.0f / (float)S;
-  for (int d = threadIdx.x; d < D; d += 256)
-    atomicAdd(out + (long long)b * D + d, (red[d] + red[D + d] + red[2 * D + d] + red[3 * D + d]) * inv);
+  if (threadIdx.x < 64 && c0 + threadIdx.x < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int ph = 0; ph < 32; ++ph) t += red[ph][threadIdx.x];
+    out[(long long)b * D + c0 + threadIdx.x] = t * (1.0f / (float)S);
+  }
 }
 // dx[row, d] = bf16(dout[b, d] / S * f(aux[row, d])) with f = 1 (aux_mode 0), aux itself (1: a saved gelu') or gelu'(aux) (2)
 __global__ __launch_bounds__(256) void seq_mean_bwd_vec_kernel(const float* __restrict__ dout, int S, int D, int ld, const bf16_t* __restrict__ aux,
@@ -94,37 +113,6 @@ __global__ __launch_bounds__(256) void seq_mean_bwd_vec_kernel(const float* __re
   *reinterpret_cast<uint4*>(dx + row * ld + c8) = o;
 }
 
-// Packed token rows (see mmdti_seq_mean_packed_fwd): 32 rows per workgroup, the representative pad row weighted by the number of
-// padded positions it stands for.
-__global__ __launch_bounds__(256) void seq_mean_packed_fwd_kernel(const bf16_t* __restrict__ x, int S, int D, int ld, const int* __restrict__ row_off,
-                                                                  const int* __restrict__ n_real, float* __restrict__ out) {
-  extern __shared__ float red[];                // [4][D]
-  const int b = blockIdx.x, s0 = blockIdx.y * 32;
-  const int r0 = row_off[b], rows = row_off[b + 1] - r0, nr = n_real[b];
-  if (s0 >= rows) return;
-  const float wpad = (float)(S - nr);
-  const int cpr = D >> 3;
-  for (int c = threadIdx.x; c < cpr * 4; c += 256) {
-    const int piece = c % cpr, phase = c / cpr;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int r = phase; r < 32 && s0 + r < rows; r += 4) {
-      const uint4 u = *reinterpret_cast<const uint4*>(x + ((long long)r0 + s0 + r) * ld + piece * 8);
-      const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
-      const float w = (s0 + r < nr) ? 1.f : wpad;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc[2 * e] += w * __uint_as_float(w4[e] << 16);
-        acc[2 * e + 1] += w * __uint_as_float(w4[e] & 0xffff0000u);
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) red[phase * D + piece * 8 + e] = acc[e];
-  }
-  __syncthreads();
-  const float inv = 1.0f / (float)S;
-  for (int d = threadIdx.x; d < D; d += 256)
-    atomicAdd(out + (long long)b * D + d, (red[d] + red[D + d] + red[2 * D + d] + red[3 * D + d]) * inv);
-}
 __global__ __launch_bounds__(256) void seq_mean_packed_bwd_kernel(const float* __restrict__ dout, int S, int D, int ld, const int* __restrict__ row_off,
                                                                   const int* __restrict__ n_real, const int* __restrict__ row_seq,
                                                                   const bf16_t* __restrict__ aux, int ld_aux, int aux_mode, bf16_t* __restrict__ dx,
@@ -735,11 +723,8 @@ using namespace mmdti;
 extern "C" int mmdti_seq_mean_fwd(mmdti_stream_t stream, const void* x_bf16, int B, int S, int D, int ld, float* out) {
   MMDTI_REQUIRE(x_bf16 && out && B > 0 && S > 0 && D > 0 && ld >= D, "seq_mean_fwd: bad arguments");
   if (D % 8 == 0 && ld % 8 == 0 && D >= 64 && D <= 4096 && aligned16(x_bf16)) {
-    if (hipMemsetAsync(out, 0, (size_t)B * D * sizeof(float), (hipStream_t)stream) != hipSuccess) {
-      set_error("seq_mean_fwd: hipMemsetAsync failed");
-      return MMDTI_ERR_LAUNCH;
-    }
-    hipLaunchKernelGGL(seq_mean_fwd_vec_kernel, dim3(B, cdiv(S, 32)), dim3(256), 4 * (size_t)D * sizeof(float), (hipStream_t)stream, (const bf16_t*)x_bf16, S, D, ld, out);
+    hipLaunchKernelGGL(seq_mean_fwd_vec_kernel, dim3(B, cdiv(D, 64)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x_bf16, S, D, ld, (const int*)nullptr,
+                       (const int*)nullptr, out);
   } else {
     hipLaunchKernelGGL(seq_mean_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x_bf16, S, D, ld, out);
   }
@@ -765,13 +750,8 @@ extern "C" int mmdti_seq_mean_packed_fwd(mmdti_stream_t stream, const void* x_bf
                                          const int* n_real, float* out) {
   MMDTI_REQUIRE(x_bf16 && out && row_off && n_real && B > 0 && S > 0 && D > 0 && ld >= D, "seq_mean_packed_fwd: bad arguments");
   MMDTI_REQUIRE(D % 8 == 0 && ld % 8 == 0 && D <= 4096 && aligned16(x_bf16), "seq_mean_packed_fwd: D %% 8, ld %% 8, D <= 4096 and 16-byte alignment required");
-  if (hipMemsetAsync(out, 0, (size_t)B * D * sizeof(float), (hipStream_t)stream) != hipSuccess) {
-    set_error("seq_mean_packed_fwd: hipMemsetAsync failed");
-    return MMDTI_ERR_LAUNCH;
-  }
-  // (a sequence has at most S rows: S - 1 real tokens + the representative pad row, or S real tokens)
-  hipLaunchKernelGGL(seq_mean_packed_fwd_kernel, dim3(B, cdiv(S, 32)), dim3(256), 4 * (size_t)D * sizeof(float), (hipStream_t)stream,
-                     (const bf16_t*)x_bf16, S, D, ld, row_off, n_real, out);
+  // (a sequence has at most S rows: S - 1 real tokens + the representative pad row, or S real tokens; fixed summation order)
+  hipLaunchKernelGGL(seq_mean_fwd_vec_kernel, dim3(B, cdiv(D, 64)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x_bf16, S, D, ld, row_off, n_real, out);
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }

@@ -399,7 +399,9 @@ def _unimol_seq_workspace(st, mod):
     timing requested.  The workspace holds one layer's temporaries and is shared by all layers of this backward."""
     lay = mod.layers[0]
     D, F, M = st.D, lay.fc1.weight.shape[0], st.M
-    ok = (not ops.kernel_timer.names and ops.GROUPED_DW and D % 256 == 0 and F % 256 == 0 and M >= ops.GROUPED_DW_MIN_ROWS
+    L0 = st.layers[0]
+    ok = ((L0.h1.dtype != torch.float16 or L0.s.dtype == torch.float16)      # (fp16 operands: the sequencer covers the compact pair planes)
+          and not ops.kernel_timer.names and ops.GROUPED_DW and D % 256 == 0 and F % 256 == 0 and M >= ops.GROUPED_DW_MIN_ROWS
           and all(p.requires_grad for p in mod.parameters()))
     if not ok:
         return False, None

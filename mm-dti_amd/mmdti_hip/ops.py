@@ -507,6 +507,7 @@ def gbf_bias_bwd(g, dist, edge_type, mul, bias, means, stds, w1, w2, u, ld, dmul
 
 
 GBF_FULL_MAXE = 1536       # edge-type tables the complete backward kernel keeps in LDS (gbf.hip GBF_FULL_MAXE)
+GBF_SLABS = os.environ.get("MMDTI_GBF_SLABS", "1") != "0"
 
 
 def gbf_bias_bwd_full(g, dist, edge_type, mul, bias, means, stds, w1, b1, w2, ld, dw1, db1, dw2, db2, dmul, dbias, dmeans, dstds,
@@ -519,11 +520,14 @@ def gbf_bias_bwd_full(g, dist, edge_type, mul, bias, means, stds, w1, b1, w2, ld
     B, N, _ = dist.shape
     Hh, Fh = w2.shape
     P = B * N * N
+    # per-workgroup slabs of partial gradients, folded in a fixed order (reproducible bits; MMDTI_GBF_SLABS=0: fp32 atomics)
+    ws = torch.empty(lib()._dll.mmdti_gbf_bias_bwd_full_workspace(mul.numel()), device=dist.device, dtype=torch.uint8) if GBF_SLABS else None
     t0 = kernel_timer.begin("gbf_bias_bwd")
     lib().mmdti_gbf_bias_bwd_full(_stream(), g.data_ptr(), dist.data_ptr(), edge_type.data_ptr(), edge_type.element_size(), mul.data_ptr(),
                                   bias.data_ptr(), means.data_ptr(), stds.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), B, N, ld,
                                   w1.shape[1], Fh, Hh, mul.numel(), _pair_layout_g(g, "gbf_bias_bwd_full"), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(),
-                                  db2.data_ptr(), dmul.data_ptr(), dbias.data_ptr(), dmeans.data_ptr(), dstds.data_ptr(), _p(tile_prefix), _p(row_blocks))
+                                  db2.data_ptr(), dmul.data_ptr(), dbias.data_ptr(), dmeans.data_ptr(), dstds.data_ptr(), _p(tile_prefix), _p(row_blocks),
+                                  _p(ws), 0 if ws is None else ws.numel())
     # Work unit: MFMA flops (the kernel reads 268 B per atom pair and is nowhere near HBM): per pair the recomputed
     # pre-activation (2*F*K), dO.W2 (2*H*F), du.W1 (2*F*K) and the two weight-gradient products (2*F*K + 2*H*F)
     K = w1.shape[1]
@@ -660,8 +664,11 @@ def pair_attn_fwd(qkv, bias_in, key_pad, B, N, H, ld, scale, drop_p=0.0, seed=0,
     _chk16(qkv, "pair_attn.qkv")
     layout = _pair_layout_s(bias_in, "pair_attn.bias")
     tiled = pair_is_tiled(bias_in)
+    o_f16 = False
     if qkv.dtype == F16 and layout != 3:
-        qkv = to_bf16(qkv)         # (the fp16 q | k | v kernels exist for the compact tiled planes; other layouts take bf16)
+        # (the fp16 q | k | v kernels exist for the compact tiled planes -- the hot path; the fallback layouts take the bf16 rounding of
+        #  q | k | v and hand their output back in the forward operand type through two cast passes)
+        qkv, o_f16 = to_bf16(qkv), True
     rows = qkv.shape[0] if row_off is not None else B * N
     if row_off is not None:
         _chk(row_off, torch.int32, "pair_attn.row_off")
@@ -683,6 +690,8 @@ def pair_attn_fwd(qkv, bias_in, key_pad, B, N, H, ld, scale, drop_p=0.0, seed=0,
     # per (pair, head): read the bias / previous logits, write S (4 B each; compact 2 B); per (token, head): q|k|v in (48 B), o out (16 B)
     kept, es = _pair_kept if key_tiles is not None else 1.0, float(s_out.element_size())
     kernel_timer.end("pair_attn_fwd", t0, float(H) * (B * N * N * (es * kept + es * (1.0 if rag_store else kept)) + rows * 64.0))
+    if o_f16:
+        o = cast_act16(cast_f32(o)) if FWD_F16 else o
     return s_out, o
 
 

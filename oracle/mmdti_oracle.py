@@ -121,6 +121,30 @@ BF16_SITES = set(ALL_SITES)
 # storage type the sites round to: bfloat16 (the HIP path's contract) or float16 (what the reference's own AMP run uses,
 # tasks/trainer.py:181-182 -- scratch/rounding_sites_fp16.py measures what that would buy; values saturate at 65504)
 ROUND_DTYPE = torch.bfloat16
+# The HIP path's DEFAULT contract since round 4 (ops.FWD_F16): the operands of FORWARD GEMMs -- sites "w", "x" and tower 1's stored
+# q | k | v -- round to float16 (saturating), everything else ("qkv2", "p", "proj", the pair-bias block's own two Linears) stays
+# bfloat16; the BACKWARD keeps bf16 operands, so the gradient that flows back through an fp16 site is rounded to bf16, exactly as it
+# is through a bf16 site (the device converts a saved fp16 activation to bf16 inside the kernel that reads it; the 2^-9 that costs the
+# weight gradients is below what these emulations resolve).  set_forward_fp16(False): every site bf16, the round-1..3 contract.
+FWD_F16 = True
+F16_SITES = frozenset({"w", "x", "qkv"})
+
+
+def set_forward_fp16(on: bool):
+    global FWD_F16
+    FWD_F16 = bool(on)
+
+
+class _RoundF16FwdBf16Bwd(torch.autograd.Function):
+    """An fp16 forward-operand site: the value rounds to fp16 (saturating), its gradient to bf16."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return torch.clamp(x, min=-65504.0, max=65504.0).to(torch.float16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
 
 
 class _RoundF16(torch.autograd.Function):
@@ -137,19 +161,21 @@ class _RoundF16(torch.autograd.Function):
         return g
 
 
-def _r(x: Tensor, on: bool, site: str = "x") -> Tensor:
-    """bf16 round-trip used by the ``emulate_bf16`` contract."""
+def _r(x: Tensor, on: bool, site: str = "x", f16ok: bool = True) -> Tensor:
+    """16-bit round-trip used by the ``emulate_bf16`` contract (f16ok=False: a site that stays bf16 in every mode)."""
     if not (on and site in BF16_SITES):
         return x
     if ROUND_DTYPE is torch.float16:
         return torch.clamp(x, min=-65504.0, max=65504.0).to(torch.float16).to(torch.float32)
+    if FWD_F16 and f16ok and site in F16_SITES:
+        return _RoundF16FwdBf16Bwd.apply(x)
     return x.to(ROUND_DTYPE).to(torch.float32)
 
 
-def linear(x: Tensor, w: Tensor, b: Optional[Tensor], bf16: bool = False) -> Tensor:
-    """nn.Linear.  Under the bf16 contract both operands are rounded, the
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor], bf16: bool = False, f16ok: bool = True) -> Tensor:
+    """nn.Linear.  Under the 16-bit contract both operands are rounded, the
     accumulation and bias add stay fp32."""
-    return F.linear(_r(x, bf16, "x"), _r(w, bf16, "w"), b)
+    return F.linear(_r(x, bf16, "x", f16ok), _r(w, bf16, "w", f16ok), b)
 
 
 def gelu(x: Tensor) -> Tensor:
@@ -247,8 +273,9 @@ def pair_bias(dist: Tensor, edge_type: Tensor, P: Params, bf16: bool = False) ->
     """mm_model.py:553-556: gbf -> gbf_proj (Linear-gelu-Linear) -> permute to
     [B*H, N, N]."""
     g = gaussian_layer(dist, edge_type, P)
-    h = gelu(linear(g, P["gbf_proj.linear1.weight"], P["gbf_proj.linear1.bias"], bf16))
-    o = linear(h, P["gbf_proj.linear2.weight"], P["gbf_proj.linear2.bias"], bf16)
+    # (the pair-bias block keeps bf16 operands in every mode: its fused kernels build basis and hidden in registers)
+    h = gelu(linear(g, P["gbf_proj.linear1.weight"], P["gbf_proj.linear1.bias"], bf16, f16ok=False))
+    o = linear(h, P["gbf_proj.linear2.weight"], P["gbf_proj.linear2.bias"], bf16, f16ok=False)
     o = o.permute(0, 3, 1, 2).contiguous()
     return o.view(-1, o.size(-2), o.size(-1))
 
@@ -266,7 +293,7 @@ def unimol_layer(x: Tensor, bias: Tensor, P: Params, pre: str, cfg: UniMolCfg,
     r = x
     h = layer_norm(x, P[pre + "self_attn_layer_norm.weight"], P[pre + "self_attn_layer_norm.bias"], cfg.ln_eps)
     qkv = linear(h, P[pre + "self_attn.in_proj.weight"], P[pre + "self_attn.in_proj.bias"], bf16)
-    qkv = _r(qkv, bf16, "qkv")                # HIP path stores q,k,v as bf16
+    qkv = _r(qkv, bf16, "qkv")                # HIP path stores q,k,v as 16-bit values (fp16 by default, bf16 in the bf16 mode)
     q, k, v = qkv.chunk(3, dim=-1)
     scaling = hd ** -0.5
 

@@ -43,18 +43,15 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     names = [n for n in gd if float(gd[n].abs().max()) > 0 and not any(z in n for z in ("pooler", "key.bias", "gbf_proj.linear2.bias"))]
     worst = max(((n, rel_l2(gr[n], gd[n])) for n in names), key=lambda t: t[1])
     noise = max(((n, rel_l2(gd2[n], gd[n])) for n in names), key=lambda t: t[1])
-    # gbf_proj.linear1.bias / gbf.stds are sums that cancel almost completely (exactly, if gelu' were constant: the rows of G sum
-    # to zero), so a different GROUPING of the fp32 partial sums shows up at 1e-2 relative there; everything else must agree tightly
-    tight = [n for n in names if not n.startswith("gbf")]
-    worst_t = max(((n, rel_l2(gr[n], gd[n])) for n in tight), key=lambda t: t[1])
-    noise_t = max(((n, rel_l2(gd2[n], gd[n])) for n in tight), key=lambda t: t[1])
-    # Two runs of the SAME dense step are not bit-identical either (loss kernels and split-K / table gradients use fp32 atomics:
-    # the loss moves by an ulp, bottom-of-the-network gradients by up to 2e-3 after the bf16 casts of the backward chain amplify
-    # it): the ragged step has to sit inside that band, not at zero.
-    # (the gbf tables' gradients are ill-conditioned enough that two runs of the SAME dense step differ by up to 2e-1 there -- trial 61
-    #  of seed 11: dense vs dense 2.1e-1, ragged vs dense 1.2e-1 --, so their bound follows the dense step's own noise on that parameter)
-    ok = (abs(float(ld) - float(lr)) <= 3e-7 * abs(float(ld)) and worst_t[1] <= max(3 * noise_t[1], 5e-3)
-          and worst[1] < max(0.1, 3 * rel_l2(gd2[worst[0]], gd[worst[0]]))
+    # Round 4: the step is reproducible -- the forward and every activation gradient bit for bit (the pooled InfoNCE embedding used to
+    # be summed with fp32 atomics: losses.hip seq_mean), parameter gradients up to the order of the remaining fp32 atomics (LayerNorm
+    # gamma / beta, embedding rows, split-K dW: ~1e-6).  So the ragged step is held to the dense step tightly, on EVERY parameter,
+    # the pair-bias tables included (round 3 had to bound those by the dense step's own 2e-1 run-to-run noise).
+    tight = names
+    worst_t, noise_t = worst, noise
+    # (the loss VALUE may still move by an ulp: the per-row loss terms of InfoNCE / SupCon meet in one fp32 atomic -- a reported number,
+    #  not an input of the backward)
+    ok = (abs(float(ld) - float(lr)) <= 3e-7 * abs(float(ld)) and abs(float(ld) - float(ld2)) <= 3e-7 * abs(float(ld)) and noise[1] <= 2e-5 and worst[1] <= 5e-5
           and bool(torch.isfinite(lr)) and all(bool(torch.isfinite(v).all()) for v in gr.values()))
     if not torch.equal(ld, ld2): print("   !! dense forward not repeatable:", float(ld), float(ld2))
     if not torch.equal(ld, lr): print("   !! ragged forward differs:", float(ld), float(lr), float(ld - lr))

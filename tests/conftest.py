@@ -28,3 +28,14 @@ def golden():
         return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
 
     return load
+
+
+@pytest.fixture(autouse=True)
+def _oracle_follows_device_precision_mode():
+    """The oracle's 16-bit emulation (oracle.mmdti_oracle with bf16=True) rounds at the sites and to the types of the device's
+    precision mode: fp16 forward operands (the default) or bf16 everywhere (MMDTI_FWD_FP16=0 / ops.set_forward_fp16(False))."""
+    from oracle import mmdti_oracle as O
+    from mmdti_hip import ops
+    O.set_forward_fp16(ops.FWD_F16)
+    yield
+    O.set_forward_fp16(ops.FWD_F16)

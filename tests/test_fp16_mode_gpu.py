@@ -22,9 +22,9 @@ from test_kernels_gpu import ops, dev, bf, rt, close, G, _pair_ref          # no
 @pytest.fixture
 def fp16_mode(ops):
     was = ops.FWD_F16
-    ops.set_forward_fp16(True)
+    ops.set_forward_fp16(True); O.set_forward_fp16(True)
     yield
-    ops.set_forward_fp16(was)
+    ops.set_forward_fp16(was); O.set_forward_fp16(was)
 
 
 def h16(t):

@@ -251,6 +251,9 @@ def test_unimol_tower_hot_path_layout_vs_oracle(M, compact, monkeypatch):
     monkeypatch.setattr(ops, "PAIR_G_BF16", compact == "g16")      # (opt-in: gradient chain as bf16)
     if not compact:
         monkeypatch.setattr(O, "BF16_SITES", set(O.ALL_SITES) - {"s16"})       # fp32 pair planes: the contract without the fp16 logits site
+        # (off the hot path the pair-attention kernels read bf16 q | k | v -- fp16 q | k | v exist for the compact planes only, other
+        #  layouts go through casts: ops.pair_attn_fwd --, so this layout is pinned in the bf16 operand mode)
+        monkeypatch.setattr(ops, "FWD_F16", False); monkeypatch.setattr(O, "FWD_F16", False)
     B, N, D, H, K, V = 2, 21, 512, 64, 128, 31
     ucfg = O.UniMolCfg(layers=2, dim=D, ffn=128, heads=H, K=K, vocab=V)
     cfg = O.ModelCfg(unimol=ucfg, roberta=O.RobertaCfg(layers=1, dim=64, heads=4, ffn=128, vocab=40, max_pos=40), cross=O.CrossCfg(dim=64, heads=4, ffn=128))

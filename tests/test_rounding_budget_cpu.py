@@ -21,8 +21,9 @@ def test_rounding_budget_at_reference_depth():
     cfg = refarch_cfg("classification", 600)
     P = O.init_params(cfg, seed=92, std=0.02)
     batch, label = O.synth_batch(4, 20, 24, cfg, seed=1, ragged=True)
-    saved = set(O.BF16_SITES)
+    saved, was16 = set(O.BF16_SITES), O.FWD_F16
     try:
+        O.set_forward_fp16(False)             # the attribution of the bf16 contract (every site bf16: MMDTI_FWD_FP16=0)
         with torch.no_grad():
             ref = O.mm_forward(batch, P, cfg, net_target=label, bf16=False)
             err = {}
@@ -31,9 +32,16 @@ def test_rounding_budget_at_reference_depth():
                 O.BF16_SITES = set(sites)
                 o = O.mm_forward(batch, P, cfg, net_target=label, bf16=True)
                 err[name] = (_rel(o["enc"], ref["enc"]), _rel(o["bert"], ref["bert"]))
+            # the default contract since round 4: "w", "x", "qkv" round to fp16 instead (ops.FWD_F16) -- the same walk, all sites on
+            O.BF16_SITES = set(O.ALL_SITES)
+            O.set_forward_fp16(True)
+            o16 = O.mm_forward(batch, P, cfg, net_target=label, bf16=True)
+            err16 = (_rel(o16["enc"], ref["enc"]), _rel(o16["bert"], ref["bert"]))
     finally:
         O.BF16_SITES = saved
+        O.set_forward_fp16(was16)
     enc = {k: v[0] for k, v in err.items()}
+    assert err16[0] < 1e-3 and err16[1] < 1e-3, err16            # fp16 forward operands: inside the north star's 1e-3 on both towers
     assert 2e-3 < enc["all"] < 6e-3, enc                       # the bf16 contract itself sits 4x above 1e-3 ...
     assert enc["w"] > 1.5e-3 and enc["x"] > 1.5e-3, enc         # ... because of operand rounding on both sides of the GEMMs
     assert enc["qkv"] < 0.5 * enc["all"] and enc["rest"] < 1e-4, enc
