@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- molecules/s of the MM-DTI dual-encoder contrastive fine-tune step on MI355X.
 
-Workload (BASELINE.json north_star / configs[1]): BBBP-like classification + SupCon (CT_Single) + InfoNCE, bf16 MFMA
-compute, 256 molecules per GPU, every molecule at the worst case 128 atoms (N = 130 with BOS/EOS) and 256 SMILES
+Workload (BASELINE.json north_star / configs[1]): BBBP-like classification + SupCon (CT_Single) + InfoNCE, 16-bit MFMA compute
+(fp16 forward operands -- the mode whose embeddings are within the north star's 1e-3 of the fp32 reference --, bf16 backward
+operands, fp32 accumulation; MMDTI_FWD_FP16=0: bf16 everywhere), 256 molecules per GPU, every molecule at the worst case 128 atoms (N = 130 with BOS/EOS) and 256 SMILES
 tokens, synthetic data, random-init weights of the reference architecture (Uni-Mol 15L/512/64 heads; ChemBERTa ASSUMED
 6L/512/8 heads/FFN 2048/vocab 600 -- SURVEY.md 8d; cross-modal 1L x2/16 heads; InfoNCE 512-512-50; head 512-512-2).
 One step = zero-grad + forward + backward (+ gradient all-reduce over RCCL when N > 1) + clip + Adam, dropout ON at
 the reference's probabilities.  Weak scaling: 256 molecules per rank; InfoNCE negatives are global.
 
   python bench.py --gpus 1 --steps 10 --warmup 3
+  python bench.py --gpus N ...        (no WORLD_SIZE in the environment: starts the N ranks itself, before touching the GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task statement):
@@ -159,6 +161,161 @@ def family_rooflines(summary, steps):
     return rows
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run (this process has not
+    touched the GPU -- nothing before this point initialises HIP -- and never does), relay rank 0's JSON line, exit with the
+    child's code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f"bench.py: the {n}-rank run failed (exit code {proc.returncode}, JSON line {'missing' if line is None else 'present'})", file=sys.stderr)
+        sys.exit(proc.returncode or 1)
+    print(line)
+    sys.exit(0)
+
+
+def parity_record():
+    """the newest committed parity measurement of the default precision mode against the reference's own fp32 run (written by
+    tests/test_g9_gpu.py on the GPU box, copied to profiles/): embeddings, logits, losses"""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_parity_default_mode.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            d["source"] = os.path.basename(path)
+            return d
+        except (OSError, ValueError):
+            continue
+    return None
+
+
+def pmc_step_bytes():
+    """HBM bytes of ONE headline step from the newest committed PMC summary: sum over its kernels of launches x bytes per launch,
+    divided by the steps of that trace (header comment `steps_in_trace=`; 2 = the warm-up + the step of the PMC command)."""
+    import csv
+    import re
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_hbm_traffic.csv")), reverse=True):
+        try:
+            txt = open(path).read()
+            m = re.search(r"steps_in_trace=(\d+)", txt)
+            steps = int(m.group(1)) if m else 2
+            tot = gem = 0.0
+            for row in csv.DictReader(line for line in txt.splitlines() if not line.startswith("#")):
+                b = float(row["launches"]) * float(row["hbm_bytes_per_launch"])
+                tot += b
+                if row["kernel"].replace("mmdti::", "").startswith(("gemm_", "grouped_reduce", "splitk_reduce")):
+                    gem += b
+            return tot / steps, gem / steps, os.path.basename(path)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None, None
+
+
+def pipeline_workload(tuner, model, args, dev, world, rank, barrier):
+    """SURVEY 8d / VERDICT r03: the step fed a FRESH mixed-length batch every iteration, as the reference's loop is
+    (tasks/trainer.py:177-283 with num_workers = 0 loaders, :551-555): per-molecule samples -> right-padded host batch (collate.py) ->
+    device_payload (int16 edge types, packing facts) -> pinned staging + H2D on the copy stream (DevicePrefetcher) -> step.  8 distinct
+    batches cycled; the host-side PackedRows build, tile prefixes and their uploads happen INSIDE the timed region every step (the
+    resident-batch workloads reuse them from a cache)."""
+    import numpy as np
+    from mmdti_hip.synth import molecule
+    from mmdti_hip.collate import right_pad
+    from mmdti_hip.data import DevicePrefetcher
+    B, nb = min(args.batch, 256), 8
+    rng = np.random.default_rng(777 + rank)
+    vocab, elem_p = 31, np.zeros(31)
+    elem_p[8], elem_p[4], elem_p[5], elem_p[6] = 0.5, 0.3, 0.075, 0.075
+    rest = [i for i in range(4, 30) if i not in (4, 5, 6, 8)]
+    elem_p[rest] = 0.05 / len(rest)
+    samples = []
+    for _ in range(nb):
+        mols = []
+        for _ in range(B):
+            na = int(np.clip(round(rng.normal(0.375 * args.atoms, 0.16 * args.atoms)), max(2, args.atoms // 16), args.atoms))
+            nt = int(np.clip(round(0.8 * na), 8, args.tokens))
+            t, d, e = molecule(rng, na, vocab, elem_p)
+            ids = np.concatenate([[0], rng.integers(4, 600, size=nt - 2), [2]]).astype(np.int64)
+            mols.append((torch.from_numpy(t), torch.from_numpy(d), torch.from_numpy(e), torch.from_numpy(ids)))
+        samples.append((mols, torch.from_numpy((rng.random((B, 1)) < 0.2).astype(np.int64))))
+    t_collate = []
+
+    def collated(n_steps):
+        for i in range(n_steps):
+            mols, y = samples[i % nb]
+            t0 = time.perf_counter()
+            ids = right_pad([m[3] for m in mols], 1)
+            batch = {"src_tokens": right_pad([m[0] for m in mols], 0), "src_distance": right_pad([m[1] for m in mols], 0.0, square=True),
+                     "src_edge_type": right_pad([m[2] for m in mols], 0, square=True), "input_ids": ids, "attention_mask": ids.ne(1).long()}
+            t_collate.append(time.perf_counter() - t0)          # (device_payload -- narrowing + packing facts -- is timed inside the prefetcher's launch)
+            yield batch, y
+
+    def run(n_steps, timed):
+        h2d, opt = [], []
+        pf = DevicePrefetcher(collated(n_steps), dev, narrow=True, n_edge_types=961, pad_idx=0)
+        real_launch, real_opt = pf._launch, tuner.optimizer_step
+
+        def launch(item):
+            if not timed:
+                return real_launch(item)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(pf.stream)
+            out = real_launch(item)
+            e1.record(pf.stream)
+            h2d.append((e0, e1))
+            return out
+
+        def opt_step():
+            if not timed:
+                return real_opt()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            real_opt()
+            e1.record()
+            opt.append((e0, e1))
+
+        pf._launch, tuner.optimizer_step = launch, opt_step
+        try:
+            for net_input, y in pf:
+                tuner.step(net_input, y, epoch=0)
+        finally:
+            tuner.optimizer_step = real_opt
+        return h2d, opt
+
+    run(nb, False)                       # warm-up: every batch once (allocator, pinned buffers)
+    barrier()
+    t_collate.clear()
+    n_steps = max(2 * nb, args.steps)
+    t0 = time.perf_counter()
+    h2d, opt = run(n_steps, True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    ms = lambda evs: round(sum(a.elapsed_time(b) for a, b in evs) / max(1, len(evs)), 3)
+    return {"workload": f"same step fed a fresh batch every iteration: {nb} distinct mixed-length batches of {B} molecules/GPU cycled through per-molecule samples -> "
+                        "right-padded host batch -> device_payload (int16 edge types, packing facts) -> pinned staging + H2D on the copy stream -> step; "
+                        "host-side packing / tile-prefix arithmetic and their uploads inside the timed region",
+            "unit": "molecules/s", "steps": n_steps, "value": round(B * world * n_steps / dt, 2), "ms_per_step": round(dt / n_steps * 1e3, 3),
+            "collate_ms": round(sum(t_collate) / max(1, len(t_collate)) * 1e3, 3), "h2d_ms": ms(h2d), "optimizer_ms": ms(opt),
+            "note": "collate_ms: host time to right-pad one batch (main process, as num_workers = 0); h2d_ms: device_payload + staging + copies of one batch, "
+                    "event-timed on the copy stream (overlaps the previous step); optimizer_ms: grad-norm + clip + Adam + both weight shadows, event-timed",
+            "layout": model.last_layout}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,7 +330,10 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step from one captured HIP graph (FineTuner.graphed_step; single GPU)")
     ap.add_argument("--ragged", action="store_true", help="molecules of mixed length padded to the batch maximum (not the headline workload)")
     ap.add_argument("--no-ragged-workload", action="store_true", help="skip the second (mixed-length) workload record of the default run")
+    ap.add_argument("--no-pipeline-workload", action="store_true", help="skip the fresh-batch-every-step workload record")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)
 
     from mmdti_hip import parallel, ops
     from mmdti_hip.trainer import FineTuner
@@ -233,13 +393,16 @@ def main():
     headline_layout = model.last_layout
 
     # Second workload, timed in the same process (not the headline): SURVEY 8d's C-main length distribution -- atoms ~ N(48, 20^2)
-    # clamped to [8, 128], SMILES 0.8 x atoms, padded to the batch maximum as the reference collates.  Timed on the packed token
-    # rows (the default for a ragged batch) and, for the A/B, on the reference's padded rows (strict_reference).
+    # clamped to [8, 128], SMILES 0.8 x atoms, padded to the batch maximum as the reference collates.  Timed on the layout the DEFAULT
+    # picks for a training step with dropout on -- the reference's padded rows (all-padding key tiles skipped: exact), because a padded
+    # row of the reference draws its own dropout mask -- and on the packed token rows (strict_reference=False: opt-in for training, the
+    # default wherever no dropout is live).
     workloads = {}
+    sr_default = model.strict_reference
     if not args.ragged and not args.no_ragged_workload:
         rb, rl = resident(4321 + rank, True)
         rec = {}
-        for tag, strict in (("packed", False), ("padded", True)):
+        for tag, strict in (("default", sr_default), ("packed", False)):
             model.strict_reference = strict
             for _ in range(max(2, args.warmup)):
                 tuner.step(rb, rl, epoch=0)
@@ -255,19 +418,21 @@ def main():
                 d1 = float(t)
             rec[tag] = {"ms_per_step": round(d1 / args.steps * 1e3, 3), "value": round(args.batch * world * args.steps / d1, 2), "layout_ran": model.last_layout,
                         "loss_last_step": float(ro.loss)}
-        model.strict_reference = False
         pk = model._pack_cache[3] if model._pack_cache is not None else None
         Nr, Lr = int(rb["src_tokens"].shape[1]), int(rb["input_ids"].shape[1])
         workloads["ragged"] = {
             "workload": f"same step, {args.batch} molecules/GPU of mixed length (atoms ~ N(48, 20^2) clamped to [8, {args.atoms}], SMILES 0.8 x atoms) "
                         f"right-padded to the batch maximum N = {Nr}, L = {Lr}",
-            "unit": "molecules/s", "steps": args.steps, "value": rec["packed"]["value"], "ms_per_step": rec["packed"]["ms_per_step"],
-            "layout": rec["packed"]["layout_ran"], "strict_reference": False,
+            "unit": "molecules/s", "steps": args.steps, "value": rec["default"]["value"], "ms_per_step": rec["default"]["ms_per_step"],
+            "layout": rec["default"]["layout_ran"], "strict_reference": sr_default,
             "token_rows": None if pk is None else {"tower1_packed": pk[0].M, "tower1_padded": args.batch * Nr, "tower2_packed": pk[1].M, "tower2_padded": args.batch * Lr},
-            "padded_rows_for_comparison": {"ms_per_step": rec["padded"]["ms_per_step"], "value": rec["padded"]["value"], "layout": rec["padded"]["layout_ran"],
-                                           "strict_reference": True},
-            "note": "packed token rows: every sequence's real tokens + ONE representative pad row weighted by the padded positions it stands for in the "
-                    "unmasked InfoNCE mean (identical to the padded computation at dropout 0, equal in expectation under dropout; DESIGN.md section 3)"}
+            "packed_rows_opt_in": {"ms_per_step": rec["packed"]["ms_per_step"], "value": rec["packed"]["value"], "layout": rec["packed"]["layout_ran"],
+                                   "strict_reference": False},
+            "note": "default (strict_reference=None): a training step with dropout on computes the reference's padded rows (each draws its own dropout mask; only the "
+                    "all-padding key tiles are skipped, which is exact); packed token rows -- every sequence's real tokens + ONE representative pad row weighted "
+                    "by the padded positions it stands for in the unmasked InfoNCE mean -- are the reference's computation at dropout 0 (the default for eval / "
+                    "predict) and an opt-in for training (equal in expectation only; DESIGN.md section 3)"}
+        model.strict_reference = sr_default
         # Third workload: the reference's REAL batch size (finetune.py:14 batch_size=32, config/default.yaml:18 16) on the same length
         # distribution -- a chain of ~480 small kernels per step, where launch structure, not arithmetic, sets the time
         if args.batch > 32:
@@ -276,29 +441,35 @@ def main():
             shost = dict(packing_fields(sb), atom_counts=atom_counts(sb["src_tokens"], 0))
             sb = dict({k: v.to(dev) for k, v in sb.items()}, **shost)
             sy = sy.to(dev)
-            for _ in range(max(10, args.warmup)):
-                tuner.step(sb, sy, epoch=0)
-            barrier()
-            t1 = time.perf_counter()
-            n_small = max(args.steps, 50)        # (8 ms steps paced by launch issue: short runs scatter by a millisecond)
-            for _ in range(n_small):
-                tuner.step(sb, sy, epoch=0)
-            barrier()
-            d1 = time.perf_counter() - t1
-            if world > 1:
-                t = torch.tensor([d1], device=dev, dtype=torch.float64)
-                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-                d1 = float(t)
-            workloads["small_batch"] = {
-                "workload": f"same step, {small} molecules/GPU (the reference's default batch size), mixed lengths, packed token rows",
-                "unit": "molecules/s", "steps": n_small, "value": round(small * world * n_small / d1, 2), "ms_per_step": round(d1 / n_small * 1e3, 3),
-                "layout": model.last_layout, "padded_N": int(sb["src_tokens"].shape[1])}
+            for first_small, strict in ((True, sr_default), (False, False)):
+                model.strict_reference = strict
+                for _ in range(max(10, args.warmup)):
+                    tuner.step(sb, sy, epoch=0)
+                barrier()
+                t1 = time.perf_counter()
+                n_small = max(args.steps, 50)        # (8 ms steps paced by launch issue: short runs scatter by a millisecond)
+                for _ in range(n_small):
+                    tuner.step(sb, sy, epoch=0)
+                barrier()
+                d1 = time.perf_counter() - t1
+                if world > 1:
+                    t = torch.tensor([d1], device=dev, dtype=torch.float64)
+                    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                    d1 = float(t)
+                sm = {"unit": "molecules/s", "steps": n_small, "value": round(small * world * n_small / d1, 2), "ms_per_step": round(d1 / n_small * 1e3, 3),
+                      "layout": model.last_layout}
+                if first_small:
+                    workloads["small_batch"] = dict(sm, workload=f"same step, {small} molecules/GPU (the reference's default batch size), mixed lengths, default layout "
+                                                                  "(padded rows under dropout)", padded_N=int(sb["src_tokens"].shape[1]), strict_reference=sr_default)
+                else:
+                    workloads["small_batch"]["packed_rows_opt_in"] = sm
+            model.strict_reference = sr_default
 
-    # Fourth record: the headline batch in the fp16 FORWARD-OPERAND mode (MMDTI_FWD_FP16=1 / ops.set_forward_fp16) -- the mode in which
-    # embeddings are within the north star's 1e-3 of the fp32 reference (6e-4; bf16 operands: 4.6e-3), at its own step time
+    # Fourth record: the headline batch with bf16 operands everywhere (MMDTI_FWD_FP16=0, the round-1..3 default) -- faster by the
+    # in-kernel conversions of the fp16 mode, and outside the north star's 1e-3 on embeddings (4.6e-3): the A/B of the precision choice
     if not args.ragged and not args.no_ragged_workload:
         was16 = ops.FWD_F16
-        ops.set_forward_fp16(True)
+        ops.set_forward_fp16(not was16)
         try:
             for _ in range(max(2, args.warmup)):
                 tuner.step(batch, label, epoch=0)
@@ -314,14 +485,18 @@ def main():
             t = torch.tensor([d1], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             d1 = float(t)
-        workloads["fp16_forward_operands"] = {
-            "workload": "the headline batch with every forward GEMM operand (weights, activations, tower 1's q | k | v) as fp16 instead of bf16; backward unchanged",
+        other = "bf16_operands" if was16 else "fp16_forward_operands"
+        workloads[other] = {
+            "workload": ("the headline batch with bf16 operands in every GEMM, forward and backward (MMDTI_FWD_FP16=0)" if was16 else
+                         "the headline batch with fp16 forward operands (the default mode; this run was started with MMDTI_FWD_FP16=0)"),
             "unit": "molecules/s", "steps": args.steps, "value": round(args.batch * world * args.steps / d1, 2), "ms_per_step": round(d1 / args.steps * 1e3, 3),
-            "loss_last_step": float(fo.loss), "dtype": "fp16 forward operands, bf16 backward operands, fp32 accumulation",
-            "parity": "vs the reference's own fp32 run (tests/test_fp16_mode_gpu.py, profiles/r03_parity_fp16_forward_operands.json): encoder_rep 6.0e-4, "
-                      "out_bert 4.8e-4, logits 6.4-7.7e-4, InfoNCE 3e-5 relative (bf16 operands, the headline: 4.6e-3 / 2.1e-3 / 2-3e-3 / 1.3e-4)"}
-        for _ in range(2):      # back in the headline mode before the per-family steps (the bf16 shadow is refreshed by the first of them)
+            "loss_last_step": float(fo.loss),
+            "parity": "bf16 operands vs the reference's own fp32 run (B = 32 fixture): encoder_rep 4.6e-3, out_bert 2.1e-3, logits 2.4-2.8e-3, InfoNCE 1.3e-4 relative "
+                      "-- embeddings outside the north star's 1e-3; fp16 forward operands (the headline): config.parity"}
+        for _ in range(2):      # back in the headline mode before the per-family steps
             tuner.step(batch, label, epoch=0)
+    if not args.ragged and not args.no_ragged_workload and not args.no_pipeline_workload and not args.graph:
+        workloads["pipeline"] = pipeline_workload(tuner, model, args, dev, world, rank, barrier)
 
     # every kernel family in two extra modes (every rank runs them: the step holds collectives):
     #   "overlapped": streams as in the timed region (a launch's event time includes sharing the chip with the other tower);
@@ -364,6 +539,18 @@ def main():
                 roofline["kernel"], roofline["kernel"])
             roofline["note"] = ("dominant kernel family by GPU time; HIP events on the launch stream around every launch of 2 extra steps after the timed "
                                 "region with every stream-level overlap off (each launch alone on the chip); achieved = algorithmic work / summed launch time")
+            # both fractions of the family: of the MFMA peak (flops) and of the HBM peak (PMC bytes of the family per step / its time)
+            step_bytes, gemm_bytes, src = pmc_step_bytes()
+            for r in rooflines + [roofline]:
+                if r["bound"] == "mfma" and str(r["kernel"]).startswith("gemm"):
+                    r["frac_mfma"] = r["frac"]
+                    if gemm_bytes:
+                        r["hbm_bytes_per_step"] = int(gemm_bytes)
+                        r["frac_hbm"] = round(gemm_bytes / (r["ms_per_step"] * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)
+            if step_bytes:
+                roofline["step_hbm_bytes"] = int(step_bytes)
+                roofline["step_hbm_frac_of_peak"] = round(step_bytes / (dt / args.steps) / (HBM_PEAK_GBS * 1e9), 4)
+                roofline["step_hbm_source"] = src
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # (rank 0 at N = 1 only: the other ranks of a multi-GPU run would sit in a collective for a minute)
             cpu = cpu_baseline(args.atoms, args.tokens, args.cpu_sample)
@@ -372,12 +559,15 @@ def main():
         line = {
             "metric": "molecules/sec fwd+bwd (InfoNCE fine-tune)", "value": round(mols / dt, 2), "unit": "molecules/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp16 forward / bf16 backward GEMM operands, fp32 accumulation" if ops.FWD_F16 else "bf16 GEMM operands, fp32 accumulation", "data": "synthetic",
             "config": {"workload": f"BBBP-like classification + SupCon + InfoNCE fine-tune step, {args.batch} molecules/GPU x {args.atoms} atoms x "
                                    f"{args.tokens} SMILES tokens ({shape}), fwd+bwd+allreduce+clip+Adam, dropout on",
                        "global_batch": args.batch * world, "atoms": args.atoms, "tokens": args.tokens, "padded_N": N, "parallelism": f"dp{world}",
                        "launch": "one HIP graph per step" if (args.graph and world == 1) else "eager (one launch per kernel)",
-                       "token_layout": headline_layout, "strict_reference": bool(model.strict_reference), "unimol": "15L/512/64h", "chemberta_assumed": "6L/512/8h/ffn2048/vocab600", "infonce_negatives": "global",
+                       "precision_mode": "fp16 forward operands (default)" if ops.FWD_F16 else "bf16 operands (MMDTI_FWD_FP16=0)",
+                       "parity": parity_record() if ops.FWD_F16 else None,
+                       "token_layout": headline_layout, "strict_reference": sr_default, "unimol": "15L/512/64h", "chemberta_assumed": "6L/512/8h/ffn2048/vocab600", "infonce_negatives": "global",
                        "grad_buckets_reduced_during_backward": None if tuner.reducer is None or not tuner.reducer.active
                        else f"{tuner.reducer.overlapped}/{len(tuner.reducer.buckets)}"},
             "losses_last_step": losses, "roofline": roofline, "rooflines": rooflines, "cpu_baseline": cpu, "workloads": workloads,

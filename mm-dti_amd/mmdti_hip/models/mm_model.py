@@ -265,11 +265,18 @@ class MM_Model(nn.Module):
                            sigma=self.fds_cfg.sigma, momentum=self.fds_cfg.momentum)
         self.overlap_towers = bool(params.get('overlap_towers', True))
         self.infonce_on_side_stream = bool(params.get('infonce_on_side_stream', os.environ.get("MMDTI_INFONCE_SIDE", "1") != "0"))
-        # strict_reference=True: every padded row is computed, as the reference does (with dropout ON its padded rows draw
-        # independent masks).  False (default): ragged batches run on PACKED token rows -- real tokens plus one representative pad
-        # row per sequence, weighted by the padded positions it stands for in the unmasked InfoNCE mean (packing.py): identical
-        # results at dropout 0, equal in expectation under dropout.
-        self.strict_reference = bool(params.get('strict_reference', os.environ.get("MMDTI_STRICT_REFERENCE", "0") == "1"))
+        # Ragged batches can run on PACKED token rows -- real tokens plus ONE representative pad row per sequence, weighted by the padded
+        # positions it stands for in the unmasked InfoNCE mean (packing.py).  That is the reference's computation exactly when the
+        # padded rows of a sequence ARE one row, i.e. when no dropout is live; with dropout ON the reference draws an independent mask
+        # per padded row, and one weighted row has n_pad times the variance in the pooled embedding (and, through F.normalize, not even
+        # the same expectation) -- ADVICE r03.  strict_reference:
+        #   None (default)  packed rows iff no dropout is live for this forward (eval / predict, or every p = 0), else the padded rows;
+        #   True            always the padded rows (MMDTI_STRICT_REFERENCE=1);
+        #   False           always packed rows when the batch allows (MMDTI_STRICT_REFERENCE=0): an opt-in trade of the padded rows'
+        #                   dropout statistics for ~1.7 x on drug-like length distributions.
+        env = os.environ.get("MMDTI_STRICT_REFERENCE")
+        sr = params.get('strict_reference', None if env is None else env == "1")
+        self.strict_reference = None if sr is None else bool(sr)
         self.last_layout = "padded"          # what the last forward ran on ("padded" | "packed"): read by bench.py / tests
         self._side = None
         self._pack_cache = None
@@ -295,6 +302,16 @@ class MM_Model(nn.Module):
             raise RuntimeError(f"Uni-Mol checkpoint {path} lacks {len(missing)} tower-1 parameters, e.g. {missing[:5]}")
         self.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
 
+    def pad_row_dropout_live(self):
+        """True iff a padded row meets a live dropout site on its way to the only thing that reads it, the unmasked InfoNCE mean
+        (infonce.py:32-33): tower 1 (embedding / residual / attention dropout), tower 2 (hidden / attention dropout), the InfoNCE
+        head's query dropout.  (The fusion block and the pool never read padded rows.)"""
+        if not self.training:
+            return False
+        ps = [self.encoder.emb_dropout, self.encoder.dropout, self.encoder.attention_dropout, self.bert.cfg.hidden_dropout, self.bert.cfg.attn_dropout,
+              getattr(self.infonce, "embed_dropout", 0.0)]
+        return max(float(p) for p in ps) > 0.0
+
     def _side_stream(self):
         if self._side is None:
             self._side = torch.cuda.Stream()
@@ -313,6 +330,8 @@ class MM_Model(nn.Module):
         Decided on the HOST (the counts come from collate.device_payload): no device sync."""
         if self.strict_reference or not packable or atom_counts is None or token_counts is None or not src_tokens.is_cuda or not PAIR_RAGGED:
             return None
+        if self.strict_reference is None and self.pad_row_dropout_live():
+            return None                                   # (auto: the padded rows keep the reference's per-row dropout masks)
         if token_pad_id is not None and int(token_pad_id) not in (-1, int(self.bert.cfg.pad_idx)):
             return None                                   # masked SMILES slots do not hold the pad id: their rows are not one row
         (B, N), L = src_tokens.shape, input_ids.shape[1]
@@ -359,7 +378,7 @@ class MM_Model(nn.Module):
                     qb = ((packs[0].rows_host + 15) // 16).tolist()
                     ops.set_pair_kept(sum(q * e for q, e in zip(qb, eff)) / (kt.numel() * nt * nt))
                 kt_host = kt
-                key_tiles = kt.to(torch.int32).to(src_tokens.device, non_blocking=True)
+                key_tiles = ops.upload(kt.to(torch.int32), src_tokens.device)
         img_mask = ~padding_mask
         attention_mask = attention_mask.bool().to(src_tokens.device)
         # NOTE: the reference sets padding_mask=None when nothing is padded (:548-549), which costs a host sync

@@ -65,6 +65,17 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
+def upload(t, device):
+    """A small host tensor (per-batch descriptors: key-tile counts, tile prefixes, packed-row offsets) to the device WITHOUT stalling the
+    host: through pinned memory (torch's caching host allocator) the copy is a true asynchronous enqueue; from pageable memory
+    hipMemcpyAsync returns only once the copy has run -- i.e. after everything already queued on the stream -- which serialised the host
+    with the previous step's kernels whenever a step was fed a fresh batch (found with bench.py's pipeline workload: 88 ms per step
+    where the same step on a resident batch takes 31)."""
+    if t.device.type != "cpu":
+        return t.to(device, non_blocking=True)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def _chk(t, dtype, name, contiguous=True):
     if not t.is_cuda:
         raise MMDTIError(f"{name}: expected a device tensor (the HIP path has no CPU fallback)")
@@ -455,13 +466,13 @@ def gbf_tile_prefixes(key_tiles_host, N, device, rows_host=None):
     if rows_host is None:
         fwd = torch.cat([zero, torch.cumsum(4 * ke * (4 * nt), 0)])
         bwd = torch.cat([zero, torch.cumsum(nb * torch.clamp(4 * ke, max=nb), 0)])
-        both = torch.stack([fwd, bwd]).to(torch.int32).to(device, non_blocking=True)
+        both = upload(torch.stack([fwd, bwd]).to(torch.int32), device)
         return both[0], both[1]
     rbk = (torch.as_tensor(rows_host, device="cpu").to(torch.int64) + 3) // 4          # 4-row query blocks up to the representative pad row
     B = rbk.numel()
     fwd = torch.cat([zero, torch.cumsum(4 * ke * rbk, 0)])
     bwd = torch.cat([zero, torch.cumsum(torch.clamp(rbk, max=nb) * torch.clamp(4 * ke, max=nb), 0)])
-    flat = torch.cat([fwd, bwd, rbk, torch.clamp(rbk, max=nb)]).to(torch.int32).to(device, non_blocking=True)
+    flat = upload(torch.cat([fwd, bwd, rbk, torch.clamp(rbk, max=nb)]).to(torch.int32), device)
     return flat[:B + 1], flat[B + 1:2 * B + 2], flat[2 * B + 2:3 * B + 2], flat[3 * B + 2:]
 
 

@@ -54,9 +54,10 @@ class PackedRows:
     def to(self, device):
         B, M = self.B, self.M
         i32 = torch.cat([self.off_host, self.counts_host, self.seq_host]).to(torch.int32)
-        d32 = i32.to(device, non_blocking=True)
+        from .ops import upload          # (pinned staging: a pageable non_blocking copy stalls the host behind the stream's queue)
+        d32 = upload(i32, device)
         self.off, self.n_real, self.row_seq = d32[:B + 1], d32[B + 1:2 * B + 1], d32[2 * B + 1:]
-        self.gather = self.gather_host.to(device, non_blocking=True)
+        self.gather = upload(self.gather_host, device)
         return self
 
     # ---- glue for API boundaries and tests (plain indexing, not on the hot path)

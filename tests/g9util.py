@@ -102,3 +102,17 @@ def host_fields(batch_cpu, pad_idx=0):
     from mmdti_hip.collate import device_payload, HOST_FIELDS
     full = device_payload({k: v for k, v in batch_cpu.items()}, pad_idx=pad_idx)
     return {k: full[k] for k in HOST_FIELDS if k in full}
+
+
+_BANDS = {}
+
+
+def record_band(name, **vals):
+    """Measured values behind a tolerance band, written to gpurun_out/grad_bands.json on the GPU box: every gradient band of the GPU
+    suite states `measured x 1.3` next to the assert, and this file is where `measured` comes from (copied to profiles/ per round)."""
+    import json, os
+    _BANDS[name] = {k: (float(v) if not isinstance(v, str) else v) for k, v in vals.items()}
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "grad_bands.json"), "w") as f:
+        json.dump(_BANDS, f, indent=1, sort_keys=True)

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from oracle import mmdti_oracle as O
-from g9util import tiny_cfg, refarch_cfg, product_model, load_fixture_weights, rel_l2, cosine, tokenizer_from
+from g9util import record_band, tiny_cfg, refarch_cfg, product_model, load_fixture_weights, rel_l2, cosine, tokenizer_from
 
 ZERO_GRADS = ("pooler", "key.bias", "gbf_proj.linear2.bias")
 
@@ -73,7 +73,8 @@ def test_unimol_tower_at_reference_crop_sizes(N, monkeypatch):
     fin = torch.isfinite(so)
     assert torch.equal(torch.isfinite(s_hip), fin) and rel_l2(s_hip[fin], so[fin]) < 3e-3
     worst, cos_min = _grad_report(model, P)
-    assert worst[1] < 6e-2 and cos_min > 0.995, (worst, cos_min)
+    record_band(f"unimol_tower_crop_{N}", worst_rel_l2=worst[1], worst_param=worst[0], cos_min=cos_min, enc=rel_l2(enc, eo))
+    assert worst[1] < 6.2e-2 and cos_min > 0.9986, (worst, cos_min)            # measured x 1.3: 2.7-4.7e-2 (gbf_proj.linear1.bias) / 0.99892-0.99965
 
 
 # ------------------------------------------------------------------------------------------------ ragged batches: key-tile skipping
@@ -163,7 +164,8 @@ def test_c3_regression_conr_fds_at_reference_architecture():
     assert abs(float(out.loss) - float(loss32)) <= 2e-3 * abs(float(loss32))
     ref_loss.backward()
     worst, cos_min = _grad_report(model, P)
-    assert worst[1] < 0.12 and cos_min > 0.99, (worst, cos_min)
+    record_band("c3_regression_conr_fds", worst_rel_l2=worst[1], worst_param=worst[0], cos_min=cos_min)
+    assert worst[1] < 0.118 and cos_min > 0.9948, (worst, cos_min)             # measured x 1.3: 9.0e-2 (gbf_proj.linear1.bias, |grad| ~ 1e-4) / 0.99599
 
 
 # ------------------------------------------------------------------------------------------------ the bench's exact workload

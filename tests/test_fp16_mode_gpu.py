@@ -182,7 +182,7 @@ def test_g9_refarch_b32_embeddings_within_1e3_with_fp16_forward_operands(golden,
         json.dump(dict(r, worst_grad_param=worst[0]), f, indent=1)
     assert r["enc"] < 1e-3 and r["bert"] < 1e-3 and r["logits"] < 1e-3, r           # north star: embeddings within 1e-3 relative
     assert r["infonce"] < 1e-3 and r["loss"] < 1e-3 and r["task_loss"] < 1e-3, r    # ... and the losses
-    assert worst[1][0] < 0.12 and r["min_grad_cos"] > 0.99, (worst, r)
+    assert worst[1][0] < 2.2e-2 and r["min_grad_cos"] > 0.99995, (worst, r)        # measured x 1.3: 7.7e-3 ... 1.64e-2 / 0.999966
 
 
 def test_fp16_mode_trains(fp16_mode):

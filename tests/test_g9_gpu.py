@@ -16,7 +16,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import mmdti_oracle as O
-from g9util import (T, samples_from, tiny_cfg, refarch_cfg, tokenizer_from, product_model, load_fixture_weights, rel_l2, cosine, host_fields)
+from g9util import (record_band, T, samples_from, tiny_cfg, refarch_cfg, tokenizer_from, product_model, load_fixture_weights, rel_l2, cosine, host_fields)
 
 ZERO_GRADS = ("pooler", "key.bias", "gbf_proj.linear2.bias")     # analytically zero (softmax shift invariance): rounding noise on both sides
 REPORT = {}
@@ -28,6 +28,24 @@ def _report(name, **vals):
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "parity_report.json"), "w") as f:
         json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+PARITY_DEFAULT = {}
+
+
+def _parity_default(key, r, worst_param):
+    PARITY_DEFAULT[key] = dict({k: float(v) for k, v in r.items()}, worst_grad_param=worst_param)
+    agg = {"what": "default precision mode (fp16 forward / bf16 backward operands) vs the reference's own fp32 CPU run, reference architecture, "
+                   "32 molecules (tests/golden/g9_model_refarch_b32_*: tests/test_g9_gpu.py::test_g9_model_refarch_b32_hip)",
+           "encoder_rep_rel_l2": max(v["enc"] for v in PARITY_DEFAULT.values()), "out_bert_rel_l2": max(v["bert"] for v in PARITY_DEFAULT.values()),
+           "logits_rel_l2": max(v["logits"] for v in PARITY_DEFAULT.values()), "infonce_rel": max(v["infonce"] for v in PARITY_DEFAULT.values()),
+           "loss_rel": max(v["loss"] for v in PARITY_DEFAULT.values()), "task_loss_rel": max(v["task_loss"] for v in PARITY_DEFAULT.values()),
+           "worst_grad_rel_l2": max(v["worst_grad_rel_l2"] for v in PARITY_DEFAULT.values()),
+           "min_grad_cos": min(v["min_grad_cos"] for v in PARITY_DEFAULT.values()), "cases": sorted(PARITY_DEFAULT)}
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_default_mode.json"), "w") as f:
+        json.dump(agg, f, indent=1, sort_keys=True)
 
 
 # ------------------------------------------------------------------------------------------------ encoder (a5)
@@ -57,10 +75,11 @@ def test_g9_encoder_hip(golden, tag):
     assert abs(float(x_norm) - float(g["x_norm"])) < 2e-3 * max(1.0, abs(float(g["x_norm"])))
     assert abs(float(delta_norm) - float(g["delta_norm"])) < 2e-3 * max(1.0, abs(float(g["delta_norm"])))
     (x * T(g["gx"]).cuda()).sum().backward()
-    assert rel_l2(emb.grad, g["d_emb"]) < 4e-2 and cosine(emb.grad, g["d_emb"]) > 0.999
+    # (every gradient band below: the value measured on MI355X in the default precision mode x 1.3 -- profiles/r04_grad_bands.json)
+    assert rel_l2(emb.grad, g["d_emb"]) < 5.0e-3 and cosine(emb.grad, g["d_emb"]) > 0.9999          # measured 2.3-3.8e-3
     keep = ~T(g["padding_mask"]).view(B, 1, 1, N).expand(B, H, N, N) if pm is not None else torch.ones(B, H, N, N, dtype=torch.bool)
     gb, rb = leaf.grad.cpu().view(B, H, N, N), T(g["d_bias"]).view(B, H, N, N)
-    assert rel_l2(gb[keep], rb[keep]) < 4e-2
+    assert rel_l2(gb[keep], rb[keep]) < 6.7e-3                                                        # measured 3.7-5.1e-3
     worst = 0.0
     for n, p in enc.named_parameters():
         if bool(g["hasgrad_" + n]):
@@ -68,7 +87,8 @@ def test_g9_encoder_hip(golden, tag):
             worst = max(worst, rel_l2(p.grad, g["g_" + n]))
         else:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
-    assert worst < 5e-2, worst
+    record_band("g9_encoder_" + tag, worst_param_rel_l2=worst, d_emb=rel_l2(emb.grad, g["d_emb"]), d_bias=rel_l2(gb[keep], rb[keep]))
+    assert worst < 1.0e-2, worst                                                                      # measured 5.3-7.6e-3
     # ---- the auxiliary outputs are differentiable too (models/transformers.py:141-181): gradients of
     #      0.7 x_norm + 1.3 delta_norm + <delta, g_delta> + <attn (finite entries), g_attn>  vs the reference's autograd
     enc.zero_grad(set_to_none=True)
@@ -200,7 +220,8 @@ def test_g9_model_tiny_hip(golden, tag, layout):
         rr = rel_l2(p.grad, ref)
         worst = max(worst, (n, rr), key=lambda t: t[1])
         cos_min = min(cos_min, cosine(p.grad, ref))
-    assert worst[1] < 8e-2 and cos_min > 0.99, (worst, cos_min)
+    record_band("g9_model_tiny_" + tag + "_" + layout, worst_rel_l2=worst[1], worst_param=worst[0], cos_min=cos_min)
+    assert worst[1] < 3.6e-2 and cos_min > 0.9995, (worst, cos_min)            # measured 1.5-2.8e-2 (pair-bias block) / 0.99962-0.99989
     # return protocol (mm_model.py:585-618): arity exact, values to bf16 tolerance
     nt = dict(net_target=tgt) if task == "regression" else {}
     with torch.no_grad():
@@ -262,22 +283,30 @@ def test_g9_model_refarch_hip(golden, tag, layout):
     worst_full = max(full.items(), key=lambda t: t[1][0])
     r.update(worst_grad_norm_err=worst_gn[1], worst_grad_rel_l2=worst_full[1][0], min_grad_cos=min(v[1] for v in full.values()))
     _report("g9_model_refarch_" + tag + ("" if layout == "padded" else "_packed"), **r, worst_grad_norm_param=worst_gn[0], worst_grad_param=worst_full[0])
-    # embeddings after 15 pre-LN layers / 6 post-LN layers with bf16 GEMM operands (bound measured)
-    assert r["enc"] < 6.5e-3 and r["bert"] < 3e-3 and r["logits"] < 4.5e-3, r      # (measured 4.7e-3 / 2.1e-3 / 2.3-3.0e-3, x 1.3)
-    # the step loss (what the trainer optimises) within the north star's 1e-3; InfoNCE alone at B = 4 sits at 1.2-1.4e-3 -- the
-    # CPU emulation of the bf16 contract gives the same 1.2e-3 on this shape (profiles/r02_rounding_sites_cpu.json): operand
-    # rounding of weights and activations, amplified by 1/temperature = 10, not a kernel property
-    # (the B = 32 fixture below holds InfoNCE to 1e-3; this 4 x 4 case stays as the amplification witness: measured 1.14-1.36e-3, x 1.3)
-    assert r["infonce"] < 1.8e-3 and r["task_loss"] < 2e-3 and r["loss"] < 1e-3, r
-    assert r["ct"] < 1e-2 or abs(float(ct) - float(g["o_ct"])) < 5e-4, r           # B=4 contrastive term (exp(x/0.07) of bf16-computed features)
-    assert worst_gn[1] < 0.1 and worst_full[1][0] < 0.12 and r["min_grad_cos"] > 0.99, (worst_gn, worst_full, r["min_grad_cos"])
+    # Default precision mode (fp16 forward operands, round 4): every band = the value measured on MI355X x 1.3 (gpurun_out/parity_report.json
+    # of the round, copied to profiles/r04_parity_report.json); the north star's 1e-3 on embeddings AND losses holds with margin even on
+    # this 4 x 4 InfoNCE (bf16 operands: 4.7e-3 / 2.1e-3 / 3.0e-3 / 1.4e-3 -- MMDTI_FWD_FP16=0, covered at B = 32 below).
+    assert r["enc"] < 7.0e-4 and r["bert"] < 5.3e-4 and r["logits"] < 8.4e-4, r      # measured 5.36e-4 / 4.01e-4 / 5.5-6.4e-4
+    assert r["infonce"] < 2.4e-4 and r["task_loss"] < 9.2e-5 and r["loss"] < 1.3e-4, r  # measured 1.81e-4 / 2.3-7.0e-5 / 1.7-9.6e-5
+    assert r["ct"] < 8.2e-5, r                                                            # measured 3.4-6.3e-5 (exp(x / 0.07) of the pooled features)
+    # gradients against the reference's own autograd: gradient NORMS 2.8e-3 ... 1.5e-2 (gbf_proj.linear1.bias), full tensors 6.2-9.9e-3
+    # (pair-bias tables / encoder.layers.0.fc1.bias), cosine 0.99996
+    assert worst_gn[1] < 2.0e-2 and worst_full[1][0] < 1.3e-2 and r["min_grad_cos"] > 0.9999, (worst_gn, worst_full, r["min_grad_cos"])
 
 
+@pytest.mark.parametrize("mode", ["default", "bf16"])
 @pytest.mark.parametrize("layout", ["padded", "packed"])
 @pytest.mark.parametrize("tag", ["cls", "reg"])
-def test_g9_model_refarch_b32_hip(golden, tag, layout):
-    """The reference architecture at B = 32 against the reference's own fp32 run: with 32 rows in the
-    InfoNCE softmax the north star's 1e-3 on every loss holds (the B = 4 fixture above is the amplification witness: 1.1-1.4e-3)."""
+def test_g9_model_refarch_b32_hip(golden, tag, layout, mode, monkeypatch):
+    """The reference architecture at B = 32 against the reference's own fp32 run.  mode "default": fp16
+    forward operands -- encoder_rep, out_bert, logits AND every loss inside the north star's 1e-3, each band the measured value x 1.3;
+    mode "bf16" (MMDTI_FWD_FP16=0, the round-1..3 contract and the bench's A/B workload): losses inside 1e-3, embeddings at the cost of
+    bf16 operands over 15 / 6 layers."""
+    from mmdti_hip import ops
+    if mode == "bf16":
+        monkeypatch.setattr(ops, "FWD_F16", False)
+    else:
+        assert ops.FWD_F16, "the default precision mode is fp16 forward operands"
     g = golden("g9_model_refarch_b32_" + tag)
     task = str(g["task"])
     ocfg = refarch_cfg(task, int(g["vocab_rob"]))
@@ -308,13 +337,22 @@ def test_g9_model_refarch_b32_hip(golden, tag, layout):
     full = {k[2:]: (rel_l2(grads[k[2:]].grad, g[k]), cosine(grads[k[2:]].grad, g[k])) for k in g if k.startswith("g_")}
     worst_full = max(full.items(), key=lambda t: t[1][0])
     r.update(worst_grad_rel_l2=worst_full[1][0], min_grad_cos=min(v[1] for v in full.values()))
-    _report("g9_model_refarch_b32_" + tag + ("" if layout == "padded" else "_packed"), **r, worst_grad_param=worst_full[0])
-    # north star: losses within 1e-3 relative -- InfoNCE included at this batch size
-    assert r["infonce"] < 1e-3 and r["loss"] < 1e-3 and r["task_loss"] < 2e-3, r
-    assert r["ct"] < 1e-2 or abs(float(ct) - float(g["o_ct"])) < 5e-4, r
-    # embeddings: measured 4.7e-3 / 2.1e-3 / 2.3-3.0e-3 (the cost of bf16 GEMM operands over 15 / 6 layers) x 1.3
-    assert r["enc"] < 6.5e-3 and r["bert"] < 3e-3 and r["logits"] < 4.5e-3, r
-    assert worst_full[1][0] < 0.12 and r["min_grad_cos"] > 0.99, (worst_full, r["min_grad_cos"])
+    _report("g9_model_refarch_b32_" + tag + ("" if layout == "padded" else "_packed") + ("" if mode == "default" else "_bf16"), **r, worst_grad_param=worst_full[0])
+    if mode == "default":
+        # the record bench.py quotes in config.parity (copied to profiles/r04_parity_default_mode.json)
+        _parity_default(tag + "_" + layout, r, worst_full[0])
+        # measured on MI355X (x 1.3 = the band): encoder_rep 5.97e-4, out_bert 4.84e-4, logits 6.4e-4 (cls) / 7.7e-4 (reg), InfoNCE 3.2e-5,
+        # total loss 4.7-7.3e-6, task loss 4.4-5.8e-6, SupCon / ConR 4e-6 ... 1.0e-5
+        assert r["enc"] < 7.8e-4 and r["bert"] < 6.3e-4 and r["logits"] < 1.0e-3, r
+        assert r["infonce"] < 4.2e-5 and r["loss"] < 9.5e-6 and r["task_loss"] < 7.6e-6 and r["ct"] < 1.4e-5, r
+        # gradients: worst full-tensor relative L2 7.7e-3 ... 1.64e-2 (gbf.means.weight), cosine >= 0.999966
+        assert worst_full[1][0] < 2.2e-2 and r["min_grad_cos"] > 0.99995, (worst_full, r["min_grad_cos"])
+    else:
+        # bf16 operands everywhere: losses within the north star's 1e-3 (measured InfoNCE 1.3e-4, loss 6e-6 ... 2.6e-5), embeddings 4.56e-3 /
+        # 2.06e-3 / 2.4-2.8e-3 (x 1.3), gradients 1.1e-2 ... 5.0e-2 (gbf.means.weight, regression) / cosine 0.9999
+        assert r["infonce"] < 1.7e-4 and r["loss"] < 3.4e-5 and r["task_loss"] < 9.1e-5, r
+        assert r["enc"] < 6.0e-3 and r["bert"] < 2.7e-3 and r["logits"] < 3.7e-3, r
+        assert worst_full[1][0] < 6.5e-2 and r["min_grad_cos"] > 0.9997, (worst_full, r["min_grad_cos"])
 
 
 # ------------------------------------------------------------------------------------------------ trainer (a18)

@@ -166,7 +166,9 @@ def test_reference_sized_step_vs_oracle():
         r = float((a - b).norm() / (b.norm() + 1e-20))
         worst = max(worst, (n, r), key=lambda t: t[1])
         cos_min = min(cos_min, float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)))
-    assert worst[1] < 0.12 and cos_min > 0.99, (worst, cos_min)
+    from g9util import record_band
+    record_band("full_size_all_max_length_step", worst_rel_l2=worst[1], worst_param=worst[0], cos_min=cos_min)
+    assert worst[1] < 3.2e-2 and cos_min > 0.9996, (worst, cos_min)            # measured x 1.3: 2.4e-2 (infonce.info_proj_query.2.bias) / 0.99971
 
 
 def test_full_size_step_properties():
@@ -323,6 +325,8 @@ def test_step_has_no_host_synchronisation(task, odim, mode, monkeypatch):
     try:
         wide = mode != "padded"                   # (the packed layout needs the fused attention kernels' head sizes)
         tuner = FineTuner(_model(task, odim, wide).train(), task, distributed=mode == "ddp")
+        if mode != "padded":
+            tuner.model.strict_reference = False      # (packed rows under live dropout are an opt-in: MM_Model.strict_reference)
 
         def resident():
             if mode == "padded":
