@@ -57,7 +57,8 @@ def stats(src, dst):
     rows = list(csv.DictReader(open(find(src, "*kernel_stats.csv"))))
     rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
     with open(dst, "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline (every step of the run is in the trace: warm-up, timed, the mixed-length workload, the per-family roofline steps)\n")
+        f.write("# " + os.environ.get("SUMMARIZE_NOTE", "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline (every step of the run is in the "
+                                                  "trace: warm-up, timed, the mixed-length workload, the per-family roofline steps)") + "\n")
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_ms", "avg_us", "percent", "min_us", "max_us"])
         for r in rows[:int(os.environ.get("SUMMARIZE_TOP", "40"))]:
@@ -92,10 +93,11 @@ def pmc(fetch_dir, write_dir, dst):
     rows.sort(key=lambda r: -r[4] * r[1])
     with open(dst, "w") as f:
         f.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python bench.py --steps 1 --warmup 1 "
-                "--no-cpu-baseline --no-rooflines --no-ragged-workload (the headline step only); hbm_bytes_per_launch = 2*FETCH_SIZE_KB*1024 + WRITE_SIZE_KB*1024 (gfx950 correction of MI355X_MICROARCH.md)\n")
+                "--no-cpu-baseline --no-rooflines --no-ragged-workload (the headline step only); hbm_bytes_per_launch = 2*FETCH_SIZE_KB*1024 + WRITE_SIZE_KB*1024 (gfx950 correction of MI355X_MICROARCH.md); "
+                "steps_in_trace=2 (the warm-up step + the step); every kernel of the trace is listed\n")
         w = csv.writer(f)
         w.writerow(["kernel", "launches", "FETCH_SIZE_KB_mean", "WRITE_SIZE_KB_mean", "hbm_bytes_per_launch"])
-        for r in rows[:30]:
+        for r in rows:
             w.writerow([r[0], r[1], f"{r[2]:.1f}", f"{r[3]:.1f}", f"{r[4]:.0f}"])
 
 

@@ -53,3 +53,12 @@ for r in out:
     print(f"{r['M']:6d} {r['N']:5d} {r['K']:6d}  {r['tA']}  {r['tB']} {r['splitk']:3d} {r['act']:3d} {r['n_per_step']:7.1f} {r['us']:7.1f} {r['tflops']:6.0f} {r['bound_us']:9.1f} {r['bound']:>5} {r['frac_of_bound']:5.2f} {r['ms_per_step']:8.3f}")
 print("total GEMM ms/step", sum(r["ms_per_step"] for r in out), " at-bound ms/step", sum(r["bound_us"] * r["n_per_step"] for r in out) / 1e3)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "gemm_shapes.json"), "w"), indent=1)
+
+import csv
+with open(os.path.join(ROOT, "gpurun_out", "gemm_shapes.csv"), "w") as f:
+    f.write("# per-shape GEMM launches of the headline step (scratch/gemm_shapes.py: HIP events around every launch, every stream overlap off); bound_us = "
+            "max(flop / 2.5 PF, algorithmic bytes / 6.3 TB/s); frac_of_bound = bound_us / us\n")
+    w = csv.DictWriter(f, fieldnames=["M", "N", "K", "tA", "tB", "batch", "splitk", "act", "n_per_step", "us", "tflops", "bound_us", "bound", "frac_of_bound", "ms_per_step", "grouped"])
+    w.writeheader()
+    for r in out:
+        w.writerow({k: (f"{v:.3f}" if isinstance(v, float) else v) for k, v in dict(r, grouped=r.get("grouped", "")).items()})
