@@ -40,6 +40,7 @@ def init_from_env(backend: Optional[str] = None, force: bool = False) -> tuple:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        host_group()        # (created HERE, where every rank is known to be: new_group is collective over the whole world -- ADVICE r03)
     return rank, local, world
 
 
@@ -229,25 +230,37 @@ _HOST_GROUP = None
 def host_group():
     """A gloo process group for HOST-side exchanges (a few integers per step, decisions of the epoch loop): a collective on host
     memory costs no device synchronisation -- an RCCL all-reduce of two lengths followed by ``int(t[0])`` stalls the host until the
-    GPU queue has drained.  The default group itself when it is gloo (CPU runs).  Created on first use: every rank must reach that
-    first use together (they do: it sits in the per-step / per-epoch control flow)."""
+    GPU queue has drained.  The default group itself when it is gloo (CPU runs).  ``dist.new_group`` is collective over the WHOLE world,
+    so the group is created eagerly where the process group is set up (init_from_env; FineTuner / Trainer under distributed=True call
+    this in their constructors, which every rank runs) -- a lazy first use inside per-step control flow would hang as soon as one
+    rank's path skipped it."""
     global _HOST_GROUP
     if _HOST_GROUP is None:
         _HOST_GROUP = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
     return _HOST_GROUP
 
 
+def _host_capable(group):
+    """the group a host-memory collective runs on: the caller's if it can take CPU tensors (gloo), else a clear error"""
+    if group is None:
+        return host_group()
+    if dist.get_backend(group) != "gloo":
+        raise ValueError("host-side exchanges (padded lengths, epoch decisions) need a gloo group: pass group=None (the library's own gloo side "
+                         f"group) or a gloo group, not a {dist.get_backend(group)} one")
+    return group
+
+
 def host_all_reduce_max(values, group=None):
     """element-wise MAX over ranks of a short list of Python ints, through host memory"""
     t = torch.tensor(list(values), dtype=torch.int64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group if group is not None else host_group())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_host_capable(group))
     return [int(v) for v in t]
 
 
 def host_broadcast_ints(values, src=0, group=None):
     """rank ``src``'s list of Python ints on every rank, through host memory"""
     t = torch.tensor(list(values), dtype=torch.int64)
-    dist.broadcast(t, src=src, group=group if group is not None else host_group())
+    dist.broadcast(t, src=src, group=_host_capable(group))
     return [int(v) for v in t]
 
 

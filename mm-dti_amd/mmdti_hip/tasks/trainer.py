@@ -58,10 +58,12 @@ def _auc(y, p):
 
 
 def _log_loss(y, p):
-    """binary log loss of P(class 1), probabilities clipped to [eps, 1 - eps] (sklearn.metrics.log_loss)"""
-    y, p = np.asarray(y).ravel().astype(np.float64), np.asarray(p).ravel().astype(np.float64)
-    eps = np.finfo(np.float64).eps
-    p = np.clip(p, eps, 1.0 - eps)
+    """binary log loss of P(class 1), probabilities clipped to [eps, 1 - eps] (sklearn.metrics.log_loss).  eps follows the dtype the
+    reference hands sklearn -- ``predict.astype(np.float32)`` (utils/metrics.py:168), so float32's eps: on saturated softmax outputs the
+    float64 eps gives another number (y = [0,1,1,0,1], p = [1,1,.7,.2,0]: 6.49 vs 14.53 -- ADVICE r03)."""
+    y, p = np.asarray(y).ravel().astype(np.float64), np.asarray(p).ravel().astype(np.float32)
+    eps = np.finfo(np.float32).eps
+    p = np.clip(p.astype(np.float64), eps, 1.0 - eps)
     return float(-np.mean(y * np.log(p) + (1.0 - y) * np.log(1.0 - p)))
 
 

@@ -70,6 +70,8 @@ class FineTuner:
             self.negs = GlobalNegatives()
             self.world = self.negs.world
             if self.negs.active:
+                from .parallel import host_group
+                host_group()            # (the gloo side group of the host-side exchanges: created where every rank is -- ADVICE r03)
                 # replicas must start identical: the cross-modal block, InfoNCE head and classification head are random-
                 # initialised, so rank 0's arena is broadcast (no reliance on every rank seeding alike) ...
                 torch.distributed.broadcast(self.arena.data, src=0)

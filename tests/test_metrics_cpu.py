@@ -14,9 +14,13 @@ def test_metric_functions_match_sklearn_and_scipy():
     y = (rng.random(300) < 0.3).astype(int)
     p = np.round(rng.random(300), 2)                                   # ties included
     q = (p > 0.5).astype(int)
-    for name, ref in (("auc", M.roc_auc_score(y, p)), ("auprc", M.average_precision_score(y, p)), ("log_loss", M.log_loss(y, p)),
+    for name, ref in (("auc", M.roc_auc_score(y, p)), ("auprc", M.average_precision_score(y, p)),
                       ("f1_score", M.f1_score(y, q)), ("mcc", M.matthews_corrcoef(y, q)), ("acc", M.accuracy_score(y, q))):
         assert abs(t._METRIC_TABLE[name][0](y, p) - ref) < 1e-12, name
+    # log loss: the reference hands sklearn float32 predictions (utils/metrics.py:168), whose eps clips saturated probabilities
+    assert abs(t._METRIC_TABLE["log_loss"][0](y, p) - M.log_loss(y, p.astype(np.float32))) < 1e-6
+    ys, ps = np.array([0, 1, 1, 0, 1]), np.array([1.0, 1.0, 0.7, 0.2, 0.0], dtype=np.float32)       # saturated softmax outputs
+    assert abs(t._METRIC_TABLE["log_loss"][0](ys, ps) - M.log_loss(ys, ps)) < 1e-5 and abs(M.log_loss(ys, ps) - 6.49) < 0.01
     a = rng.normal(size=200)
     b = np.round(a + rng.normal(size=200), 1)
     for name, ref in (("pearsonr", st.pearsonr(a, b)[0]), ("spearmanr", st.spearmanr(a, b)[0]), ("mse", M.mean_squared_error(a, b)),
