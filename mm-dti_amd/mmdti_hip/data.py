@@ -91,70 +91,154 @@ def epoch_cost(batches, atoms, tokens) -> float:
 
 
 class DevicePrefetcher:
-    """Iterate ``(net_input: dict[str, Tensor], label: Tensor)`` batches with the NEXT batch's host-to-device copies in
-    flight on a side HIP stream while the current step runs (collate / transfer off the critical path).
+    """Iterate ``(net_input: dict[str, Tensor], label: Tensor)`` batches with the NEXT batch's host-to-device copies in flight on a
+    side HIP stream while the current step runs (collate / transfer off the critical path).
 
-    The reference moves each batch with synchronous ``.cuda()`` calls inside the step loop (tasks/trainer.py:181-183).
-    Here every host tensor is staged through a pinned buffer (re-used while the shapes repeat), copied with
-    ``non_blocking=True`` on ``self.stream``, and the consumer's stream waits on the copy's event only when it takes the
-    batch -- so a step never waits for PCIe unless the loader itself is the bottleneck.  ``narrow`` (default): only what the
-    kernels read is copied (``collate.device_payload``: ``src_edge_type`` as int16, no ``src_coord``) -- at 256 molecules of
-    130 atoms the int64 edge types alone are 34.6 MB per batch, 8.7 MB as int16; values are unchanged.
+    The reference moves each batch with synchronous ``.cuda()`` calls inside the step loop (tasks/trainer.py:181-183) and collates
+    in the main process (num_workers = 0, :551-555).  Here a batch is handed to the consumer FIRST -- which enqueues its step,
+    asynchronously -- and only then is the next one pulled from the wrapped iterable, narrowed (``collate.device_payload``: int16 edge
+    types, no ``src_coord``, packing facts; values unchanged -- at 256 molecules of 130 atoms the int64 edge types alone are 34.6 MB
+    per batch, 8.7 MB as int16), staged and copied with ``non_blocking=True`` on ``self.stream``; the consumer's stream waits for the
+    copy event when it takes the batch.  Staging: tensors that arrive PINNED (a ``DataLoader(pin_memory=True)`` whose worker processes
+    ran ``collate.HostCollate`` -- the production form, ``tasks.Trainer(num_workers=k)``) are copied from where they lie; pageable ones
+    go through a ring of ``depth + 1`` pinned buffer sets, a set being rewritten only after the copy that last read it has completed.
+
+    Round 4 (bench.py ``workloads.pipeline``): with ONE staging set the loop waited 15 ms per step for the previous copy (the blit
+    shares the chip with the step's kernels) before it could stage the next batch, and it prepared batch i + 1 BEFORE handing over batch
+    i, so the GPU idled through every collate: 87 ms per mixed-length step for 31 ms of kernels.  ``threaded=True`` moves payload and
+    staging to a Python thread -- which only pays when the wrapped iterable's own work releases the GIL (measured with a Python-loop
+    collate: 113 ms per step, the two threads fighting over the interpreter); worker PROCESSES are what takes collate off the
+    critical path.
     """
 
-    def __init__(self, batches, device, narrow=True, n_edge_types=None, pad_idx=0):
+    def __init__(self, batches, device, narrow=True, n_edge_types=None, pad_idx=0, depth=2, threaded=False):
         import torch
         self._torch = torch
         self.narrow, self.n_edge_types, self.pad_idx = narrow, n_edge_types, pad_idx
         self.batches = batches
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
-        self._pinned = {}
+        self.depth = max(1, int(depth))
+        self.threaded = bool(threaded) and self.stream is not None
+        self._ring = [dict(buf={}, event=None) for _ in range(self.depth + 1)]
 
-    def _stage(self, name, t):
-        torch = self._torch
-        if self.stream is None or t.device.type != "cpu":
-            return t.to(self.device)
-        key = (name, tuple(t.shape), t.dtype)
-        buf = self._pinned.get(name)
-        if buf is None or (tuple(buf.shape), buf.dtype) != key[1:]:
-            buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-            self._pinned[name] = buf
-        buf.copy_(t)
-        return buf.to(self.device, non_blocking=True)
-
-    def _launch(self, item):
+    # ---- host side (background thread): payload + pinned staging
+    def _stage_host(self, slot, item):
+        """-> (staged: {name: pinned tensor | host field}, label pinned tensor).  Runs on the staging thread."""
         torch = self._torch
         net_input, label = item
         if self.narrow:
             from .collate import device_payload
             net_input = device_payload(net_input, self.n_edge_types, self.pad_idx)
+        def pin(name, t):
+            if not torch.is_tensor(t) or t.device.type != "cpu" or self.stream is None or t.is_pinned():
+                return t                       # (pinned already -- a pin_memory DataLoader: copied from where it lies, torch's host allocator keeps it alive)
+            if slot["event"] is not None:      # the copy that last read this set of staging buffers must be done before they are rewritten
+                slot["event"].synchronize()
+                slot["event"] = None
+            buf = slot["buf"].get(name)
+            if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+                buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                slot["buf"][name] = buf
+            buf.copy_(t)
+            return buf
+
+        staged = {k: (v if k in HOST_FIELDS else pin(k, v)) for k, v in net_input.items()}
+        return staged, pin("__label__", label)
+
+    # ---- device side (calling thread): enqueue the copies
+    def _enqueue(self, slot, staged, label):
+        torch = self._torch
         if self.stream is None:
-            return {k: (v if k in HOST_FIELDS else self._stage(k, v)) for k, v in net_input.items()}, self._stage("__label__", label), None
+            dev_in = {k: (v if k in HOST_FIELDS else v.to(self.device)) for k, v in staged.items()}
+            return dev_in, label.to(self.device), None
         with torch.cuda.stream(self.stream):
-            dev_in = {k: (v if k in HOST_FIELDS else self._stage(k, v)) for k, v in net_input.items()}
-            dev_lab = self._stage("__label__", label)
+            dev_in = {k: (v if k in HOST_FIELDS else v.to(self.device, non_blocking=True)) for k, v in staged.items()}
+            dev_lab = label.to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)
+        slot["event"] = ev
         return dev_in, dev_lab, ev
 
-    def __iter__(self):
+    def _launch(self, item, slot=None):
+        """stage + enqueue on the calling thread (the unthreaded path; bench.py wraps it to time one batch's transfer)"""
+        slot = self._ring[0] if slot is None else slot
+        staged, label = self._stage_host(slot, item)
+        return self._enqueue(slot, staged, label)
+
+    def _hand_over(self, dev_in, dev_lab, ev):
         torch = self._torch
-        it = iter(self.batches)
+        if ev is not None:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            for t in [v for k, v in dev_in.items() if k not in HOST_FIELDS] + [dev_lab]:
+                t.record_stream(cur)
+        return dev_in, dev_lab
+
+    def __iter__(self):
+        if not self.threaded:
+            yield from self._iter_inline()
+            return
+        import queue
+        import threading
+        q = queue.Queue(maxsize=self.depth)
+        stop = threading.Event()
+
+        def produce():
+            try:
+                k = 0
+                for item in self.batches:
+                    if stop.is_set():
+                        return
+                    slot = self._ring[k % len(self._ring)]
+                    staged, label = self._stage_host(slot, item)
+                    q.put((slot, staged, label))
+                    k += 1
+                q.put(None)
+            except BaseException as e:      # noqa: BLE001  (handed to the consumer, re-raised there)
+                q.put(e)
+
+        th = threading.Thread(target=produce, name="mmdti-stage", daemon=True)
+        th.start()
         try:
-            nxt = self._launch(next(it))
+            nxt = q.get()
+            pending = None
+            while True:
+                if isinstance(nxt, BaseException):
+                    raise nxt
+                if nxt is not None:
+                    slot, staged, label = nxt
+                    ready = self._enqueue(slot, staged, label)       # copies of batch i + 1 in flight ...
+                else:
+                    ready = None
+                if pending is not None:
+                    yield self._hand_over(*pending)                  # ... while the consumer enqueues the step on batch i
+                if ready is None:
+                    break
+                pending = ready
+                nxt = q.get()
+        finally:
+            stop.set()
+            while th.is_alive():            # unblock a producer waiting on a full queue
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    th.join(timeout=0.01)
+
+    def _iter_inline(self):
+        it = iter(self.batches)
+        k = 0
+        try:
+            nxt = self._launch(next(it), self._ring[0])
         except StopIteration:
             return
         while nxt is not None:
-            dev_in, dev_lab, ev = nxt
-            if ev is not None:
-                torch.cuda.current_stream(self.device).wait_event(ev)
-                for t in [v for k, v in dev_in.items() if k not in HOST_FIELDS] + [dev_lab]:
-                    t.record_stream(torch.cuda.current_stream(self.device))
-                # (the staging buffers are rewritten by the next _launch: its host-side copy_ must not race the DMA)
-                ev.synchronize()
+            cur = self._hand_over(*nxt)
+            k += 1
+            # hand the batch over FIRST: the consumer enqueues its step (asynchronously), and only then does this generator resume to
+            # collate / stage the next batch -- on the host, while the GPU runs the step just enqueued
+            yield cur
             try:
-                nxt = self._launch(next(it))
+                nxt = self._launch(next(it), self._ring[k % len(self._ring)])
             except StopIteration:
                 nxt = None
-            yield dev_in, dev_lab

@@ -71,7 +71,7 @@ def upload(t, device):
     hipMemcpyAsync returns only once the copy has run -- i.e. after everything already queued on the stream -- which serialised the host
     with the previous step's kernels whenever a step was fed a fresh batch (found with bench.py's pipeline workload: 88 ms per step
     where the same step on a resident batch takes 31)."""
-    if t.device.type != "cpu":
+    if t.device.type != "cpu" or torch.device(device).type == "cpu":
         return t.to(device, non_blocking=True)
     return t.pin_memory().to(device, non_blocking=True)
 

@@ -241,7 +241,14 @@ class Trainer(object):
             return {}
         # (not persistent: a persistent iterator skips the per-epoch base-seed draw, and the shuffle stream would then differ
         # from the in-process loader's -- the epoch order is part of what the G10 fixtures pin)
-        return dict(num_workers=self.num_workers, pin_memory=self.device.type == "cuda")
+        # spawned workers, not forked ones: a child forked from a process that has initialised HIP inherits its driver state, and on this
+        # stack the parent's GPU work then crawls (measured with bench.py's pipeline workload, 4 forked loader workers: 160-220 ms per step --
+        # the host blocked for 0.1-0.35 s at a time in event waits and inside the backward -- against 42 ms with spawned ones and 31 ms of
+        # kernels).  Costs a process start-up per loader; the dataset and collate.HostCollate are picklable by construction.
+        kw = dict(num_workers=self.num_workers, pin_memory=self.device.type == "cuda")
+        if self.device.type == "cuda":
+            kw["multiprocessing_context"] = "spawn"
+        return kw
 
     def _require_device(self):
         if self.device.type != "cuda":
