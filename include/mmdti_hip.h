@@ -146,6 +146,35 @@ int mmdti_unimol_layer_bwd(mmdti_stream_t stream, int M, int B, int N, int H, in
                            int pair_layout, int g_in_zero, const int* key_tiles, const int* row_off, void* ws,
                            long long ws_bytes, int fwd_f16 /* 1: the saved a_act, h2, o_att, h1, qkv hold fp16 (weights: the bf16 shadow) */);
 
+/* ---- ALL layers of the Uni-Mol encoder behind one call per direction (the loop of models/transformers.py:136-139 in :96-183).  At
+ * the reference's 16-32 molecules even the per-layer calls leave ~90 us of Python per layer and direction; these take the layers'
+ * parameters as pointer tables and keep every saved tensor at a fixed offset of ONE caller-owned arena.  The launches are those of
+ * nl x mmdti_unimol_layer_fwd / _bwd: bit-identical results.
+ *   mmdti_unimol_stack_layout: out[0] = arena bytes per layer, out[1] = bytes of the backward workspace (s_bytes: one layer's pair
+ *     logits; dw_slab_bytes: split-K slabs of one layer's grouped weight gradients, see mmdti_linear_dw_grouped_splits).
+ *   params [nl][12]: w_in, b_in, w_out, b_out, g_ln2, bt_ln2, w_fc1, b_fc1, w_fc2, b_fc2, g_ln1, bt_ln1 (16-bit forward weights).
+ *   bparams [nl][6]: w_fc2, w_fc1, w_out, w_in (bf16), g_ln2, g_ln1.   grads [nl][12]: dw_fc2, dw_fc1, dw_out, dw_in, db_fc2, db_fc1,
+ *     db_out, db_in, dg_ln2, dbt_ln2, dg_ln1, dbt_ln1 (fp32, accumulated).
+ *   x0 / h1_0 / m1_0 / r1_0: the stream entering layer 0 and its LayerNorm-1 output + statistics (the caller's); the last layer writes
+ *   x_last, s_last and (g_final non-null) the final LayerNorm out_final / mean_final / rstd_final.  Dropout sites: site0 + 3 l + {0, 1, 2}.
+ *   dw_stream + events (hipEvent_t [3]; both null: everything on `stream`): the grouped weight gradients of a layer run on dw_stream
+ *   under the layer below; `stream` has joined dw_stream when mmdti_unimol_stack_bwd returns. */
+int mmdti_unimol_stack_layout(int M, int D, int F, long long s_bytes, long long dw_slab_bytes, long long* out);
+int mmdti_unimol_stack_fwd(mmdti_stream_t stream, int nl, int M, int B, int N, int H, int D, int F, int ld, float scale, float p_res,
+                           float p_att, unsigned long long seed, unsigned int site0, const float* x0, const void* h1_0,
+                           const void* s_in, const unsigned char* key_pad, int pair_layout, const int* key_tiles,
+                           int rag_store_last, const int* row_off, const void* const* params, int act_fwd, float eps_ln,
+                           const float* g_final, const float* bt_final, float eps_final, int ln_max_k, void* arena,
+                           long long arena_bytes, long long s_bytes, float* x_last, void* s_last, float* out_final,
+                           float* mean_final, float* rstd_final, int fwd_f16);
+int mmdti_unimol_stack_bwd(mmdti_stream_t stream, int nl, int M, int B, int N, int H, int D, int F, int ld, float scale, float p_res,
+                           float p_att, unsigned long long seed, unsigned int site0, const float* dx_in, const void* dy2_in,
+                           float* dx_final, const float* x0, const void* h1_0, const float* m1_0, const float* r1_0,
+                           const void* s_last, const void* const* bparams, int act_dx, void* const* grads, void* G, int pair_layout,
+                           int g_first_zero, const int* key_tiles, const int* row_off, const void* arena, long long arena_bytes,
+                           long long s_bytes, void* ws, long long ws_bytes, long long dw_slab_bytes, int fwd_f16,
+                           mmdti_stream_t dw_stream, void* const* events);
+
 /* The same for one post-LN BERT layer with self-attention, fused q | k | v projection and the fused attention kernels (HF RobertaLayer
  * reached from models/mm_model.py:562): six launches forward, eight backward.  Shapes and the workspace layout: layers.hip. */
 int mmdti_bert_layer_fwd(mmdti_stream_t stream, int Mq, int B, int L, int heads, int D, int F, float scale, float p_hid, float p_att,

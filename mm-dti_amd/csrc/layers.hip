@@ -81,7 +81,7 @@ extern "C" int mmdti_unimol_layer_fwd(mmdti_stream_t stream, int M, int B, int N
  *   backward above).  dx_out [M,D] fp32 / dx16_out [M,D] bf16 (nullable: the lowest layer): the same two for the layer below,
  *   whose fc2 bias gradient db_below (nullable) receives the column sums of dx16_out.
  *   ws: du [M,F] | dh2 [M,D] | dy1 [M,D] | do [M,D] | dqkv [M,3D] | dh1 [M,D] (bf16) | dx_mid [M,D] fp32 | grouped-dW slabs. */
-extern "C" int mmdti_unimol_layer_bwd(mmdti_stream_t stream, int M, int B, int N, int H, int D, int F, int ld, float scale,
+static int unimol_layer_bwd_core(mmdti_stream_t stream, int M, int B, int N, int H, int D, int F, int ld, float scale,
                                       float p_res, float p_att, unsigned long long seed, unsigned int site_f_below, unsigned int site_o,
                                       unsigned int site_att, const float* dx_in, const void* dy2, float* dx_out, void* dx16_out,
                                       float* db_below, const void* a_act, const void* u_aux, int act_dx, const void* h2, const float* x1,
@@ -91,7 +91,7 @@ extern "C" int mmdti_unimol_layer_bwd(mmdti_stream_t stream, int M, int B, int N
                                       float* dw_fc2, float* dw_fc1, float* dw_out, float* dw_in, float* db_fc1, float* db_out,
                                       float* db_in, float* dg_ln2, float* dbt_ln2, float* dg_ln1, float* dbt_ln1, void* G,
                                       int pair_layout, int g_in_zero, const int* key_tiles, const int* row_off, void* ws,
-                                      long long ws_bytes, int fwd_f16) {
+                                      long long ws_bytes, int fwd_f16, mmdti_stream_t dw_stream, hipEvent_t ev_fork, hipEvent_t ev_done) {
   MMDTI_REQUIRE(M > 0 && D > 0 && F > 0 && D % 8 == 0 && F % 8 == 0, "unimol_layer_bwd: bad shape");
   MMDTI_REQUIRE(dx_in && dy2 && dx_out && a_act && u_aux && h2 && x1 && m2 && r2 && o_att && qkv && s_logits && h1 && x0 && m1 && r1 && w_fc2 && w_fc1 &&
                     w_out && w_in && g_ln2 && g_ln1 && dw_fc2 && dw_fc1 && dw_out && dw_in && G && ws,
@@ -133,7 +133,178 @@ extern "C" int mmdti_unimol_layer_bwd(mmdti_stream_t stream, int M, int B, int N
   float* dbs[4] = {nullptr, db_fc1, nullptr, db_in};
   const int n_out[4] = {D, F, D, 3 * D}, n_in[4] = {F, D, D, D};
   const int ldy[4] = {D, F, D, 3 * D}, ldx[4] = {F, D, D, D}, lddw[4] = {F, D, D, D};
-  return mmdti_linear_dw_grouped(stream, 4, dys, xs, dws, dbs, n_out, n_in, ldy, ldx, lddw, M, slabs, slab_bytes, fwd_f16 ? 1 : 0);
+  if (!dw_stream) return mmdti_linear_dw_grouped(stream, 4, dys, xs, dws, dbs, n_out, n_in, ldy, ldx, lddw, M, slabs, slab_bytes, fwd_f16 ? 1 : 0);
+  // (the stack call at small batches: the weight gradients -- leaves of the backward graph -- leave on their own stream behind
+  //  ev_fork and run under the layer below; ev_done marks them finished)
+  if (hipEventRecord(ev_fork, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent((hipStream_t)dw_stream, ev_fork, 0) != hipSuccess) {
+    set_error("unimol_layer_bwd: event fork failed");
+    return MMDTI_ERR_LAUNCH;
+  }
+  if (int e = mmdti_linear_dw_grouped(dw_stream, 4, dys, xs, dws, dbs, n_out, n_in, ldy, ldx, lddw, M, slabs, slab_bytes, fwd_f16 ? 1 : 0)) return e;
+  if (hipEventRecord(ev_done, (hipStream_t)dw_stream) != hipSuccess) {
+    set_error("unimol_layer_bwd: hipEventRecord failed");
+    return MMDTI_ERR_LAUNCH;
+  }
+  return MMDTI_OK;
+}
+
+extern "C" int mmdti_unimol_layer_bwd(mmdti_stream_t stream, int M, int B, int N, int H, int D, int F, int ld, float scale,
+                                      float p_res, float p_att, unsigned long long seed, unsigned int site_f_below, unsigned int site_o,
+                                      unsigned int site_att, const float* dx_in, const void* dy2, float* dx_out, void* dx16_out,
+                                      float* db_below, const void* a_act, const void* u_aux, int act_dx, const void* h2, const float* x1,
+                                      const float* m2, const float* r2, const void* o_att, const void* qkv, const void* s_logits,
+                                      const void* h1, const float* x0, const float* m1, const float* r1, const void* w_fc2,
+                                      const void* w_fc1, const void* w_out, const void* w_in, const float* g_ln2, const float* g_ln1,
+                                      float* dw_fc2, float* dw_fc1, float* dw_out, float* dw_in, float* db_fc1, float* db_out,
+                                      float* db_in, float* dg_ln2, float* dbt_ln2, float* dg_ln1, float* dbt_ln1, void* G,
+                                      int pair_layout, int g_in_zero, const int* key_tiles, const int* row_off, void* ws,
+                                      long long ws_bytes, int fwd_f16) {
+  return unimol_layer_bwd_core(stream, M, B, N, H, D, F, ld, scale, p_res, p_att, seed, site_f_below, site_o, site_att, dx_in, dy2, dx_out, dx16_out, db_below,
+                               a_act, u_aux, act_dx, h2, x1, m2, r2, o_att, qkv, s_logits, h1, x0, m1, r1, w_fc2, w_fc1, w_out, w_in, g_ln2, g_ln1, dw_fc2,
+                               dw_fc1, dw_out, dw_in, db_fc1, db_out, db_in, dg_ln2, dbt_ln2, dg_ln1, dbt_ln1, G, pair_layout, g_in_zero, key_tiles, row_off,
+                               ws, ws_bytes, fwd_f16, nullptr, nullptr, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- whole stacks
+// At the reference's batch size the per-layer calls above still leave ~90 us of Python per layer and direction (17 allocations, 60
+// marshalled arguments): the stack calls issue ALL layers of a tower from one call.  The saved tensors of a layer live at fixed
+// offsets of one caller-owned arena (mmdti_unimol_stack_layout), the parameters come as pointer tables.
+namespace {
+inline long long up256(long long b) { return (b + 255) / 256 * 256; }
+struct UniArena {      // byte offsets inside one layer's slice
+  long long qkv, o, s, x1, h2, m2, r2, u, a, x_out, ln_out, mn, rn, stride;
+  UniArena(long long M, long long D, long long F, long long s_bytes) {
+    long long at = 0;
+    auto take = [&](long long b) { const long long r = at; at += up256(b); return r; };
+    qkv = take(M * 3 * D * 2); o = take(M * D * 2); s = take(s_bytes); x1 = take(M * D * 4); h2 = take(M * D * 2); m2 = take(M * 4); r2 = take(M * 4);
+    u = take(M * F * 2); a = take(M * F * 2); x_out = take(M * D * 4); ln_out = take(M * D * 2); mn = take(M * 4); rn = take(M * 4);
+    stride = at;
+  }
+};
+// backward workspace of the stack: two layer workspaces (the side-stream weight gradients of layer l read slot l & 1 while layer
+// l - 1 fills the other), a ring of three bf16 gradient copies, two fp32 gradients
+struct UniBwdWs {
+  long long layer_ws, lws[2], dx16[3], dx32[2], total;
+  UniBwdWs(long long M, long long D, long long F, long long slab_bytes) {
+    layer_ws = up256((M * F + 7 * M * D) * 2 + M * D * 4 + slab_bytes);
+    long long at = 0;
+    for (int i = 0; i < 2; ++i) { lws[i] = at; at += layer_ws; }
+    for (int i = 0; i < 3; ++i) { dx16[i] = at; at += up256(M * D * 2); }
+    for (int i = 0; i < 2; ++i) { dx32[i] = at; at += up256(M * D * 4); }
+    total = at;
+  }
+};
+}  // namespace
+
+/* out[0] = bytes of one layer's slice of the activation arena, out[1] = bytes of the backward workspace (given the bytes of the
+ * grouped weight-gradient slabs of ONE layer: mmdti_linear_dw_grouped_splits) */
+extern "C" int mmdti_unimol_stack_layout(int M, int D, int F, long long s_bytes, long long dw_slab_bytes, long long* out) {
+  MMDTI_REQUIRE(M > 0 && D > 0 && F > 0 && s_bytes >= 0 && dw_slab_bytes >= 0 && out, "unimol_stack_layout: bad arguments");
+  out[0] = UniArena(M, D, F, s_bytes).stride;
+  out[1] = UniBwdWs(M, D, F, dw_slab_bytes).total;
+  return MMDTI_OK;
+}
+
+/* Forward of ALL layers of the Uni-Mol encoder (models/transformers.py:136-139 looped by :96-183) behind one call: nl x
+ * mmdti_unimol_layer_fwd with the tensors a layer hands the next taken from the arena.  x0 / h1_0: the input stream and the first
+ * layer's LayerNorm-1 output (the caller's).  params [nl][12]: w_in, b_in, w_out, b_out, g_ln2, bt_ln2, w_fc1, b_fc1, w_fc2, b_fc2,
+ * g_ln1, bt_ln1 (16-bit forward weights).  The last layer writes the tensors the caller returns: s_last, x_last and -- with a final
+ * LayerNorm (g_final non-null) -- out_final [M,D] fp32 with its statistics.  Dropout sites: site0 + 3 l + {0: attention, 1: out_proj, 2: fc2}. */
+extern "C" int mmdti_unimol_stack_fwd(mmdti_stream_t stream, int nl, int M, int B, int N, int H, int D, int F, int ld, float scale, float p_res,
+                                      float p_att, unsigned long long seed, unsigned int site0, const float* x0, const void* h1_0,
+                                      const void* s_in, const unsigned char* key_pad, int pair_layout, const int* key_tiles,
+                                      int rag_store_last, const int* row_off, const void* const* params, int act_fwd, float eps_ln,
+                                      const float* g_final, const float* bt_final, float eps_final, int ln_max_k, void* arena,
+                                      long long arena_bytes, long long s_bytes, float* x_last, void* s_last, float* out_final,
+                                      float* mean_final, float* rstd_final, int fwd_f16) {
+  MMDTI_REQUIRE(nl > 0 && params && arena && aligned16(arena) && x0 && h1_0 && s_in && x_last && s_last, "unimol_stack_fwd: null argument");
+  MMDTI_REQUIRE(!g_final || (bt_final && out_final && mean_final && rstd_final), "unimol_stack_fwd: the final LayerNorm needs its outputs");
+  const UniArena A(M, D, F, s_bytes);
+  MMDTI_REQUIRE(arena_bytes >= A.stride * nl, "unimol_stack_fwd: arena too small (%lld bytes per layer)", A.stride);
+  char* base = reinterpret_cast<char*>(arena);
+  for (int l = 0; l < nl; ++l) {
+    char* a = base + A.stride * l;
+    const char* prev = a - A.stride;
+    const void* const* P = params + 12 * l;
+    const bool last = l == nl - 1;
+    const float* x = l ? reinterpret_cast<const float*>(prev + A.x_out) : x0;
+    const void* h1 = l ? static_cast<const void*>(prev + A.ln_out) : h1_0;
+    const void* sp = l ? static_cast<const void*>(prev + A.s) : s_in;
+    const int next_mode = last ? (g_final ? 2 : 0) : 1;
+    const float* gn = last ? g_final : reinterpret_cast<const float*>(params[12 * (l + 1) + 10]);
+    const float* bn = last ? bt_final : reinterpret_cast<const float*>(params[12 * (l + 1) + 11]);
+    if (int e = mmdti_unimol_layer_fwd(
+            stream, M, B, N, H, D, F, ld, scale, p_res, p_att, seed, site0 + 3 * l, site0 + 3 * l + 1, site0 + 3 * l + 2, x, h1, sp, l ? nullptr : key_pad,
+            pair_layout, key_tiles, last ? rag_store_last : 0, row_off, P[0], (const float*)P[1], P[2], (const float*)P[3], (const float*)P[4],
+            (const float*)P[5], eps_ln, P[6], (const float*)P[7], act_fwd, P[8], (const float*)P[9], next_mode, gn, bn, last ? eps_final : eps_ln,
+            ln_max_k, a + A.qkv, last ? s_last : static_cast<void*>(a + A.s), a + A.o, reinterpret_cast<float*>(a + A.x1), a + A.h2,
+            reinterpret_cast<float*>(a + A.m2), reinterpret_cast<float*>(a + A.r2), a + A.u, a + A.a,
+            last ? x_last : reinterpret_cast<float*>(a + A.x_out), last ? static_cast<void*>(out_final) : static_cast<void*>(a + A.ln_out),
+            last ? mean_final : reinterpret_cast<float*>(a + A.mn), last ? rstd_final : reinterpret_cast<float*>(a + A.rn), fwd_f16))
+      return e;
+  }
+  return MMDTI_OK;
+}
+
+/* Backward of the same stack, top layer first: nl x mmdti_unimol_layer_bwd.  dx_in [M,D] fp32 / dy2_in [M,D] bf16: the gradient of
+ * the top layer's output and its dropout-backward bf16 copy (from the final LayerNorm's backward); dx_final [M,D] fp32: the gradient
+ * of x0.  m1_0 / r1_0: LayerNorm-1 statistics of the first layer (the caller's, like x0 / h1_0); s_last: the top layer's logits.
+ * bparams [nl][6]: w_fc2, w_fc1, w_out, w_in (bf16), g_ln2, g_ln1;  grads [nl][12]: dw_fc2, dw_fc1, dw_out, dw_in, db_fc2, db_fc1,
+ * db_out, db_in, dg_ln2, dbt_ln2, dg_ln1, dbt_ln1 (fp32, accumulated).  G: the pair-gradient chain (g_first_zero: not yet written).
+ * dw_stream + events (hipEvent_t [3], nullable together): the weight gradients run on dw_stream under the layer below; `stream`
+ * has joined dw_stream when the call returns. */
+extern "C" int mmdti_unimol_stack_bwd(mmdti_stream_t stream, int nl, int M, int B, int N, int H, int D, int F, int ld, float scale, float p_res,
+                                      float p_att, unsigned long long seed, unsigned int site0, const float* dx_in, const void* dy2_in,
+                                      float* dx_final, const float* x0, const void* h1_0, const float* m1_0, const float* r1_0,
+                                      const void* s_last, const void* const* bparams, int act_dx, void* const* grads, void* G, int pair_layout,
+                                      int g_first_zero, const int* key_tiles, const int* row_off, const void* arena, long long arena_bytes,
+                                      long long s_bytes, void* ws, long long ws_bytes, long long dw_slab_bytes, int fwd_f16,
+                                      mmdti_stream_t dw_stream, void* const* events) {
+  MMDTI_REQUIRE(nl > 0 && bparams && grads && arena && ws && aligned16(ws) && dx_in && dy2_in && dx_final && x0 && h1_0 && m1_0 && r1_0 && s_last && G,
+                "unimol_stack_bwd: null argument");
+  MMDTI_REQUIRE(!dw_stream || (events && events[0] && events[1] && events[2]), "unimol_stack_bwd: a weight-gradient stream needs three events");
+  const UniArena A(M, D, F, s_bytes);
+  const UniBwdWs W(M, D, F, dw_slab_bytes);
+  MMDTI_REQUIRE(arena_bytes >= A.stride * nl && ws_bytes >= W.total, "unimol_stack_bwd: arena / workspace too small (%lld / %lld bytes)", A.stride * nl, W.total);
+  const char* base = reinterpret_cast<const char*>(arena);
+  char* wb = reinterpret_cast<char*>(ws);
+  hipEvent_t fork = dw_stream ? (hipEvent_t)events[0] : nullptr;
+  const float* dx = dx_in;
+  const void* dy2 = dy2_in;
+  for (int l = nl - 1, it = 0; l >= 0; --l, ++it) {
+    const char* a = base + A.stride * l;
+    const char* prev = a - A.stride;
+    hipEvent_t done = dw_stream ? (hipEvent_t)events[1 + (it & 1)] : nullptr;
+    // (the weight gradients issued two layers ago read this layer workspace and the ring slot about to be written)
+    if (dw_stream && it >= 2 && hipStreamWaitEvent((hipStream_t)stream, done, 0) != hipSuccess) {
+      set_error("unimol_stack_bwd: hipStreamWaitEvent failed");
+      return MMDTI_ERR_LAUNCH;
+    }
+    float* dx_out = l ? reinterpret_cast<float*>(wb + W.dx32[it & 1]) : dx_final;
+    void* dx16_out = l ? static_cast<void*>(wb + W.dx16[it % 3]) : nullptr;
+    const void* const* P = bparams + 6 * l;
+    void* const* Gr = grads + 12 * l;
+    if (int e = unimol_layer_bwd_core(
+            stream, M, B, N, H, D, F, ld, scale, p_res, p_att, seed, l ? site0 + 3 * (l - 1) + 2 : 0u, site0 + 3 * l + 1, site0 + 3 * l, dx, dy2, dx_out,
+            dx16_out, l ? reinterpret_cast<float*>(grads[12 * (l - 1) + 4]) : nullptr, a + A.a, a + A.u, act_dx, a + A.h2,
+            reinterpret_cast<const float*>(a + A.x1), reinterpret_cast<const float*>(a + A.m2), reinterpret_cast<const float*>(a + A.r2), a + A.o, a + A.qkv,
+            l == nl - 1 ? s_last : static_cast<const void*>(a + A.s), l ? static_cast<const void*>(prev + A.ln_out) : h1_0,
+            l ? reinterpret_cast<const float*>(prev + A.x_out) : x0, l ? reinterpret_cast<const float*>(prev + A.mn) : m1_0,
+            l ? reinterpret_cast<const float*>(prev + A.rn) : r1_0, P[0], P[1], P[2], P[3], (const float*)P[4], (const float*)P[5], (float*)Gr[0], (float*)Gr[1],
+            (float*)Gr[2], (float*)Gr[3], (float*)Gr[5], (float*)Gr[6], (float*)Gr[7], (float*)Gr[8], (float*)Gr[9], (float*)Gr[10], (float*)Gr[11], G,
+            pair_layout, it == 0 ? g_first_zero : 0, key_tiles, row_off, wb + W.lws[it & 1], W.layer_ws, fwd_f16, dw_stream, fork, done))
+      return e;
+    dx = dx_out;
+    dy2 = dx16_out;
+  }
+  if (dw_stream) {
+    for (int i = 0; i < 2 && i < nl; ++i)
+      if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)events[1 + i], 0) != hipSuccess) {
+        set_error("unimol_stack_bwd: join failed");
+        return MMDTI_ERR_LAUNCH;
+      }
+  }
+  return MMDTI_OK;
 }
 
 /* Forward of one post-LN BERT layer with SELF-attention, the q | k | v projection as one GEMM and the fused attention kernels

@@ -611,8 +611,10 @@ template <int MODE>
 __global__ __launch_bounds__(256) void linear_f32_tile_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
                                                               const float* __restrict__ y, const float* __restrict__ dy, int rows, int in_f,
                                                               int out_f, int act, float* __restrict__ out, float* __restrict__ db) {
-  __shared__ float sA[32][33];   // [m][k]
-  __shared__ float sB[32][33];   // [k][n]
+  // (four 32-deep k slices per barrier pair: at the head's 32 rows the grid is a dozen workgroups and the loop is pure load latency --
+  //  sixteen loads in flight per thread per trip instead of four)
+  __shared__ float sA[4][32][33];   // [slice][m][k]
+  __shared__ float sB[4][32][33];   // [slice][k][n]
   const int M = MODE == 2 ? out_f : rows, N = MODE == 0 ? out_f : (MODE == 1 ? in_f : in_f + 1), K = MODE == 0 ? in_f : (MODE == 1 ? out_f : rows);
   const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -625,31 +627,39 @@ __global__ __launch_bounds__(256) void linear_f32_tile_kernel(const float* __res
     return g;
   };
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < K; k0 += 32) {
+  for (int kb0 = 0; kb0 < K; kb0 += 128) {
+    const int ns = (min(128, K - kb0) + 31) / 32;      // slices of this trip (uniform over the workgroup)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int u = ty + 8 * i;   // the slow index of this thread's element, tx the contiguous one
-      if (MODE == 0) {
-        const int m = m0 + u, n = n0 + u, k = k0 + tx;
-        sA[u][tx] = (m < M && k < K) ? x[(long long)m * in_f + k] : 0.f;
-        sB[tx][u] = (n < N && k < K) ? W[(long long)n * in_f + k] : 0.f;
-      } else if (MODE == 1) {
-        const int m = m0 + u, k = k0 + tx;
-        sA[u][tx] = (m < M && k < K) ? dz(m, k) : 0.f;
-        const int kb = k0 + u, n = n0 + tx;
-        sB[u][tx] = (kb < K && n < N) ? W[(long long)kb * in_f + n] : 0.f;
-      } else {
-        const int k = k0 + u, m = m0 + tx, n = n0 + tx;
-        sA[tx][u] = (k < K && m < M) ? dz(k, m) : 0.f;
-        sB[u][tx] = (k < K && n < N) ? (n < in_f ? x[(long long)k * in_f + n] : 1.f) : 0.f;
+    for (int sl = 0; sl < 4; ++sl) {
+      if (sl >= ns) break;
+      const int k0 = kb0 + sl * 32;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int u = ty + 8 * i;   // the slow index of this thread's element, tx the contiguous one
+        if (MODE == 0) {
+          const int m = m0 + u, n = n0 + u, k = k0 + tx;
+          sA[sl][u][tx] = (m < M && k < K) ? x[(long long)m * in_f + k] : 0.f;
+          sB[sl][tx][u] = (n < N && k < K) ? W[(long long)n * in_f + k] : 0.f;
+        } else if (MODE == 1) {
+          const int m = m0 + u, k = k0 + tx;
+          sA[sl][u][tx] = (m < M && k < K) ? dz(m, k) : 0.f;
+          const int kb = k0 + u, n = n0 + tx;
+          sB[sl][u][tx] = (kb < K && n < N) ? W[(long long)kb * in_f + n] : 0.f;
+        } else {
+          const int k = k0 + u, m = m0 + tx, n = n0 + tx;
+          sA[sl][tx][u] = (k < K && m < M) ? dz(k, m) : 0.f;
+          sB[sl][u][tx] = (k < K && n < N) ? (n < in_f ? x[(long long)k * in_f + n] : 1.f) : 0.f;
+        }
       }
     }
     __syncthreads();
+    for (int sl = 0; sl < ns; ++sl) {
 #pragma unroll 8
-    for (int kk = 0; kk < 32; ++kk) {
-      const float bv = sB[kk][tx];
+      for (int kk = 0; kk < 32; ++kk) {
+        const float bv = sB[sl][kk][tx];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] += sA[ty * 4 + i][kk] * bv;
+        for (int i = 0; i < 4; ++i) acc[i] += sA[sl][ty * 4 + i][kk] * bv;
+      }
     }
     __syncthreads();
   }

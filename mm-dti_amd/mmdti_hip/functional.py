@@ -203,7 +203,13 @@ class PairEncoderFn(torch.autograd.Function):
         # (fp16 forward operands: the library's sequence covers the compact pair planes -- the only layout with fp16 q | k | v kernels)
         seq = LAYER_SEQ and emb.is_cuda and (compact or not ops.FWD_F16) and not ops.kernel_timer.names and D == H * 8
         kp0 = ops._u8(padding_mask) if seq else None
-        for li, layer in enumerate(mod.layers):
+        # small batches: ALL layers from one library call (see _unimol_stack_fwd); the per-layer loop below then has nothing left to do
+        st.stack = None
+        T = (_unimol_stack_tables(mod, M) if (seq and keep and STACK_SEQ and nlayers and M < STACK_MAX_ROWS and not aux_grads
+                                                and mod.final_layer_norm is not None) else None)
+        if T is not None:
+            x, out, s_prev = _unimol_stack_fwd(st, T, mod, x, s_prev, kp0, key_tiles, pack is None, row_off, scale, sites, tiled)
+        for li, layer in enumerate(mod.layers if T is None else ()):
             L = SimpleNamespace(x=x)
             ln1, ln2 = layer.self_attn_layer_norm, layer.final_layer_norm
             att = layer.self_attn
@@ -282,6 +288,8 @@ class PairEncoderFn(torch.autograd.Function):
         if mod.final_layer_norm is not None:
             fl = mod.final_layer_norm
             nxt = (st.p_res, st.layers[-1].site_f, gbuf(mod.layers[-1].fc2.bias)) if st.layers else None
+            if st.stack is not None:
+                nxt = (st.p_res, st.stack.site0 + 3 * (st.stack.T.nl - 1) + 2, gbuf(mod.layers[-1].fc2.bias))
             dx = ops.layernorm_bwd(dout, st.x_last, fl.weight, st.f_mean, st.f_rstd, gbuf(fl.weight), gbuf(fl.bias), dres=dx_pre, bf16_copy=nxt)
             dx, dx16 = dx if nxt is not None else (dx, None)
         else:
@@ -295,6 +303,10 @@ class PairEncoderFn(torch.autograd.Function):
                 G.masked_fill_(st.pad.view(B, 1, 1, N), 0.0)
             if G.shape[-1] > N and not ops.pair_is_tiled(G):
                 G[..., N:] = 0.0
+        if st.stack is not None:
+            dx, G = _unimol_stack_bwd(st, dx, dx16, scale)
+            notify_grads_ready(st.stack.T.params)
+            st.stack = None
         below = [Lb.site_f for Lb in st.layers[:-1]]      # site of the FFN dropout of the layer UNDER each layer
         deferred, deferred_layers = [], []
         # (holding weight gradients back for the end pays where the pair-bias backward has work to hide -- large batches; at a few
@@ -361,6 +373,166 @@ class PairEncoderFn(torch.autograd.Function):
         _launch_deferred_wgrads(deferred, deferred_layers)
         _join_stream_after_backward()
         return (demb if st.packed else demb.view(B, N, D)), G, None, None, None, None, None, None
+
+
+# ---- all layers of the tower behind one library call per direction (csrc/layers.hip: mmdti_unimol_stack_fwd / _bwd).  At the
+# reference's batch size (16-32 molecules) the step is paced by the host: the per-layer calls below still cost ~90 us of Python per
+# layer and direction (17 allocations, 60 marshalled arguments, shadow look-ups).  The stack calls take the parameters as pointer
+# tables cached per model and keep the saved tensors at fixed offsets of one arena: one allocation and one call for 15 layers.
+# Above MMDTI_STACK_MAX_ROWS rows the GPU sets the pace and the per-layer path (which frees each layer's activations as the
+# backward advances and holds the last layers' weight gradients back) stays in charge.
+STACK_SEQ = os.environ.get("MMDTI_STACK_SEQ", "1") != "0"
+STACK_MAX_ROWS = int(os.environ.get("MMDTI_STACK_MAX_ROWS", "8192"))
+# (weight gradients of the stack backward on a side stream, under the layer below: measured at 32 molecules -- 6.92 vs 6.95 ms, no
+#  gain, the step is bound by the chip's throughput on small kernels, not by the length of one stream's chain -- so it stays opt-in)
+STACK_SIDE_WGRAD = os.environ.get("MMDTI_STACK_SIDE_WGRAD", "0") != "0"
+_stack_layouts = {}
+_stack_sides = {}
+
+
+def _ptr_table(ptrs):
+    import ctypes
+    arr = (ctypes.c_void_p * len(ptrs))(*ptrs)
+    return arr, ctypes.addressof(arr)
+
+
+def _unimol_stack_tables(mod, M):
+    """Pointer tables of the encoder's layers for the stack calls (cached on the parameter arena), or None when the stack calls do not
+    cover this model: parameters outside one arena or frozen, layers of different shapes, dimensions the grouped weight-gradient kernels
+    do not take."""
+    layers = list(mod.layers)
+    l0 = layers[0]
+    arena = getattr(l0.fc1.weight, "_mmdti_arena", None)
+    if arena is None or not ops.GROUPED_DW or M < ops.GROUPED_DW_MIN_ROWS:
+        return None
+    cache = arena.__dict__.setdefault("_stack_tables", {})
+    key = (id(mod), ops.FWD_F16)
+    T = cache.get(key)
+    if T is None:
+        D, F = l0.fc1.weight.shape[1], l0.fc1.weight.shape[0]
+        eps = l0.final_layer_norm.eps
+
+        def plist(l):
+            a = l.self_attn
+            return [a.in_proj.weight, a.in_proj.bias, a.out_proj.weight, a.out_proj.bias, l.final_layer_norm.weight, l.final_layer_norm.bias,
+                    l.fc1.weight, l.fc1.bias, l.fc2.weight, l.fc2.bias, l.self_attn_layer_norm.weight, l.self_attn_layer_norm.bias]
+        ok = D % 256 == 0 and F % 256 == 0
+        for l in layers:
+            ps = plist(l)
+            ok = ok and all(q is not None and q.requires_grad and getattr(q, "_mmdti_arena", None) is arena for q in ps)
+            ok = ok and tuple(l.fc1.weight.shape) == (F, D) and l.final_layer_norm.eps == eps and l.self_attn_layer_norm.eps == eps
+            ok = ok and len(list(l.parameters())) == 12
+        if not ok:
+            cache[key] = False
+            return None
+        if ops.FWD_F16:
+            arena._fresh16()
+        sh16 = (arena.shadow16 if ops.FWD_F16 else arena.shadow).data_ptr()
+        shb, gr, off = arena.shadow.data_ptr(), arena.grad.data_ptr(), arena.offsets
+        fwd, bwd, grads, weights, params = [], [], [], [], []
+        for l in layers:
+            ps = plist(l)
+            params += ps
+            w_in, b_in, w_out, b_out, g2, bt2, w1, b1, w2, b2, g1, bt1 = ps
+            for i, q in enumerate(ps):
+                fwd.append(sh16 + 2 * off[id(q)] if i in (0, 2, 6, 8) else q.data_ptr())
+            bwd += [shb + 2 * off[id(w2)], shb + 2 * off[id(w1)], shb + 2 * off[id(w_out)], shb + 2 * off[id(w_in)], g2.data_ptr(), g1.data_ptr()]
+            grads += [gr + 4 * off[id(q)] for q in (w2, w1, w_out, w_in, b2, b1, b_out, b_in, g2, bt2, g1, bt1)]
+            weights += [(q, id(q)) for q in (w_in, w_out, w1, w2)]
+        T = cache[key] = SimpleNamespace(nl=len(layers), D=D, F=F, eps=eps, fwd=_ptr_table(fwd), bwd=_ptr_table(bwd), grads=_ptr_table(grads),
+                                         weights=weights, params=params, arena=arena, f16=ops.FWD_F16, n_shadow16=arena.shadow16 is not None,
+                                         probes=[(l.fc1.weight, l.fc1.weight.data_ptr(), gr + 4 * off[id(l.fc1.weight)]) for l in layers])
+    if T is False:
+        return None
+    ver = arena._version
+    for q, i in T.weights:                       # an in-place write since the last cast (load_state_dict on a bound model): re-cast
+        if q._version != ver[i]:
+            arena._fresh(q)
+    if T.f16:
+        arena._fresh16()
+    for q, dptr, gptr in T.probes:               # storage or gradient views re-bound behind our back: the per-layer path looks them up
+        g = q.grad
+        if g is None or g.data_ptr() != gptr or q.data_ptr() != dptr:
+            return None
+    return T
+
+
+def _unimol_stack_layout(M, D, F, s_bytes):
+    key = (M, D, F, s_bytes)
+    r = _stack_layouts.get(key)
+    if r is None:
+        import ctypes
+        tiles = (D // 256) * (F // 256) * 2 + (D // 256) ** 2 * 4
+        slab = ops.lib()._dll.mmdti_linear_dw_grouped_splits(tiles, M) * (2 * D * F + 4 * D * D) * 4
+        out = (ctypes.c_longlong * 2)()
+        ops.lib().mmdti_unimol_stack_layout(M, D, F, s_bytes, slab, ctypes.addressof(out))
+        if len(_stack_layouts) > 4096:
+            _stack_layouts.clear()
+        r = _stack_layouts[key] = (int(out[0]), int(out[1]), slab)
+    return r
+
+
+def _stack_side():
+    """(stream handle, address of the three events) for the side-stream weight gradients of a stack backward, or (0, 0)."""
+    if not STACK_SIDE_WGRAD or torch.cuda.is_current_stream_capturing():
+        return 0, 0
+    main = torch.cuda.current_stream()
+    key = (main.device.index, main.cuda_stream)
+    ent = _stack_sides.get(key)
+    if ent is None:
+        side = torch.cuda.Stream(device=main.device)
+        evs = [torch.cuda.Event() for _ in range(3)]
+        for e in evs:
+            e.record(main)                       # (creates the hipEvent_t behind the handle)
+        ent = _stack_sides[key] = (side, evs, _ptr_table([e.cuda_event for e in evs]))
+    return ent[0].cuda_stream, ent[2][1]
+
+
+def _unimol_stack_fwd(st, T, mod, x, s_prev, key_pad, key_tiles, rag_store_last, row_off, scale, sites, tiled):
+    """All layers' forward as ONE library call -> (x_last fp32, final LayerNorm output fp32, S of the last layer)."""
+    M, D, F, B, N, H, ld = st.M, st.D, T.F, st.B, st.N, st.H, st.ld
+    dev = x.device
+    l0 = mod.layers[0]
+    ln1, fl = l0.self_attn_layer_norm, mod.final_layer_norm
+    _, h1, m1, r1 = ops.layernorm_fwd(x, ln1.weight, ln1.bias, ln1.eps)
+    e = torch.empty
+    s_last = torch.empty_like(s_prev) if tiled else e(B, H, N, ld, device=dev, dtype=F32)
+    s_bytes = s_last.numel() * s_last.element_size()
+    stride, ws_bytes, slab = _unimol_stack_layout(M, D, F, s_bytes)
+    arena = e(stride * T.nl, device=dev, dtype=torch.uint8)
+    x_last, out = e(M, D, device=dev, dtype=F32), e(M, D, device=dev, dtype=F32)
+    st.f_mean, st.f_rstd = e(M, device=dev, dtype=F32), e(M, device=dev, dtype=F32)
+    site0 = sites.n + 1
+    sites.n += 3 * T.nl
+    p = ops._p
+    ops.lib().mmdti_unimol_stack_fwd(
+        ops._stream(), T.nl, M, B, N, H, D, F, ld, float(scale), float(st.p_res), float(st.p_att), int(st.seed), site0, x.data_ptr(), h1.data_ptr(),
+        s_prev.data_ptr(), p(key_pad), ops._pair_layout_s(s_prev, "pair_attn.bias"), p(key_tiles), int(rag_store_last), p(row_off), T.fwd[1],
+        ops.ACT_GELU_FWD, float(T.eps), fl.weight.data_ptr(), fl.bias.data_ptr(), float(fl.eps), ops.GEMM_LN_MAX_K if ops.GEMM_LN else 0, arena.data_ptr(),
+        arena.numel(), s_bytes, x_last.data_ptr(), s_last.data_ptr(), out.data_ptr(), st.f_mean.data_ptr(), st.f_rstd.data_ptr(),
+        int(h1.dtype == torch.float16))
+    st.stack = SimpleNamespace(T=T, arena=arena, s_bytes=s_bytes, ws_bytes=ws_bytes, slab=slab, site0=site0, x0=x, h1=h1, m1=m1, r1=r1, s_last=s_last)
+    return x_last, out, s_last
+
+
+def _unimol_stack_bwd(st, dx, dx16, scale):
+    """All layers' backward as ONE library call -> (gradient of the stream entering layer 0, pair-gradient chain G)."""
+    S = st.stack
+    T = S.T
+    M, D = st.M, st.D
+    dev = dx.device
+    G = (torch.empty if st.kt is None else torch.zeros)(S.s_last.shape, device=dev, dtype=ops.pair_grad_dtype(S.s_last))
+    layout = ops._pair_layout_s(S.s_last, "pair_attn_bwd.s") | (4 if G.dtype == BF16 else 0)
+    dx_final = torch.empty_like(dx)
+    ws = torch.empty(S.ws_bytes, device=dev, dtype=torch.uint8)
+    side, events = _stack_side()
+    p = ops._p
+    ops.lib().mmdti_unimol_stack_bwd(
+        ops._stream(), T.nl, M, st.B, st.N, st.H, D, T.F, st.ld, float(scale), float(st.p_res), float(st.p_att), int(st.seed), S.site0, dx.data_ptr(),
+        dx16.data_ptr(), dx_final.data_ptr(), S.x0.data_ptr(), S.h1.data_ptr(), S.m1.data_ptr(), S.r1.data_ptr(), S.s_last.data_ptr(), T.bwd[1],
+        ops.ACT_GELU_DX, T.grads[1], G.data_ptr(), layout, 1, p(st.kt), p(st.row_off), S.arena.data_ptr(), S.arena.numel(), S.s_bytes, ws.data_ptr(),
+        ws.numel(), S.slab, int(S.h1.dtype == torch.float16), side, events)
+    return dx_final, G
 
 
 def _unimol_layer_fwd_seq(st, layer, L, s_prev, key_pad, key_tiles, rag_store, row_off, scale, nl, next_mode):

@@ -353,6 +353,85 @@ def test_unimol_layer_backward_sequenced_in_the_library_equals_the_op_by_op_path
 
 
 @pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("side", [True, False])
+def test_unimol_stack_sequenced_in_the_library_equals_the_per_layer_calls(M, packed, side, monkeypatch):
+    """Small batches (below functional.STACK_MAX_ROWS rows, parameters in a ParamArena): ALL layers of the tower leave from one library
+    call per direction (mmdti_unimol_stack_fwd / _bwd: pointer tables + one activation arena), the weight gradients on a side stream
+    under the layer below (`side`).  The launches are those of the per-layer calls: output, input gradient and pair-bias gradients
+    bit-identical, parameter gradients to the atomics' noise.  Training mode, dense and packed rows, 4 layers (so that both layer
+    workspaces and all three slots of the bf16 gradient ring are reused), with the encoder's final LayerNorm."""
+    from mmdti_hip import functional as Fn, ops
+    from mmdti_hip.functional import PairBiasFn
+    from mmdti_hip.runtime import dropout_state, ParamArena
+    from mmdti_hip.packing import PackedRows
+    monkeypatch.setattr(Fn, "STACK_SIDE_WGRAD", side)
+    B, N, D, H, K, V = 6, 40, 512, 64, 128, 31
+    ucfg = O.UniMolCfg(layers=4, dim=D, ffn=256, heads=H, K=K, vocab=V)
+    cfg = O.ModelCfg(unimol=ucfg, roberta=O.RobertaCfg(layers=1, dim=64, heads=4, ffn=128, vocab=40, max_pos=40), cross=O.CrossCfg(dim=64, heads=4, ffn=128))
+    P = O.init_params(cfg, seed=3, std=0.06)
+    g = torch.Generator().manual_seed(6)
+    lens = [40, 23, 31, 12, 35, 28]
+    pad = torch.zeros(B, N, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        pad[b, n:] = True
+    emb, dist = torch.randn(B, N, D, generator=g), torch.rand(B, N, N, generator=g) * 6
+    et = torch.randint(0, V * V, (B, N, N), generator=g)
+    enc = M.tr.TransformerEncoderWithPair(encoder_layers=4, embed_dim=D, ffn_embed_dim=256, attention_heads=H, no_final_head_layer_norm=True).cuda().train()
+    gbf, proj = M.mm.GaussianLayer(K, V * V).cuda(), M.mm.NonLinearHead(K, H, "gelu").cuda()
+    load_params(enc, P, "encoder."); load_params(gbf, P, "gbf."); load_params(proj, P, "gbf_proj.")
+    arena = ParamArena(list(enc.parameters()) + list(gbf.parameters()) + list(proj.parameters()))
+    counts = torch.tensor(lens)
+    kt_host = (counts + 15) // 16
+    kt = kt_host.to(torch.int32).cuda()
+    pk = PackedRows(counts, N, "cuda") if packed else None
+    calls = []
+    real_f, real_b, real_l = Fn._unimol_stack_fwd, Fn._unimol_stack_bwd, Fn._unimol_layer_bwd_seq
+    monkeypatch.setattr(Fn, "_unimol_stack_fwd", lambda *a, **k: (calls.append("F"), real_f(*a, **k))[1])
+    monkeypatch.setattr(Fn, "_unimol_stack_bwd", lambda *a, **k: (calls.append("B"), real_b(*a, **k))[1])
+    monkeypatch.setattr(Fn, "_unimol_layer_bwd_seq", lambda *a, **k: (calls.append("l"), real_l(*a, **k))[1])
+
+    def run(stack):
+        monkeypatch.setattr(Fn, "STACK_SEQ", stack)
+        arena.zero_grad()
+        dropout_state.reseed(4242)
+        if packed:
+            e = emb.cuda().reshape(B * N, D)[pk.gather].clone().requires_grad_()
+            bias = PairBiasFn.apply(gbf.means.weight, dist.cuda(), et.cuda(), gbf, proj, ops.pair_ld(N), kt_host, pk.rows_host)
+            x = enc.encode(e, bias, pad.cuda().reshape(-1)[pk.gather], kt, pack=pk)[0]
+        else:
+            e = emb.cuda().clone().requires_grad_()
+            bias = PairBiasFn.apply(gbf.means.weight, dist.cuda(), et.cuda(), gbf, proj, ops.pair_ld(N), kt_host)
+            x = enc.encode(e, bias, pad.cuda(), kt)[0]
+        w = torch.randn(x.shape, generator=torch.Generator().manual_seed(9)).cuda()
+        (x * w).sum().backward()
+        torch.cuda.synchronize()
+        grads = {n: p.grad.clone() for mod, pre in ((enc, "encoder."), (gbf, "gbf."), (proj, "gbf_proj.")) for n, p in ((pre + k, v) for k, v in mod.named_parameters())
+                 if p.grad is not None}
+        return x.detach().clone(), e.grad.clone(), grads
+
+    x0, de0, g0 = run(False)
+    assert calls.count("l") == 4 and "F" not in calls and "B" not in calls
+    del calls[:]
+    x1, de1, g1 = run(True)
+    assert calls == ["F", "B"]                                        # one call per direction, no per-layer call left
+    assert torch.equal(x0, x1)
+    assert torch.equal(de0, de1)
+    assert set(g0) == set(g1)
+    for n in g0:
+        d = float((g0[n].double() - g1[n].double()).norm()) / (float(g0[n].double().norm()) + 1e-30)
+        # (pair-bias tables: the gradient chain G they are reduced from is bit-identical; mul / bias collect per-edge-type sums with
+        #  LDS atomics inside a workgroup)
+        assert d < (1e-5 if n.startswith("gbf") else 2e-4), (n, d)
+    # an in-place reload of a bound model (tasks/trainer.py:406-410 loads the best checkpoint into the trained model): the cached
+    # tables still point at the arena, whose shadows are re-cast before the stack reads them
+    with torch.no_grad():
+        enc.layers[1].fc1.weight.mul_(0.5)
+    x2, _, _ = run(True)
+    x3, _, _ = run(False)
+    assert torch.equal(x2, x3) and not torch.equal(x2, x1)
+
+
+@pytest.mark.parametrize("packed", [False, True])
 def test_bert_layer_sequenced_in_the_library_equals_the_op_by_op_path(M, packed, monkeypatch):
     """The same for tower 2: a RoBERTa layer's six forward / eight backward launches from one library call each (self-attention, fused
     q | k | v projection, fused attention kernels -- the hot variant).  Training mode, dense and packed sequences: output and input
