@@ -219,6 +219,22 @@ static inline uint32_t dropout_thresh(float p) {
   return (uint32_t)t;
 }
 
+// ---- Tiled pair planes ("blocked rows").  A (molecule, head) plane of N x N pair values is stored per block of 16 queries; inside a
+// block the 4-key groups follow each other, each holding its `vr` query rows x 4 keys (vr = 16, or N - 16 qb in the last block):
+//     off(query i, key j) = 16 qb N4 + vr (j & ~3) + 4 (i & 15) + (j & 3),      qb = i >> 4, N4 = N rounded up to 4
+// A 16 x 16 tile of a complete block is therefore 256 contiguous elements in MFMA accumulator order (lane = (key group, query), 4
+// consecutive keys per lane) -- what the pair-attention kernels stream with one 8- / 16-byte access per lane -- and NOTHING is stored for
+// queries or 4-key groups past N: at the reference's 128 atoms + BOS / EOS (N = 130) the planes hold 130 x 132 slots instead of the
+// 144 x 144 of whole 16 x 16 tiles, 17 % less traffic in every pass over S and G.  Keys N .. N4 - 1 of a real query are pad slots: -inf
+// in S, 0 in G, written by the pair-bias kernel and preserved by every store.  Plane stride: pair_plane(N) elements (a multiple of 8,
+// so that planes of 2-byte elements stay 16-byte aligned).
+__host__ __device__ __forceinline__ int pair_n4(int N) { return (N + 3) & ~3; }
+__host__ __device__ __forceinline__ long long pair_plane(int N) { return ((long long)N * pair_n4(N) + 7) & ~7ll; }
+__host__ __device__ __forceinline__ long long pair_off(int N, int i, int j) {
+  const int q0 = i & ~15, vr = N - q0 < 16 ? N - q0 : 16;
+  return (long long)q0 * pair_n4(N) + vr * (j & ~3) + ((i & 15) << 2) + (j & 3);
+}
+
 // erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32-exact for GELU purposes): one v_exp + one v_rcp + 6
 // FMAs instead of ocml's branchy erff (~40 instructions) -- the GELU epilogue was costing 40 % of the fc1 GEMM.
 __device__ __forceinline__ float fast_erf(float x) {

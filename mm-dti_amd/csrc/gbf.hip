@@ -155,11 +155,9 @@ __global__ __launch_bounds__(256) void pair_permute_bwd_kernel(const float* __re
   extern __shared__ float tile[];  // [H][NP], NP odd
   const int bi = blockIdx.x, b = bi / N, i = bi - b * N;
   const int NP = N | 1;
-  const int nt = (N + 15) >> 4;
   for (int t = threadIdx.x; t < H * N; t += 256) {
     const int h = t / N, j = t - h * N;
-    const long long off = tiled ? ((long long)(b * H + h) * nt * nt + (i >> 4) * nt + (j >> 4)) * 256 + (((j & 15) >> 2) * 16 + (i & 15)) * 4 + (j & 3)
-                                : (((long long)b * H + h) * N + i) * ld + j;
+    const long long off = tiled ? (long long)(b * H + h) * pair_plane(N) + pair_off(N, i, j) : (((long long)b * H + h) * N + i) * ld + j;
     tile[h * NP + j] = g[off];
   }
   __syncthreads();
@@ -303,11 +301,11 @@ __global__ __launch_bounds__(512, 2) void gbf_bias_fwd_kernel(const float* __res
   const int nwaves = (int)gridDim.x * 8;
   int b_run = 0;   // (fetch is called with increasing tiles: the molecule index only moves forward)
   // Pair tiles of 16.  Row-major planes: 16 consecutive q = i*ld + j (64 contiguous bytes of every head plane).  Tiled
-  // planes ([nt][nt][256], 16x16 tiles in MFMA accumulator order -- the layout the pair-attention kernels stream): a
-  // 4x4 (query, key) block, which is again 64 contiguous bytes; blocks past N are visited too so that EVERY pad slot of
-  // the plane holds -inf (the attention kernels then need no masking of pad keys / rows).
-  const int nt = (N + 15) >> 4, nblk = nt * 4;
-  const long long plane = TILED ? (long long)nt * nt * 256 : (long long)N * ld;
+  // planes (the blocked rows of common.h, 16x16 tiles in MFMA accumulator order -- the layout the pair-attention kernels
+  // stream): a 4x4 (query, key) block, which is again 64 contiguous bytes.  The blocks that hold a real pair cover every slot
+  // of the plane; the pad keys N .. N4-1 of a real query receive -inf (the attention kernels then need no masking of pad keys).
+  const int nblk = (N + 3) >> 2;
+  const long long plane = TILED ? pair_plane(N) : (long long)N * ld;
   // flags: bit 0 valid pair, bit 1 slot inside the plane, bit 2 whole block past N
   auto fetch = [&](int tile, int& b, int& q, int& flags, unsigned& pl, int& e, float& d) {
     tile = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : ntiles - 1);
@@ -329,10 +327,11 @@ __global__ __launch_bounds__(512, 2) void gbf_bias_fwd_kernel(const float* __res
       // 4-row blocks are produced (the pair-attention kernels read no query row past it)
       const int rbk = (rag && row_blocks) ? row_blocks[b] : nblk;
       const int cb = (int)((unsigned)tq / (unsigned)rbk), rb = tq - cb * rbk;
-      past = 4 * rb >= N || 4 * cb >= N;   // (the same for every lane of the wave)
+      past = 4 * rb >= N || 4 * cb >= N;   // (the same for every lane of the wave; no such block is enumerated: nothing is stored for it)
       ii = 4 * rb + (i >> 2);
       jj = 4 * cb + (i & 3);
-      q = ((rb >> 2) * nt + (cb >> 2)) * 256 + (cb & 3) * 64 + (rb & 3) * 16 + i;
+      inplane = ii < N;                    // (a row past N has no slot)
+      q = (int)pair_off(N, inplane ? ii : 0, jj);
     } else {
       q = tq * 16 + i;
       ii = (int)((unsigned)q / (unsigned)ld);
@@ -358,7 +357,6 @@ __global__ __launch_bounds__(512, 2) void gbf_bias_fwd_kernel(const float* __res
     const float padv = TILED ? -INFINITY : 0.f;
     OT* ob = out + (long long)b * GBF_H * plane + q;
     if (TILED && past) {
-      for (int hh = 0; hh < GBF_H; ++hh) gbf_put(ob + (long long)hh * plane, padv);
     } else {
     const long long p = (long long)b * N * N + pl;
     const float y = ltab ? sMul[e] * d + sBia[e] : mul[e] * d + bias[e];
@@ -482,8 +480,8 @@ __global__ __launch_bounds__(256, 2) void gbf_bias_bwd_kernel(const GT* __restri
   const int g = lane >> 4, i = lane & 15;
   const long long ntiles = (long long)B * tpm;
   const long long nwaves = (long long)gridDim.x * 4;
-  const int nt = (N + 15) >> 4, nblk = nt * 4;
-  const long long plane = TILED ? (long long)nt * nt * 256 : (long long)N * ld;
+  const int nblk = (N + 3) >> 2;
+  const long long plane = TILED ? pair_plane(N) : (long long)N * ld;
   // d means / d stds partial sums of this lane: k = 16*kt + 4g + r
   gf32x4 amu[8], asg[8];
 #pragma unroll
@@ -506,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void gbf_bias_bwd_kernel(const GT* __restri
       if (4 * rb >= N || 4 * cb >= N) return;            // whole block past N (the same for every lane of the wave)
       ii = 4 * rb + (i >> 2);
       jj = 4 * cb + (i & 3);
-      q = ((rb >> 2) * nt + (cb >> 2)) * 256 + (cb & 3) * 64 + (rb & 3) * 16 + i;
+      q = (int)pair_off(N, ii < N ? ii : 0, jj);
     } else {
       q = tq * 16 + i;
       ii = q / ld;
@@ -761,8 +759,8 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
   const bool rag = TILED && tile_prefix != nullptr;
   const int ntiles = rag ? tile_prefix[B] : B * tpm;
   int b_run = 0;
-  const int nt = (N + 15) >> 4, nb = (N + 3) >> 2;
-  const long long plane = TILED ? (long long)nt * nt * 256 : (long long)N * ld;
+  const int nb = (N + 3) >> 2;
+  const long long plane = TILED ? pair_plane(N) : (long long)N * ld;
   gf32x4 amu = {0.f, 0.f, 0.f, 0.f}, asg = {0.f, 0.f, 0.f, 0.f};
   gf32x4 aW1[8], aW2[4], aB1 = {0.f, 0.f, 0.f, 0.f}, aB2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -793,7 +791,7 @@ __global__ __launch_bounds__(512, 1) void gbf_bias_bwd_full_kernel(
       const int cb = (int)((unsigned)tq / (unsigned)rbk), rb = tq - cb * rbk;   // query block fastest: see the forward kernel
       ii = 4 * rb + (i >> 2);
       jj = 4 * cb + (i & 3);
-      q = ((rb >> 2) * nt + (cb >> 2)) * 256 + (cb & 3) * 64 + (rb & 3) * 16 + i;
+      q = (int)pair_off(N, ii < N ? ii : 0, jj);
     } else {
       q = tq * 16 + i;
       ii = (int)((unsigned)q / (unsigned)ld);
@@ -1112,20 +1110,22 @@ __global__ __launch_bounds__(256) void gbf_slab_reduce_kernel(const float* __res
   *dst += t;
 }
 
-// Tiled G ([B,H,nt,nt,256], tiles in accumulator order) -> [B,N,N,H] bf16.  One block per (molecule, query block, key
-// tile): the 64 head tiles are 64 contiguous KiB reads; the 16x16 pairs x H heads are regrouped in LDS so that each of
-// the 16 query rows leaves as one contiguous run of 16 keys x H heads.
+// Tiled G (blocked rows, common.h) -> [B,N,N,H] bf16.  One block per (molecule, query block, key tile): a complete tile of a
+// head is one contiguous KiB; the 16x16 pairs x H heads are regrouped in LDS so that each of the 16 query rows leaves as one
+// contiguous run of 16 keys x H heads.
 __global__ __launch_bounds__(256) void pair_untile_bwd_kernel(const float* __restrict__ g, bf16_t* __restrict__ out, int N, int H,
                                                               int nt) {
   extern __shared__ bf16_t ptile[];  // [256 pairs][H + 2]
   const int HP = H + 2;
   const int t = blockIdx.x % nt, qb = (blockIdx.x / nt) % nt, b = blockIdx.x / (nt * nt);
-  const long long plane = (long long)nt * nt * 256;
-  const float* src = g + (long long)b * H * plane + ((long long)qb * nt + t) * 256;
+  const long long plane = pair_plane(N);
+  const int vr = min(16, N - qb * 16);
+  const float* src = g + (long long)b * H * plane + (long long)qb * 16 * pair_n4(N) + vr * 16 * t;
   for (int e = threadIdx.x; e < H * 64; e += 256) {      // one float4 (4 keys of one query) per step
     const int h = e >> 6, l = e & 63;
-    const float4 v = *reinterpret_cast<const float4*>(src + (long long)h * plane + l * 4);
     const int q = l & 15, k0 = (l >> 4) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < vr && t * 16 + k0 < N) v = *reinterpret_cast<const float4*>(src + (long long)h * plane + ((l >> 4) * vr + q) * 4);
     bf16_t* d = ptile + (q * 16 + k0) * HP + h;
     d[0] = f2bf(v.x); d[HP] = f2bf(v.y); d[2 * HP] = f2bf(v.z); d[3 * HP] = f2bf(v.w);
   }
@@ -1226,8 +1226,8 @@ extern "C" int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, cons
   const bool save = feat_bf16 || u_bf16 || h_bf16;
   MMDTI_REQUIRE(!save || (feat_bf16 && u_bf16 && h_bf16 && aligned16(feat_bf16) && aligned16(u_bf16) && aligned16(h_bf16)),
                 "gbf_bias_fwd: the three saved intermediates come together, 16-byte aligned");
-  const int nt = (N + 15) / 16;
-  const int tpm = tiled ? 16 * nt * nt : cdiv((long long)N * ld, 16);
+  const int nb4 = (N + 3) / 4;      // tiled planes: the 4x4 blocks that hold a real pair
+  const int tpm = tiled ? nb4 * nb4 : cdiv((long long)N * ld, 16);
   const long long ntiles = (long long)B * tpm;
   MMDTI_REQUIRE(ntiles < (1ll << 30) && (long long)N * N < (1ll << 30), "gbf_bias_fwd: batch too large for 32-bit tile indices");
   const int grid = (int)((ntiles + 7) / 8 < 512 ? (ntiles + 7) / 8 : 512);     // two resident workgroups per CU
@@ -1273,8 +1273,8 @@ extern "C" int mmdti_gbf_bias_bwd(mmdti_stream_t stream, const void* g, const fl
   MMDTI_REQUIRE(B > 0 && N > 0 && ld >= N && ld % 4 == 0 && E > 0 && E <= GBF_MAXE, "gbf_bias_bwd: bad shape (E <= %d)", GBF_MAXE);
   MMDTI_REQUIRE(edge_bytes_ok(edge_bytes), "gbf_bias_bwd: edge types must be int64, int32 or int16 (edge_bytes=%d)", edge_bytes);
   MMDTI_REQUIRE(aligned16(u_bf16) && aligned16(do_bf16) && aligned16(du_bf16), "gbf_bias_bwd: 16-byte alignment required");
-  const int nt = (N + 15) / 16;
-  const int tpm = tiled ? 16 * nt * nt : cdiv((long long)N * ld, 16);
+  const int nb4 = (N + 3) / 4;      // tiled planes: the 4x4 blocks that hold a real pair
+  const int tpm = tiled ? nb4 * nb4 : cdiv((long long)N * ld, 16);
   const long long ntiles = (long long)B * tpm;
   const int grid = (int)(ntiles / 4 + 1 < 1024 ? ntiles / 4 + 1 : 1024);
   const size_t smem = (size_t)GBF_K * GBF_WS * 2 + (size_t)GBF_F * GBF_W2S * 2 + (size_t)(3 * GBF_K + 4 * E) * 4;

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, NT > 9 ? 2 : 4) void pair_attn_fwd_mfma_kernel
   __syncthreads();
   const int g = lane >> 4, c16 = lane & 15;
   const float NEG_INF = -INFINITY;
-  // Layouts (TILED): row-major [N][ld] planes, or [nKB][nKB][256] planes whose 16x16 tiles are stored in accumulator
+  // Layouts (TILED): row-major [N][ld] planes, or the blocked-row planes of common.h whose 16x16 tiles are stored in accumulator
   // order -- a wave's access to a tile is then one contiguous KiB at a compile-time offset from the query block's base,
   // and, because every pad slot of a tiled tensor holds -inf (written by mmdti_gbf_bias_fwd, preserved by every S
   // store), interior tiles need no predicate and no pad masking at all.  Only the last query block (EDGE) and the last
@@ -185,12 +185,16 @@ __global__ __launch_bounds__(256, NT > 9 ? 2 : 4) void pair_attn_fwd_mfma_kernel
     const pa_s16x4 zero4 = {0, 0, 0, 0};
     // B of S^T = K.Q^T : Q[query c16][d = 4g..4g+3] (k = d: lane groups 2, 3 carry zeros)
     const pa_s16x4 qv = g < 2 ? *reinterpret_cast<const pa_s16x4*>(sQ + (qb * 16 + c16) * 8 + 4 * g) : zero4;
-    const long long tbase = ((long long)bh * nKB + qb) * nKB * 256 + lane * 4;
+    // (tiled planes, common.h "blocked rows": the block of 16 queries starts at 16 qb N4, a lane's 4 keys of tile t sit at
+    //  vr (16 t + 4 g) + 4 c16 -- 256 t + 4 lane in a complete block; lanes past the last query of an incomplete block point at query 0,
+    //  key groups past N4 -- N <= 12 only -- at group 0: whatever a predicate-off lane reads lies inside the plane)
+    const int vr = EDGE ? min(16, N - qb * 16) : 16;
+    const long long tbase = (long long)bh * pair_plane(N) + (long long)qb * 16 * pair_n4(N) + ((4 * g < pair_n4(N) ? g : 0) * vr + (qvalid ? c16 : 0)) * 4;
     // (row-major: the lane's 4 keys of tile t start at rowoff + 16t + 4g; a lane whose predicate is off reads the row's
     //  first 16 bytes instead -- always inside the tensor, unlike "tile 0 + 4g" when ld < 16)
     const ST* bin = bias_in + (TILED ? tbase : rowoff);
     ST* sout = s_out + (TILED ? tbase : rowoff);
-    constexpr int TSTEP = TILED ? 256 : 16;
+    const int TSTEP = TILED ? (EDGE ? vr * 16 : 256) : 16;
     const int goff = TILED ? 0 : 4 * g;
 #define PA_PRED(T) (!TILED ? (qvalid && (T) * 16 + 4 * g < N) \
                            : (qvalid && (FULL ? ((T) < NT - 1 || colok) : ((T) < nlast || ((T) == nlast && colok)))))

@@ -88,11 +88,12 @@ __global__ __launch_bounds__(64 * NW, NT > 9 ? ((NT >= 16 && NW == 3) ? 2 : 1) :
     const uint32_t t8 = thresh ? rng24_row_t8(rk, (uint32_t)qi, thresh) : 0u;   // this query row's drop threshold
     const bool qvalid = EDGE ? qi < rows : true;
     const long long rowoff = ((long long)bh * N + (qvalid ? qi : 0)) * ld;   // (also the dropout counter base)
-    const long long tbase = ((long long)bh * nKB + qb) * nKB * 256 + lane * 4;
+    const int vr = EDGE ? min(16, N - qb * 16) : 16;       // (tiled planes: the blocked rows of common.h, see the forward kernel)
+    const long long tbase = (long long)bh * pair_plane(N) + (long long)qb * 16 * pair_n4(N) + ((4 * g < pair_n4(N) ? g : 0) * vr + (qvalid ? c16 : 0)) * 4;
     const ST* sin_p = s_in + (TILED ? tbase : rowoff);     // (predicate-off lanes read the row's first 16 bytes: in bounds)
     const GT* gin_p = gin + (TILED ? tbase : rowoff);
     GT* gout_p = gout + (TILED ? tbase : rowoff);
-    constexpr int TSTEP = TILED ? 256 : 16;
+    const int TSTEP = TILED ? (EDGE ? vr * 16 : 256) : 16;
     const int goff = TILED ? 0 : 4 * g;
 #define PA_PRED(T) (!TILED ? (qvalid && (T) * 16 + 4 * g < N) \
                            : (qvalid && (FULL ? ((T) < NT - 1 || colok) : ((T) < nlast || ((T) == nlast && colok)))))

@@ -460,19 +460,18 @@ def gbf_tile_prefixes(key_tiles_host, N, device, rows_host=None):
     pair-attention kernels cover (pair_key_tiles_effective).  key_tiles_host: [B] ints on the HOST (no device sync).
     rows_host ([B] ints on the host: packed token rows per molecule, packing.PackedRows.rows_host): the blocks stop at the molecule's
     representative pad row as well -- then (fwd prefix, bwd prefix, fwd row blocks [B], bwd row blocks [B]) come back."""
+    # (both kernels enumerate the 4x4 blocks that hold a real pair -- the tiled planes store nothing else --, column block slowest)
     nt, nb = pair_tiles(N), (N + 3) // 4
     ke = torch.tensor([pair_key_tiles_effective(int(k), nt) for k in key_tiles_host.tolist()], dtype=torch.int64)
     zero = torch.zeros(1, dtype=torch.int64)
     if rows_host is None:
-        fwd = torch.cat([zero, torch.cumsum(4 * ke * (4 * nt), 0)])
-        bwd = torch.cat([zero, torch.cumsum(nb * torch.clamp(4 * ke, max=nb), 0)])
-        both = upload(torch.stack([fwd, bwd]).to(torch.int32), device)
+        pre = torch.cat([zero, torch.cumsum(nb * torch.clamp(4 * ke, max=nb), 0)])
+        both = upload(torch.stack([pre, pre]).to(torch.int32), device)
         return both[0], both[1]
-    rbk = (torch.as_tensor(rows_host, device="cpu").to(torch.int64) + 3) // 4          # 4-row query blocks up to the representative pad row
+    rbk = torch.clamp((torch.as_tensor(rows_host, device="cpu").to(torch.int64) + 3) // 4, max=nb)   # 4-row query blocks up to the representative pad row
     B = rbk.numel()
-    fwd = torch.cat([zero, torch.cumsum(4 * ke * rbk, 0)])
-    bwd = torch.cat([zero, torch.cumsum(torch.clamp(rbk, max=nb) * torch.clamp(4 * ke, max=nb), 0)])
-    flat = upload(torch.cat([fwd, bwd, rbk, torch.clamp(rbk, max=nb)]).to(torch.int32), device)
+    pre = torch.cat([zero, torch.cumsum(rbk * torch.clamp(4 * ke, max=nb), 0)])
+    flat = upload(torch.cat([pre, pre, rbk, rbk]).to(torch.int32), device)
     return flat[:B + 1], flat[B + 1:2 * B + 2], flat[2 * B + 2:3 * B + 2], flat[3 * B + 2:]
 
 
@@ -572,11 +571,19 @@ def pair_permute_bwd(g, B, N, H, ld):
 # --------------------------------------------------------------------------------------------- pair-bias attention
 # Pair tensors (attention bias, per-layer logits S_l, their gradient G) come in two layouts:
 #   standard  [B, H, N, ld]            row-major planes (ld = pair_ld(N))
-#   tiled     [B, H, nt, nt, 256]      nt = ceil(N/16): every 16x16 (query, key) tile stored in MFMA accumulator order, element
-#             (q, k) of a tile at ((k%16)//4 * 16 + q%16) * 4 + k%4 -- a wave's access to a tile is ONE contiguous KiB.
+#   tiled     [B, H, pair_plane(N)]    "blocked rows" (csrc/common.h): per block of 16 queries the 4-key groups follow each other, each
+#             holding its vr query rows x 4 keys (vr = 16, or N - 16 qb in the last block):
+#                 off(q, k) = 16 (q // 16) N4 + vr (k - k % 4) + 4 (q % 16) + k % 4,        N4 = N rounded up to 4
+#             -- a 16x16 tile of a complete block is 256 contiguous elements in MFMA accumulator order (a wave's access to it is ONE
+#             contiguous KiB) and nothing is stored for queries or 4-key groups past N (130 atoms: 130 x 132 slots, not 144 x 144).
 # The tiled form is what the hot path uses (N <= 272: the reference crops at 256 atoms, N <= 258); pair_tile / pair_untile convert at the boundary (tests, aux outputs).
 def pair_is_tiled(t):
-    return t.dim() == 5
+    return t.dim() == 3
+
+
+def pair_plane(N):
+    """elements of one (molecule, head) plane of a tiled pair tensor (a multiple of 8: 2-byte planes stay 16-byte aligned)."""
+    return (N * pair_ld(N) + 7) // 8 * 8
 
 
 def pair_tiles(N):
@@ -588,9 +595,11 @@ def pair_tiled_ok(N):
 
 
 def pair_empty(B, H, N, device, tiled, zero=False, dtype=F32):
-    nt = pair_tiles(N)
-    shape = (B, H, nt, nt, 256) if tiled else (B, H, N, pair_ld(N))
-    return (torch.zeros if zero else torch.empty)(shape, device=device, dtype=dtype)
+    shape = (B, H, pair_plane(N)) if tiled else (B, H, N, pair_ld(N))
+    t = (torch.zeros if zero else torch.empty)(shape, device=device, dtype=dtype)
+    if tiled and not zero and shape[2] != N * pair_ld(N):
+        t[:, :, N * pair_ld(N):] = 0          # (the alignment tail of a plane -- no kernel touches it: N * N4 / 4 odd only -- holds defined bits)
+    return t
 
 
 # Element types.  fp32 everywhere, or -- COMPACT tiled planes, what the hot path runs -- the logits chain as fp16
@@ -627,21 +636,28 @@ def _pair_layout_g(g, what):
     return int(tiled)
 
 
-def _tile_index(N, device):
-    nt = pair_tiles(N)
+def _tile_index(N, device, cols=None):
+    """[N, cols] flat offsets inside a tiled plane of (query, key); cols = N (the real pairs) or pair_ld(N) (every slot: the pad keys too)."""
     q = torch.arange(N, device=device).view(N, 1)
-    k = torch.arange(N, device=device).view(1, N)
-    return ((q // 16) * nt + k // 16) * 256 + ((k % 16) // 4 * 16 + q % 16) * 4 + k % 4          # [N, N] flat offsets
+    k = torch.arange(N if cols is None else cols, device=device).view(1, -1)
+    vr = torch.clamp(N - q // 16 * 16, max=16)
+    return (q // 16 * 16) * pair_ld(N) + vr * (k - k % 4) + (q % 16) * 4 + k % 4
+
+
+def pair_slots(N, device, q_lo=0, q_hi=None, k_lo=0, k_hi=None):
+    """flat offsets of every slot of a tiled plane -- pad keys N .. N4-1 included -- whose query lies in [q_lo, q_hi) and key in [k_lo, k_hi)
+    (test / debugging glue: e.g. "everything behind key tile k" is k_lo = 16 k)."""
+    idx = _tile_index(N, device, pair_ld(N))
+    return idx[q_lo:(N if q_hi is None else q_hi), k_lo:(pair_ld(N) if k_hi is None else k_hi)].reshape(-1)
 
 
 def pair_tile(x, N, pad=float("-inf")):
     """standard [B,H,N,>=N] -> tiled (layout glue for tests / API boundaries).  Pad slots: -inf for logits-like tensors
     (the invariant the attention kernels rely on), pass pad=0 for gradients."""
     B, H = x.shape[:2]
-    nt = pair_tiles(N)
-    out = torch.full((B, H, nt * nt * 256), pad, device=x.device, dtype=x.dtype)
+    out = torch.full((B, H, pair_plane(N)), pad, device=x.device, dtype=x.dtype)
     out[:, :, _tile_index(N, x.device).reshape(-1)] = x[..., :N, :N].reshape(B, H, N * N)
-    return out.view(B, H, nt, nt, 256)
+    return out
 
 
 def pair_untile(t, N):

@@ -263,17 +263,14 @@ def test_pair_attn(ops, B, N, H, tiled):
     dq3 = ops.pair_attn_bwd(dev(bf(qkv)).view(B * N, 3 * D), s_np, dev(bf(dO)).view(B * N, D), g3, B, N, H, ld, scale, True)
     close(down(g3), dbias_np, 1e-4, 1e-4)
     close(dq3.view(B, N, 3 * D), rt(dqkv_np), 2e-2, 2e-2)
-    if tiled:   # pads of a tiled S stay -inf, pads of a tiled G stay 0 (what the next layer's unpredicated loads rely on)
-        nt = ops.pair_tiles(N)
-        assert int(torch.isinf(s_np).sum()) >= 0
+    if tiled:   # pads of a tiled S stay -inf, pads of a tiled G stay 0 (what the next layer's unpredicated loads rely on):
+        # the only pad slots of the blocked-row planes are the keys N .. N4-1 of a real query (+ the alignment tail of a plane)
         s_pads = s_np.reshape(B, H, -1).clone(); g_pads = g3.reshape(B, H, -1).clone()
         idx = ops._tile_index(N, s_np.device).reshape(-1)
         s_pads[:, :, idx] = float("-inf"); g_pads[:, :, idx] = 0.0
-        full_q = (N // 16) * 16                                  # rows of complete query blocks: every slot of their tiles is defined
-        tiles = s_pads.view(B, H, nt, nt, 256)[:, :, :N // 16] if N >= 16 else None
-        if tiles is not None and tiles.numel():
-            lastcol_ok = torch.isinf(tiles[:, :, :, nt - 1].reshape(B, H, -1, 4, 16, 4)[..., :max(1, (N - 16 * (nt - 1) + 3) // 4), :, :]).all()
-            assert lastcol_ok
+        used = N * ops.pair_ld(N)
+        assert torch.isinf(s_pads[:, :, :used]).all() and (s_pads[:, :, :used] < 0).all()
+        assert (g_pads[:, :, :used] == 0).all()
     if tiled:   # the two layouts run the same arithmetic: identical bits
         s_std, o_std = ops.pair_attn_fwd(dev(bf(qkv)).view(B * N, 3 * D), dev(bias_ld), dev(key_pad), B, N, H, ld, scale)
         assert torch.equal(o_std, o) and torch.equal(s_std.cpu()[..., :N], s_cpu)
@@ -283,9 +280,13 @@ def test_pair_tile_roundtrip(ops):
     N = 37
     x = torch.randn(2, 3, N, N, generator=G(1))
     t = ops.pair_tile(dev(x), N)
-    assert t.shape == (2, 3, 3, 3, 256) and torch.equal(ops.pair_untile(t, N).cpu(), x)
-    # element (q, k) of tile (q//16, k//16) sits at ((k%16)//4*16 + q%16)*4 + k%4  (MFMA accumulator order)
-    assert t[1, 2, 1, 2, ((35 % 16) // 4 * 16 + 20 % 16) * 4 + 35 % 4].item() == x[1, 2, 20, 35].item()
+    assert t.shape == (2, 3, ops.pair_plane(N)) and ops.pair_plane(N) == 37 * 40 and torch.equal(ops.pair_untile(t, N).cpu(), x)
+    # blocked rows: element (q, k) at 16 (q//16) N4 + vr (k - k%4) + 4 (q%16) + k%4, vr = rows of the query block (16, or N - 16 qb)
+    assert t[1, 2, 16 * 40 + 16 * 32 + 4 * (20 % 16) + 35 % 4].item() == x[1, 2, 20, 35].item()
+    assert t[1, 2, 32 * 40 + 5 * 32 + 4 * (36 % 16) + 35 % 4].item() == x[1, 2, 36, 35].item()       # (the last block holds 5 queries)
+    # a complete 16x16 tile is 256 contiguous elements in MFMA accumulator order: ((k%16)//4*16 + q%16)*4 + k%4
+    tile = t[0, 1, 16 * 40 + 256:16 * 40 + 512]
+    assert tile[((22 % 16) // 4 * 16 + 27 % 16) * 4 + 22 % 4].item() == x[0, 1, 27, 22].item()
 
 
 @pytest.mark.parametrize("B,N,H,p", [(2, 7, 8, 0.0), (3, 70, 4, 0.0), (2, 130, 64, 0.1), (1, 210, 64, 0.0), (2, 240, 8, 0.1), (1, 258, 64, 0.0), (1, 272, 4, 0.0)])
@@ -334,7 +335,7 @@ def test_pair_attn_compact_planes_are_the_fp32_kernels_plus_rounding(ops, B, N, 
     dqz32 = ops.pair_attn_bwd(qkv, s16.float(), dO, gz32, B, N, H, ld, scale, True, **kw)
     assert torch.equal(dqz16, dqz32) and torch.equal(un(gz16), un(gz32).bfloat16())
     # saturation instead of +inf: logits beyond the fp16 range stay finite
-    big = b16.clone(); big[0, 0, 0, 0, :4] = 65504.0
+    big = b16.clone(); big[0, 0, :4] = 65504.0
     qbig = (qkv.float() * 16).bfloat16()
     sbig, obig = ops.pair_attn_fwd(qbig, big, None, B, N, H, ld, scale)
     assert not torch.isnan(obig.float()).any() and not torch.isposinf(un(sbig).float()).any()
@@ -385,7 +386,7 @@ def test_pair_attn_ragged_key_tile_skipping_equals_dense(ops, B, N, H, lens, p, 
     s2_d, o2_d = ops.pair_attn_fwd(qkv, s_d, None, B, N, H, ld, scale, **kw)
     s_poison = s_n.clone()
     for b in range(B):
-        s_poison[b, :, :, ke[b]:] = float("nan")
+        s_poison[b][:, ops.pair_slots(N, "cuda", k_lo=16 * ke[b])] = float("nan")
     s2_r, o2_r = ops.pair_attn_fwd(qkv, s_poison, None, B, N, H, ld, scale, key_tiles=kt, rag_store=True, **kw)
     assert torch.equal(o2_r, o2_d) and torch.equal(rows(s2_r), rows(s2_d))
     # backward
@@ -828,8 +829,8 @@ def test_gbf_bias_fused_matches_unfused_chain(ops, B, N):
     # tiled output: same numbers in the tile layout, every pad slot -inf
     out_t, _ = ops.gbf_bias_fwd(*d, dev(bf(w1)), dev(b1), dev(bf(w2)), dev(b2), ld, save=False, tiled=True)
     assert torch.equal(ops.pair_untile(out_t, N), out[..., :N])
-    nt = ops.pair_tiles(N)
-    assert int(torch.isinf(out_t).sum()) == B * H * (nt * nt * 256 - N * N)
+    used = N * ops.pair_ld(N)             # (every slot of the blocked-row planes: N real keys + the pad keys up to N4 of each query)
+    assert int(torch.isinf(out_t.reshape(B, H, -1)[:, :, :used]).sum()) == B * H * (used - N * N)
     # and against the fp32 oracle of the same chain
     P = {"gbf.means.weight": means.view(1, K), "gbf.stds.weight": stds.view(1, K), "gbf.mul.weight": mul.view(E, 1), "gbf.bias.weight": bias.view(E, 1)}
     g = O.gaussian_layer(dist, et, P) if hasattr(O, "gaussian_layer") else None
@@ -963,6 +964,7 @@ def test_gbf_bias_compact_planes(ops, B, N):
     assert torch.equal(o16, o32.half())                                # every slot, pads (-inf) included
     idx = ops._tile_index(N, o16.device).reshape(-1)
     pads = torch.ones(o16[0, 0].numel(), dtype=torch.bool, device=o16.device); pads[idx] = False
+    pads[N * ld:] = False                                              # (the alignment tail of a plane is no slot)
     assert torch.isneginf(o16.reshape(B, H, -1)[:, :, pads]).all()
     with pytest.raises(ops.MMDTIError):
         ops.gbf_bias_fwd(*d, w1, b1, w2, b2, ld, save=False, tiled=False, compact=True)
@@ -1007,7 +1009,8 @@ def test_gbf_bias_ragged_tile_prefixes(ops, B, N, lens):
     kt = torch.tensor([(n + 15) // 16 for n in lens])
     ke = [ops.pair_key_tiles_effective(int(k), nt) for k in kt]
     pre_f, pre_b = ops.gbf_tile_prefixes(kt, N, "cuda")
-    assert pre_f.dtype == torch.int32 and pre_f.shape == (B + 1,) and int(pre_f[-1]) == sum(4 * k * 4 * nt for k in ke)
+    nb4 = (N + 3) // 4
+    assert pre_f.dtype == torch.int32 and pre_f.shape == (B + 1,) and int(pre_f[-1]) == sum(min(4 * k, nb4) * nb4 for k in ke)
     dense, _ = ops.gbf_bias_fwd(*d, w1, b1, w2, b2, ld, save=False, tiled=True, compact=True)
     canary = 123.0
     import mmdti_hip.ops as O_
@@ -1018,13 +1021,14 @@ def test_gbf_bias_ragged_tile_prefixes(ops, B, N, lens):
     finally:
         O_.pair_empty = orig_empty
     for b in range(B):
-        assert torch.equal(rag[b, :, :, :ke[b]], dense[b, :, :, :ke[b]])             # [B,H,tq,tk,256]: key tiles < ke, every query tile, pads included
+        kept, behind = ops.pair_slots(N, "cuda", k_hi=16 * ke[b]), ops.pair_slots(N, "cuda", k_lo=16 * ke[b])
+        assert torch.equal(rag[b][:, kept], dense[b][:, kept])             # key tiles < ke, every query, pad keys included
         if ke[b] < nt:
-            assert bool((rag[b, :, :, ke[b]:] == canary).all())        # (the bias of padded keys: the ragged attention kernels never read it)
+            assert bool((rag[b][:, behind] == canary).all())           # (the bias of padded keys: the ragged attention kernels never read it)
     # backward: g is zero behind the kept tiles (as the ragged attention backward leaves it)
     g = ops.pair_tile(dev(torch.randn(B, H, N, N, generator=gen)), N, 0.0)
     for b in range(B):
-        g[b, :, :, ke[b]:] = 0.0
+        g[b][:, ops.pair_slots(N, "cuda", k_lo=16 * ke[b])] = 0.0
     names = ("dw1", "db1", "dw2", "db2", "dmul", "dbias", "dmeans", "dstds")
     shapes = ((Fh, K), (Fh,), (H, Fh), (H,), (E,), (E,), (K,), (K,))
     got = {}
@@ -1033,7 +1037,7 @@ def test_gbf_bias_ragged_tile_prefixes(ops, B, N, lens):
         gg = g.clone()
         if pre is not None:
             for b in range(B):
-                gg[b, :, :, ke[b]:] = float("nan")                                    # never read
+                gg[b][:, ops.pair_slots(N, "cuda", k_lo=16 * ke[b])] = float("nan")          # never read
         ops.gbf_bias_bwd_full(gg, *d, w1, b1, w2, ld, *[got[tag][n].view(-1) for n in names], tile_prefix=pre)
     for n in names:
         a, b_ = got["ragged"][n], got["dense"][n]

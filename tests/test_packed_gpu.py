@@ -83,8 +83,8 @@ def test_pair_attn_packed_rows_equal_padded_rows(ops, B, N, H, lens, p):
     for b, n in enumerate(lens):
         r = min(n + 1, N)
         q_blocks = (r + 15) // 16
-        s_poison[b, :, q_blocks:] = float("nan")                    # query blocks past the representative row
-        s_poison[b, :, :, ke[b]:] = float("nan")                    # key tiles past the effective count
+        s_poison[b][:, ops.pair_slots(N, "cuda", q_lo=16 * q_blocks)] = float("nan")       # query blocks past the representative row
+        s_poison[b][:, ops.pair_slots(N, "cuda", k_lo=16 * ke[b])] = float("nan")          # key tiles past the effective count
     s2_d, o2_d = ops.pair_attn_fwd(qkv, s_d, None, B, N, H, ld, scale, key_tiles=kt, **kw)
     s2_p, o2_p = ops.pair_attn_fwd(qkv_p, s_poison, None, B, N, H, ld, scale, key_tiles=kt, row_off=pk.off, **kw)
     assert torch.equal(o2_p, o2_d[gat]) and bool(torch.isfinite(o2_p.float()).all())
@@ -123,7 +123,7 @@ def test_pair_attn_packed_rejects_bad_arguments(ops):
     B, N, H = 2, 20, 8
     pk = _pack([20, 7], N)
     qkv = torch.zeros(pk.M, 3 * H * 8, device="cuda", dtype=torch.bfloat16)
-    bias = torch.zeros(B, H, 2, 2, 256, device="cuda", dtype=torch.float16)
+    bias = torch.zeros(B, H, ops.pair_plane(N), device="cuda", dtype=torch.float16)
     kt = torch.tensor([2, 1], dtype=torch.int32, device="cuda")
     with pytest.raises(ops.MMDTIError):
         ops.pair_attn_fwd(qkv, bias, None, B, N, H, 20, 0.35, row_off=pk.off)                        # row_off without key_tiles
@@ -379,7 +379,8 @@ def test_gbf_bias_packed_rows_stop_at_the_representative_pad_row(ops, B, N, lens
     ke = [ops.pair_key_tiles_effective(int(k), nt) for k in kt]
     rows = torch.tensor([min(n + 1, N) for n in lens])
     pre_f, pre_b, rb_f, rb_b = ops.gbf_tile_prefixes(kt, N, "cuda", rows)
-    assert rb_f.tolist() == [(int(r) + 3) // 4 for r in rows] and int(pre_f[-1]) == sum(4 * k * ((int(r) + 3) // 4) for k, r in zip(ke, rows))
+    nb4 = (N + 3) // 4
+    assert rb_f.tolist() == [min((int(r) + 3) // 4, nb4) for r in rows] and int(pre_f[-1]) == sum(min(4 * k, nb4) * min((int(r) + 3) // 4, nb4) for k, r in zip(ke, rows))
     ref_f, ref_b = ops.gbf_tile_prefixes(kt, N, "cuda")
     dense, _ = ops.gbf_bias_fwd(*d, w1, b1, w2, b2, ld, save=False, tiled=True, compact=True, tile_prefix=ref_f)
     canary = 123.0
