@@ -136,10 +136,14 @@ class DevicePrefetcher:
             if slot["event"] is not None:      # the copy that last read this set of staging buffers must be done before they are rewritten
                 slot["event"].synchronize()
                 slot["event"] = None
-            buf = slot["buf"].get(name)
-            if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
-                buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-                slot["buf"][name] = buf
+            # (one grow-only pinned byte buffer per field and set: the padded length changes from batch to batch, and a pinned
+            #  allocation per new shape -- page-locking 26 MB -- costs more than the copy it serves)
+            need = t.numel() * t.element_size()
+            raw = slot["buf"].get(name)
+            if raw is None or raw.numel() < need:
+                raw = torch.empty(max(256, need + need // 4), dtype=torch.uint8, pin_memory=True)
+                slot["buf"][name] = raw
+            buf = raw[:need].view(t.dtype).view(t.shape)
             buf.copy_(t)
             return buf
 

@@ -162,7 +162,7 @@ def test_worker_side_collate_yields_the_batches_of_the_in_process_collate():
 def test_ragged_key_tile_counts_and_pair_bias_prefixes_host_logic():
     """Host arithmetic of the ragged path (no GPU): the key-tile count a molecule's sweeps cover is the next SUPPORTED count (every
     count up to 9 tiles, every 2nd up to 13, every 4th beyond, and the full count), and the pair-bias kernels' tile prefixes follow
-    from it -- forward: 4 x 4 pair blocks of the covered key tiles over ALL 4 * nt row blocks; backward: blocks of real pairs only."""
+    from it -- the 4 x 4 pair blocks of the covered key tiles that hold a real pair, forward and backward alike."""
     import torch
     from mmdti_hip import ops
     for nt in range(1, 18):
@@ -176,7 +176,8 @@ def test_ragged_key_tile_counts_and_pair_bias_prefixes_host_logic():
     N = 130                                                                        # nt = 9, nb = 33
     kt = torch.tensor([9, 3, 4, 1])
     f, b = ops.gbf_tile_prefixes(kt, N, "cpu")
-    assert f.dtype == b.dtype == torch.int32 and f.tolist() == [0] + torch.cumsum(4 * kt * 36, 0).tolist()
-    assert b.tolist() == [0] + torch.cumsum(33 * torch.clamp(4 * kt, max=33), 0).tolist()
-    f2, _ = ops.gbf_tile_prefixes(torch.tensor([1, 11, 15]), 258, "cpu")           # nt = 17: counts round up to 4, 12, 16
-    assert (f2[1:] - f2[:-1]).tolist() == [4 * 4 * 68, 4 * 12 * 68, 4 * 16 * 68]
+    # (the tiled planes store nothing past N: forward and backward enumerate the same blocks -- those that hold a real pair)
+    assert f.dtype == b.dtype == torch.int32 and f.tolist() == [0] + torch.cumsum(33 * torch.clamp(4 * kt, max=33), 0).tolist()
+    assert b.tolist() == f.tolist()
+    f2, _ = ops.gbf_tile_prefixes(torch.tensor([1, 11, 15]), 258, "cpu")           # nt = 17, nb = 65: counts round up to 4, 12, 16
+    assert (f2[1:] - f2[:-1]).tolist() == [4 * 4 * 65, 4 * 12 * 65, 4 * 16 * 65]
