@@ -280,9 +280,12 @@ def pipeline_workload(tuner, model, args, dev, world, rank, barrier):
 
     n_steps = max(3 * nb, args.steps)
     # ONE loader for the warm-up pass and the timed pass (persistent workers: process start-up, imports and the synthetic molecules are
-    # paid once, before the clock starts)
+    # paid once, before the clock starts).  pin_memory=True as tasks.Trainer builds its loaders: the loader's pin thread moves a batch out
+    # of the worker's shared-memory segment -- 26 MB of first-touch page faults, 30 ms when the step loop does it itself (measured:
+    # 49.9 ms per step with pin_memory=False against 29.8 ms, the GPU time of the step) -- and DevicePrefetcher copies from the pinned
+    # tensors where they lie.
     dl = torch.utils.data.DataLoader(PipelineBatches(n_steps, nb, B, args.atoms, args.tokens, 777 + rank), batch_size=None, shuffle=False, num_workers=4,
-                                     pin_memory=False, prefetch_factor=2, multiprocessing_context="spawn", persistent_workers=True)
+                                     pin_memory=True, prefetch_factor=2, multiprocessing_context="spawn", persistent_workers=True)
 
     def collated(_n):
         for batch, y, dt_c in dl:
@@ -339,8 +342,8 @@ def pipeline_workload(tuner, model, args, dev, world, rank, barrier):
         dt = float(t)
     ms = lambda evs: round(sum(a.elapsed_time(b) for a, b in evs) / max(1, len(evs)), 3)
     return {"workload": f"same step fed a fresh batch every iteration: {nb} distinct mixed-length batches of {B} molecules/GPU cycled through per-molecule samples -> "
-                        "right-padded host batch -> device_payload (int16 edge types, packing facts) in 4 spawned DataLoader worker processes -> pinned staging + "
-                        "H2D on the copy stream (DevicePrefetcher) -> step; host-side key-tile / tile-prefix arithmetic and their uploads inside the timed region",
+                        "right-padded host batch -> device_payload (int16 edge types, packing facts) in 4 spawned DataLoader worker processes -> the loader's pin "
+                        "thread -> H2D on the copy stream (DevicePrefetcher) -> step; host-side key-tile / tile-prefix arithmetic and their uploads inside the timed region",
             "unit": "molecules/s", "steps": n, "value": round(B * world * n / dt, 2), "ms_per_step": round(dt / n * 1e3, 3),
             "collate_ms": round(sum(t_collate) / max(1, len(t_collate)) * 1e3, 3), "h2d_ms": ms(h2d), "optimizer_ms": ms(opt),
             "note": "collate_ms: time one worker process spends on one batch (right-pad + device_payload; 4 workers run ahead of the step); h2d_ms: the copies "
