@@ -225,6 +225,37 @@ class Trainer(object):
     _n_edge_types = None
     _pad_idx = 0
 
+    def device_batches(self, dataloader, feature_name=None):
+        """(net_input, net_target) on the device for every batch of ``dataloader``, the host-to-device copies of batch i + 1 in flight
+        on the copy stream while step i runs (data.DevicePrefetcher) -- the reference moves each batch with synchronous ``.cuda()``
+        calls inside the step loop (tasks/trainer.py:181-183).  What decorate_torch_batch does to a batch happens here too, in the
+        same order: narrowing, the move, the global padded length under data parallelism, the target dtype rule.  A loader whose
+        batches are not the (dict, target) pairs of the model's collate goes through decorate_batch unchanged."""
+        import itertools
+        it = iter(dataloader)
+        try:
+            first = next(it)
+        except StopIteration:
+            return
+        batches = itertools.chain([first], it)
+        if self.device.type != "cuda" or not isinstance(first[0], dict):
+            for batch in batches:
+                yield self.decorate_batch(batch, feature_name)
+            return
+        from ..data import DevicePrefetcher
+        for net_input, net_target in DevicePrefetcher(batches, self.device, narrow=self.narrow_inputs, n_edge_types=self._n_edge_types,
+                                                      pad_idx=self._pad_idx):
+            if self.distributed:
+                from ..parallel import pad_to_global_lengths
+                net_input = pad_to_global_lengths(net_input)        # the unmasked InfoNCE mean needs one padded length on all ranks
+            if self.task == 'repr':
+                net_target = None
+            elif self.task in ['classification', 'multiclass', 'multilabel_classification']:
+                net_target = net_target.long()
+            else:
+                net_target = net_target.float()
+            yield net_input, net_target
+
     def _collate_for(self, model):
         """The model's own ``batch_collate_fn`` in-process; with worker processes, the same collate as a small picklable
         object (the workers get the pad index and the tokenizer, not the model)."""
@@ -293,8 +324,7 @@ class Trainer(object):
                 sampler.set_epoch(epoch)
             start_time = time.time()
             logged = []
-            for batch in train_dataloader:
-                net_input, net_target = self.decorate_batch(batch, feature_name)
+            for net_input, net_target in self.device_batches(train_dataloader, feature_name):
                 out = engine.step(net_input, net_target, epoch=epoch, use_weight=use_weight, return_infonce_loss=return_infonce_loss,
                                   return_ct_loss=return_ct_loss, loss_func=task_loss)
                 logged.append(torch.stack([out.loss, out.task_loss,
@@ -383,8 +413,7 @@ class Trainer(object):
         val_loss, y_preds, y_truths = [], [], []
         builtin = _is_builtin_loss(loss_func, self.task)
         with torch.no_grad():
-            for batch in dataloader:
-                net_input, net_target = self.decorate_batch(batch, feature_name)
+            for net_input, net_target in self.device_batches(dataloader, feature_name):
                 outputs = model(**net_input)       # both auxiliary losses are force-disabled in the reference's predict (:427-428)
                 if not load_model:
                     tl = _builtin_loss(self.task)(outputs, net_target) if builtin else loss_func(outputs, net_target)
