@@ -531,7 +531,9 @@ def main():
                       "-- embeddings outside the north star's 1e-3; fp16 forward operands (the headline): config.parity"}
         for _ in range(2):      # back in the headline mode before the per-family steps
             tuner.step(batch, label, epoch=0)
-    if not args.ragged and not args.no_ragged_workload and not args.no_pipeline_workload and not args.graph:
+    # (N = 1 only: the loader's worker processes are per rank -- four more processes on every GPU of a node say nothing the one-GPU
+    #  record does not, and the scaling runs stay what they measure)
+    if not args.ragged and not args.no_ragged_workload and not args.no_pipeline_workload and not args.graph and world == 1:
         workloads["pipeline"] = pipeline_workload(tuner, model, args, dev, world, rank, barrier)
 
     # every kernel family in two extra modes (every rank runs them: the step holds collectives):

@@ -47,21 +47,12 @@ __device__ __forceinline__ uint32_t pack16x2(int f16, float lo, float hi) {
 // forward activation is the B operand of a weight-gradient GEMM whose A operand -- an activation gradient -- needs bf16's range, so the
 // fp16 tile is fetched as it lies in memory and converted on its way from LDS to the matrix pipe instead of in a pass over HBM.
 __device__ __forceinline__ bf16x8 frag_h2bf(const bf16x8& v) {
-#if defined(BCVT_EXP) && BCVT_EXP == 1
-  return v;
-#elif defined(BCVT_EXP) && BCVT_EXP == 2
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 w = __builtin_bit_cast(u32x4, v);
-  for (int e = 0; e < 4; ++e) w[e] = (w[e] >> 3) + 0x38003800u;
-  return __builtin_bit_cast(bf16x8, w);
-#else
   typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
   const f16x8 h = __builtin_bit_cast(f16x8, v);
   bf16x8 o;
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = (__bf16)(float)h[e];
   return o;
-#endif
 }
 template <bool CVT>
 __device__ __forceinline__ bf16x8 frag_cvt(const bf16x8& v) {
