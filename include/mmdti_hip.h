@@ -265,8 +265,8 @@ int mmdti_gbf_features_bwd(mmdti_stream_t stream, const float* dist, const long 
 /* gbf -> gbf_proj (Linear+GELU+Linear, NonLinearHead mm_model.py:190-208) -> permute (mm_model.py:553-556) in one kernel:
  * out[b,h,i,j] (fp32, [B,H,N,ld], pad columns j >= N written 0).  w1: [F,K] bf16, w2: [H,F] bf16; built for K=128, F=128,
  * H=64.  feat/u/h (nullable, together): the [B*N*N, 128] bf16 basis / pre-activation / hidden rows for the backward.
- * tiled != 0: out is [B,H,nt,nt,256] (nt = ceil(N/16); 16x16 tiles in MFMA accumulator order, the layout the pair-attention
- * kernels stream -- see mmdti_pair_attn_fwd) and every pad slot (query or key >= N) is written -inf. */
+ * tiled != 0: out is [B,H,plane] in the blocked-row tile layout the pair-attention kernels stream (see mmdti_pair_attn_fwd, layout 1)
+ * and the pad keys N .. N4-1 of every query are written -inf. */
 int mmdti_gbf_bias_fwd(mmdti_stream_t stream, const float* dist, const void* edge_type,
                        int edge_bytes /* 8, 4 or 2: int64 as the reference collates (mm_model.py:657-660), or narrowed */, const float* mul,
                        const float* bias, const float* means, const float* stds, const void* w1_bf16, const float* b1,
@@ -314,7 +314,7 @@ int mmdti_gbf_bias_bwd_full(mmdti_stream_t stream, const void* g, const float* d
 /* bytes of workspace for mmdti_gbf_bias_bwd_full with E edge types (a value, not a status code) */
 int mmdti_gbf_bias_bwd_full_workspace(int E);
 /* [B,N,N,H] fp32 -> [B,H,N,ld] fp32 (mm_model.py:555-556 permute(0,3,1,2).contiguous()) and its gradient
- * [B,H,N,ld] fp32 (or, tiled != 0, the [B,H,nt,nt,256] tile layout of mmdti_gbf_bias_fwd) -> [B,N,N,H] bf16 */
+ * [B,H,N,ld] fp32 (or, tiled != 0, the blocked-row tile layout of mmdti_gbf_bias_fwd) -> [B,N,N,H] bf16 */
 int mmdti_pair_permute_fwd(mmdti_stream_t stream, const float* x, float* out, int B, int N, int H, int ld);
 int mmdti_pair_permute_bwd(mmdti_stream_t stream, const float* g, void* out_bf16, int B, int N, int H, int ld, int tiled);
 
@@ -324,7 +324,12 @@ int mmdti_pair_permute_bwd(mmdti_stream_t stream, const float* g, void* out_bf16
  * O = dropout(softmax(S)).v.   qkv: [B,N,3*H*8] bf16 (q|k|v).
  * layout (of bias_in / s_out, and of s / g in the backward):
  *   0  row-major planes [B,H,N,ld] fp32;
- *   1  tiled planes [B,H,nt,nt,256] fp32 (nt = ceil(N/16); 16x16 tiles in MFMA accumulator order, N <= 272);
+ *   1  tiled planes [B,H,plane] fp32, N <= 272, "blocked rows": per block of 16 queries the 4-key groups follow each other, each
+ *      holding its vr query rows x 4 keys (vr = 16, or N - 16 qb in the last block) --
+ *          off(query i, key j) = 16 qb N4 + vr (j - j % 4) + 4 (i % 16) + j % 4,   qb = i / 16, N4 = N rounded up to 4,
+ *          plane = N * N4 rounded up to 8 elements
+ *      -- so a 16x16 tile of a complete block is 256 contiguous elements in MFMA accumulator order (one contiguous KiB per wave
+ *      access) and nothing is stored for queries or 4-key groups past N.  Pad keys N .. N4-1 hold -inf in S, 0 in G;
  *   3  COMPACT tiled planes: same element order, the logits chain as fp16 -- half the bytes of the forward's dominant traffic,
  *      a sixth less in the backward.  The reference carries these logits as fp16 itself when it runs under AMP (autocast makes
  *      attn_weights fp16; tasks/trainer.py:266-282).  Each layer rounds S once (to nearest even, saturating at 65504) and its own
