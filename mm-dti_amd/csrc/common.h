@@ -225,7 +225,8 @@ static inline uint32_t dropout_thresh(float p) {
 // A 16 x 16 tile of a complete block is therefore 256 contiguous elements in MFMA accumulator order (lane = (key group, query), 4
 // consecutive keys per lane) -- what the pair-attention kernels stream with one 8- / 16-byte access per lane -- and NOTHING is stored for
 // queries or 4-key groups past N: at the reference's 128 atoms + BOS / EOS (N = 130) the planes hold 130 x 132 slots instead of the
-// 144 x 144 of whole 16 x 16 tiles, 17 % less traffic in every pass over S and G.  Keys N .. N4 - 1 of a real query are pad slots: -inf
+// 144 x 144 of whole 16 x 16 tiles (17 % less memory; the traffic was already close to it -- the pad lanes of edge tiles are
+// predicated off).  Keys N .. N4 - 1 of a real query are pad slots: -inf
 // in S, 0 in G, written by the pair-bias kernel and preserved by every store.  Plane stride: pair_plane(N) elements (a multiple of 8,
 // so that planes of 2-byte elements stay 16-byte aligned).
 __host__ __device__ __forceinline__ int pair_n4(int N) { return (N + 3) & ~3; }

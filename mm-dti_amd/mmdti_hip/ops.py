@@ -575,7 +575,8 @@ def pair_permute_bwd(g, B, N, H, ld):
 #             holding its vr query rows x 4 keys (vr = 16, or N - 16 qb in the last block):
 #                 off(q, k) = 16 (q // 16) N4 + vr (k - k % 4) + 4 (q % 16) + k % 4,        N4 = N rounded up to 4
 #             -- a 16x16 tile of a complete block is 256 contiguous elements in MFMA accumulator order (a wave's access to it is ONE
-#             contiguous KiB) and nothing is stored for queries or 4-key groups past N (130 atoms: 130 x 132 slots, not 144 x 144).
+#             contiguous KiB) and nothing is stored for queries or 4-key groups past N (130 atoms: 130 x 132 slots, not 144 x 144: memory, not time -- the
+#             kernels never touched most pad slots).
 # The tiled form is what the hot path uses (N <= 272: the reference crops at 256 atoms, N <= 258); pair_tile / pair_untile convert at the boundary (tests, aux outputs).
 def pair_is_tiled(t):
     return t.dim() == 3
