@@ -353,8 +353,8 @@ def test_unimol_layer_backward_sequenced_in_the_library_equals_the_op_by_op_path
 
 
 @pytest.mark.parametrize("packed", [False, True])
-@pytest.mark.parametrize("side", [True, False])
-def test_unimol_stack_sequenced_in_the_library_equals_the_per_layer_calls(M, packed, side, monkeypatch):
+@pytest.mark.parametrize("side,B,N", [(True, 6, 40), (False, 6, 40), (True, 44, 100)])
+def test_unimol_stack_sequenced_in_the_library_equals_the_per_layer_calls(M, packed, side, B, N, monkeypatch):
     """Small batches (below functional.STACK_MAX_ROWS rows, parameters in a ParamArena): ALL layers of the tower leave from one library
     call per direction (mmdti_unimol_stack_fwd / _bwd: pointer tables + one activation arena), the weight gradients on a side stream
     under the layer below (`side`).  The launches are those of the per-layer calls: output, input gradient and pair-bias gradients
@@ -364,13 +364,15 @@ def test_unimol_stack_sequenced_in_the_library_equals_the_per_layer_calls(M, pac
     from mmdti_hip.functional import PairBiasFn
     from mmdti_hip.runtime import dropout_state, ParamArena
     from mmdti_hip.packing import PackedRows
+    # (44 x 100: 4400 padded rows -- above the 64 x 64-tile weight-gradient kernel's 4096 rows, so the stack's layer workspaces carry the
+    #  split-K slabs of the 256 x 256 grouped launch)
     monkeypatch.setattr(Fn, "STACK_SIDE_WGRAD", side)
-    B, N, D, H, K, V = 6, 40, 512, 64, 128, 31
+    D, H, K, V = 512, 64, 128, 31
     ucfg = O.UniMolCfg(layers=4, dim=D, ffn=256, heads=H, K=K, vocab=V)
     cfg = O.ModelCfg(unimol=ucfg, roberta=O.RobertaCfg(layers=1, dim=64, heads=4, ffn=128, vocab=40, max_pos=40), cross=O.CrossCfg(dim=64, heads=4, ffn=128))
     P = O.init_params(cfg, seed=3, std=0.06)
     g = torch.Generator().manual_seed(6)
-    lens = [40, 23, 31, 12, 35, 28]
+    lens = [40, 23, 31, 12, 35, 28] if B == 6 else [N] + torch.randint(N - 12, N + 1, (B - 1,), generator=g).tolist()
     pad = torch.zeros(B, N, dtype=torch.bool)
     for b, n in enumerate(lens):
         pad[b, n:] = True
