@@ -196,6 +196,26 @@ int mmdti_bert_layer_bwd(mmdti_stream_t stream, int Mq, int B, int L, int heads,
                          float* dw_qkv, int lddw_qkv, float* db_qkv, float* dw_o, float* db_o, float* dw_i, float* db_i,
                          float* dw_o2, float* db_o2, float* dg_ln1, float* dbt_ln1, float* dg_ln2, float* dbt_ln2, void* ws,
                          long long ws_bytes, int fwd_f16 /* 1: the saved s1_16, ctx, a16, i_act hold fp16 (weights: the bf16 shadow) */);
+/* ---- ALL layers of tower 2 behind one call per direction (HF RobertaEncoder's layer loop, reached from models/mm_model.py:562): as
+ * the Uni-Mol stack above -- pointer tables for the parameters, one activation arena, nl x mmdti_bert_layer_fwd / _bwd, bit-identical.
+ *   mmdti_bert_stack_layout: out[0] = arena bytes per layer, out[1] = backward workspace bytes (stats_bytes: one layer's softmax
+ *     statistics; nrow: heads * q_rows packed, B * heads * L dense; dw_slab_bytes: split-K slabs of one layer's weight gradients).
+ *   params [nl][12]: w_qkv, b_qkv, w_o, b_o, g_ln1, bt_ln1, w_i, b_i, w_o2, b_o2, g_ln2, bt_ln2 (16-bit forward weights, q | k | v fused).
+ *   bparams [nl][6]: w_qkv, w_o, w_i, w_o2 (bf16), g_ln1, g_ln2.   grads [nl][12]: dw_qkv, db_qkv, dw_o, db_o, dw_i, db_i, dw_o2, db_o2,
+ *     dg_ln1, dbt_ln1, dg_ln2, dbt_ln2 (fp32, accumulated).  Dropout sites: site0 + 3 l + {0: attention, 1: output.dense, 2: FFN}. */
+int mmdti_bert_stack_layout(int Mq, int D, int F, long long stats_bytes, long long nrow, long long dw_slab_bytes, long long* out);
+int mmdti_bert_stack_fwd(mmdti_stream_t stream, int nl, int Mq, int B, int L, int heads, int D, int F, float scale, float p_hid,
+                         float p_att, unsigned long long seed, unsigned int site0, const float* s1_32_0, const void* s1_16_0,
+                         const float* key_add, const int* q_off, const int* k_off, const int* k_cnt, int q_rows,
+                         const void* const* params, int act_fwd, float eps, int ln_max_k, void* arena, long long arena_bytes,
+                         long long stats_bytes, float* out32_last, int fwd_f16);
+int mmdti_bert_stack_bwd(mmdti_stream_t stream, int nl, int Mq, int B, int L, int heads, int D, int F, float scale, float p_hid,
+                         float p_att, unsigned long long seed, unsigned int site0, const float* dout, float* ds1_final,
+                         const void* s1_16_0, const float* key_add, const int* q_off, const int* k_off, const int* k_cnt,
+                         int q_rows, const void* const* bparams, int act_dx, void* const* grads, int lddw_qkv, const void* arena,
+                         long long arena_bytes, long long stats_bytes, void* ws, long long ws_bytes, long long dw_slab_bytes,
+                         int fwd_f16);
+
 
 /* ---- LayerNorm (unicore LayerNorm eps 1e-5: transformers.py:69,71,114,161; BertLayerNorm eps 1e-12:
  * mm_module.py:320-333; HF nn.LayerNorm) -------------------------------------------------------

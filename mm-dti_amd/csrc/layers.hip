@@ -399,3 +399,106 @@ extern "C" int mmdti_bert_layer_bwd(mmdti_stream_t stream, int Mq, int B, int L,
   // (fwd_f16: the saved s1_16, i_act, a16 and ctx hold fp16 -- converted between LDS and the matrix pipe)
   return mmdti_linear_dw_grouped(stream, 4, dys, xs, dws, dbs, n_out, n_in, ldy, ldx, lddw, Mq, slabs, slab_bytes, fwd_f16 ? 1 : 0);
 }
+
+// ---------------------------------------------------------------------------------------------------------------- tower 2's stack
+namespace {
+struct BertArena {     // byte offsets inside one layer's slice
+  long long qkv, ctx, stats, y, a32, a16, am, ar, u, i, z, out32, out16, zm, zr, stride;
+  BertArena(long long M, long long D, long long F, long long stats_bytes) {
+    long long at = 0;
+    auto take = [&](long long b) { const long long r = at; at += up256(b); return r; };
+    qkv = take(M * 3 * D * 2); ctx = take(M * D * 2); stats = take(stats_bytes); y = take(M * D * 4); a32 = take(M * D * 4); a16 = take(M * D * 2);
+    am = take(M * 4); ar = take(M * 4); u = take(M * F * 2); i = take(M * F * 2); z = take(M * D * 4); out32 = take(M * D * 4); out16 = take(M * D * 2);
+    zm = take(M * 4); zr = take(M * 4);
+    stride = at;
+  }
+};
+struct BertBwdWs {     // one layer workspace (mmdti_bert_layer_bwd's) + two fp32 gradients handed from layer to layer
+  long long layer_ws, lws, ds[2], total;
+  BertBwdWs(long long M, long long D, long long F, long long nrow, long long slab_bytes) {
+    layer_ws = up256((M * F + 7 * M * D) * 2 + M * D * 4 + ((nrow * 4 + 15) / 16) * 16 + slab_bytes);
+    lws = 0;
+    long long at = layer_ws;
+    for (int k = 0; k < 2; ++k) { ds[k] = at; at += up256(M * D * 4); }
+    total = at;
+  }
+};
+}  // namespace
+
+/* out[0] = arena bytes per layer, out[1] = backward workspace bytes (stats_bytes: one layer's softmax statistics; nrow: rows of the
+ * attention backward's row term -- heads * q_rows packed, B * heads * L dense; dw_slab_bytes: see mmdti_unimol_stack_layout) */
+extern "C" int mmdti_bert_stack_layout(int Mq, int D, int F, long long stats_bytes, long long nrow, long long dw_slab_bytes, long long* out) {
+  MMDTI_REQUIRE(Mq > 0 && D > 0 && F > 0 && stats_bytes >= 0 && nrow >= 0 && dw_slab_bytes >= 0 && out, "bert_stack_layout: bad arguments");
+  out[0] = BertArena(Mq, D, F, stats_bytes).stride;
+  out[1] = BertBwdWs(Mq, D, F, nrow, dw_slab_bytes).total;
+  return MMDTI_OK;
+}
+
+/* Forward of ALL layers of tower 2 (HF RobertaEncoder's layer loop, reached from models/mm_model.py:562) behind one call: nl x
+ * mmdti_bert_layer_fwd, a layer's out32 / out16 being the next one's input.  s1_32_0 / s1_16_0: the embeddings' LayerNorm output (the
+ * caller's).  params [nl][12]: w_qkv, b_qkv, w_o, b_o, g_ln1, bt_ln1, w_i, b_i, w_o2, b_o2, g_ln2, bt_ln2 (16-bit forward weights,
+ * q | k | v fused).  The last layer's fp32 output goes to out32_last (the caller's).  Dropout sites: site0 + 3 l + {0: attention, 1, 2}. */
+extern "C" int mmdti_bert_stack_fwd(mmdti_stream_t stream, int nl, int Mq, int B, int L, int heads, int D, int F, float scale, float p_hid,
+                                    float p_att, unsigned long long seed, unsigned int site0, const float* s1_32_0, const void* s1_16_0,
+                                    const float* key_add, const int* q_off, const int* k_off, const int* k_cnt, int q_rows,
+                                    const void* const* params, int act_fwd, float eps, int ln_max_k, void* arena, long long arena_bytes,
+                                    long long stats_bytes, float* out32_last, int fwd_f16) {
+  MMDTI_REQUIRE(nl > 0 && params && arena && aligned16(arena) && s1_32_0 && s1_16_0 && out32_last, "bert_stack_fwd: null argument");
+  const BertArena A(Mq, D, F, stats_bytes);
+  MMDTI_REQUIRE(arena_bytes >= A.stride * nl, "bert_stack_fwd: arena too small (%lld bytes per layer)", A.stride);
+  char* base = reinterpret_cast<char*>(arena);
+  for (int l = 0; l < nl; ++l) {
+    char* a = base + A.stride * l;
+    const char* prev = a - A.stride;
+    const void* const* P = params + 12 * l;
+    const bool last = l == nl - 1;
+    if (int e = mmdti_bert_layer_fwd(
+            stream, Mq, B, L, heads, D, F, scale, p_hid, p_att, seed, site0 + 3 * l, site0 + 3 * l + 1, site0 + 3 * l + 2,
+            l ? reinterpret_cast<const float*>(prev + A.out32) : s1_32_0, l ? static_cast<const void*>(prev + A.out16) : s1_16_0, key_add, q_off, k_off, k_cnt,
+            q_rows, P[0], (const float*)P[1], P[2], (const float*)P[3], (const float*)P[4], (const float*)P[5], P[6], (const float*)P[7], act_fwd, P[8],
+            (const float*)P[9], (const float*)P[10], (const float*)P[11], eps, ln_max_k, a + A.qkv, a + A.ctx, reinterpret_cast<float*>(a + A.stats),
+            reinterpret_cast<float*>(a + A.y), reinterpret_cast<float*>(a + A.a32), a + A.a16, reinterpret_cast<float*>(a + A.am),
+            reinterpret_cast<float*>(a + A.ar), a + A.u, a + A.i, reinterpret_cast<float*>(a + A.z), last ? out32_last : reinterpret_cast<float*>(a + A.out32),
+            a + A.out16, reinterpret_cast<float*>(a + A.zm), reinterpret_cast<float*>(a + A.zr), fwd_f16))
+      return e;
+  }
+  return MMDTI_OK;
+}
+
+/* Backward of the same stack, top layer first: nl x mmdti_bert_layer_bwd.  dout [Mq,D] fp32: the gradient of the tower's output;
+ * ds1_final [Mq,D] fp32: the gradient of s1_32_0.  bparams [nl][6]: w_qkv, w_o, w_i, w_o2 (bf16), g_ln1, g_ln2;  grads [nl][12]:
+ * dw_qkv, db_qkv, dw_o, db_o, dw_i, db_i, dw_o2, db_o2, dg_ln1, dbt_ln1, dg_ln2, dbt_ln2 (fp32, accumulated; lddw_qkv: row stride of
+ * the fused q | k | v weight gradient). */
+extern "C" int mmdti_bert_stack_bwd(mmdti_stream_t stream, int nl, int Mq, int B, int L, int heads, int D, int F, float scale, float p_hid,
+                                    float p_att, unsigned long long seed, unsigned int site0, const float* dout, float* ds1_final,
+                                    const void* s1_16_0, const float* key_add, const int* q_off, const int* k_off, const int* k_cnt,
+                                    int q_rows, const void* const* bparams, int act_dx, void* const* grads, int lddw_qkv, const void* arena,
+                                    long long arena_bytes, long long stats_bytes, void* ws, long long ws_bytes, long long dw_slab_bytes,
+                                    int fwd_f16) {
+  MMDTI_REQUIRE(nl > 0 && bparams && grads && arena && ws && aligned16(ws) && dout && ds1_final && s1_16_0, "bert_stack_bwd: null argument");
+  const BertArena A(Mq, D, F, stats_bytes);
+  const long long nrow = q_off ? (long long)heads * q_rows : (long long)B * heads * L;
+  const BertBwdWs W(Mq, D, F, nrow, dw_slab_bytes);
+  MMDTI_REQUIRE(arena_bytes >= A.stride * nl && ws_bytes >= W.total, "bert_stack_bwd: arena / workspace too small (%lld / %lld bytes)", A.stride * nl, W.total);
+  const char* base = reinterpret_cast<const char*>(arena);
+  char* wb = reinterpret_cast<char*>(ws);
+  const float* d = dout;
+  for (int l = nl - 1, it = 0; l >= 0; --l, ++it) {
+    const char* a = base + A.stride * l;
+    const char* prev = a - A.stride;
+    float* ds1 = l ? reinterpret_cast<float*>(wb + W.ds[it & 1]) : ds1_final;
+    const void* const* P = bparams + 6 * l;
+    void* const* G = grads + 12 * l;
+    if (int e = mmdti_bert_layer_bwd(
+            stream, Mq, B, L, heads, D, F, scale, p_hid, p_att, seed, site0 + 3 * l, site0 + 3 * l + 1, site0 + 3 * l + 2, d, ds1,
+            l ? static_cast<const void*>(prev + A.out16) : s1_16_0, key_add, q_off, k_off, k_cnt, q_rows, a + A.qkv, a + A.ctx,
+            reinterpret_cast<const float*>(a + A.stats), reinterpret_cast<const float*>(a + A.y), a + A.a16, reinterpret_cast<const float*>(a + A.am),
+            reinterpret_cast<const float*>(a + A.ar), a + A.u, act_dx, a + A.i, reinterpret_cast<const float*>(a + A.z),
+            reinterpret_cast<const float*>(a + A.zm), reinterpret_cast<const float*>(a + A.zr), P[0], P[1], P[2], P[3], (const float*)P[4], (const float*)P[5],
+            (float*)G[0], lddw_qkv, (float*)G[1], (float*)G[2], (float*)G[3], (float*)G[4], (float*)G[5], (float*)G[6], (float*)G[7], (float*)G[8],
+            (float*)G[9], (float*)G[10], (float*)G[11], wb + W.lws, W.layer_ws, fwd_f16))
+      return e;
+    d = ds1;
+  }
+  return MMDTI_OK;
+}

@@ -942,6 +942,124 @@ def _bert_layer_bwd_seq(st, L, dout, seed):
     return ds1
 
 
+def _bert_stack_tables(mod, st):
+    """Pointer tables of tower 2's layers for mmdti_bert_stack_fwd / _bwd (cached on the parameter arena), or None when the stack
+    calls do not cover this model: parameters outside one arena or frozen, q | k | v not back to back, shapes the fused attention /
+    grouped weight-gradient kernels do not take."""
+    layers = list(mod.layers)
+    W0 = bert_weights(layers[0])
+    arena = getattr(W0.i_w, "_mmdti_arena", None)
+    heads = mod.cfg.heads
+    D, F = W0.i_w.shape[1], W0.i_w.shape[0]
+    if (arena is None or not ops.GROUPED_DW or st.Mq < ops.GROUPED_DW_MIN_ROWS or D % heads or not ops.attn_eligible(st.Lq, st.Lk, D // heads, D)):
+        return None
+    cache = arena.__dict__.setdefault("_stack_tables", {})
+    key = (id(mod), ops.FWD_F16, "bert")
+    T = cache.get(key)
+    if T is None:
+        ok = D % 256 == 0 and F % 256 == 0
+        Ws = [bert_weights(l) for l in layers]
+        off = arena.offsets
+
+        def plist(W):
+            return [W.q_w, W.k_w, W.v_w, W.q_b, W.k_b, W.v_b, W.o_w, W.o_b, W.ln1_w, W.ln1_b, W.i_w, W.i_b, W.o2_w, W.o2_b, W.ln2_w, W.ln2_b]
+        for l, W in zip(layers, Ws):
+            ps = plist(W)
+            ok = ok and all(q is not None and q.requires_grad and getattr(q, "_mmdti_arena", None) is arena for q in ps)
+            ok = ok and tuple(W.i_w.shape) == (F, D) and len(list(l.parameters())) == 16
+            if ok:      # q | k | v (weights and biases) back to back in the arena: one [3D, D] matrix, one [3D] bias
+                ok = (off[id(W.k_w)] == off[id(W.q_w)] + W.q_w.numel() and off[id(W.v_w)] == off[id(W.k_w)] + W.k_w.numel()
+                      and off[id(W.k_b)] == off[id(W.q_b)] + W.q_b.numel() and off[id(W.v_b)] == off[id(W.k_b)] + W.k_b.numel())
+        if not ok:
+            cache[key] = False
+            return None
+        if ops.FWD_F16:
+            arena._fresh16()
+        sh16 = (arena.shadow16 if ops.FWD_F16 else arena.shadow).data_ptr()
+        shb, gr = arena.shadow.data_ptr(), arena.grad.data_ptr()
+        fwd, bwd, grads, weights, params, probes = [], [], [], [], [], []
+        for W in Ws:
+            params += plist(W)
+            w16 = lambda q: sh16 + 2 * off[id(q)]
+            wb = lambda q: shb + 2 * off[id(q)]
+            g = lambda q: gr + 4 * off[id(q)]
+            fwd += [w16(W.q_w), W.q_b.data_ptr(), w16(W.o_w), W.o_b.data_ptr(), W.ln1_w.data_ptr(), W.ln1_b.data_ptr(), w16(W.i_w), W.i_b.data_ptr(),
+                    w16(W.o2_w), W.o2_b.data_ptr(), W.ln2_w.data_ptr(), W.ln2_b.data_ptr()]
+            bwd += [wb(W.q_w), wb(W.o_w), wb(W.i_w), wb(W.o2_w), W.ln1_w.data_ptr(), W.ln2_w.data_ptr()]
+            grads += [g(W.q_w), g(W.q_b), g(W.o_w), g(W.o_b), g(W.i_w), g(W.i_b), g(W.o2_w), g(W.o2_b), g(W.ln1_w), g(W.ln1_b), g(W.ln2_w), g(W.ln2_b)]
+            weights += [(q, id(q)) for q in (W.q_w, W.k_w, W.v_w, W.o_w, W.i_w, W.o2_w)]
+            probes.append((W.i_w, W.i_w.data_ptr(), g(W.i_w)))
+        T = cache[key] = SimpleNamespace(nl=len(layers), D=D, F=F, heads=heads, fwd=_ptr_table(fwd), bwd=_ptr_table(bwd), grads=_ptr_table(grads),
+                                         weights=weights, params=params, f16=ops.FWD_F16, probes=probes)
+    if T is False:
+        return None
+    ver = arena._version
+    for q, i in T.weights:
+        if q._version != ver[i]:
+            arena._fresh(q)
+    if T.f16:
+        arena._fresh16()
+    for q, dptr, gptr in T.probes:
+        g = q.grad
+        if g is None or g.data_ptr() != gptr or q.data_ptr() != dptr:
+            return None
+    return T
+
+
+_bert_layouts = {}
+
+
+def _bert_stack_layout(st, T):
+    heads, D, F = T.heads, T.D, T.F
+    nrow = heads * st.Mq if st.vl is not None else st.B * heads * st.Lq
+    key = (st.Mq, D, F, nrow)
+    r = _bert_layouts.get(key)
+    if r is None:
+        import ctypes
+        tiles = 3 * (D // 256) ** 2 + 2 * (D // 256) * (F // 256) + (D // 256) ** 2
+        slab = ops.lib()._dll.mmdti_linear_dw_grouped_splits(tiles, st.Mq) * (4 * D * D + 2 * D * F) * 4
+        out = (ctypes.c_longlong * 2)()
+        ops.lib().mmdti_bert_stack_layout(st.Mq, D, F, nrow * 8, nrow, slab, ctypes.addressof(out))
+        if len(_bert_layouts) > 4096:
+            _bert_layouts.clear()
+        r = _bert_layouts[key] = (int(out[0]), int(out[1]), slab, nrow * 8)
+    return r
+
+
+def _bert_stack_fwd(st, T, x32, x16, key_add, cfg, p_hid, p_att, seed, sites):
+    """All layers of tower 2 as ONE library call -> the tower's fp32 output [Mq, D]."""
+    stride, ws_bytes, slab, stats_bytes = _bert_stack_layout(st, T)
+    dev = x32.device
+    arena = torch.empty(stride * T.nl, device=dev, dtype=torch.uint8)
+    out32 = torch.empty(st.Mq, T.D, device=dev, dtype=F32)
+    site0 = sites.n + 1
+    sites.n += 3 * T.nl
+    vl = st.vl
+    ops.lib().mmdti_bert_stack_fwd(
+        ops._stream(), T.nl, st.Mq, st.B, st.Lq, T.heads, T.D, T.F, float(1.0 / math.sqrt(T.D // T.heads)), float(p_hid), float(p_att), int(seed), site0,
+        x32.data_ptr(), x16.data_ptr(), ops._p(key_add), *(ops._NO_VARLEN if vl is None else vl.args()), T.fwd[1], ops.ACT_GELU_FWD, float(cfg.ln_eps),
+        ops.GEMM_LN_MAX_K if ops.GEMM_LN else 0, arena.data_ptr(), arena.numel(), stats_bytes, out32.data_ptr(), int(x16.dtype == torch.float16))
+    st.stack = SimpleNamespace(T=T, arena=arena, ws_bytes=ws_bytes, slab=slab, stats_bytes=stats_bytes, site0=site0, x16=x16, key_add=key_add, p_hid=p_hid,
+                               p_att=p_att)
+    return out32
+
+
+def _bert_stack_bwd(st, dout):
+    """All layers' backward as ONE library call -> the gradient of the embeddings' LayerNorm output (fp32 [Mq, D])."""
+    S = st.stack
+    T = S.T
+    dev = dout.device
+    ds1 = torch.empty(st.Mq, T.D, device=dev, dtype=F32)
+    ws = torch.empty(S.ws_bytes, device=dev, dtype=torch.uint8)
+    vl = st.vl
+    ops.lib().mmdti_bert_stack_bwd(
+        ops._stream(), T.nl, st.Mq, st.B, st.Lq, T.heads, T.D, T.F, float(1.0 / math.sqrt(T.D // T.heads)), float(S.p_hid), float(S.p_att), int(st.seed),
+        S.site0, dout.data_ptr(), ds1.data_ptr(), S.x16.data_ptr(), ops._p(S.key_add), *(ops._NO_VARLEN if vl is None else vl.args()), T.bwd[1],
+        ops.ACT_GELU_DX, T.grads[1], T.D, S.arena.data_ptr(), S.arena.numel(), S.stats_bytes, ws.data_ptr(), ws.numel(), S.slab,
+        int(S.x16.dtype == torch.float16))
+    return ds1
+
+
 def bert_weights(layer) -> SimpleNamespace:
     """Parameter view of an HF RobertaLayer / mm_module BertCrossAttentionLayer (identical sub-module names)."""
     a, o = layer.attention.self, layer.attention.output
@@ -982,7 +1100,13 @@ class RobertaEncoderFn(torch.autograd.Function):
         x32, x16, st.em, st.er = ops.layernorm_fwd(e.view(Mq, D), mod.emb_ln_w, mod.emb_ln_b, cfg.ln_eps, want_f32=True, want_bf16=True,
                                                    drop_p=p_hid, seed=seed, site=st.site_emb)
         key_add = ((1.0 - attention_mask.to(F32)) * torch.finfo(torch.float32).min).contiguous() if vl is None else None
-        for layer in mod.layers:
+        # small batches: ALL layers from one library call (see _bert_stack_fwd); the per-layer loop then has nothing left to do
+        st.stack = None
+        T = (_bert_stack_tables(mod, st) if (LAYER_SEQ and STACK_SEQ and keep and x32.is_cuda and Mq < STACK_MAX_ROWS and len(mod.layers)
+                                             and not ops.kernel_timer.names) else None)
+        if T is not None:
+            x32 = _bert_stack_fwd(st, T, x32, x16, key_add, cfg, p_hid, p_att, seed, sites)
+        for layer in (mod.layers if T is None else ()):
             L, x32, x16 = _bert_layer_fwd(st, x32, x16, x16, key_add, bert_weights(layer), cfg.heads, p_hid, p_att, cfg.ln_eps, seed, sites, True)
             if keep:
                 st.layers.append(L)
@@ -995,6 +1119,10 @@ class RobertaEncoderFn(torch.autograd.Function):
         st, mod = ctx.st, ctx.mod
         B, Lq, D = st.B, st.Lq, st.D
         dx = dout.contiguous().view(st.Mq, D)
+        if st.stack is not None:
+            dx = _bert_stack_bwd(st, dx)
+            notify_grads_ready(st.stack.T.params)
+            st.stack = None
         for layer, L in zip(reversed(list(mod.layers)), reversed(st.layers)):
             dx, _ = _bert_layer_bwd(st, L, dx, st.seed)
             L.__dict__.clear()

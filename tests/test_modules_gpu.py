@@ -455,6 +455,7 @@ def test_bert_layer_sequenced_in_the_library_equals_the_op_by_op_path(M, packed,
         ids[b, n:] = 1
     pk = PackedRows(torch.tensor(lens), L, "cuda") if packed else None
     calls = []
+    monkeypatch.setattr(Fn, "STACK_SEQ", False)                                    # (this test is about the per-layer calls; the stack call has its own)
     real_f, real_b = Fn._bert_layer_fwd_seq, Fn._bert_layer_bwd_seq
     monkeypatch.setattr(Fn, "_bert_layer_fwd_seq", lambda *a, **k: (calls.append("f"), real_f(*a, **k))[1])
     monkeypatch.setattr(Fn, "_bert_layer_bwd_seq", lambda *a, **k: (calls.append("b"), real_b(*a, **k))[1])
@@ -785,3 +786,57 @@ def test_split_tower_encoders_match_fused_model(M):
     ce.bert.load_state_dict(model.bert.state_dict(), strict=True)
     out = ce(batch["input_ids"].cuda(), batch["attention_mask"].cuda())
     check(out, O.roberta_encoder(batch["input_ids"], batch["attention_mask"], P, ocfg.roberta, bf16=True), 3e-3, "ChembertaEncoder")
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_bert_stack_sequenced_in_the_library_equals_the_per_layer_calls(M, packed, monkeypatch):
+    """Tower 2 at small batches: ALL RoBERTa layers from one library call per direction (mmdti_bert_stack_fwd / _bwd: pointer tables, one
+    activation arena) -- the launches of the per-layer calls: output and input gradient bit-identical, parameter gradients to the atomics'
+    noise; 3 layers, training mode, dense and packed sequences, and an in-place weight reload in between."""
+    from mmdti_hip import functional as Fn
+    from mmdti_hip.runtime import dropout_state, ParamArena
+    from mmdti_hip.packing import PackedRows
+    from mmdti_hip.trainer import _qkv_groups
+    cfg = SimpleNamespace(layers=3, dim=512, heads=8, ffn=256, vocab=40, max_pos=64, type_vocab=1, pad_idx=1, ln_eps=1e-12, hidden_dropout=0.1, attn_dropout=0.1)
+    tower = M.bl.RobertaTower(cfg).cuda().train()
+    arena = ParamArena(tower.parameters(), adjacent=_qkv_groups(tower))
+    B, L = 6, 40
+    lens = [40, 23, 31, 12, 35, 28]
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(4, 40, (B, L), generator=g)
+    am = torch.zeros(B, L, dtype=torch.long)
+    for b, n in enumerate(lens):
+        am[b, :n] = 1
+        ids[b, n:] = 1
+    pk = PackedRows(torch.tensor(lens), L, "cuda") if packed else None
+    calls = []
+    real_f, real_b, real_lf = Fn._bert_stack_fwd, Fn._bert_stack_bwd, Fn._bert_layer_fwd_seq
+    monkeypatch.setattr(Fn, "_bert_stack_fwd", lambda *a, **k: (calls.append("F"), real_f(*a, **k))[1])
+    monkeypatch.setattr(Fn, "_bert_stack_bwd", lambda *a, **k: (calls.append("B"), real_b(*a, **k))[1])
+    monkeypatch.setattr(Fn, "_bert_layer_fwd_seq", lambda *a, **k: (calls.append("l"), real_lf(*a, **k))[1])
+
+    def run(stack):
+        monkeypatch.setattr(Fn, "STACK_SEQ", stack)
+        arena.zero_grad()
+        dropout_state.reseed(777)
+        out = tower(ids.cuda(), am.cuda(), return_dict=True, pack=pk)[0]
+        w = torch.randn(out.shape, generator=torch.Generator().manual_seed(5)).cuda()
+        (out * w).sum().backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), {n: p.grad.clone() for n, p in tower.named_parameters() if p.grad is not None}
+
+    o0, g0 = run(False)
+    assert calls == ["l"] * 3
+    del calls[:]
+    o1, g1 = run(True)
+    assert calls == ["F", "B"]
+    assert torch.equal(o0, o1) and set(g0) == set(g1)
+    for n in g0:
+        d = float((g0[n].double() - g1[n].double()).norm()) / (float(g0[n].double().norm()) + 1e-30)
+        assert d < 2e-4, (n, d)
+    with torch.no_grad():
+        tower.layers[1].intermediate.dense.weight.mul_(0.5)
+    o2, _ = run(True)
+    o3, _ = run(False)
+    assert torch.equal(o2, o3) and not torch.equal(o2, o1)
+
