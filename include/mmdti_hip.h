@@ -196,6 +196,30 @@ int mmdti_bert_layer_bwd(mmdti_stream_t stream, int Mq, int B, int L, int heads,
                          float* dw_qkv, int lddw_qkv, float* db_qkv, float* dw_o, float* db_o, float* dw_i, float* db_i,
                          float* dw_o2, float* db_o2, float* dg_ln1, float* dbt_ln1, float* dg_ln2, float* dbt_ln2, void* ws,
                          long long ws_bytes, int fwd_f16 /* 1: the saved s1_16, ctx, a16, i_act hold fp16 (weights: the bf16 shadow) */);
+/* The CROSS-attention variant (BertCrossAttentionLayer, mm_module.py:615-626 through :663-677: queries from s1 [Mq rows], keys and values
+ * from s2 [Mk rows]): the six forward launches behind one call (query projection, fused key | value projection, fused attention, the two
+ * closers, intermediate + GELU), and the backward UP TO the weight gradients (ten launches; ds1 / ds2: the gradients of the two inputs).
+ * The backward's five bf16 activation gradients (dzb, du, dyb, dq, dkv) are the caller's: they are the A operands of the layer's weight
+ * gradients, which the caller launches (mmdti_linear_dw_grouped takes one token-row count per launch, this layer has two).
+ * ws of the backward: da [Mq,D] | dctx [Mq,D] (bf16) | dz [Mq,D] f32 | the attention backward's row term. */
+int mmdti_bert_cross_layer_fwd(mmdti_stream_t stream, int Mq, int Mk, int B, int Lq, int Lk, int heads, int D, int F, float scale,
+                               float p_hid, float p_att, unsigned long long seed, unsigned int site_att, unsigned int site_o,
+                               unsigned int site_f, const float* s1_32, const void* s1_16, const void* s2_16, const float* key_add,
+                               const int* q_off, const int* k_off, const int* k_cnt, int q_rows, const void* w_q, const float* b_q,
+                               const void* w_kv, const float* b_kv, const void* w_o, const float* b_o, const float* g_ln1,
+                               const float* bt_ln1, const void* w_i, const float* b_i, int act_fwd, const void* w_o2,
+                               const float* b_o2, const float* g_ln2, const float* bt_ln2, float eps, int ln_max_k, void* q,
+                               void* kv, void* ctx, float* stats, float* y, float* a32, void* a16, float* am, float* ar,
+                               void* u_aux, void* i_act, float* z, float* out32, void* out16, float* zm, float* zr, int fwd_f16);
+int mmdti_bert_cross_layer_bwd(mmdti_stream_t stream, int Mq, int Mk, int B, int Lq, int Lk, int heads, int D, int F, float scale,
+                               float p_hid, float p_att, unsigned long long seed, unsigned int site_att, unsigned int site_o,
+                               unsigned int site_f, const float* dout, float* ds1, float* ds2, const float* key_add,
+                               const int* q_off, const int* k_off, const int* k_cnt, int q_rows, const void* q, const void* kv,
+                               const float* stats, const float* y, const float* am, const float* ar, const void* u_aux,
+                               int act_dx, const float* z, const float* zm, const float* zr, const void* w_q, const void* w_kv,
+                               const void* w_o, const void* w_i, const void* w_o2, const float* g_ln1, const float* g_ln2,
+                               float* db_o, float* db_o2, float* dg_ln1, float* dbt_ln1, float* dg_ln2, float* dbt_ln2, void* dzb,
+                               void* du, void* dyb, void* dq, void* dkv, void* ws, long long ws_bytes);
 /* ---- ALL layers of tower 2 behind one call per direction (HF RobertaEncoder's layer loop, reached from models/mm_model.py:562): as
  * the Uni-Mol stack above -- pointer tables for the parameters, one activation arena, nl x mmdti_bert_layer_fwd / _bwd, bit-identical.
  *   mmdti_bert_stack_layout: out[0] = arena bytes per layer, out[1] = backward workspace bytes (stats_bytes: one layer's softmax

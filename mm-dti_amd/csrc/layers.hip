@@ -165,6 +165,85 @@ extern "C" int mmdti_unimol_layer_bwd(mmdti_stream_t stream, int M, int B, int N
                                ws, ws_bytes, fwd_f16, nullptr, nullptr, nullptr);
 }
 
+/* The CROSS-attention variant of the same layer (BertCrossAttentionLayer, mm_module.py:615-626 through :663-677: the queries come from
+ * s1, keys and values from s2): the six forward launches behind one call -- query projection, fused key | value projection, fused
+ * attention (Lq queries x Lk keys per sequence; packed: q_off / k_off / k_cnt as mmdti_attn_fwd), output.dense + residual + LayerNorm,
+ * intermediate + GELU, output + residual + LayerNorm.  Mq / Mk: token rows of the two sides.  Outputs as mmdti_bert_layer_fwd, with
+ * q [Mq,D] and kv [Mk,2D] (bf16) in place of qkv. */
+extern "C" int mmdti_bert_cross_layer_fwd(mmdti_stream_t stream, int Mq, int Mk, int B, int Lq, int Lk, int heads, int D, int F, float scale,
+                                          float p_hid, float p_att, unsigned long long seed, unsigned int site_att, unsigned int site_o,
+                                          unsigned int site_f, const float* s1_32, const void* s1_16, const void* s2_16, const float* key_add,
+                                          const int* q_off, const int* k_off, const int* k_cnt, int q_rows, const void* w_q, const float* b_q,
+                                          const void* w_kv, const float* b_kv, const void* w_o, const float* b_o, const float* g_ln1,
+                                          const float* bt_ln1, const void* w_i, const float* b_i, int act_fwd, const void* w_o2,
+                                          const float* b_o2, const float* g_ln2, const float* bt_ln2, float eps, int ln_max_k, void* q,
+                                          void* kv, void* ctx, float* stats, float* y, float* a32, void* a16, float* am, float* ar,
+                                          void* u_aux, void* i_act, float* z, float* out32, void* out16, float* zm, float* zr, int fwd_f16) {
+  MMDTI_REQUIRE(Mq > 0 && Mk > 0 && D > 0 && F > 0 && heads > 0 && D % heads == 0, "bert_cross_layer_fwd: bad shape");
+  MMDTI_REQUIRE(s1_32 && s1_16 && s2_16 && w_q && w_kv && w_o && g_ln1 && bt_ln1 && w_i && w_o2 && g_ln2 && bt_ln2 && q && kv && ctx && stats && y && a32 &&
+                    a16 && am && ar && u_aux && i_act && z && out32 && out16 && zm && zr, "bert_cross_layer_fwd: null argument");
+  const int hd = D / heads;
+  const int ab = fwd_f16 ? MMDTI_DT_AB_F16 : 0;
+  const char* kp = reinterpret_cast<const char*>(kv);
+  if (int e = fwd_gemm(stream, s1_16, D, w_q, D, b_q, q, Mq, D, D, MMDTI_ACT_NONE, nullptr, nullptr, MMDTI_DT_BF16 | ab, 0.f, 0ull, 0u)) return e;
+  if (int e = fwd_gemm(stream, s2_16, D, w_kv, D, b_kv, kv, Mk, 2 * D, D, MMDTI_ACT_NONE, nullptr, nullptr, MMDTI_DT_BF16 | ab, 0.f, 0ull, 0u)) return e;
+  if (int e = mmdti_attn_fwd(stream, q, kp, kp + (size_t)D * 2, key_add, ctx, stats, B, heads, Lq, Lk, hd, D, 2 * D, D, scale, p_att, seed, site_att, q_off,
+                             k_off, k_cnt, q_rows, fwd_f16 ? 1 : 0))
+    return e;
+  if (int e = closer(stream, ctx, w_o, b_o, s1_32, Mq, D, D, p_hid, seed, site_o, y, g_ln1, bt_ln1, eps, a32, a16, am, ar, ln_max_k, fwd_f16)) return e;
+  if (int e = fwd_gemm(stream, a16, D, w_i, D, b_i, i_act, Mq, F, D, act_fwd, u_aux, nullptr, (fwd_f16 ? MMDTI_DT_F16 : MMDTI_DT_BF16) | ab, 0.f, 0ull, 0u)) return e;
+  return closer(stream, i_act, w_o2, b_o2, a32, Mq, D, F, p_hid, seed, site_f, z, g_ln2, bt_ln2, eps, out32, out16, zm, zr, ln_max_k, fwd_f16);
+}
+
+/* Its backward up to the weight gradients: LayerNorm-2 backward, the FFN's two input gradients, LayerNorm-1 backward, the output
+ * projection's input gradient, the fused attention backward (dq [Mq,D]; dk | dv straight into dkv [Mk,2D]), ds1 += dq . W_q (ds1 [Mq,D]
+ * fp32 holds LayerNorm-1's residual gradient), ds2 = dkv . W_kv ([Mk,D] fp32, written).  The caller owns the five activation gradients
+ * (dzb [Mq,D], du [Mq,F], dyb [Mq,D], dq, dkv: bf16) -- they are the A operands of the layer's weight gradients, which it launches
+ * itself (two token-row counts: mmdti_linear_dw_grouped takes one per launch).  ws: da [Mq,D] | dctx [Mq,D] bf16 | dz [Mq,D] f32 | drow. */
+extern "C" int mmdti_bert_cross_layer_bwd(mmdti_stream_t stream, int Mq, int Mk, int B, int Lq, int Lk, int heads, int D, int F, float scale,
+                                          float p_hid, float p_att, unsigned long long seed, unsigned int site_att, unsigned int site_o,
+                                          unsigned int site_f, const float* dout, float* ds1, float* ds2, const float* key_add,
+                                          const int* q_off, const int* k_off, const int* k_cnt, int q_rows, const void* q, const void* kv,
+                                          const float* stats, const float* y, const float* am, const float* ar, const void* u_aux,
+                                          int act_dx, const float* z, const float* zm, const float* zr, const void* w_q, const void* w_kv,
+                                          const void* w_o, const void* w_i, const void* w_o2, const float* g_ln1, const float* g_ln2,
+                                          float* db_o, float* db_o2, float* dg_ln1, float* dbt_ln1, float* dg_ln2, float* dbt_ln2, void* dzb,
+                                          void* du, void* dyb, void* dq, void* dkv, void* ws, long long ws_bytes) {
+  MMDTI_REQUIRE(Mq > 0 && Mk > 0 && D > 0 && F > 0 && heads > 0 && D % heads == 0, "bert_cross_layer_bwd: bad shape");
+  MMDTI_REQUIRE(dout && ds1 && ds2 && q && kv && stats && y && am && ar && u_aux && z && zm && zr && w_q && w_kv && w_o && w_i && w_o2 && g_ln1 && g_ln2 && dzb &&
+                    du && dyb && dq && dkv && ws, "bert_cross_layer_bwd: null argument");
+  const int hd = D / heads;
+  const long long MD = (long long)Mq * D;
+  const long long nrow = q_off ? (long long)heads * q_rows : (long long)B * heads * Lq;
+  const long long need = 2 * MD * 2 + MD * 4 + ((nrow * 4 + 15) / 16) * 16;
+  MMDTI_REQUIRE(ws_bytes >= need && aligned16(ws), "bert_cross_layer_bwd: workspace too small (%lld bytes)", need);
+  char* wp = reinterpret_cast<char*>(ws);
+  void* da = wp;   wp += MD * 2;
+  void* dctx = wp; wp += MD * 2;
+  float* dz = reinterpret_cast<float*>(wp); wp += MD * 4;
+  float* drow = reinterpret_cast<float*>(wp);
+  if (int e = mmdti_layernorm_bwd(stream, dout, MMDTI_DT_F32, nullptr, z, g_ln2, zm, zr, Mq, D, nullptr, dz, dg_ln2, dbt_ln2, nullptr, 0.f, 0ull, 0u, dzb, p_hid,
+                                  site_f, db_o2))
+    return e;
+  if (int e = dx_gemm(stream, dzb, D, w_o2, F, du, Mq, F, D, act_dx, u_aux, F)) return e;
+  if (int e = dx_gemm(stream, du, F, w_i, D, da, Mq, D, F, MMDTI_ACT_NONE, nullptr, 0)) return e;
+  if (int e = mmdti_layernorm_bwd(stream, da, MMDTI_DT_BF16, dz, y, g_ln1, am, ar, Mq, D, nullptr, ds1, dg_ln1, dbt_ln1, nullptr, 0.f, 0ull, 0u, dyb, p_hid,
+                                  site_o, db_o))
+    return e;
+  if (int e = dx_gemm(stream, dyb, D, w_o, D, dctx, Mq, D, D, MMDTI_ACT_NONE, nullptr, 0)) return e;
+  const char* kp = reinterpret_cast<const char*>(kv);
+  char* dkp = reinterpret_cast<char*>(dkv);
+  if (int e = mmdti_attn_bwd(stream, q, kp, kp + (size_t)D * 2, key_add, dctx, stats, drow, dq, dkp, dkp + (size_t)D * 2, B, heads, Lq, Lk, hd, D, 2 * D, D, D,
+                             2 * D, scale, p_att, seed, site_att, q_off, k_off, k_cnt, q_rows))
+    return e;
+  // ds1 += dq . W_q   (fp32, beta = 1);  ds2 = dkv . W_kv
+  if (int e = mmdti_gemm_bf16(stream, dq, w_q, ds1, Mq, D, D, D, D, D, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.f, 1.f, nullptr, nullptr, D, MMDTI_ACT_NONE, nullptr,
+                              nullptr, D, MMDTI_DT_F32, 0.f, 0ull, 0u, nullptr, nullptr, nullptr, 0))
+    return e;
+  return mmdti_gemm_bf16(stream, dkv, w_kv, ds2, Mk, D, 2 * D, 2 * D, D, D, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.f, 0.f, nullptr, nullptr, D, MMDTI_ACT_NONE, nullptr,
+                         nullptr, D, MMDTI_DT_F32, 0.f, 0ull, 0u, nullptr, nullptr, nullptr, 0);
+}
+
 // ---------------------------------------------------------------------------------------------------------------- whole stacks
 // At the reference's batch size the per-layer calls above still leave ~90 us of Python per layer and direction (17 allocations, 60
 // marshalled arguments): the stack calls issue ALL layers of a tower from one call.  The saved tensors of a layer live at fixed

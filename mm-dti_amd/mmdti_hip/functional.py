@@ -774,6 +774,10 @@ def _bert_layer_fwd(st, s1_32, s1_16, s2_16, key_add, W, heads, p_hid, p_att, ep
             and W.i_w.shape[0] % 256 == 0 and Mq >= ops.GROUPED_DW_MIN_ROWS and ops.GROUPED_DW):
         # the layer's six launches from ONE library call (csrc/layers.hip: the same kernels, arguments and order as below)
         return _bert_layer_fwd_seq(st, L, s1_32, s1_16, key_add, W, heads, p_hid, p_att, eps, seed, sites)
+    if (LAYER_SEQ and not self_attn and L.fw is not None and L.fused and s1_32.is_cuda and not ops.kernel_timer.names and D % 8 == 0
+            and W.i_w.shape[0] % 8 == 0 and W.q_b is not None):
+        # the cross-attention layer's six launches from ONE library call (csrc/layers.hip: mmdti_bert_cross_layer_fwd)
+        return _bert_cross_layer_fwd_seq(st, L, s1_32, s1_16, s2_16, key_add, W, heads, p_hid, p_att, eps, seed, sites)
     if L.fw is not None:
         if self_attn:
             # (L.fw[3]: the forward-GEMM shadow of the fused weights; q, k, v are stored bf16 in every mode -- the attention kernels'
@@ -821,9 +825,11 @@ def _bert_layer_bwd(st, L, dout, seed):
     Mq, Mk, vl = st.Mq, st.Mk, st.vl
     W, heads, ld = L.W, L.heads, L.ld
     hd = D // heads
-    if getattr(L, "seq", False) and not ops.kernel_timer.names and all(gbuf(p) is not None for p in (W.o_w, W.o_b, W.i_w, W.i_b, W.o2_w, W.o2_b, W.ln1_w, W.ln1_b,
+    if getattr(L, "seq", False) is True and not ops.kernel_timer.names and all(gbuf(p) is not None for p in (W.o_w, W.o_b, W.i_w, W.i_b, W.o2_w, W.o2_b, W.ln1_w, W.ln1_b,
                                                                                                         W.ln2_w, W.ln2_b)):
         return _bert_layer_bwd_seq(st, L, dout, seed), None
+    if getattr(L, "seq", False) == "cross" and not ops.kernel_timer.names and all(gbuf(p) is not None for p in (W.o_b, W.o2_b, W.ln1_w, W.ln1_b, W.ln2_w, W.ln2_b)):
+        return _bert_cross_layer_bwd_seq(st, L, dout, seed)
     pend, raw = [], []                     # the layer's weight gradients leave as one grouped launch (see _lin_bwd_params_many)
     dz, dzb = ops.layernorm_bwd(dout, L.z, W.ln2_w, L.zm, L.zr, gbuf(W.ln2_w), gbuf(W.ln2_b), bf16_copy=(L.p_hid, L.site_f, gbuf(W.o2_b)))
     pend.append(((dzb, L.i, W.o2_w, W.o2_b), dict(bias_done=True)))
@@ -886,6 +892,64 @@ def _bert_layer_bwd(st, L, dout, seed):
         return ds1, None
     ds2 = ops.gemm(dk, wbf16(W.k_w), M=Mk, N=D, K=D, lda=D, ldb=D, transB=True, out_dtype=F32)
     ops.gemm(dv, wbf16(W.v_w), M=Mk, N=D, K=D, lda=D, ldb=D, transB=True, out=ds2, ldc=D, beta=1.0)
+    return ds1, ds2
+
+
+def _bert_cross_layer_fwd_seq(st, L, s1_32, s1_16, s2_16, key_add, W, heads, p_hid, p_att, eps, seed, sites):
+    """_bert_layer_fwd's cross-attention variant (queries from s1, fused key | value projection of s2, fused attention) as ONE library call."""
+    B, Lq, Lk, D, Mq, Mk, vl = st.B, st.Lq, st.Lk, st.D, st.Mq, st.Mk, st.vl
+    F = W.i_w.shape[0]
+    dev = s1_32.device
+    e = torch.empty
+    L.site_o, L.site_f = sites.next(), sites.next()
+    a16 = s1_16.dtype
+    L.q, L.qkv, L.ctx = e(Mq, D, device=dev, dtype=BF16), e(Mk, 2 * D, device=dev, dtype=BF16), e(Mq, D, device=dev, dtype=a16)
+    L.k, L.v = L.qkv[:, :D], L.qkv[:, D:]
+    L.stats = e((B, heads, Lq, 2) if vl is None else (heads, Mq, 2), device=dev, dtype=F32)
+    L.y, L.a32, L.a16 = e(Mq, D, device=dev, dtype=F32), e(Mq, D, device=dev, dtype=F32), e(Mq, D, device=dev, dtype=a16)
+    L.am, L.ar, L.zm, L.zr = (e(Mq, device=dev, dtype=F32) for _ in range(4))
+    L.u, L.i = e(Mq, F, device=dev, dtype=BF16), e(Mq, F, device=dev, dtype=a16)
+    L.z, out32, out16 = e(Mq, D, device=dev, dtype=F32), e(Mq, D, device=dev, dtype=F32), e(Mq, D, device=dev, dtype=a16)
+    L.seq, L.p_hid, L.p_att = "cross", p_hid, p_att
+    p = ops._p
+    ops.lib().mmdti_bert_cross_layer_fwd(
+        ops._stream(), Mq, Mk, B, Lq, Lk, heads, D, F, float(1.0 / math.sqrt(D // heads)), float(p_hid), float(p_att), int(seed), int(L.site_att),
+        int(L.site_o), int(L.site_f), s1_32.data_ptr(), s1_16.data_ptr(), s2_16.data_ptr(), p(key_add), *(ops._NO_VARLEN if vl is None else vl.args()),
+        wfwd(W.q_w).data_ptr(), p(W.q_b), L.fw[3].data_ptr(), L.fb[1].data_ptr(), wfwd(W.o_w).data_ptr(), p(W.o_b), W.ln1_w.data_ptr(), W.ln1_b.data_ptr(),
+        wfwd(W.i_w).data_ptr(), p(W.i_b), ops.ACT_GELU_FWD, wfwd(W.o2_w).data_ptr(), p(W.o2_b), W.ln2_w.data_ptr(), W.ln2_b.data_ptr(), float(eps),
+        ops.GEMM_LN_MAX_K if ops.GEMM_LN else 0, L.q.data_ptr(), L.qkv.data_ptr(), L.ctx.data_ptr(), L.stats.data_ptr(), L.y.data_ptr(), L.a32.data_ptr(),
+        L.a16.data_ptr(), L.am.data_ptr(), L.ar.data_ptr(), L.u.data_ptr(), L.i.data_ptr(), L.z.data_ptr(), out32.data_ptr(), out16.data_ptr(),
+        L.zm.data_ptr(), L.zr.data_ptr(), int(a16 == torch.float16))
+    return L, out32, out16
+
+
+def _bert_cross_layer_bwd_seq(st, L, dout, seed):
+    """_bert_layer_bwd of a layer that went through _bert_cross_layer_fwd_seq: its ten launches up to the weight gradients as ONE library
+    call, then the weight gradients exactly as the op-by-op path launches them -> (ds1, ds2) fp32."""
+    B, Lq, Lk, D, Mq, Mk, vl = st.B, st.Lq, st.Lk, st.D, st.Mq, st.Mk, st.vl
+    W, heads = L.W, L.heads
+    F = W.i_w.shape[0]
+    dev = dout.device
+    dout = dout.contiguous()
+    e = torch.empty
+    ds1, ds2 = e(Mq, D, device=dev, dtype=F32), e(Mk, D, device=dev, dtype=F32)
+    dzb, du, dyb = e(Mq, D, device=dev, dtype=BF16), e(Mq, F, device=dev, dtype=BF16), e(Mq, D, device=dev, dtype=BF16)
+    dq, dqkv = e(Mq, D, device=dev, dtype=BF16), torch.empty_like(L.qkv)
+    nrow = heads * Mq if vl is not None else B * heads * Lq
+    ws = e(4 * Mq * D + 4 * Mq * D + (nrow * 4 + 15) // 16 * 16 + 256, device=dev, dtype=torch.uint8)
+    p = ops._p
+    ops.lib().mmdti_bert_cross_layer_bwd(
+        ops._stream(), Mq, Mk, B, Lq, Lk, heads, D, F, float(1.0 / math.sqrt(D // heads)), float(L.p_hid), float(L.p_att), int(seed), int(L.site_att),
+        int(L.site_o), int(L.site_f), dout.data_ptr(), ds1.data_ptr(), ds2.data_ptr(), p(L.key_add), *(ops._NO_VARLEN if vl is None else vl.args()),
+        L.q.data_ptr(), L.qkv.data_ptr(), L.stats.data_ptr(), L.y.data_ptr(), L.am.data_ptr(), L.ar.data_ptr(), L.u.data_ptr(), ops.ACT_GELU_DX,
+        L.z.data_ptr(), L.zm.data_ptr(), L.zr.data_ptr(), wbf16(W.q_w).data_ptr(), L.fw[0].data_ptr(), wbf16(W.o_w).data_ptr(), wbf16(W.i_w).data_ptr(),
+        wbf16(W.o2_w).data_ptr(), W.ln1_w.data_ptr(), W.ln2_w.data_ptr(), gbuf(W.o_b).data_ptr(), gbuf(W.o2_b).data_ptr(), gbuf(W.ln1_w).data_ptr(),
+        gbuf(W.ln1_b).data_ptr(), gbuf(W.ln2_w).data_ptr(), gbuf(W.ln2_b).data_ptr(), dzb.data_ptr(), du.data_ptr(), dyb.data_ptr(), dq.data_ptr(),
+        dqkv.data_ptr(), (ws.data_ptr() + 255) // 256 * 256, ws.numel() - 256)
+    # the weight gradients, as the op-by-op path hands them over (same items, same order: _lin_bwd_params_many groups them by row count)
+    pend = [((dzb, L.i, W.o2_w, W.o2_b), dict(bias_done=True)), ((du, L.a16, W.i_w, W.i_b), {}), ((dyb, L.ctx, W.o_w, W.o_b), dict(bias_done=True)),
+            ((dq, L.s1_16, W.q_w, W.q_b), {})]
+    _lin_bwd_params_many(pend, [(dqkv, L.s2_16, L.fw[2], L.fb[2].view(-1), None)])
     return ds1, ds2
 
 

@@ -840,3 +840,62 @@ def test_bert_stack_sequenced_in_the_library_equals_the_per_layer_calls(M, packe
     o3, _ = run(False)
     assert torch.equal(o2, o3) and not torch.equal(o2, o1)
 
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_cross_layer_sequenced_in_the_library_equals_the_op_by_op_path(M, packed, monkeypatch):
+    """The cross-attention layer (BertCrossAttentionLayer, mm_module.py:615-626): its six forward launches and the ten backward launches up
+    to the weight gradients from one library call each (mmdti_bert_cross_layer_fwd / _bwd), the weight gradients launched as the op-by-op
+    path launches them.  Training mode, queries and keys of different lengths, dense and packed rows, key | value parameters back to back
+    in an arena: output and BOTH input gradients bit-identical, parameter gradients to the atomics' noise."""
+    from mmdti_hip import functional as Fn
+    from mmdti_hip.runtime import dropout_state, ParamArena
+    from mmdti_hip.packing import PackedRows
+    from mmdti_hip.trainer import _qkv_groups
+    D, heads, ffn = 512, 16, 256
+    ccfg = SimpleNamespace(hidden_size=D, num_attention_heads=heads, intermediate_size=ffn, attention_probs_dropout_prob=0.1, hidden_dropout_prob=0.1,
+                           hidden_act="gelu", layer_norm_eps=1e-12)
+    enc = M.bl.BertCrossEncoder(ccfg, 1).cuda().train()
+    arena = ParamArena(enc.parameters(), adjacent=_qkv_groups(enc))
+    with torch.no_grad():
+        for prm in enc.parameters():
+            prm.copy_(torch.randn(prm.shape, generator=torch.Generator().manual_seed(prm.numel() % 97)) * (0.05 if prm.dim() > 1 else 0.1) + (1.0 if "LayerNorm.weight" in "" else 0.0))
+    B, Lq, Lk = 5, 40, 56
+    ql, kl = [40, 17, 33, 8, 25], [56, 30, 41, 5, 56]
+    g = torch.Generator().manual_seed(11)
+    s1, s2 = torch.randn(B, Lq, D, generator=g), torch.randn(B, Lk, D, generator=g)
+    mask2 = torch.zeros(B, Lk)
+    for b, n in enumerate(kl):
+        mask2[b, :n] = 1
+    ext = ((1.0 - mask2) * -10000.0).view(B, 1, 1, Lk).cuda()
+    pq, pk = (PackedRows(torch.tensor(ql), Lq, "cuda"), PackedRows(torch.tensor(kl), Lk, "cuda")) if packed else (None, None)
+    calls = []
+    rf, rb = Fn._bert_cross_layer_fwd_seq, Fn._bert_cross_layer_bwd_seq
+    monkeypatch.setattr(Fn, "_bert_cross_layer_fwd_seq", lambda *a, **k: (calls.append("f"), rf(*a, **k))[1])
+    monkeypatch.setattr(Fn, "_bert_cross_layer_bwd_seq", lambda *a, **k: (calls.append("b"), rb(*a, **k))[1])
+
+    def run(seq):
+        monkeypatch.setattr(Fn, "LAYER_SEQ", seq)
+        arena.zero_grad()
+        dropout_state.reseed(31)
+        if packed:
+            a = s1.cuda().reshape(B * Lq, D)[pq.gather].clone().requires_grad_()
+            b_ = s2.cuda().reshape(B * Lk, D)[pk.gather].clone().requires_grad_()
+            out = enc(a, b_, None, packs=(pq, pk))[-1]
+        else:
+            a, b_ = s1.cuda().clone().requires_grad_(), s2.cuda().clone().requires_grad_()
+            out = enc(a, b_, ext)[-1]
+        w = torch.randn(out.shape, generator=torch.Generator().manual_seed(5)).cuda()
+        (out * w).sum().backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), a.grad.clone(), b_.grad.clone(), {n: prm.grad.clone() for n, prm in enc.named_parameters() if prm.grad is not None}
+
+    o0, da0, db0, g0 = run(False)
+    assert not calls
+    o1, da1, db1, g1 = run(True)
+    assert calls == ["f", "b"]
+    assert torch.equal(o0, o1) and torch.equal(da0, da1) and torch.equal(db0, db1)
+    assert set(g0) == set(g1)
+    for n in g0:
+        d = float((g0[n].double() - g1[n].double()).norm()) / (float(g0[n].double().norm()) + 1e-30)
+        assert d < 2e-4, (n, d)
+
