@@ -29,6 +29,11 @@ def init_from_env(backend: Optional[str] = None, force: bool = False) -> tuple:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the multi-rank control flow on a ONE-GPU box (MMDTI_DIST_BACKEND=gloo MMDTI_ONE_GPU=1): every rank on device 0, the
+    # collectives through gloo (RCCL refuses two ranks on one device).  Not a performance configuration.
+    backend = backend or os.environ.get("MMDTI_DIST_BACKEND") or None
+    if os.environ.get("MMDTI_ONE_GPU") == "1":
+        local = 0
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
