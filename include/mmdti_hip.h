@@ -475,9 +475,10 @@ int mmdti_l2norm_fwd(mmdti_stream_t stream, const float* x, int B, int D, int ld
 int mmdti_l2norm_bwd(mmdti_stream_t stream, const float* dxhat, const float* xhat, const float* inv_norm, int B,
                      int D, int ldx, float* dx);
 /* One direction of the symmetric CE (infonce.py:93-98) for anchors rows [row0,row0+Bl) of qh_all against all
- * Bg keys kh_all (global negatives under DDP).  loss_sum += sum_i CE_i (atomic); dq_all rows [row0,row0+Bl) and all
+ * Bg keys kh_all (global negatives under DDP).  loss_sum += sum_i CE_i (the rows' terms added in row order by one thread of the
+ * column pass: reproducible to the bit); dq_all rows [row0,row0+Bl) and all
  * Bg rows of dk_all are accumulated (+=, caller zero-initialises).  Gradients are of (1/(2*Bg)) * sum_i CE_i.
- * scratch: Bl*Bg floats (the logit-gradient matrix handed from the row pass to the column pass).
+ * scratch: Bl*(Bg+1) floats (the logit-gradient matrix handed from the row pass to the column pass + the Bl per-row loss terms).
  * Feature width D <= 64 (the reference's 50): the Bl x Bg similarity matrix and both gradient products run as fp32 MFMAs
  * (v_mfma_f32_16x16x4_f32 -- fp32 products and accumulation, the loss keeps fp32 precision); wider D takes scalar kernels. */
 int mmdti_infonce_dir(mmdti_stream_t stream, const float* qh_all, const float* kh_all, int Bg, int D, int row0,
@@ -489,7 +490,9 @@ int mmdti_infonce_dir(mmdti_stream_t stream, const float* qh_all, const float* k
  * Outputs: loss (scalar, overwritten), G [B,B] = dL/dprod. */
 int mmdti_ct_loss_fwd(mmdti_stream_t stream, int mode, const float* fhat, int B, int D, const float* labels_f,
                       const long long* labels_i, int C, const float* pred, const float* weights, float w, float t,
-                      float e, float coef, float* loss, float* G);
+                      float e, float coef, float* loss, float* G,
+                      float* row_ws /* nullable, [B] floats: the per-row loss terms, summed in row order (bitwise reproducible loss);
+                                       null: fp32 atomics */);
 /* dfhat[i] = (1/t) * sum_j (G[i,j]+G[j,i]) fhat[j] */
 int mmdti_ct_loss_bwd(mmdti_stream_t stream, const float* fhat, const float* G, int B, int D, float t, float* dfhat);
 

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void infonce_rows_kernel(const float* __restri
   for (int j = threadIdx.x; j < Bg; j += 256) se += __expf(lg[j] - m);
   se = block_sum(se, red);
   const float lse = m + __logf(se);
-  if (threadIdx.x == 0) atomicAdd(loss_sum, lse - lg[i]);
+  if (threadIdx.x == 0) gl_out[(long long)gridDim.x * Bg + il] = lse - lg[i];     // (this row's loss term: summed in row order by the column pass)
   const float gscale = 0.5f / (float)Bg;  // d[(CE_a + CE_b)/2 mean over Bg]/d CE_i
   __syncthreads();
   for (int j = threadIdx.x; j < Bg; j += 256) {
@@ -210,8 +210,13 @@ __global__ __launch_bounds__(256) void infonce_rows_kernel(const float* __restri
 }
 
 __global__ __launch_bounds__(64) void infonce_cols_kernel(const float* __restrict__ q, const float* __restrict__ gl, int Bg, int D, int row0,
-                                                          int Bl, float* __restrict__ dk) {
+                                                          int Bl, float* __restrict__ dk, float* __restrict__ loss_sum) {
   const int j = blockIdx.x;
+  if (j == 0 && threadIdx.x == 0) {      // loss_sum += the rows' loss terms, in row order (one writer: reproducible to the bit)
+    float t = 0.f;
+    for (int il = 0; il < Bl; ++il) t += gl[(long long)Bl * Bg + il];
+    *loss_sum += t;
+  }
   for (int d = threadIdx.x; d < D; d += 64) {
     float acc = 0.f;
     for (int il = 0; il < Bl; ++il) acc += gl[(long long)il * Bg + j] * q[(long long)(row0 + il) * D + d];
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(256) void infonce_rows_mfma_kernel(const float* __r
         const bool diag = key == row0 + il;
         gl = (__expf(l - lse) - (diag ? 1.f : 0.f)) * gscale * invT;
         gl_out[(long long)il * Bg + key] = gl;
-        if (diag) atomicAdd(loss_sum, lse - l);
+        if (diag) gl_out[(long long)Bl * Bg + il] = lse - l;      // (this row's loss term: summed in row order by the column pass)
       }
       pw[a * 17 + i] = gl;
     }
@@ -352,8 +357,13 @@ __global__ __launch_bounds__(256) void infonce_rows_mfma_kernel(const float* __r
 }
 
 __global__ __launch_bounds__(256) void infonce_cols_mfma_kernel(const float* __restrict__ q, const float* __restrict__ gl, int Bg, int D, int row0,
-                                                                int Bl, float* __restrict__ dk) {
+                                                                int Bl, float* __restrict__ dk, float* __restrict__ loss_sum) {
   __shared__ float sDk[4 * 16 * 64];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {      // loss_sum += the rows' loss terms, in row order (one writer: reproducible to the bit)
+    float t = 0.f;
+    for (int il = 0; il < Bl; ++il) t += gl[(long long)Bl * Bg + il];
+    *loss_sum += t;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
   const int j0 = blockIdx.x * 16, NU = (D + 15) >> 4;
   const int key = j0 + i;
@@ -393,7 +403,7 @@ __global__ __launch_bounds__(256) void infonce_cols_mfma_kernel(const float* __r
 __global__ __launch_bounds__(256) void ct_fwd_kernel(int mode, const float* __restrict__ fh, int B, int D, const float* __restrict__ lab_f,
                                                      const long long* __restrict__ lab_i, int C, const float* __restrict__ pred,
                                                      const float* __restrict__ wts, float w, float invt, float e, float thr,
-                                                     float* __restrict__ loss, float* __restrict__ G) {
+                                                     float* __restrict__ loss, float* __restrict__ G, float* __restrict__ row_ws) {
   extern __shared__ float sm[];  // frow[D] | prod[B] | red[4]
   float* frow = sm;
   float* prod = sm + D;
@@ -448,7 +458,10 @@ __global__ __launch_bounds__(256) void ct_fwd_kernel(int mode, const float* __re
   const float Dn = e_pos + e_neg;
   const float flag = nneg > 0.f ? 1.f : 0.f;
   const float li = flag * (npos * __logf(Dn) - spos) / denom;
-  if (threadIdx.x == 0) atomicAdd(loss, li / (float)B);
+  if (threadIdx.x == 0) {
+    if (row_ws) row_ws[i] = li / (float)B;      // (summed in row order by ordered_sum_kernel: reproducible to the bit)
+    else atomicAdd(loss, li / (float)B);
+  }
   const float cg = flag / denom / (float)B;
   for (int j = threadIdx.x; j < B; j += 256) {
     const float cls = G[(long long)i * B + j];
@@ -463,6 +476,13 @@ __global__ __launch_bounds__(256) void ct_fwd_kernel(int mode, const float* __re
     }
     G[(long long)i * B + j] = g;
   }
+}
+
+// out = x[0] + x[1] + ... in index order (one thread: the n per-row terms of a loss)
+__global__ void ordered_sum_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+  float t = 0.f;
+  for (int i = 0; i < n; ++i) t += x[i];
+  *out = t;
 }
 
 __global__ __launch_bounds__(256) void ct_bwd_kernel(const float* __restrict__ fh, const float* __restrict__ G, int B, int D, float invt,
@@ -800,7 +820,7 @@ extern "C" int mmdti_infonce_dir(mmdti_stream_t stream, const float* qh_all, con
     hipLaunchKernelGGL(infonce_rows_mfma_kernel, dim3(cdiv(Bl, 16)), dim3(256), smem_m, (hipStream_t)stream, qh_all, kh_all, Bg, D, row0, Bl,
                        1.0f / temperature, loss_sum, dq_all, scratch);
     MMDTI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(infonce_cols_mfma_kernel, dim3(cdiv(Bg, 16)), dim3(256), 0, (hipStream_t)stream, qh_all, scratch, Bg, D, row0, Bl, dk_all);
+    hipLaunchKernelGGL(infonce_cols_mfma_kernel, dim3(cdiv(Bg, 16)), dim3(256), 0, (hipStream_t)stream, qh_all, scratch, Bg, D, row0, Bl, dk_all, loss_sum);
     MMDTI_LAUNCH_CHECK();
     return MMDTI_OK;
   }
@@ -809,14 +829,14 @@ extern "C" int mmdti_infonce_dir(mmdti_stream_t stream, const float* qh_all, con
   hipLaunchKernelGGL(infonce_rows_kernel, dim3(Bl), dim3(256), smem, (hipStream_t)stream, qh_all, kh_all, Bg, D, row0,
                      1.0f / temperature, loss_sum, dq_all, scratch);
   MMDTI_LAUNCH_CHECK();
-  hipLaunchKernelGGL(infonce_cols_kernel, dim3(Bg), dim3(64), 0, (hipStream_t)stream, qh_all, scratch, Bg, D, row0, Bl, dk_all);
+  hipLaunchKernelGGL(infonce_cols_kernel, dim3(Bg), dim3(64), 0, (hipStream_t)stream, qh_all, scratch, Bg, D, row0, Bl, dk_all, loss_sum);
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }
 
 extern "C" int mmdti_ct_loss_fwd(mmdti_stream_t stream, int mode, const float* fhat, int B, int D, const float* labels_f,
                                  const long long* labels_i, int C, const float* pred, const float* weights, float w, float t,
-                                 float e, float coef, float* loss, float* G) {
+                                 float e, float coef, float* loss, float* G, float* row_ws) {
   MMDTI_REQUIRE(mode >= 0 && mode <= 2, "ct_loss_fwd: bad mode %d", mode);
   MMDTI_REQUIRE(fhat && loss && G && B > 0 && D > 0 && t > 0.f, "ct_loss_fwd: bad arguments");
   MMDTI_REQUIRE(mode == MMDTI_CT_MULTI ? (labels_i && C > 0) : (labels_f != nullptr), "ct_loss_fwd: labels missing");
@@ -824,10 +844,12 @@ extern "C" int mmdti_ct_loss_fwd(mmdti_stream_t stream, int mode, const float* f
   const size_t smem = ((size_t)D + B + 4) * sizeof(float);
   MMDTI_REQUIRE(smem <= 64 * 1024, "ct_loss_fwd: B+D too large for LDS");
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) { set_error("ct_loss_fwd: memset failed"); return MMDTI_ERR_LAUNCH; }
+  // (row_ws: the per-row terms are stored and summed in row order by one thread; without it they meet in an fp32 atomic)
+  if (!row_ws && hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) { set_error("ct_loss_fwd: memset failed"); return MMDTI_ERR_LAUNCH; }
   const float thr = mode == MMDTI_CT_MULTI ? (float)((double)coef / (double)C) : 0.f;
   hipLaunchKernelGGL(ct_fwd_kernel, dim3(B), dim3(256), smem, s, mode, fhat, B, D, labels_f, labels_i, C, pred, weights, w,
-                     1.0f / t, e, thr, loss, G);
+                     1.0f / t, e, thr, loss, G, row_ws);
+  if (row_ws) hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(1), 0, s, row_ws, B, loss);
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }

@@ -887,7 +887,7 @@ def l2norm_bwd(dxh, xh, inv):
 
 def infonce_dir(qh_all, kh_all, row0, Bl, temperature, loss_sum, dq_all, dk_all):
     Bg, D = qh_all.shape
-    scratch = torch.empty(Bl, Bg, device=qh_all.device, dtype=F32)
+    scratch = torch.empty(Bl * (Bg + 1), device=qh_all.device, dtype=F32)      # (logit gradients [Bl, Bg] + the Bl per-row loss terms)
     lib().mmdti_infonce_dir(_stream(), qh_all.data_ptr(), kh_all.data_ptr(), Bg, D, row0, Bl, float(temperature), loss_sum.data_ptr(),
                             dq_all.data_ptr(), dk_all.data_ptr(), scratch.data_ptr())
 
@@ -895,11 +895,12 @@ def infonce_dir(qh_all, kh_all, row0, Bl, temperature, loss_sum, dq_all, dk_all)
 # --------------------------------------------------------------------------------------------- ConR / SupCon
 def ct_loss_fwd(mode, fhat, labels_f=None, labels_i=None, pred=None, weights=None, w=0.2, t=0.07, e=0.01, coef=1.0):
     B, D = fhat.shape
-    loss = torch.empty(1, device=fhat.device, dtype=F32)
+    buf = torch.empty(1 + B, device=fhat.device, dtype=F32)        # loss | per-row terms (summed in row order: reproducible)
+    loss = buf[:1]
     G = torch.empty(B, B, device=fhat.device, dtype=F32)
     C = 0 if labels_i is None else labels_i.shape[1]
     lib().mmdti_ct_loss_fwd(_stream(), mode, fhat.data_ptr(), B, D, _p(labels_f), _p(labels_i), C, _p(pred), _p(weights), float(w),
-                            float(t), float(e), float(coef), loss.data_ptr(), G.data_ptr())
+                            float(t), float(e), float(coef), loss.data_ptr(), G.data_ptr(), buf.data_ptr() + 4)
     return loss, G
 
 
