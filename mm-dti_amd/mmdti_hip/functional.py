@@ -278,6 +278,9 @@ class PairEncoderFn(torch.autograd.Function):
     def backward(ctx, dout, ds_last, dx_pre):
         # ds_last / dx_pre: gradients of the auxiliary outputs (aux_grads; None otherwise -- gradients are not materialised)
         st, mod = ctx.st, ctx.mod
+        if getattr(st, "consumed", False):     # (the saved activations are released layer by layer as the backward advances)
+            raise ops.MMDTIError("PairEncoderFn: backward through the same forward twice (retain_graph) is not supported")
+        st.consumed = True
         B, N, D, H, ld, M, seed = st.B, st.N, st.D, st.H, st.ld, st.M, st.seed
         scale = (D // H) ** -0.5
         if dout is None:                       # (nothing downstream used the encoder output)
@@ -1181,6 +1184,9 @@ class RobertaEncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         st, mod = ctx.st, ctx.mod
+        if getattr(st, "consumed", False):
+            raise ops.MMDTIError("RobertaEncoderFn: backward through the same forward twice (retain_graph) is not supported")
+        st.consumed = True
         B, Lq, D = st.B, st.Lq, st.D
         dx = dout.contiguous().view(st.Mq, D)
         if st.stack is not None:
