@@ -358,9 +358,12 @@ def test_device_prefetcher_feeds_the_step():
     from mmdti_hip.data import DevicePrefetcher
     from mmdti_hip.trainer import FineTuner
     ocfg = _ocfg("classification", 2)
-    host = [O.synth_batch(8, 10, 14, ocfg, seed=20 + i, ragged=True) for i in range(3)] + [O.synth_batch(6, 7, 9, ocfg, seed=30, ragged=True)]
+    # (shapes shrink and grow along the sequence and there are more batches than staging sets: the grow-only pinned buffers of a set are
+    #  re-used, re-viewed and re-allocated, each only after the copy that last read it has completed)
+    host = ([O.synth_batch(8, 10, 14, ocfg, seed=20 + i, ragged=True) for i in range(3)] + [O.synth_batch(6, 7, 9, ocfg, seed=30, ragged=True)]
+            + [O.synth_batch(10, 16, 20, ocfg, seed=31 + i, ragged=True) for i in range(3)] + [O.synth_batch(3, 5, 6, ocfg, seed=40, ragged=True)])
     got = list(DevicePrefetcher(host, "cuda", narrow=False))
-    assert len(got) == 4
+    assert len(got) == len(host) == 8
     for (bi, li), (bo, lo) in zip(host, got):
         assert all(bo[k].is_cuda and bo[k].dtype == bi[k].dtype and torch.equal(bo[k].cpu(), bi[k]) for k in bi) and torch.equal(lo.cpu(), li)
     # default: only what the kernels read crosses PCIe -- int16 edge types (same values), no src_coord
