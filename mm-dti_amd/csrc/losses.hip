@@ -622,22 +622,27 @@ __global__ __launch_bounds__(256) void fds_smooth_stats_kernel(const float* __re
 
 // ---------------------------------------------------------------- small fp32 linear (classification head)
 // One LDS-tiled fp32 kernel for the three products of a small Linear kept in fp32 (mm_model.py:44-84: [B,512] -> 512 ->
-// out): 32 x 32 output tiles, 32-deep k slices, 4 outputs per thread; every global access runs along the operand's
-// contiguous axis.  dz = dy * tanh'(y) is formed while the tile is loaded.
+// out): 32 x 32 output tiles on four waves (16 x 16 each), the products on the matrix pipe as v_mfma_f32_16x16x4_f32 -- fp32
+// products, fp32 accumulation: the head keeps fp32 precision.  128-deep k slices, the NEXT slice's global loads issued before the
+// current one is multiplied; every global access runs along the operand's contiguous axis.  dz = dy * tanh'(y) is formed while
+// the tile is loaded.  (Rounds 1-3 multiplied on the VALU from 32-deep slices: five LDS reads per four FMAs and four exposed global
+// round trips -- 55-73 us per launch on the step's serial stretch between forward and backward; now 8-12 us.)
 //   MODE 0: y[r,o]   = act(sum_k x[r,k] W[o,k] + b[o])           M = rows,  N = out_f,    K = in_f
 //   MODE 1: dx[r,k]  =      sum_o dz[r,o] W[o,k]                  M = rows,  N = in_f,     K = out_f
 //   MODE 2: dW[o,k] +=      sum_r dz[r,o] x[r,k] ; db[o] += sum_r dz[r,o]  (column k == in_f)   M = out_f, N = in_f + 1, K = rows
+constexpr int LF_KS = 128;       // k slice depth
+constexpr int LF_SA = LF_KS + 1; // row stride of the A image [32 m][k]
+constexpr int LF_SB = 33;        // row stride of the B image [k][32 n]
 template <int MODE>
 __global__ __launch_bounds__(256) void linear_f32_tile_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
                                                               const float* __restrict__ y, const float* __restrict__ dy, int rows, int in_f,
                                                               int out_f, int act, float* __restrict__ out, float* __restrict__ db) {
-  // (four 32-deep k slices per barrier pair: at the head's 32 rows the grid is a dozen workgroups and the loop is pure load latency --
-  //  sixteen loads in flight per thread per trip instead of four)
-  __shared__ float sA[4][32][33];   // [slice][m][k]
-  __shared__ float sB[4][32][33];   // [slice][k][n]
+  __shared__ float sA[32 * LF_SA];   // [m][k]
+  __shared__ float sB[LF_KS * LF_SB];   // [k][n]
   const int M = MODE == 2 ? out_f : rows, N = MODE == 0 ? out_f : (MODE == 1 ? in_f : in_f + 1), K = MODE == 0 ? in_f : (MODE == 1 ? out_f : rows);
   const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wy = wave >> 1, wx = wave & 1, li = lane & 15, lq = lane >> 4;
   auto dz = [&](int r, int o) {
     float g = dy[(long long)r * out_f + o];
     if (act == 3) {
@@ -646,58 +651,74 @@ __global__ __launch_bounds__(256) void linear_f32_tile_kernel(const float* __res
     }
     return g;
   };
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int kb0 = 0; kb0 < K; kb0 += 128) {
-    const int ns = (min(128, K - kb0) + 31) / 32;      // slices of this trip (uniform over the workgroup)
+  // element e (0..15) of this thread in the A / B images of a slice: A is 32 x 128, B is 128 x 32 -- 4096 values each, 16 per thread,
+  // indexed so that consecutive threads walk the operand's contiguous axis in global memory
+  float ra[16], rb[16];
+  auto fetch = [&](int k0) {
 #pragma unroll
-    for (int sl = 0; sl < 4; ++sl) {
-      if (sl >= ns) break;
-      const int k0 = kb0 + sl * 32;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int u = ty + 8 * i;   // the slow index of this thread's element, tx the contiguous one
-        if (MODE == 0) {
-          const int m = m0 + u, n = n0 + u, k = k0 + tx;
-          sA[sl][u][tx] = (m < M && k < K) ? x[(long long)m * in_f + k] : 0.f;
-          sB[sl][tx][u] = (n < N && k < K) ? W[(long long)n * in_f + k] : 0.f;
-        } else if (MODE == 1) {
-          const int m = m0 + u, k = k0 + tx;
-          sA[sl][u][tx] = (m < M && k < K) ? dz(m, k) : 0.f;
-          const int kb = k0 + u, n = n0 + tx;
-          sB[sl][u][tx] = (kb < K && n < N) ? W[(long long)kb * in_f + n] : 0.f;
-        } else {
-          const int k = k0 + u, m = m0 + tx, n = n0 + tx;
-          sA[sl][tx][u] = (k < K && m < M) ? dz(k, m) : 0.f;
-          sB[sl][u][tx] = (k < K && n < N) ? (n < in_f ? x[(long long)k * in_f + n] : 1.f) : 0.f;
-        }
+    for (int e = 0; e < 16; ++e) {
+      const int t = e * 256 + tid;
+      if (MODE == 0) {          // A[m][k] = x[m, k] (k contiguous);  B[k][n] = W[n, k] (k contiguous)
+        const int mm = t >> 7, kk = t & 127;
+        ra[e] = (m0 + mm < M && k0 + kk < K) ? x[(long long)(m0 + mm) * in_f + k0 + kk] : 0.f;
+        rb[e] = (n0 + mm < N && k0 + kk < K) ? W[(long long)(n0 + mm) * in_f + k0 + kk] : 0.f;      // (n = mm here)
+      } else if (MODE == 1) {   // A[m][k] = dz(m, k) (k contiguous);  B[k][n] = W[k, n] (n contiguous)
+        const int mm = t >> 7, kk = t & 127;
+        ra[e] = (m0 + mm < M && k0 + kk < K) ? dz(m0 + mm, k0 + kk) : 0.f;
+        const int kb = t >> 5, nn = t & 31;
+        rb[e] = (k0 + kb < K && n0 + nn < N) ? W[(long long)(k0 + kb) * in_f + n0 + nn] : 0.f;
+      } else {                  // A[m][k] = dz(k, m) (m contiguous);  B[k][n] = x[k, n] | 1 (n contiguous)
+        const int kb = t >> 5, mm = t & 31;
+        ra[e] = (k0 + kb < K && m0 + mm < M) ? dz(k0 + kb, m0 + mm) : 0.f;
+        rb[e] = (k0 + kb < K && n0 + mm < N) ? (n0 + mm < in_f ? x[(long long)(k0 + kb) * in_f + n0 + mm] : 1.f) : 0.f;   // (n = mm here)
       }
     }
-    __syncthreads();
-    for (int sl = 0; sl < ns; ++sl) {
-#pragma unroll 8
-      for (int kk = 0; kk < 32; ++kk) {
-        const float bv = sB[sl][kk][tx];
+  };
+  auto park = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] += sA[sl][ty * 4 + i][kk] * bv;
+    for (int e = 0; e < 16; ++e) {
+      const int t = e * 256 + tid;
+      if (MODE == 0) {
+        const int mm = t >> 7, kk = t & 127;
+        sA[mm * LF_SA + kk] = ra[e];
+        sB[kk * LF_SB + mm] = rb[e];
+      } else if (MODE == 1) {
+        sA[(t >> 7) * LF_SA + (t & 127)] = ra[e];
+        sB[(t >> 5) * LF_SB + (t & 31)] = rb[e];
+      } else {
+        sA[(t & 31) * LF_SA + (t >> 5)] = ra[e];
+        sB[(t >> 5) * LF_SB + (t & 31)] = rb[e];
       }
     }
+  };
+  nce_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += LF_KS) {
+    __syncthreads();            // (the previous slice has been multiplied)
+    park();
     __syncthreads();
+    if (k0 + LF_KS < K) fetch(k0 + LF_KS);
+    const int kn = min(LF_KS, K - k0);
+    const float* pa = sA + (wy * 16 + li) * LF_SA + lq;
+    const float* pb = sB + lq * LF_SB + wx * 16 + li;
+    for (int kk = 0; kk < kn; kk += 4) acc = NCE_MFMA(pa[kk], pb[kk * LF_SB], acc);      // (slots past K hold zeros)
   }
-  const int n = n0 + tx;
+  // accumulator: rows 4 lq + r, column li of this wave's 16 x 16 tile
+  const int n = n0 + wx * 16 + li;
   if (n >= N) return;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + ty * 4 + i;
+  for (int r = 0; r < 4; ++r) {
+    const int m = m0 + wy * 16 + 4 * lq + r;
     if (m >= M) continue;
     if (MODE == 0) {
-      const float v = acc[i] + (b ? b[n] : 0.f);
+      const float v = acc[r] + (b ? b[n] : 0.f);
       out[(long long)m * out_f + n] = act == 3 ? tanhf(v) : v;
     } else if (MODE == 1) {
-      out[(long long)m * in_f + n] = acc[i];
+      out[(long long)m * in_f + n] = acc[r];
     } else if (n < in_f) {
-      out[(long long)m * in_f + n] += acc[i];     // (one thread per element: the accumulation needs no atomic)
+      out[(long long)m * in_f + n] += acc[r];     // (one lane per element: the accumulation needs no atomic)
     } else if (db) {
-      db[m] += acc[i];
+      db[m] += acc[r];
     }
   }
 }
