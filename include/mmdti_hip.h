@@ -549,8 +549,9 @@ int mmdti_ce_loss(mmdti_stream_t stream, const float* logits, const long long* t
 int mmdti_bce_logits_loss(mmdti_stream_t stream, const float* logits, const float* target, int n, float* loss, float* dlogits);
 
 /* ---- optimizer step on the flat arenas (tasks/trainer.py:160,270-282) ---------------------- */
-/* sum of squares of g into out[0] (atomic; zero first) */
-int mmdti_sumsq_f32(mmdti_stream_t stream, const float* g, long long n, float* out);
+/* out[0] += sum of squares of g (zero first).  ws (nullable, ws_floats >= 1; 2048 used at most): one partial per workgroup folded in a
+ * fixed order -- the gradient norm is then the same to the bit from run to run; null: fp32 atomics */
+int mmdti_sumsq_f32(mmdti_stream_t stream, const float* g, long long n, float* out, float* ws, int ws_floats);
 /* Adam (torch.optim.Adam semantics, eps outside sqrt of bias-corrected v): p,m,v updated in place; also refreshes the
  * bf16 shadow copy of p (the backward GEMMs' weights) and, when p_f16 is given, the fp16 one (the forward GEMMs' weights in the fp16
  * forward-operand mode; saturating).  grad is multiplied by *grad_scale_dev (device scalar, e.g. clip coefficient) if non-null.

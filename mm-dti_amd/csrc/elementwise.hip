@@ -476,6 +476,38 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
+// The reproducible form (a workspace is given): 16-byte loads, one partial per workgroup, and the partials folded in a FIXED order by
+// sumsq_fold_kernel -- the gradient norm, and with it the clip coefficient of every Adam step, is the same to the bit from run to run
+// (the atomic form above differs in the last bit, and a training trajectory with it).
+constexpr int SUMSQ_WGS = 2048;
+__global__ __launch_bounds__(256) void sumsq_part_kernel(const float* __restrict__ g, long long n, float* __restrict__ part) {
+  const long long n4 = n >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = g4[i];
+    a.x += v.x * v.x; a.y += v.y * v.y; a.z += v.z * v.z; a.w += v.w * v.w;
+  }
+  float s = (a.x + a.y) + (a.z + a.w);
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[(n4 << 2) + threadIdx.x]; s += v * v; }
+  s = wave_sum(s);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_fold_kernel(const float* __restrict__ part, int np, float* __restrict__ out) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < np; i += 256) s += part[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out += red[0];
+}
 
 // Step state kept on the device so that a whole training step can be replayed from a captured HIP graph (host-side
 // counters would be frozen into the graph): st[0] = optimizer steps taken, st[1] = learning rate of THIS step (HF linear
@@ -757,9 +789,15 @@ extern "C" int mmdti_masked_pool_packed_bwd(mmdti_stream_t stream, const float* 
   return MMDTI_OK;
 }
 
-extern "C" int mmdti_sumsq_f32(mmdti_stream_t stream, const float* g, long long n, float* out) {
+extern "C" int mmdti_sumsq_f32(mmdti_stream_t stream, const float* g, long long n, float* out, float* ws, int ws_floats) {
   MMDTI_REQUIRE(g && out && n > 0, "sumsq_f32: bad arguments");
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  if (ws && ws_floats >= 1 && aligned16(g)) {
+    const int wgs = (int)min((long long)min(ws_floats, SUMSQ_WGS), (n / 4 + 255) / 256 + 1);
+    hipLaunchKernelGGL(sumsq_part_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, g, n, ws);
+    hipLaunchKernelGGL(sumsq_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, wgs, out);
+  } else {
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  }
   MMDTI_LAUNCH_CHECK();
   return MMDTI_OK;
 }

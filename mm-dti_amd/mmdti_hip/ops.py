@@ -1023,8 +1023,9 @@ def bce_logits_loss(logits, target):
     return loss, d
 
 
-def sumsq(g, out):
-    lib().mmdti_sumsq_f32(_stream(), g.data_ptr(), g.numel(), out.data_ptr())
+def sumsq(g, out, ws=None):
+    """out[0] += sum of squares of g.  ws: fp32 scratch (up to 2048 values) -- per-workgroup partials folded in a fixed order: reproducible."""
+    lib().mmdti_sumsq_f32(_stream(), g.data_ptr(), g.numel(), out.data_ptr(), _p(ws), 0 if ws is None else ws.numel())
     return out
 
 

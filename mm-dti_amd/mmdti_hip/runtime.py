@@ -140,8 +140,9 @@ class ParamArena:
         self.step_count += 1
         scale = None
         if max_norm is not None:
-            ss = torch.zeros(1, device=self.data.device, dtype=torch.float32)
-            ops.sumsq(self.grad, ss)
+            buf = torch.zeros(1 + 2048, device=self.data.device, dtype=torch.float32)      # the sum | per-workgroup partials (fixed-order fold)
+            ss = buf[:1]
+            ops.sumsq(self.grad, ss, buf[1:])
             # clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1 (tiny scalar math; stays on device, no sync)
             scale = torch.clamp(max_norm / (ss.sqrt() + 1e-6), max=1.0)
         # (the Adam pass writes BOTH 16-bit shadows -- bf16 for the backward GEMMs, fp16 for the forward ones -- through raw pointers:

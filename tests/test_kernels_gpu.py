@@ -776,6 +776,16 @@ def test_adam_matches_torch(ops):
     ss = torch.zeros(1, device="cuda")
     ops.sumsq(dev(g), ss)
     close(ss, (g * g).sum().reshape(1), 1e-5, 1e-5)
+    # the reproducible form (what ParamArena.adam_step calls): per-workgroup partials folded in a fixed order -- same bits every time
+    for nn in (1000, 1003, 5_000_003):
+        gg = torch.randn(nn, generator=G(7))
+        outs = []
+        for _ in range(3):
+            buf = torch.zeros(1 + 2048, device="cuda")
+            ops.sumsq(dev(gg), buf[:1], buf[1:])
+            outs.append(buf[:1].clone())
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        close(outs[0], (gg.double() * gg.double()).sum().float().reshape(1), 2e-6, 0)
 
 
 def test_colsum_and_casts(ops):
