@@ -289,11 +289,14 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const bf16_t* __restric
         dacc = ATTN_MFMA(attn_frag_rm<HD>(sV, t * 16, c, lane), dof[c], dacc);
       }
       const f32x4 ka = *reinterpret_cast<const f32x4*>(&sKA[t * 16 + 4 * g]);
-      const uint32_t km = thresh16 ? attn_keep4(rkey, (uint32_t)qi * (NP / 4) + t * 4 + g, t8) : 15u;
+      // (the quad's four uniform bytes are compared where they are used -- one byte compare + select per element, as in the forward;
+      //  building a 4-bit mask first and testing its bits cost three more instructions per element and spilled compare results.
+      //  Without dropout t8 == 0: every byte keeps.)
+      const uint32_t hw = thresh16 ? attn_hash24(rkey, (uint32_t)qi * (NP / 4) + t * 4 + g) : 0u;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float p = __builtin_amdgcn_exp2f(acc[r] * scale2 + ka[r] - st.x) * st.y;
-        const bool keep = (km >> r) & 1u;
+        const bool keep = ((hw >> (8 * r)) & 0xffu) >= t8;
         dsum += keep ? dacc[r] * p : 0.f;
         acc[r] = keep ? p : -p;
       }
